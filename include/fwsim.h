@@ -1,0 +1,312 @@
+/*
+ * fwsim.h -- C ABI of the MI355X-native vectorised fixed-wing env step.
+ *
+ * This is the drop-in boundary for the hot path named by BASELINE.json:north_star:
+ * N independent fixed-wing aircraft advanced in lockstep for one *agent step*
+ * (= 4 Aviary steps = 8 physics ticks @240 Hz, with observation, reward,
+ * termination/truncation and SB3-style auto-reset fused in).
+ *
+ * The reference (WdBlink/pyflyt-drone) has no FFI: its boundary is Python
+ * duck typing (Gymnasium Env aggregated by SB3's VecEnv).  Each entry point
+ * below names the reference interface it replaces (paths relative to the
+ * reference repo root):
+ *
+ *   fw_create   <- gym.make(...)/FixedwingBaseEnv.__init__ x N inside SubprocVecEnv
+ *                  envs/fixedwing_envs/fixedwing_base_env.py:21-106,
+ *                  train/train_Fixedwing_Waypoints_v3.py:82-121,251
+ *   fw_reset    <- Env.reset(): begin_reset/end_reset
+ *                  envs/fixedwing_envs/fixedwing_base_env.py:193-257,
+ *                  envs/fixedwing_objlock_env.py:177-251
+ *   fw_step     <- Env.step(action) + the VecEnv worker's auto-reset
+ *                  envs/fixedwing_envs/fixedwing_base_env.py:314-348
+ *   fw_seed     <- VecEnv.seed(seed) / env.reset(seed=seed+rank)
+ *                  train/train_Fixedwing_Waypoints_v3.py:119
+ *   fw_get_state/fw_set_state <- (no reference twin) parity tests + checkpoints
+ *   fw_destroy  <- Env.close()  envs/fixedwing_envs/fixedwing_base_env.py:187-191
+ *
+ * Conventions
+ *   - All I/O buffers of fw_reset/fw_step are DEVICE pointers owned by the
+ *     caller (e.g. torch tensor .data_ptr()); nothing is retained past the call.
+ *   - fw_get_state/fw_set_state take HOST pointers (double, canonical record).
+ *   - Calls are asynchronous w.r.t. the host and ordered on `hip_stream`
+ *     (a hipStream_t passed as void*; NULL = the legacy default stream).
+ *   - A handle is not re-entrant.  Different handles are independent.
+ *   - Return value: 0 = FW_OK, <0 = error enum; message via fw_last_error().
+ *     Nothing throws across the ABI.
+ *   - Element type T of action/obs/reward buffers is fw_config.dtype
+ *     (FW_F64: double, the reference's arithmetic; FW_F32: float).
+ */
+#ifndef FWSIM_H
+#define FWSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FW_ABI_VERSION 3
+
+#define FW_NUM_SURFACES 5         /* left aileron, right aileron, h-tail, v-tail, main wing */
+#define FW_NUM_ACTUATORS 6        /* 5 surfaces + throttle (aux_state order) */
+#define FW_MAX_TARGETS 8
+#define FW_MAX_COLLISION_PTS 8
+#define FW_MAX_OBSTACLES 20
+#define FW_VISION_FEATS 9         /* envs/fixedwing_objlock_env.py:745-761 */
+#define FW_VISION_HIST 3          /* duck_vision_history_len default :69 */
+
+/* error codes */
+enum {
+  FW_OK = 0,
+  FW_EINVAL = -1,      /* bad argument / bad config (maps to ValueError) */
+  FW_EHIP = -2,        /* HIP runtime error (no device, launch failure ...) */
+  FW_ENOMEM = -3,
+  FW_EVERSION = -4,    /* abi_version mismatch */
+  FW_EUNSUPPORTED = -5
+};
+
+/* fw_config.task */
+enum {
+  FW_TASK_WAYPOINTS = 0,        /* PyFlyt/Fixedwing-Waypoints-v3 (train/train_Fixedwing_Waypoints_v3.py:100-110) */
+  FW_TASK_OBJLOCK = 1,          /* envs/fixedwing_objlock_env.py */
+  FW_TASK_WAYPOINT_OBJLOCK = 2  /* envs/fixedwing_waypoint_objlock_env.py */
+};
+
+/* fw_config.dtype */
+enum { FW_F64 = 0, FW_F32 = 1 };
+
+/* fw_config.wind_mode  (envs/fixedwing_envs/fixedwing_base_env.py:113-115) */
+enum { FW_WIND_OFF = 0, FW_WIND_CONSTANT = 1, FW_WIND_GUST_SINE = 2 };
+
+/* fw_config.wind_coupling: how the registered wind vector enters the dynamics.
+ * Not in the reference (lives in un-vendored PyFlyt) -> explicit, build-owned. */
+enum {
+  FW_WIND_COUPLE_NONE = 0,
+  FW_WIND_COUPLE_FORCE = 1,     /* world-frame force = wind_force_coef * w(t) on the base */
+  FW_WIND_COUPLE_AIRSPEED = 2   /* w(t) subtracted from every surface's air velocity */
+};
+
+/* One lifting surface.  First 11 fields are my_models/fixedwing/fixewing.yaml:8-71
+ * verbatim (angles in degrees); the geometry (units, link origin) is build-owned
+ * because the URDF is not in the reference. */
+typedef struct fw_surface_params {
+  double Cl_alpha_2D;
+  double chord;
+  double span;
+  double flap_to_chord;
+  double eta;
+  double alpha_0_base_deg;
+  double alpha_stall_P_base_deg;
+  double alpha_stall_N_base_deg;
+  double Cd_0;
+  double deflection_limit_deg;
+  double tau;
+  double lift_unit[3];     /* body frame */
+  double forward_unit[3];  /* body frame */
+  double pos[3];           /* link origin relative to the composite COM, body frame [m] */
+} fw_surface_params;
+
+/* my_models/fixedwing/fixewing.yaml:1-6 + geometry */
+typedef struct fw_motor_params {
+  double total_thrust;
+  double thrust_coef;
+  double torque_coef;
+  double noise_ratio;
+  double tau;
+  double thrust_unit[3];
+  double pos[3];
+} fw_motor_params;
+
+typedef struct fw_config {
+  /* ---- integers ---- */
+  int32_t abi_version;          /* must be FW_ABI_VERSION */
+  int32_t task;                 /* FW_TASK_* */
+  int32_t dtype;                /* FW_F64 | FW_F32 */
+  int32_t angle_representation; /* 0 euler (attitude 12), 1 quaternion (13)  fixedwing_base_env.py:65-72 */
+  int32_t agent_hz;             /* must divide 120              fixedwing_base_env.py:48-53 */
+  int32_t physics_hz;           /* 240 */
+  int32_t control_hz;           /* 120  => 2 ticks per Aviary step */
+  int32_t warmup_aviary_steps;  /* 10                          fixedwing_base_env.py:254-255 */
+  int32_t auto_reset;           /* 1: SB3 VecEnv worker semantics; 0: bare Gymnasium env */
+  int32_t sparse_reward;
+  int32_t num_targets;          /* <= FW_MAX_TARGETS */
+  int32_t context_length;       /* flatten_waypoint_env.py:16 */
+  int32_t wind_mode;            /* FW_WIND_* */
+  int32_t wind_randomize_on_reset;
+  int32_t wind_randomize_phase;
+  int32_t wind_coupling;        /* FW_WIND_COUPLE_* */
+  int32_t gyroscopic;           /* include  -w x (I w)  in the angular acceleration */
+  int32_t n_collision_pts;      /* <= FW_MAX_COLLISION_PTS */
+  int32_t num_obstacles;        /* <= FW_MAX_OBSTACLES (objlock tasks) */
+  int32_t duck_camera_capture_interval_steps;
+  int32_t duck_lock_hold_steps;
+  int32_t duck_lock_decay_steps;
+  int32_t duck_switch_min_consecutive_seen;
+  int32_t camera_resolution;    /* square, pixels (analytic camera model) */
+  int32_t reserved_i[8];
+
+  /* ---- env / task scalars ---- */
+  double flight_dome_size;
+  double max_duration_seconds;
+  double goal_reach_distance;
+  double waypoint_min_height;       /* 0.5  fixedwing_waypoint_objlock_env.py:103 */
+  double waypoint_spawn_size;       /* dome used by the target sampler */
+  double start_pos[3];
+  double start_orn[3];              /* euler */
+  double start_vel[3];              /* world frame, PyFlyt starting_velocity */
+
+  /* ---- wind (fixedwing_base_env.py:108-173) ---- */
+  double wind_enu_mps[3];
+  double wind_enu_mps_range[3][2];
+  double gust_amp_enu_mps[3];
+  double gust_amp_enu_mps_range[3][2];
+  double gust_freq_hz;
+  double gust_phase_rad;
+  double wind_force_coef;           /* N per (m/s) for FW_WIND_COUPLE_FORCE */
+
+  /* ---- vehicle (build-owned: URDF is not in the reference) ---- */
+  double mass;
+  double inertia[6];                /* ixx iyy izz ixy ixz iyz, body frame about the COM */
+  double gravity;                   /* 9.81, acts along -z world */
+  double air_density;               /* 1.225 */
+  double collision_pts[FW_MAX_COLLISION_PTS][3]; /* body-frame points; contact <=> world z <= 0 */
+  double mixer[FW_NUM_ACTUATORS][4];/* mode-0: cmd = mixer * [roll,pitch,yaw,thrust01] */
+  fw_surface_params surfaces[FW_NUM_SURFACES];
+  fw_motor_params motor;
+
+  /* ---- objlock tasks (envs/fixedwing_objlock_env.py:54-80) ---- */
+  double duck_strike_distance_m;
+  double duck_strike_reward;
+  double duck_lock_step_reward;
+  double duck_approach_reward_scale;
+  double duck_global_scaling;
+  double duck_distance_reward_scale;
+  double duck_lock_center_radius;
+  double duck_centering_reward_scale;
+  double duck_visible_step_reward;
+  double duck_area_reward_scale;
+  double duck_lock_lost_penalty;
+  double duck_approach_reward_clip_m;
+  double duck_switch_min_area;
+  double duck_radius_per_scale;     /* analytic duck = sphere of radius scale*this */
+  double obstacle_radius;
+  double obstacle_height_range[2];
+  double obstacle_safe_distance_m;
+  double obstacle_avoid_reward_scale;
+  double obstacle_avoid_max_penalty;
+  double camera_offset[3];          /* cockpit_fpv [0.8,0,0.12]  fixedwing_objlock_env.py:185 */
+  double camera_angle_deg;          /* -5 */
+  double camera_fov_deg;            /* 90 */
+  double camera_near;               /* 0.1   fixedwing_objlock_env.py:692 */
+  double camera_far;                /* 255.0 */
+  double reserved_d[8];
+} fw_config;
+
+/* ---- canonical per-env state record (doubles; used by fw_get_state/fw_set_state) ---- */
+enum {
+  FW_S_POS = 0,        /* 3  world position */
+  FW_S_QUAT = 3,       /* 4  x y z w, body->world */
+  FW_S_VEL = 7,        /* 3  world-frame linear velocity */
+  FW_S_OMEGA = 10,     /* 3  world-frame angular velocity */
+  FW_S_ACT = 13,       /* 6  surface actuations (5) + throttle */
+  FW_S_ACTION = 19,    /* 4  raw action of the last step (obs[12:16]) */
+  FW_S_STEP_COUNT = 23,
+  FW_S_TICK_COUNT = 24,/* physics ticks since reset (elapsed_time * physics_hz) */
+  FW_S_EPISODE = 25,   /* episode index (RNG counter word) */
+  FW_S_FLAGS = 26,     /* bit0 termination, bit1 truncation, bit2 collision, bit3 oob, bit4 env_complete */
+  FW_S_NUM_REACHED = 27,
+  FW_S_NEW_DIST = 28,  /* WaypointHandler.new_distance */
+  FW_S_WIND = 29,      /* 7  base[3], gust amp[3], phase */
+  FW_S_EP_RETURN = 36,
+  FW_S_TARGETS = 37,   /* FW_MAX_TARGETS x 3 (world) */
+  FW_S_TASK = 61,      /* task-specific tail, see FW_ST_* */
+  FW_STATE_DIM = 128
+};
+
+/* objlock tail (offsets from FW_S_TASK) */
+enum {
+  FW_ST_DUCK_POS = 0,      /* 3 */
+  FW_ST_LOCK_STEPS = 3,
+  FW_ST_PREV_EST = 4,      /* _prev_est_dist_m, <0 encodes None */
+  FW_ST_LAST_CX = 5,
+  FW_ST_LAST_CY = 6,
+  FW_ST_LAST_AREA = 7,
+  FW_ST_LAST_DEPTH = 8,
+  FW_ST_SINCE_SEEN = 9,
+  FW_ST_HIST_FILLED = 10,
+  FW_ST_CAM = 11,          /* 5 latest camera frame: visible,d_left,d_center,d_right, has_frame */
+  FW_ST_HIST = 16,         /* FW_VISION_HIST x FW_VISION_FEATS = 27 */
+  FW_ST_DUCK_PHASE = 43,   /* combined env: bit0 duck_phase, bit1 post_waypoints */
+  FW_ST_SEEN_CONSEC = 44,
+  FW_ST_OBST = 45          /* FW_MAX_OBSTACLES x 3 (x,y,h) = 60 -> 105 <= 128-61 */
+};
+
+/* info_i32 columns written by fw_step (info of the step that just ran, i.e. of
+ * the finished episode when the env was auto-reset). */
+enum {
+  FW_INFO_NUM_TARGETS_REACHED = 0,
+  FW_INFO_COLLISION = 1,
+  FW_INFO_OUT_OF_BOUNDS = 2,
+  FW_INFO_ENV_COMPLETE = 3,
+  FW_INFO_DUCK_STRIKE = 4,
+  FW_INFO_IS_SUCCESS = 5,
+  FW_INFO_EP_LEN = 6,     /* agent steps of the finished episode (valid when done) */
+  FW_INFO_RESERVED = 7,
+  FW_INFO_DIM = 8
+};
+
+typedef struct fw_env* fw_handle;
+
+/* Size of fw_config as compiled into the library (binding self-check). */
+int32_t fw_sizeof_config(void);
+int32_t fw_abi_version(void);
+
+/* Observation width D for a config (22/23 attitude + task part); <0 on error. */
+int32_t fw_obs_dim(const fw_config* cfg);
+
+/* Validate a config exactly like the reference constructors do.  On error
+ * returns FW_EINVAL and writes a message (same wording class as the
+ * reference's ValueError) into msg[msg_len]. */
+int32_t fw_validate_config(const fw_config* cfg, char* msg, int32_t msg_len);
+
+/* Create N envs on HIP device `device`.  global_env_offset is added to the
+ * local env index to form the RNG key, so that a sharded job (rank r owns
+ * [r*N, (r+1)*N)) draws the same scenarios as a single-device job. */
+int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device,
+                  uint64_t seed, int64_t global_env_offset, fw_handle* out);
+
+/* Reset envs.  mask: device u8[N] (non-zero = reset) or NULL = all.
+ * obs_out: device T[N,D] or NULL.  Rows of non-reset envs are rewritten with
+ * their current observation. */
+int32_t fw_reset(fw_handle h, const uint8_t* mask, void* obs_out, void* hip_stream);
+
+/* One agent step for all N envs.
+ *   actions       T[N,4]  in [-1,1] (caller clips, as SB3 does)
+ *   obs           T[N,D]  next observation (first obs of the new episode if auto-reset fired)
+ *   reward        T[N]
+ *   terminated    u8[N]
+ *   truncated     u8[N]
+ *   terminal_obs  T[N,D]  rows written only where terminated|truncated (may be NULL)
+ *   info_i32      i32[N,FW_INFO_DIM] (may be NULL) */
+int32_t fw_step(fw_handle h, const void* actions, void* obs, void* reward,
+                uint8_t* terminated, uint8_t* truncated, void* terminal_obs,
+                int32_t* info_i32, void* hip_stream);
+
+/* Re-key the RNG: subsequent resets use (seed, global env id, episode=0...). */
+int32_t fw_seed(fw_handle h, uint64_t seed);
+
+/* Canonical state records, HOST memory, double[N, FW_STATE_DIM]. Synchronous. */
+int32_t fw_get_state(fw_handle h, double* state_out);
+int32_t fw_set_state(fw_handle h, const double* state_in);
+
+/* Recompute the observation from the current state (no dynamics), device T[N,D]. */
+int32_t fw_observe(fw_handle h, void* obs_out, void* hip_stream);
+
+int32_t fw_num_envs(fw_handle h);
+const char* fw_last_error(fw_handle h); /* h may be NULL: last create/validate error */
+int32_t fw_destroy(fw_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FWSIM_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of ``csrc/libfwsim_hip.so`` (the C ABI of ``include/fwsim.h``).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device
+is present, env construction raises.  Building is done by
+``__graft_entry__.build()`` / :func:`build` with ``hipcc --offload-arch=gfx950``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+from . import config as K
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libfwsim_hip.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+EXPORTS = (
+    "fw_sizeof_config", "fw_abi_version", "fw_obs_dim", "fw_validate_config", "fw_create", "fw_reset",
+    "fw_step", "fw_seed", "fw_get_state", "fw_set_state", "fw_observe", "fw_num_envs", "fw_last_error",
+    "fw_destroy",
+)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))]
+    deps = srcs + [os.path.join(INCLUDE, "fwsim.h")]
+    stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(p) for p in deps)
+    if force or stale:
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-o", LIB_PATH, os.path.join(CSRC, "fwsim.hip")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "pyflyt_drone_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, u64, i64 = C.c_void_p, C.c_int32, C.c_uint64, C.c_int64
+        L.fw_sizeof_config.restype = i32; L.fw_sizeof_config.argtypes = []
+        L.fw_abi_version.restype = i32; L.fw_abi_version.argtypes = []
+        L.fw_obs_dim.restype = i32; L.fw_obs_dim.argtypes = [vp]
+        L.fw_validate_config.restype = i32; L.fw_validate_config.argtypes = [vp, C.c_char_p, i32]
+        L.fw_create.restype = i32; L.fw_create.argtypes = [vp, i32, i32, u64, i64, C.POINTER(vp)]
+        L.fw_reset.restype = i32; L.fw_reset.argtypes = [vp, vp, vp, vp]
+        L.fw_step.restype = i32; L.fw_step.argtypes = [vp] * 9
+        L.fw_observe.restype = i32; L.fw_observe.argtypes = [vp, vp, vp]
+        L.fw_seed.restype = i32; L.fw_seed.argtypes = [vp, u64]
+        L.fw_get_state.restype = i32; L.fw_get_state.argtypes = [vp, vp]
+        L.fw_set_state.restype = i32; L.fw_set_state.argtypes = [vp, vp]
+        L.fw_num_envs.restype = i32; L.fw_num_envs.argtypes = [vp]
+        L.fw_last_error.restype = C.c_char_p; L.fw_last_error.argtypes = [vp]
+        L.fw_destroy.restype = i32; L.fw_destroy.argtypes = [vp]
+        if L.fw_abi_version() != K.FW_ABI_VERSION:
+            raise RuntimeError("libfwsim_hip.so ABI version does not match the Python binding; rebuild")
+        if L.fw_sizeof_config() != C.sizeof(K.FwConfig):
+            raise RuntimeError("fw_config layout mismatch between include/fwsim.h and config.FwConfig")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, handle=None) -> None:
+    """Map ABI error codes onto the reference's exception types
+    (``ValueError`` for bad configuration, ``RuntimeError`` otherwise)."""
+    if rc == K.FW_OK:
+        return
+    msg = lib().fw_last_error(handle)
+    msg = msg.decode() if msg else f"fwsim error {rc}"
+    if rc in (K.FW_EINVAL, K.FW_EVERSION):
+        raise ValueError(msg)
+    if rc == K.FW_ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def validate(cfg: K.FwConfig) -> None:
+    buf = C.create_string_buffer(256)
+    rc = lib().fw_validate_config(C.byref(cfg), buf, 256)
+    if rc != K.FW_OK:
+        raise ValueError(buf.value.decode())

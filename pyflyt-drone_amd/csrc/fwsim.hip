@@ -1,0 +1,588 @@
+// fwsim.hip -- kernels + C-ABI host side of libfwsim_hip.so (gfx950 only).
+// See include/fwsim.h for the contract and fwsim_device.hpp for the device code.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fwsim_device.hpp"
+
+using namespace fwsim;
+
+// ======================================================================
+// kernels
+// ======================================================================
+
+// K0: mark every env as an un-reset shell (step() before reset() is inert).
+template <typename T>
+__global__ void fw_init_kernel(DevState<T> D) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= D.npad) return;
+  for (int f = 0; f < RF_COUNT; ++f) D.r[(size_t)f * D.npad + env] = (T)0;
+  D.r[(size_t)(RF_QUAT + 3) * D.npad + env] = (T)1;
+  for (int f = 0; f < IF_COUNT; ++f) D.i[(size_t)f * D.npad + env] = 0;
+  D.i[(size_t)IF_FLAGS * D.npad + env] = FL_TERM;
+  D.i[(size_t)IF_EPISODE * D.npad + env] = -1;
+}
+
+// Kw: one lane integrates the wind-free warm-up once; resets then copy it.
+template <typename T>
+__global__ void fw_warm_kernel(Params<T>* Pm) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const Params<T>& P = *Pm;
+  Rigid<T> S;
+  for (int k = 0; k < 3; ++k) { S.p[k] = P.start_pos[k]; S.v[k] = P.start_vel[k]; S.w[k] = (T)0; }
+  for (int k = 0; k < 4; ++k) S.q[k] = P.start_quat[k];
+  for (int k = 0; k < FW_NUM_ACTUATORS; ++k) S.act[k] = (T)0;
+  T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
+  T wind0[3] = {(T)0, (T)0, (T)0};
+  int ticks = P.warmup_aviary_steps * P.ticks_per_aviary;
+  for (int t = 0; t < ticks; ++t) (void)physics_tick<T>(P, S, cmd0, (T)0, wind0);
+  for (int k = 0; k < 3; ++k) { Pm->warm[k] = S.p[k]; Pm->warm[7 + k] = S.v[k]; Pm->warm[10 + k] = S.w[k]; }
+  for (int k = 0; k < 4; ++k) Pm->warm[3 + k] = S.q[k];
+  for (int k = 0; k < FW_NUM_ACTUATORS; ++k) Pm->warm[13 + k] = S.act[k];
+  Pm->warm_ticks = ticks;
+}
+
+// K1: one agent step for 64 envs per workgroup (one wave), everything fused.
+template <typename T>
+__global__ __launch_bounds__(kWave, 4) void fw_step_kernel(const Params<T>* __restrict__ Pp, DevState<T> D,
+                                                        const T* __restrict__ actions, T* __restrict__ obs,
+                                                        T* __restrict__ reward, uint8_t* __restrict__ terminated,
+                                                        uint8_t* __restrict__ truncated, T* __restrict__ terminal_obs,
+                                                        int32_t* __restrict__ info) {
+  __shared__ T tile[kWave * (kMaxObs + 1)];
+  const Params<T>& P = *Pp;
+  const int lane = threadIdx.x;
+  const int env0 = blockIdx.x * kWave;
+  const int env = env0 + lane;
+  const bool active = env < D.n;
+  const size_t n = D.npad;
+  const int Dobs = P.obs_dim;
+  const int ld = Dobs + 1;
+
+  if (active) {
+    Rigid<T> S;
+    load_rigid<T>(D, env, S);
+    int32_t step_count = D.i[IF_STEP * n + env];
+    int32_t tick = D.i[IF_TICK * n + env];
+    int32_t episode = D.i[IF_EPISODE * n + env];
+    int32_t flags = D.i[IF_FLAGS * n + env];
+    int32_t num_reached = D.i[IF_NUM_REACHED * n + env];
+    T new_dist = D.r[RF_NEW_DIST * n + env];
+    T ep_return = D.r[RF_EP_RETURN * n + env];
+    T wb[3] = {(T)0, (T)0, (T)0}, wa[3] = {(T)0, (T)0, (T)0}, wphase = (T)0;
+    if (P.wind_mode != FW_WIND_OFF) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { wb[k] = D.r[(RF_WIND + k) * n + env]; wa[k] = D.r[(RF_WIND + 3 + k) * n + env]; }
+      wphase = D.r[(RF_WIND + 6) * n + env];
+    }
+    T a[4];
+    {
+      const T* ap = actions + (size_t)env * 4;
+      a[0] = ap[0]; a[1] = ap[1]; a[2] = ap[2]; a[3] = ap[3];
+    }
+    // fixedwing_base_env.py:325-331
+    T rew = (T)-0.1;
+    T sp[4] = { a[0], a[1], a[2], a[3] / (T)2 + (T)0.5 };
+    T cmd[FW_NUM_ACTUATORS];
+#pragma unroll
+    for (int c = 0; c < FW_NUM_ACTUATORS; ++c)
+      cmd[c] = P.mixer[c][0] * sp[0] + P.mixer[c][1] * sp[1] + P.mixer[c][2] * sp[2] + P.mixer[c][3] * sp[3];
+
+    const uint32_t genv = (uint32_t)(P.env_offset + env);
+    int tgt_obs = num_reached;   // target index the last compute_state() saw
+
+#pragma unroll 1
+    for (int sub = 0; sub < P.step_ratio; ++sub) {              // :334
+      if (flags & (FL_TERM | FL_TRUNC)) break;                  // :336
+      bool contact = aviary_step<T>(P, S, cmd, tick, genv, (uint32_t)episode, wb, wa, wphase);   // :339
+      // compute_state(): WaypointHandler.distance_to_targets side effects
+      const int nleft = P.num_targets - num_reached;
+      T old_dist = new_dist;
+      if (P.task != FW_TASK_OBJLOCK && nleft > 0) {
+        const T* tp = D.r + (size_t)(RF_TARGETS + 3 * num_reached) * n + env;
+        T dx = tp[0] - S.p[0], dy = tp[n] - S.p[1], dz = tp[2 * n] - S.p[2];
+        new_dist = M<T>::sqrt_(dx * dx + dy * dy + dz * dz);
+      }
+      tgt_obs = num_reached;
+      // compute_base_term_trunc_reward(): :296-312
+      if (step_count > P.max_steps) flags |= FL_TRUNC;
+      if (contact) { rew = (T)-100; flags |= FL_COLLISION | FL_TERM; }
+      if (M<T>::sqrt_(S.p[0] * S.p[0] + S.p[1] * S.p[1] + S.p[2] * S.p[2]) > P.dome) { rew = (T)-100; flags |= FL_OOB | FL_TERM; }
+      // waypoint reward (upstream FixedwingWaypointsEnv; mirrored at fixedwing_waypoint_objlock_env.py:286-294)
+      if (P.task != FW_TASK_OBJLOCK && nleft > 0) {
+        if (!P.sparse) {
+          T progress = (old_dist != (T)0) ? (old_dist - new_dist) : (T)0;
+          rew += M<T>::fmax_((T)3 * progress, (T)0);
+          rew += (T)1 / new_dist;
+        }
+        if (new_dist < P.reach) {
+          rew = (T)100;
+          num_reached += 1;
+          if (num_reached == P.num_targets) flags |= FL_TRUNC | FL_COMPLETE;
+        }
+      }
+    }
+    step_count += 1;                                            // :346
+    ep_return += rew;
+
+    const bool done = (flags & (FL_TERM | FL_TRUNC)) != 0;
+    reward[env] = rew;
+    terminated[env] = (uint8_t)((flags & FL_TERM) ? 1 : 0);
+    truncated[env] = (uint8_t)((flags & FL_TRUNC) ? 1 : 0);
+    if (info) {
+      int4* ip = reinterpret_cast<int4*>(info + (size_t)env * FW_INFO_DIM);
+      ip[0] = make_int4(num_reached, (flags & FL_COLLISION) ? 1 : 0, (flags & FL_OOB) ? 1 : 0, (flags & FL_COMPLETE) ? 1 : 0);
+      ip[1] = make_int4(0, 0, step_count, 0);
+    }
+    T act_obs[4] = { a[0], a[1], a[2], a[3] };
+    if (done && P.auto_reset) {
+      if (terminal_obs) {
+        T* row = terminal_obs + (size_t)env * Dobs;
+        write_obs<T>(P, D, env, S, act_obs, tgt_obs, [&](int k, T v) { row[k] = v; });
+      }
+      reset_env<T>(P, D, env, S, tick, episode, num_reached, new_dist, wb, wa, wphase);
+      step_count = 0; flags = 0; ep_return = (T)0;
+      act_obs[0] = act_obs[1] = act_obs[2] = act_obs[3] = (T)0;
+      tgt_obs = 0;
+    }
+    write_obs<T>(P, D, env, S, act_obs, tgt_obs, [&](int k, T v) { tile[lane * ld + k] = v; });
+
+    store_rigid<T>(D, env, S);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) D.r[(RF_ACTION + k) * n + env] = act_obs[k];
+    D.r[RF_NEW_DIST * n + env] = new_dist;
+    D.r[RF_EP_RETURN * n + env] = ep_return;
+    D.i[IF_STEP * n + env] = step_count;
+    D.i[IF_TICK * n + env] = tick;
+    D.i[IF_EPISODE * n + env] = episode;
+    D.i[IF_FLAGS * n + env] = flags;
+    D.i[IF_NUM_REACHED * n + env] = num_reached;
+  }
+  __syncthreads();
+  flush_obs_tile<T>(tile, ld, obs, env0, D.n, Dobs);
+}
+
+// K2: reset (masked) + observation.
+template <typename T>
+__global__ __launch_bounds__(kWave, 4) void fw_reset_kernel(const Params<T>* __restrict__ Pp, DevState<T> D,
+                                                         const uint8_t* __restrict__ mask, T* __restrict__ obs, int do_reset) {
+  __shared__ T tile[kWave * (kMaxObs + 1)];
+  const Params<T>& P = *Pp;
+  const int lane = threadIdx.x;
+  const int env0 = blockIdx.x * kWave;
+  const int env = env0 + lane;
+  const size_t n = D.npad;
+  const int Dobs = P.obs_dim;
+  const int ld = Dobs + 1;
+  if (env < D.n) {
+    Rigid<T> S;
+    load_rigid<T>(D, env, S);
+    T action[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) action[k] = D.r[(RF_ACTION + k) * n + env];
+    int32_t num_reached = D.i[IF_NUM_REACHED * n + env];
+    if (do_reset && (!mask || mask[env])) {
+      int32_t tick = 0, episode = D.i[IF_EPISODE * n + env];
+      T new_dist, wb[3], wa[3], wphase;
+      reset_env<T>(P, D, env, S, tick, episode, num_reached, new_dist, wb, wa, wphase);
+      action[0] = action[1] = action[2] = action[3] = (T)0;
+      store_rigid<T>(D, env, S);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) D.r[(RF_ACTION + k) * n + env] = (T)0;
+      D.r[RF_NEW_DIST * n + env] = new_dist;
+      D.r[RF_EP_RETURN * n + env] = (T)0;
+      D.i[IF_STEP * n + env] = 0;
+      D.i[IF_TICK * n + env] = tick;
+      D.i[IF_EPISODE * n + env] = episode;
+      D.i[IF_FLAGS * n + env] = 0;
+      D.i[IF_NUM_REACHED * n + env] = num_reached;
+    }
+    if (obs) write_obs<T>(P, D, env, S, action, num_reached, [&](int k, T v) { tile[lane * ld + k] = v; });
+  }
+  __syncthreads();
+  if (obs) flush_obs_tile<T>(tile, ld, obs, env0, D.n, Dobs);
+}
+
+// ======================================================================
+// host side
+// ======================================================================
+namespace {
+
+thread_local std::string g_err;
+
+struct HostDerived {
+  double area, aspect, Cl3, a0b, asPb, asNb, theta_f, tau_f, tq[3];
+};
+
+int validate(const fw_config* c, std::string& msg) {
+  char buf[256];
+  auto fail = [&](int code) { msg = buf; return code; };
+  if (!c) { snprintf(buf, sizeof buf, "null config"); return fail(FW_EINVAL); }
+  if (c->abi_version != FW_ABI_VERSION) { snprintf(buf, sizeof buf, "abi_version %d != %d", c->abi_version, FW_ABI_VERSION); return fail(FW_EVERSION); }
+  if (c->agent_hz <= 0 || 120 % c->agent_hz != 0) {
+    int lowest = c->agent_hz > 0 ? (int)(120 / ((int)(120 / c->agent_hz) + 1)) : 1;
+    int highest = (c->agent_hz > 0 && c->agent_hz <= 120) ? (int)(120 / (int)(120 / c->agent_hz)) : 120;
+    snprintf(buf, sizeof buf, "`agent_hz` must be round denominator of 120, try %d or %d.", lowest, highest);
+    return fail(FW_EINVAL);
+  }
+  if (c->angle_representation != 0 && c->angle_representation != 1) {
+    snprintf(buf, sizeof buf, "angle_representation must be either `euler` or `quaternion`, not %d", c->angle_representation);
+    return fail(FW_EINVAL);
+  }
+  if (c->wind_mode < FW_WIND_OFF || c->wind_mode > FW_WIND_GUST_SINE) { snprintf(buf, sizeof buf, "Unsupported wind mode: %d", c->wind_mode); return fail(FW_EINVAL); }
+  if (c->wind_mode != FW_WIND_OFF && c->wind_randomize_on_reset) {
+    for (int i = 0; i < 3; ++i) {
+      if (!(c->wind_enu_mps_range[i][0] <= c->wind_enu_mps_range[i][1])) { snprintf(buf, sizeof buf, "Invalid wind_enu_mps_range"); return fail(FW_EINVAL); }
+      if (!(c->gust_amp_enu_mps_range[i][0] <= c->gust_amp_enu_mps_range[i][1])) { snprintf(buf, sizeof buf, "Invalid gust_amp_enu_mps_range"); return fail(FW_EINVAL); }
+    }
+  }
+  if (c->task < FW_TASK_WAYPOINTS || c->task > FW_TASK_WAYPOINT_OBJLOCK) { snprintf(buf, sizeof buf, "unknown task %d", c->task); return fail(FW_EINVAL); }
+  if (c->dtype != FW_F64 && c->dtype != FW_F32) { snprintf(buf, sizeof buf, "unknown dtype %d", c->dtype); return fail(FW_EINVAL); }
+  if (c->num_targets < 0 || c->num_targets > FW_MAX_TARGETS) { snprintf(buf, sizeof buf, "num_targets must be in [0,%d]", FW_MAX_TARGETS); return fail(FW_EINVAL); }
+  if (c->task != FW_TASK_OBJLOCK && (c->context_length < 0 || c->context_length > FW_MAX_TARGETS + 1)) { snprintf(buf, sizeof buf, "bad context_length"); return fail(FW_EINVAL); }
+  if (c->n_collision_pts < 0 || c->n_collision_pts > FW_MAX_COLLISION_PTS) { snprintf(buf, sizeof buf, "bad n_collision_pts"); return fail(FW_EINVAL); }
+  if (c->num_obstacles < 0 || c->num_obstacles > FW_MAX_OBSTACLES) { snprintf(buf, sizeof buf, "bad num_obstacles"); return fail(FW_EINVAL); }
+  if (c->physics_hz <= 0 || c->control_hz <= 0 || c->physics_hz % c->control_hz != 0) { snprintf(buf, sizeof buf, "physics_hz must be a multiple of control_hz"); return fail(FW_EINVAL); }
+  if (!(c->mass > 0.0)) { snprintf(buf, sizeof buf, "mass must be > 0"); return fail(FW_EINVAL); }
+  if (c->wind_coupling < FW_WIND_COUPLE_NONE || c->wind_coupling > FW_WIND_COUPLE_AIRSPEED) { snprintf(buf, sizeof buf, "bad wind_coupling"); return fail(FW_EINVAL); }
+  return FW_OK;
+}
+
+int obs_dim_of(const fw_config* c) {
+  int att = (c->angle_representation == 0 ? 12 : 13) + 4 + 6;
+  if (c->task == FW_TASK_OBJLOCK) return att + 3 + FW_VISION_FEATS * FW_VISION_HIST + 4;
+  return att + 3 * c->context_length;
+}
+
+bool invert3(const double m[9], double inv[9]) {
+  double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+  if (det == 0.0) return false;
+  double id = 1.0 / det;
+  inv[0] = (m[4] * m[8] - m[5] * m[7]) * id; inv[1] = (m[2] * m[7] - m[1] * m[8]) * id; inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+  inv[3] = (m[5] * m[6] - m[3] * m[8]) * id; inv[4] = (m[0] * m[8] - m[2] * m[6]) * id; inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  inv[6] = (m[3] * m[7] - m[4] * m[6]) * id; inv[7] = (m[1] * m[6] - m[0] * m[7]) * id; inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+  return true;
+}
+
+// Fold fw_config into the wave-uniform constant block (all derivations in double).
+template <typename T>
+bool build_params(const fw_config& c, uint64_t seed, int64_t env_offset, Params<T>& P, std::string& err) {
+  std::memset(&P, 0, sizeof P);
+  const double dt = 1.0 / (double)c.physics_hz;
+  const double d2r = kPi / 180.0;
+  for (int s = 0; s < FW_NUM_SURFACES; ++s) {
+    const fw_surface_params& sp = c.surfaces[s];
+    SurfC<T>& o = P.s[s];
+    double area = sp.chord * sp.span, AR = sp.span / sp.chord;
+    double Cl3 = sp.Cl_alpha_2D * (AR / (AR + ((2.0 * (AR + 4.0)) / (AR + 2.0))));
+    double theta_f = std::acos(2.0 * sp.flap_to_chord - 1.0);
+    double tau_f = 1.0 - ((theta_f - std::sin(theta_f)) / kPi);
+    double a0b = sp.alpha_0_base_deg * d2r, asPb = sp.alpha_stall_P_base_deg * d2r, asNb = sp.alpha_stall_N_base_deg * d2r;
+    o.dt_tau = (T)(dt / sp.tau);
+    for (int k = 0; k < 3; ++k) { o.lift[k] = (T)sp.lift_unit[k]; o.fwd[k] = (T)sp.forward_unit[k]; o.pos[k] = (T)sp.pos[k]; }
+    const double* L = sp.lift_unit; const double* F = sp.forward_unit;
+    o.tq[0] = (T)(L[1] * F[2] - L[2] * F[1]); o.tq[1] = (T)(L[2] * F[0] - L[0] * F[2]); o.tq[2] = (T)(L[0] * F[1] - L[1] * F[0]);
+    o.hra = (T)(0.5 * c.air_density * area);
+    o.chord = (T)sp.chord;
+    o.Cl3 = (T)Cl3; o.inv_Cl3 = (T)(1.0 / Cl3); o.inv_piAR = (T)(1.0 / (kPi * AR));
+    o.a0b = (T)a0b;
+    o.defl_scale = (T)(sp.deflection_limit_deg * d2r);
+    o.k_dCl = (T)(Cl3 * tau_f * sp.eta * sp.deflection_limit_deg * d2r);
+    o.ClmaxPb = (T)(Cl3 * (asPb - a0b)); o.ClmaxNb = (T)(Cl3 * (asNb - a0b));
+    o.ftc = (T)sp.flap_to_chord; o.Cd0 = (T)sp.Cd_0;
+    o.k_exp = (T)(0.41 * (1.0 - std::exp(-17.0 / AR)));
+  }
+  const double max_rpm = std::sqrt(c.motor.total_thrust / c.motor.thrust_coef);
+  P.motor_dt_tau = (T)(dt / c.motor.tau);
+  P.noise_ratio = (T)c.motor.noise_ratio;
+  P.has_noise = c.motor.noise_ratio != 0.0;
+  for (int k = 0; k < 3; ++k) {
+    P.m_force[k] = (T)(max_rpm * max_rpm * c.motor.thrust_coef * c.motor.thrust_unit[k]);
+    P.m_torque[k] = (T)(max_rpm * max_rpm * c.motor.torque_coef * c.motor.thrust_unit[k]);
+    P.m_pos[k] = (T)c.motor.pos[k];
+  }
+  for (int a = 0; a < FW_NUM_ACTUATORS; ++a) for (int k = 0; k < 4; ++k) P.mixer[a][k] = (T)c.mixer[a][k];
+  P.inv_mass = (T)(1.0 / c.mass); P.gravity = (T)c.gravity;
+  const double* I = c.inertia;
+  double m[9] = { I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2] }, mi[9];
+  if (!invert3(m, mi)) { err = "singular inertia"; return false; }
+  for (int k = 0; k < 9; ++k) { P.I[k] = (T)m[k]; P.Iinv[k] = (T)mi[k]; }
+  for (int i = 0; i < FW_MAX_COLLISION_PTS; ++i) for (int k = 0; k < 3; ++k) P.coll[i][k] = (T)c.collision_pts[i][k];
+  P.n_coll = c.n_collision_pts; P.gyroscopic = c.gyroscopic;
+  P.dt = (T)dt; P.inv_physics_hz = (T)dt;
+  P.dome = (T)c.flight_dome_size; P.reach = (T)c.goal_reach_distance;
+  P.min_height = (T)c.waypoint_min_height; P.spawn_hi = (T)(c.waypoint_spawn_size * 0.9);
+  {
+    double hr = 0.5 * c.start_orn[0], hp = 0.5 * c.start_orn[1], hy = 0.5 * c.start_orn[2];
+    double cr = std::cos(hr), sr = std::sin(hr), cp = std::cos(hp), sp = std::sin(hp), cy = std::cos(hy), sy = std::sin(hy);
+    P.start_quat[0] = (T)(sr * cp * cy - cr * sp * sy); P.start_quat[1] = (T)(cr * sp * cy + sr * cp * sy);
+    P.start_quat[2] = (T)(cr * cp * sy - sr * sp * cy); P.start_quat[3] = (T)(cr * cp * cy + sr * sp * sy);
+  }
+  for (int k = 0; k < 3; ++k) {
+    P.start_pos[k] = (T)c.start_pos[k]; P.start_vel[k] = (T)c.start_vel[k];
+    P.wind_base[k] = (T)c.wind_enu_mps[k]; P.wind_amp[k] = (T)c.gust_amp_enu_mps[k];
+    for (int j = 0; j < 2; ++j) { P.wind_base_range[k][j] = c.wind_enu_mps_range[k][j]; P.wind_amp_range[k][j] = c.gust_amp_enu_mps_range[k][j]; }
+  }
+  P.wind_phase = (T)c.gust_phase_rad; P.gust_omega = (T)(2.0 * kPi * c.gust_freq_hz); P.wind_force_coef = (T)c.wind_force_coef;
+  P.wind_mode = c.wind_mode; P.wind_randomize = c.wind_randomize_on_reset; P.wind_randomize_phase = c.wind_randomize_phase;
+  P.wind_coupling = (c.wind_mode == FW_WIND_OFF) ? FW_WIND_COUPLE_NONE : c.wind_coupling;
+  P.task = c.task; P.angle_repr = c.angle_representation;
+  P.att_dim = (c.angle_representation == 0 ? 12 : 13) + 4 + 6;
+  P.obs_dim = obs_dim_of(&c); P.ctx = c.context_length;
+  P.num_targets = c.num_targets; P.sparse = c.sparse_reward; P.auto_reset = c.auto_reset;
+  P.max_steps = (int32_t)(c.agent_hz * c.max_duration_seconds);
+  P.step_ratio = 120 / c.agent_hz;
+  P.ticks_per_aviary = c.physics_hz / c.control_hz;
+  P.warmup_aviary_steps = c.warmup_aviary_steps;
+  // The warm-up is env-independent iff wind cannot act on the dynamics (throttle
+  // stays exactly 0 under a zero setpoint, so motor noise multiplies 0).
+  P.warm_valid = (P.wind_coupling == FW_WIND_COUPLE_NONE) ? 1 : 0;
+  P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
+  P.env_offset = env_offset;
+  if (P.obs_dim > kMaxObs) { err = "obs_dim exceeds kMaxObs"; return false; }
+  return true;
+}
+
+}  // namespace
+
+struct fw_env {
+  fw_config cfg;
+  int32_t n = 0, npad = 0, device = 0;
+  uint64_t seed = 0;
+  int64_t env_offset = 0;
+  void* params_dev = nullptr;   // Params<T>
+  void* r_dev = nullptr;        // T[RF_COUNT][npad]
+  int32_t* i_dev = nullptr;     // i32[IF_COUNT][npad]
+  std::string err;
+};
+
+#define HIP_TRY(h, expr)                                                                  \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e_);                 \
+      if (h) (h)->err = m_; else g_err = m_;                                              \
+      return FW_EHIP;                                                                     \
+    }                                                                                     \
+  } while (0)
+
+namespace {
+struct DeviceGuard {
+  int prev = -1; bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) { switched = hipSetDevice(dev) == hipSuccess; }
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+template <typename T> DevState<T> dev_state(fw_env* h) {
+  DevState<T> D; D.r = (T*)h->r_dev; D.i = h->i_dev; D.n = h->n; D.npad = h->npad; return D;
+}
+
+template <typename T>
+int upload_params(fw_env* h) {
+  Params<T> P;
+  if (!build_params<T>(h->cfg, h->seed, h->env_offset, P, h->err)) return FW_EINVAL;
+  if (!h->params_dev) HIP_TRY(h, hipMalloc(&h->params_dev, sizeof(Params<T>)));
+  HIP_TRY(h, hipMemcpy(h->params_dev, &P, sizeof P, hipMemcpyHostToDevice));
+  if (P.warm_valid) {
+    hipLaunchKernelGGL(fw_warm_kernel<T>, dim3(1), dim3(kWave), 0, 0, (Params<T>*)h->params_dev);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipDeviceSynchronize());
+  }
+  return FW_OK;
+}
+
+template <typename T>
+int create_T(fw_env* h) {
+  const size_t npad = (size_t)h->npad;
+  HIP_TRY(h, hipMalloc(&h->r_dev, sizeof(T) * RF_COUNT * npad));
+  HIP_TRY(h, hipMalloc((void**)&h->i_dev, sizeof(int32_t) * IF_COUNT * npad));
+  int rc = upload_params<T>(h);
+  if (rc != FW_OK) return rc;
+  hipLaunchKernelGGL(fw_init_kernel<T>, dim3((h->npad + 255) / 256), dim3(256), 0, 0, dev_state<T>(h));
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipDeviceSynchronize());
+  return FW_OK;
+}
+
+template <typename T>
+int step_T(fw_env* h, const void* actions, void* obs, void* reward, uint8_t* term, uint8_t* trunc, void* tobs,
+           int32_t* info, hipStream_t st) {
+  hipLaunchKernelGGL(fw_step_kernel<T>, dim3(h->npad / kWave), dim3(kWave), 0, st, (const Params<T>*)h->params_dev,
+                     dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term, trunc, (T*)tobs, info);
+  HIP_TRY(h, hipGetLastError());
+  return FW_OK;
+}
+
+template <typename T>
+int reset_T(fw_env* h, const uint8_t* mask, void* obs, int do_reset, hipStream_t st) {
+  hipLaunchKernelGGL(fw_reset_kernel<T>, dim3(h->npad / kWave), dim3(kWave), 0, st, (const Params<T>*)h->params_dev,
+                     dev_state<T>(h), mask, (T*)obs, do_reset);
+  HIP_TRY(h, hipGetLastError());
+  return FW_OK;
+}
+
+// canonical record <-> SoA field maps
+struct FieldMap { int rec; int rf; int count; };
+const FieldMap kRealMap[] = {
+  {FW_S_POS, RF_POS, 3}, {FW_S_QUAT, RF_QUAT, 4}, {FW_S_VEL, RF_VEL, 3}, {FW_S_OMEGA, RF_OMEGA, 3},
+  {FW_S_ACT, RF_ACT, 6}, {FW_S_ACTION, RF_ACTION, 4}, {FW_S_NEW_DIST, RF_NEW_DIST, 1}, {FW_S_WIND, RF_WIND, 7},
+  {FW_S_EP_RETURN, RF_EP_RETURN, 1}, {FW_S_TARGETS, RF_TARGETS, 3 * FW_MAX_TARGETS},
+  {FW_S_TASK, RF_TASK, FW_STATE_DIM - FW_S_TASK},
+};
+const FieldMap kIntMap[] = {
+  {FW_S_STEP_COUNT, IF_STEP, 1}, {FW_S_TICK_COUNT, IF_TICK, 1}, {FW_S_EPISODE, IF_EPISODE, 1},
+  {FW_S_FLAGS, IF_FLAGS, 1}, {FW_S_NUM_REACHED, IF_NUM_REACHED, 1},
+};
+
+template <typename T>
+int get_state_T(fw_env* h, double* out) {
+  const size_t npad = (size_t)h->npad;
+  std::vector<T> r(RF_COUNT * npad);
+  std::vector<int32_t> iv(IF_COUNT * npad);
+  HIP_TRY(h, hipDeviceSynchronize());
+  HIP_TRY(h, hipMemcpy(r.data(), h->r_dev, sizeof(T) * r.size(), hipMemcpyDeviceToHost));
+  HIP_TRY(h, hipMemcpy(iv.data(), h->i_dev, sizeof(int32_t) * iv.size(), hipMemcpyDeviceToHost));
+  for (int e = 0; e < h->n; ++e) {
+    double* rec = out + (size_t)e * FW_STATE_DIM;
+    std::memset(rec, 0, sizeof(double) * FW_STATE_DIM);
+    for (const FieldMap& f : kRealMap) for (int k = 0; k < f.count; ++k) rec[f.rec + k] = (double)r[(size_t)(f.rf + k) * npad + e];
+    for (const FieldMap& f : kIntMap) rec[f.rec] = (double)iv[(size_t)f.rf * npad + e];
+  }
+  return FW_OK;
+}
+
+template <typename T>
+int set_state_T(fw_env* h, const double* in) {
+  const size_t npad = (size_t)h->npad;
+  std::vector<T> r(RF_COUNT * npad, (T)0);
+  std::vector<int32_t> iv(IF_COUNT * npad, 0);
+  HIP_TRY(h, hipDeviceSynchronize());
+  HIP_TRY(h, hipMemcpy(r.data(), h->r_dev, sizeof(T) * r.size(), hipMemcpyDeviceToHost));
+  HIP_TRY(h, hipMemcpy(iv.data(), h->i_dev, sizeof(int32_t) * iv.size(), hipMemcpyDeviceToHost));
+  for (int e = 0; e < h->n; ++e) {
+    const double* rec = in + (size_t)e * FW_STATE_DIM;
+    for (const FieldMap& f : kRealMap) for (int k = 0; k < f.count; ++k) r[(size_t)(f.rf + k) * npad + e] = (T)rec[f.rec + k];
+    for (const FieldMap& f : kIntMap) iv[(size_t)f.rf * npad + e] = (int32_t)rec[f.rec];
+  }
+  HIP_TRY(h, hipMemcpy(h->r_dev, r.data(), sizeof(T) * r.size(), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(h->i_dev, iv.data(), sizeof(int32_t) * iv.size(), hipMemcpyHostToDevice));
+  return FW_OK;
+}
+}  // namespace
+
+// ======================================================================
+// C ABI
+// ======================================================================
+extern "C" {
+
+int32_t fw_sizeof_config(void) { return (int32_t)sizeof(fw_config); }
+int32_t fw_abi_version(void) { return FW_ABI_VERSION; }
+int32_t fw_obs_dim(const fw_config* cfg) { return cfg ? obs_dim_of(cfg) : FW_EINVAL; }
+
+int32_t fw_validate_config(const fw_config* cfg, char* msg, int32_t msg_len) {
+  std::string m;
+  int rc = validate(cfg, m);
+  if (rc != FW_OK && msg && msg_len > 0) snprintf(msg, (size_t)msg_len, "%s", m.c_str());
+  return rc;
+}
+
+int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64_t seed, int64_t global_env_offset,
+                  fw_handle* out) {
+  if (!cfg || !out || num_envs <= 0) { g_err = "bad arguments"; return FW_EINVAL; }
+  int rc = validate(cfg, g_err);
+  if (rc != FW_OK) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device available (this library has no CPU fallback)"; return FW_EHIP; }
+  if (device < 0 || device >= ndev) { g_err = "device index out of range"; return FW_EINVAL; }
+  fw_env* h = new (std::nothrow) fw_env();
+  if (!h) return FW_ENOMEM;
+  h->cfg = *cfg; h->n = num_envs; h->npad = (num_envs + kWave - 1) / kWave * kWave;
+  h->device = device; h->seed = seed; h->env_offset = global_env_offset;
+  DeviceGuard g(device);
+  rc = (cfg->dtype == FW_F64) ? create_T<double>(h) : create_T<float>(h);
+  if (rc != FW_OK) {
+    g_err = h->err;
+    if (h->params_dev) (void)hipFree(h->params_dev);
+    if (h->r_dev) (void)hipFree(h->r_dev);
+    if (h->i_dev) (void)hipFree(h->i_dev);
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return FW_OK;
+}
+
+int32_t fw_reset(fw_handle h, const uint8_t* mask, void* obs_out, void* hip_stream) {
+  if (!h) return FW_EINVAL;
+  DeviceGuard g(h->device);
+  hipStream_t st = (hipStream_t)hip_stream;
+  return (h->cfg.dtype == FW_F64) ? reset_T<double>(h, mask, obs_out, 1, st) : reset_T<float>(h, mask, obs_out, 1, st);
+}
+
+int32_t fw_observe(fw_handle h, void* obs_out, void* hip_stream) {
+  if (!h || !obs_out) { if (h) h->err = "obs_out is NULL"; return FW_EINVAL; }
+  DeviceGuard g(h->device);
+  hipStream_t st = (hipStream_t)hip_stream;
+  return (h->cfg.dtype == FW_F64) ? reset_T<double>(h, nullptr, obs_out, 0, st) : reset_T<float>(h, nullptr, obs_out, 0, st);
+}
+
+int32_t fw_step(fw_handle h, const void* actions, void* obs, void* reward, uint8_t* terminated, uint8_t* truncated,
+                void* terminal_obs, int32_t* info_i32, void* hip_stream) {
+  if (!h) return FW_EINVAL;
+  if (!actions || !obs || !reward || !terminated || !truncated) { h->err = "actions/obs/reward/terminated/truncated must be non-NULL"; return FW_EINVAL; }
+  DeviceGuard g(h->device);
+  hipStream_t st = (hipStream_t)hip_stream;
+  return (h->cfg.dtype == FW_F64)
+             ? step_T<double>(h, actions, obs, reward, terminated, truncated, terminal_obs, info_i32, st)
+             : step_T<float>(h, actions, obs, reward, terminated, truncated, terminal_obs, info_i32, st);
+}
+
+int32_t fw_seed(fw_handle h, uint64_t seed) {
+  if (!h) return FW_EINVAL;
+  DeviceGuard g(h->device);
+  h->seed = seed;
+  HIP_TRY(h, hipDeviceSynchronize());
+  int rc = (h->cfg.dtype == FW_F64) ? upload_params<double>(h) : upload_params<float>(h);
+  if (rc != FW_OK) return rc;
+  std::vector<int32_t> ep((size_t)h->npad, -1);
+  HIP_TRY(h, hipMemcpy(h->i_dev + (size_t)IF_EPISODE * h->npad, ep.data(), sizeof(int32_t) * ep.size(), hipMemcpyHostToDevice));
+  return FW_OK;
+}
+
+int32_t fw_get_state(fw_handle h, double* state_out) {
+  if (!h || !state_out) return FW_EINVAL;
+  DeviceGuard g(h->device);
+  return (h->cfg.dtype == FW_F64) ? get_state_T<double>(h, state_out) : get_state_T<float>(h, state_out);
+}
+
+int32_t fw_set_state(fw_handle h, const double* state_in) {
+  if (!h || !state_in) return FW_EINVAL;
+  DeviceGuard g(h->device);
+  return (h->cfg.dtype == FW_F64) ? set_state_T<double>(h, state_in) : set_state_T<float>(h, state_in);
+}
+
+int32_t fw_num_envs(fw_handle h) { return h ? h->n : FW_EINVAL; }
+
+const char* fw_last_error(fw_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int32_t fw_destroy(fw_handle h) {
+  if (!h) return FW_EINVAL;
+  DeviceGuard g(h->device);
+  (void)hipDeviceSynchronize();
+  if (h->params_dev) (void)hipFree(h->params_dev);
+  if (h->r_dev) (void)hipFree(h->r_dev);
+  if (h->i_dev) (void)hipFree(h->i_dev);
+  delete h;
+  return FW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,576 @@
+// fwsim_device.hpp -- gfx950 device code of the vectorised fixed-wing env step.
+//
+// One wavefront lane per env.  State is SoA in HBM ([field][Npad], coalesced
+// per field); wave-uniform vehicle/task constants live in one device-resident
+// `Params<T>` block that every lane addresses uniformly, so the compiler
+// fetches them with scalar loads (SGPRs / scalar cache) instead of burning
+// VGPRs or LDS bandwidth; LDS is used for the [64 x D] observation tile so that
+// the row-major obs[N,D] the policy GEMM wants is written with fully coalesced
+// stores.  All 8 physics ticks, the 4 reward/termination evaluations, the
+// observation and the SB3-style auto-reset of one agent step run in registers
+// inside a single launch.  No MFMA: this is element-wise physics.
+//
+// Algorithm provenance (reference paths relative to the reference repo root):
+//   step loop / reward / termination : envs/fixedwing_envs/fixedwing_base_env.py:296-348
+//   observation layout               : envs/fixedwing_objlock_env.py:260-267, envs/flatten_waypoint_env.py:52-72
+//   wind                             : envs/fixedwing_envs/fixedwing_base_env.py:108-173
+//   aero / motor coefficients        : my_models/fixedwing/fixewing.yaml:1-71
+//   un-vendored PyFlyt/Bullet parts  : SURVEY.md appendix A (spec), DESIGN.md section 3
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fwsim.h"
+
+namespace fwsim {
+
+constexpr int kWave = 64;
+constexpr int kMaxObs = 64;
+
+// ---- SoA field indices (real-valued fields) ----
+enum RF : int {
+  RF_POS = 0, RF_QUAT = 3, RF_VEL = 7, RF_OMEGA = 10, RF_ACT = 13, RF_ACTION = 19,
+  RF_NEW_DIST = 23, RF_WIND = 24, RF_EP_RETURN = 31, RF_TARGETS = 32,
+  RF_TASK = 32 + 3 * FW_MAX_TARGETS,              // 56
+  RF_COUNT = RF_TASK + (FW_STATE_DIM - FW_S_TASK) // 56 + 67 = 123
+};
+// ---- SoA integer fields ----
+enum IF : int { IF_STEP = 0, IF_TICK = 1, IF_EPISODE = 2, IF_FLAGS = 3, IF_NUM_REACHED = 4, IF_COUNT = 5 };
+
+enum Flags : int { FL_TERM = 1, FL_TRUNC = 2, FL_COLLISION = 4, FL_OOB = 8, FL_COMPLETE = 16 };
+
+template <typename T>
+struct SurfC {
+  T dt_tau;                 // physics_period / tau
+  T lift[3], fwd[3], pos[3], tq[3];
+  T hra;                    // 0.5 * rho * area
+  T chord;
+  T Cl3, inv_Cl3, inv_piAR;
+  T a0b;                    // alpha_0_base [rad]
+  T k_dCl;                  // Cl3 * tau_f * eta * deg2rad(deflection_limit): delta_Cl = k_dCl * actuation
+  T ClmaxPb, ClmaxNb;       // Cl3 * (alpha_stall_{P,N}_base - alpha_0_base)
+  T ftc;                    // flap_to_chord
+  T Cd0;
+  T defl_scale;             // deg2rad(deflection_limit)
+  T k_exp;                  // 0.41 * (1 - exp(-17/AR))
+};
+
+template <typename T>
+struct Params {
+  SurfC<T> s[FW_NUM_SURFACES];
+  T motor_dt_tau, noise_ratio;
+  T m_force[3], m_torque[3], m_pos[3];   // thrust/torque at throttle=1 (max_rpm^2 * coef * unit)
+  T mixer[FW_NUM_ACTUATORS][4];
+  T inv_mass, gravity;
+  T I[9], Iinv[9];
+  T coll[FW_MAX_COLLISION_PTS][3];
+  T dt, inv_physics_hz;
+  T dome, reach, min_height, spawn_hi;
+  T start_pos[3], start_quat[4], start_vel[3];
+  T wind_base[3], wind_amp[3], wind_phase, gust_omega, wind_force_coef;
+  double wind_base_range[3][2], wind_amp_range[3][2];
+  T warm[19];                             // cached post-warm-up rigid(13)+act(6) state
+  int32_t warm_valid, warm_ticks;
+  int32_t n_coll, gyroscopic;
+  int32_t task, angle_repr, att_dim, obs_dim, ctx;
+  int32_t num_targets, sparse, auto_reset;
+  int32_t max_steps, step_ratio, ticks_per_aviary, warmup_aviary_steps;
+  int32_t wind_mode, wind_randomize, wind_randomize_phase, wind_coupling;
+  int32_t has_noise;
+  uint32_t seed_lo, seed_hi;
+  int64_t env_offset;
+};
+
+template <typename T>
+struct DevState {
+  T* r;          // [RF_COUNT][npad]
+  int32_t* i;    // [IF_COUNT][npad]
+  int32_t n, npad;
+};
+
+// ------------------------------------------------------------------------
+// math helpers (T = double | float)
+// ------------------------------------------------------------------------
+template <typename T> struct M;
+template <> struct M<double> {
+  static __device__ __forceinline__ double sqrt_(double x) { return ::sqrt(x); }
+  static __device__ __forceinline__ double atan2_(double y, double x) { return ::atan2(y, x); }
+  static __device__ __forceinline__ double asin_(double x) { return ::asin(x); }
+  static __device__ __forceinline__ void sincos_(double x, double* s, double* c) { ::sincos(x, s, c); }
+  static __device__ __forceinline__ double sin_(double x) { return ::sin(x); }
+  static __device__ __forceinline__ double cos_(double x) { return ::cos(x); }
+  static __device__ __forceinline__ double fabs_(double x) { return ::fabs(x); }
+  static __device__ __forceinline__ double fmax_(double a, double b) { return ::fmax(a, b); }
+  static __device__ __forceinline__ double log_(double x) { return ::log(x); }
+};
+template <> struct M<float> {
+  static __device__ __forceinline__ float sqrt_(float x) { return ::sqrtf(x); }
+  static __device__ __forceinline__ float atan2_(float y, float x) { return ::atan2f(y, x); }
+  static __device__ __forceinline__ float asin_(float x) { return ::asinf(x); }
+  static __device__ __forceinline__ void sincos_(float x, float* s, float* c) { ::sincosf(x, s, c); }
+  static __device__ __forceinline__ float sin_(float x) { return ::sinf(x); }
+  static __device__ __forceinline__ float cos_(float x) { return ::cosf(x); }
+  static __device__ __forceinline__ float fabs_(float x) { return ::fabsf(x); }
+  static __device__ __forceinline__ float fmax_(float a, float b) { return ::fmaxf(a, b); }
+  static __device__ __forceinline__ float log_(float x) { return ::logf(x); }
+};
+
+constexpr double kPi = 3.14159265358979323846;
+
+// ---- Philox4x32-10, identical counter/key convention to the spec in DESIGN.md ----
+enum { STREAM_SCENARIO = 0, STREAM_NOISE = 1 };
+enum { J_WIND_BASE = 0, J_WIND_AMP = 3, J_WIND_PHASE = 6, J_THETA = 8, J_PHI = 16, J_DIST = 24,
+       J_DUCK_X = 32, J_DUCK_Y = 33, J_DUCK_YAW = 34, J_OBST = 40 };
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+template <typename T>
+__device__ __forceinline__ uint64_t rng_u64(const Params<T>& P, uint32_t genv, uint32_t ep, uint32_t stream, uint32_t j) {
+  uint32_t o[4];
+  philox4x32_10(j >> 1, ep, genv, stream, P.seed_lo, P.seed_hi, o);
+  uint32_t lo = (j & 1) ? o[2] : o[0], hi = (j & 1) ? o[3] : o[1];
+  return ((uint64_t)hi << 32) | lo;
+}
+template <typename T>
+__device__ __forceinline__ double rng_uniform(const Params<T>& P, uint32_t genv, uint32_t ep, uint32_t j, double lo, double hi) {
+  double u = (double)(rng_u64(P, genv, ep, STREAM_SCENARIO, j) >> 11) * (1.0 / 9007199254740992.0);
+  return lo + (hi - lo) * u;
+}
+// two N(0,1) for Aviary step `astep`; both 64-bit words come from ONE Philox block
+template <typename T>
+__device__ __forceinline__ void rng_normal2(const Params<T>& P, uint32_t genv, uint32_t ep, uint32_t astep, T& z0, T& z1) {
+  uint32_t o[4];
+  philox4x32_10(astep, ep, genv, STREAM_NOISE, P.seed_lo, P.seed_hi, o);
+  uint64_t a = ((uint64_t)o[1] << 32) | o[0], b = ((uint64_t)o[3] << 32) | o[2];
+  double u1 = (double)((a >> 11) + 1) * (1.0 / 9007199254740992.0);
+  double u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+  T r = M<T>::sqrt_((T)-2.0 * M<T>::log_((T)u1));
+  T s, c;
+  M<T>::sincos_((T)(2.0 * kPi * u2), &s, &c);
+  z0 = r * c; z1 = r * s;
+}
+
+// ------------------------------------------------------------------------
+// rigid state in registers
+// ------------------------------------------------------------------------
+template <typename T>
+struct Rigid {
+  T p[3], q[4], v[3], w[3];    // world-frame velocities, q = (x,y,z,w) body->world
+  T act[FW_NUM_ACTUATORS];
+};
+
+template <typename T>
+__device__ __forceinline__ void rot_from_quat(const T q[4], T m[9]) {
+  T x = q[0], y = q[1], z = q[2], w = q[3];
+  T d = x * x + y * y + z * z + w * w;
+  T s = (T)2 / d;
+  T xs = x * s, ys = y * s, zs = z * s;
+  T wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+  m[0] = (T)1 - (yy + zz); m[1] = xy - wz;           m[2] = xz + wy;
+  m[3] = xy + wz;           m[4] = (T)1 - (xx + zz); m[5] = yz - wx;
+  m[6] = xz - wy;           m[7] = yz + wx;           m[8] = (T)1 - (xx + yy);
+}
+template <typename T> __device__ __forceinline__ void mv(const T m[9], const T v[3], T o[3]) {
+  o[0] = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  o[1] = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  o[2] = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+}
+template <typename T> __device__ __forceinline__ void mtv(const T m[9], const T v[3], T o[3]) {
+  o[0] = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
+  o[1] = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
+  o[2] = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+}
+template <typename T> __device__ __forceinline__ void cross(const T a[3], const T b[3], T o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// np.interp(x,[x0,x1],[y0,y1]) with end clamping
+template <typename T> __device__ __forceinline__ T interp2(T x, T x0, T x1, T y0, T y1) {
+  T t = (x - x0) / (x1 - x0);
+  T y = y0 + (y1 - y0) * t;
+  y = (x <= x0) ? y0 : y;
+  y = (x >= x1) ? y1 : y;
+  return y;
+}
+
+// One lifting surface: branch-free Khan&Nahon flat-plate model (pre- and post-stall
+// evaluated on the same sincos, selected per lane => no wave divergence).
+// cos(alpha), sin(alpha) are never formed: V*cos = v_f, V*sin = -v_l.
+template <typename T>
+__device__ __forceinline__ void surface_wrench(const SurfC<T>& S, T act, const T v_b[3], const T w_b[3],
+                                               const T wind_b[3], T F[3], T Tq[3]) {
+  T wxr[3];
+  cross(w_b, S.pos, wxr);
+  T vl0 = v_b[0] + wxr[0] - wind_b[0], vl1 = v_b[1] + wxr[1] - wind_b[1], vl2 = v_b[2] + wxr[2] - wind_b[2];
+  T v_l = vl0 * S.lift[0] + vl1 * S.lift[1] + vl2 * S.lift[2];
+  T v_f = vl0 * S.fwd[0] + vl1 * S.fwd[1] + vl2 * S.fwd[2];
+  T V2 = v_f * v_f + v_l * v_l;
+  T V = M<T>::sqrt_(V2);
+  T alpha = M<T>::atan2_(-v_l, v_f);
+
+  T defl = S.defl_scale * act;
+  T dCl = S.k_dCl * act;
+  T dClmax = S.ftc * dCl;
+  T a0 = S.a0b - dCl * S.inv_Cl3;
+  T asP = a0 + (S.ClmaxPb + dClmax) * S.inv_Cl3;
+  T asN = a0 + (S.ClmaxNb + dClmax) * S.inv_Cl3;
+  bool nostall = (asN < alpha) && (alpha < asP);
+
+  // induced angle: linear pre-stall, np.interp'd to zero at +-pi/2 post-stall
+  T Cl_lin = S.Cl3 * (alpha - a0);
+  T ai_lin = Cl_lin * S.inv_piAR;
+  const T hpi = (T)(0.5 * kPi);
+  T ai_stP = S.Cl3 * (asP - a0) * S.inv_piAR;
+  T ai_stN = S.Cl3 * (asN - a0) * S.inv_piAR;
+  T ai_pos = interp2<T>(alpha, asP, hpi, ai_stP, (T)0);
+  T ai_neg = interp2<T>(alpha, -hpi, asN, (T)0, ai_stN);
+  T ai_st = (alpha > (T)0) ? ai_pos : ai_neg;
+  T ai = nostall ? ai_lin : ai_st;
+  T ae = alpha - a0 - ai;
+  T sn, cs;
+  M<T>::sincos_(ae, &sn, &cs);
+
+  // pre-stall
+  T CT_a = S.Cd0 * cs;
+  T CN_a = (Cl_lin + CT_a * sn) / cs;
+  T CM_a = -CN_a * ((T)0.25 - (T)0.175 * ((T)1 - ((T)2 * ae) * (T)(1.0 / kPi)));
+  // post-stall
+  T Cd90 = ((T)-4.26e-2 * (defl * defl)) + ((T)2.1e-1 * defl) + (T)1.98;
+  T CN_b = Cd90 * sn * ((T)1 / ((T)0.56 + (T)0.44 * M<T>::fabs_(sn)) - S.k_exp);
+  T CT_b = (T)0.5 * S.Cd0 * cs;
+  T CM_b = -CN_b * ((T)0.25 - (T)0.175 * ((T)1 - ((T)2 * M<T>::fabs_(ae)) * (T)(1.0 / kPi)));
+
+  T CN = nostall ? CN_a : CN_b;
+  T CT = nostall ? CT_a : CT_b;
+  T CM = nostall ? CM_a : CM_b;
+  T Cl = nostall ? Cl_lin : (CN * cs - CT * sn);
+  T Cd = CN * sn + CT * cs;
+
+  // force_normal = Q*area*(Cl cos a + Cd sin a) = hra * V * (Cl v_f - Cd v_l), etc.
+  T hV = S.hra * V;
+  T Fn = hV * (Cl * v_f - Cd * v_l);
+  T Fp = hV * (-Cl * v_l - Cd * v_f);
+  T Mq = S.hra * V2 * CM * S.chord;
+  T f[3] = { S.lift[0] * Fn + S.fwd[0] * Fp, S.lift[1] * Fn + S.fwd[1] * Fp, S.lift[2] * Fn + S.fwd[2] * Fp };
+  T rxf[3];
+  cross(S.pos, f, rxf);
+  F[0] += f[0]; F[1] += f[1]; F[2] += f[2];
+  Tq[0] += rxf[0] + Mq * S.tq[0]; Tq[1] += rxf[1] + Mq * S.tq[1]; Tq[2] += rxf[2] + Mq * S.tq[2];
+}
+
+// wind vector at time t (envs/fixedwing_envs/fixedwing_base_env.py:145-171)
+template <typename T>
+__device__ __forceinline__ void wind_at(const Params<T>& P, const T wb[3], const T wa[3], T phase, int32_t tick, T w[3]) {
+  if (P.wind_mode == FW_WIND_OFF) { w[0] = w[1] = w[2] = (T)0; return; }
+  if (P.wind_mode == FW_WIND_CONSTANT) { w[0] = wb[0]; w[1] = wb[1]; w[2] = wb[2]; return; }
+  T t = (T)tick * P.inv_physics_hz;
+  T s = M<T>::sin_(P.gust_omega * t + phase);
+  w[0] = wb[0] + wa[0] * s; w[1] = wb[1] + wa[1] * s; w[2] = wb[2] + wa[2] * s;
+}
+
+// One 1/240 s physics tick.  Returns true if a body-fixed collision point touched z<=0.
+template <typename T>
+__device__ __forceinline__ bool physics_tick(const Params<T>& P, Rigid<T>& S, const T cmd[FW_NUM_ACTUATORS], T noise_z,
+                                             const T wind[3]) {
+  const T dt = P.dt;
+  // actuator lags
+#pragma unroll
+  for (int s = 0; s < FW_NUM_SURFACES; ++s) S.act[s] += P.s[s].dt_tau * (cmd[s] - S.act[s]);
+  T thr = S.act[FW_NUM_SURFACES];
+  thr += P.motor_dt_tau * (cmd[FW_NUM_SURFACES] - thr);
+  thr += noise_z * thr * P.noise_ratio;
+  S.act[FW_NUM_SURFACES] = thr;
+
+  T R[9];
+  rot_from_quat(S.q, R);
+  T v_b[3], w_b[3], wind_b[3] = {(T)0, (T)0, (T)0};
+  mtv(R, S.v, v_b);
+  mtv(R, S.w, w_b);
+  if (P.wind_coupling == FW_WIND_COUPLE_AIRSPEED) mtv(R, wind, wind_b);
+
+  T F[3] = {(T)0, (T)0, (T)0}, Tq[3] = {(T)0, (T)0, (T)0};
+  // rolled on purpose: per-surface constants are fetched by scalar loads at a
+  // wave-uniform runtime index; unrolling makes hipcc hoist ~100 constants into
+  // SGPRs for the whole kernel and spill them (724 SGPR spills, 256 VGPRs).
+#pragma unroll 1
+  for (int s = 0; s < FW_NUM_SURFACES; ++s) {
+    T a_s = (s == 0) ? S.act[0] : (s == 1) ? S.act[1] : (s == 2) ? S.act[2] : (s == 3) ? S.act[3] : S.act[4];
+    surface_wrench(P.s[s], a_s, v_b, w_b, wind_b, F, Tq);
+  }
+  {
+    T t2 = thr * thr;
+    T f[3] = { t2 * P.m_force[0], t2 * P.m_force[1], t2 * P.m_force[2] };
+    T rxf[3];
+    cross(P.m_pos, f, rxf);
+    F[0] += f[0]; F[1] += f[1]; F[2] += f[2];
+    Tq[0] += rxf[0] + t2 * P.m_torque[0]; Tq[1] += rxf[1] + t2 * P.m_torque[1]; Tq[2] += rxf[2] + t2 * P.m_torque[2];
+  }
+  T Fw[3];
+  mv(R, F, Fw);
+  if (P.wind_coupling == FW_WIND_COUPLE_FORCE) {
+    Fw[0] += P.wind_force_coef * wind[0]; Fw[1] += P.wind_force_coef * wind[1]; Fw[2] += P.wind_force_coef * wind[2];
+  }
+  T acc[3] = { Fw[0] * P.inv_mass, Fw[1] * P.inv_mass, Fw[2] * P.inv_mass - P.gravity };
+
+  T Iw[3], rhs[3] = { Tq[0], Tq[1], Tq[2] }, al_b[3], al_w[3];
+  mv(P.I, w_b, Iw);
+  if (P.gyroscopic) {
+    T g[3];
+    cross(w_b, Iw, g);
+    rhs[0] -= g[0]; rhs[1] -= g[1]; rhs[2] -= g[2];
+  }
+  mv(P.Iinv, rhs, al_b);
+  mv(R, al_b, al_w);
+
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { S.v[k] += acc[k] * dt; S.w[k] += al_w[k] * dt; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) S.p[k] += S.v[k] * dt;
+
+  // exponential-map quaternion update (Bullet), dq(w*dt) (x) q, renormalised
+  {
+    T ang = M<T>::sqrt_(S.w[0] * S.w[0] + S.w[1] * S.w[1] + S.w[2] * S.w[2]);
+    const T lim = (T)(0.25 * kPi);
+    ang = (ang * dt > lim) ? lim / dt : ang;
+    T sh, ch;
+    M<T>::sincos_((T)0.5 * ang * dt, &sh, &ch);
+    T k_small = (T)0.5 * dt - (dt * dt * dt) * (T)0.020833333333 * ang * ang;
+    T k = (ang < (T)0.001) ? k_small : sh / ang;
+    T ax = S.w[0] * k, ay = S.w[1] * k, az = S.w[2] * k;
+    T x = S.q[0], y = S.q[1], z = S.q[2], w = S.q[3];
+    T nx = ch * x + ax * w + ay * z - az * y;
+    T ny = ch * y + ay * w + az * x - ax * z;
+    T nz = ch * z + az * w + ax * y - ay * x;
+    T nw = ch * w - ax * x - ay * y - az * z;
+    T inv = (T)1 / M<T>::sqrt_(nx * nx + ny * ny + nz * nz + nw * nw);
+    S.q[0] = nx * inv; S.q[1] = ny * inv; S.q[2] = nz * inv; S.q[3] = nw * inv;
+  }
+  // contacts: third row of R(q_new) dotted with the body-fixed points
+  bool contact = false;
+  {
+    T x = S.q[0], y = S.q[1], z = S.q[2], w = S.q[3];
+    T d = x * x + y * y + z * z + w * w;
+    T s2 = (T)2 / d;
+    T r6 = (x * z - w * y) * s2, r7 = (y * z + w * x) * s2, r8 = (T)1 - (x * x + y * y) * s2;
+    for (int i = 0; i < P.n_coll; ++i) {
+      T zc = S.p[2] + r6 * P.coll[i][0] + r7 * P.coll[i][1] + r8 * P.coll[i][2];
+      contact |= (zc <= (T)0);
+    }
+  }
+  return contact;
+}
+
+// Aviary.step(): ticks_per_aviary ticks; returns any-contact
+template <typename T>
+__device__ __forceinline__ bool aviary_step(const Params<T>& P, Rigid<T>& S, const T cmd[FW_NUM_ACTUATORS], int32_t& tick,
+                                            uint32_t genv, uint32_t ep, const T wb[3], const T wa[3], T wphase) {
+  T z0 = (T)0, z1 = (T)0;
+  if (P.has_noise) rng_normal2<T>(P, genv, ep, (uint32_t)(tick / P.ticks_per_aviary), z0, z1);
+  bool contact = false;
+#pragma unroll 1
+  for (int t = 0; t < P.ticks_per_aviary; ++t) {
+    T wind[3];
+    wind_at<T>(P, wb, wa, wphase, tick, wind);
+    contact |= physics_tick<T>(P, S, cmd, (t & 1) ? z1 : z0, wind);
+    tick += 1;
+  }
+  return contact;
+}
+
+// pybullet.getEulerFromQuaternion incl. the gimbal guard
+template <typename T>
+__device__ __forceinline__ bool euler_from_quat(const T q[4], T e[3]) {
+  T x = q[0], y = q[1], z = q[2], w = q[3];
+  T sarg = (T)-2 * (x * z - w * y);
+  bool lock = (sarg <= (T)-0.99999) || (sarg >= (T)0.99999);
+  if (lock) {
+    bool neg = sarg <= (T)-0.99999;
+    e[0] = (T)0;
+    e[1] = neg ? (T)(-0.5 * kPi) : (T)(0.5 * kPi);
+    e[2] = (T)2 * (neg ? M<T>::atan2_(x, -y) : M<T>::atan2_(-x, y));
+  } else {
+    T sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
+    e[0] = M<T>::atan2_((T)2 * (y * z + w * x), squ - sqx - sqy + sqz);
+    e[1] = M<T>::asin_(sarg);
+    e[2] = M<T>::atan2_((T)2 * (x * y + w * z), squ + sqx - sqy - sqz);
+  }
+  return lock;
+}
+template <typename T>
+__device__ __forceinline__ void quat_from_euler(const T e[3], T q[4]) {
+  T sr, cr, sp, cp, sy, cy;
+  M<T>::sincos_((T)0.5 * e[0], &sr, &cr);
+  M<T>::sincos_((T)0.5 * e[1], &sp, &cp);
+  M<T>::sincos_((T)0.5 * e[2], &sy, &cy);
+  q[0] = sr * cp * cy - cr * sp * sy;
+  q[1] = cr * sp * cy + sr * cp * sy;
+  q[2] = cr * cp * sy - sr * sp * cy;
+  q[3] = cr * cp * cy + sr * sp * sy;
+}
+
+// Observation writer.  W(k, value) stores element k of this env's row.
+// Waypoints layout: attitude[att_dim] ++ ctx target deltas (zero padded).
+//   The reference rebuilds the quaternion from the Euler angles before rotating
+//   (fixedwing_base_env.py:288); away from the gimbal guard that round trip is
+//   the identity on the rotation, so q itself is used and the round trip is
+//   taken only on the (rare) guarded branch or when the quaternion is observed.
+template <typename T, typename W>
+__device__ __forceinline__ void write_obs(const Params<T>& P, const DevState<T>& D, int env, const Rigid<T>& S,
+                                          const T action[4], int tgt_idx, W&& put) {
+  T R[9];
+  rot_from_quat(S.q, R);
+  T ang_vel[3], lin_vel[3], eul[3];
+  mtv(R, S.w, ang_vel);
+  mtv(R, S.v, lin_vel);
+  bool lock = euler_from_quat(S.q, eul);
+  T qrt[4] = { S.q[0], S.q[1], S.q[2], S.q[3] };
+  if (lock || P.angle_repr == 1) {
+    quat_from_euler(eul, qrt);
+    rot_from_quat(qrt, R);
+  }
+  int o = 0;
+  put(o++, ang_vel[0]); put(o++, ang_vel[1]); put(o++, ang_vel[2]);
+  if (P.angle_repr == 0) { put(o++, eul[0]); put(o++, eul[1]); put(o++, eul[2]); }
+  else { put(o++, qrt[0]); put(o++, qrt[1]); put(o++, qrt[2]); put(o++, qrt[3]); }
+  put(o++, lin_vel[0]); put(o++, lin_vel[1]); put(o++, lin_vel[2]);
+  put(o++, S.p[0]); put(o++, S.p[1]); put(o++, S.p[2]);
+  put(o++, action[0]); put(o++, action[1]); put(o++, action[2]); put(o++, action[3]);
+#pragma unroll
+  for (int k = 0; k < FW_NUM_ACTUATORS; ++k) put(o++, S.act[k]);
+  for (int i = 0; i < P.ctx; ++i) {
+    int t = tgt_idx + i;
+    T d[3] = {(T)0, (T)0, (T)0}, b[3] = {(T)0, (T)0, (T)0};
+    if (t < P.num_targets) {
+      const T* tp = D.r + (size_t)(RF_TARGETS + 3 * t) * D.npad + env;
+      d[0] = tp[0] - S.p[0]; d[1] = tp[D.npad] - S.p[1]; d[2] = tp[2 * (size_t)D.npad] - S.p[2];
+      mtv(R, d, b);
+    }
+    put(o++, b[0]); put(o++, b[1]); put(o++, b[2]);
+  }
+}
+
+// ---- SoA load/store of the register-resident part ----
+template <typename T>
+__device__ __forceinline__ void load_rigid(const DevState<T>& D, int env, Rigid<T>& S) {
+  const T* b = D.r + env;
+  const size_t n = D.npad;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { S.p[k] = b[(RF_POS + k) * n]; S.v[k] = b[(RF_VEL + k) * n]; S.w[k] = b[(RF_OMEGA + k) * n]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) S.q[k] = b[(RF_QUAT + k) * n];
+#pragma unroll
+  for (int k = 0; k < FW_NUM_ACTUATORS; ++k) S.act[k] = b[(RF_ACT + k) * n];
+}
+template <typename T>
+__device__ __forceinline__ void store_rigid(const DevState<T>& D, int env, const Rigid<T>& S) {
+  T* b = D.r + env;
+  const size_t n = D.npad;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { b[(RF_POS + k) * n] = S.p[k]; b[(RF_VEL + k) * n] = S.v[k]; b[(RF_OMEGA + k) * n] = S.w[k]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b[(RF_QUAT + k) * n] = S.q[k];
+#pragma unroll
+  for (int k = 0; k < FW_NUM_ACTUATORS; ++k) b[(RF_ACT + k) * n] = S.act[k];
+}
+
+// ------------------------------------------------------------------------
+// reset of one env (begin_reset / scenario sampling / end_reset)
+// ------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void reset_env(const Params<T>& P, const DevState<T>& D, int env, Rigid<T>& S, int32_t& tick,
+                                          int32_t& episode, int32_t& num_reached, T& new_dist, T wb[3], T wa[3], T& wphase) {
+  episode += 1;
+  const uint32_t ep = (uint32_t)episode;
+  const uint32_t genv = (uint32_t)(P.env_offset + env);
+  const size_t n = D.npad;
+  // wind: base(3), gust amp(3), phase -- fixedwing_base_env.py:139-165
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { wb[k] = P.wind_base[k]; wa[k] = P.wind_amp[k]; }
+  wphase = P.wind_phase;
+  if (P.wind_mode != FW_WIND_OFF && P.wind_randomize) {
+    for (int k = 0; k < 3; ++k)
+      wb[k] = (T)rng_uniform<T>(P, genv, ep, J_WIND_BASE + k, P.wind_base_range[k][0], P.wind_base_range[k][1]);
+    if (P.wind_mode == FW_WIND_GUST_SINE) {
+      for (int k = 0; k < 3; ++k)
+        wa[k] = (T)rng_uniform<T>(P, genv, ep, J_WIND_AMP + k, P.wind_amp_range[k][0], P.wind_amp_range[k][1]);
+      if (P.wind_randomize_phase) wphase = (T)rng_uniform<T>(P, genv, ep, J_WIND_PHASE, 0.0, 2.0 * kPi);
+    }
+  }
+  if (P.wind_mode != FW_WIND_OFF) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { D.r[(RF_WIND + k) * n + env] = wb[k]; D.r[(RF_WIND + 3 + k) * n + env] = wa[k]; }
+    D.r[(RF_WIND + 6) * n + env] = wphase;
+  }
+  // WaypointHandler.reset: polar sampling (always in double, cast once)
+  if (P.task != FW_TASK_OBJLOCK) {
+    for (int i = 0; i < P.num_targets; ++i) {
+      double theta = rng_uniform<T>(P, genv, ep, J_THETA + i, 0.0, 2.0 * kPi);
+      double phi = rng_uniform<T>(P, genv, ep, J_PHI + i, 0.0, 2.0 * kPi);
+      double dist = rng_uniform<T>(P, genv, ep, J_DIST + i, 1.0, (double)P.spawn_hi);
+      double sphi, cphi, sth, cth;
+      ::sincos(phi, &sphi, &cphi);
+      ::sincos(theta, &sth, &cth);
+      double x = dist * sphi * cth, y = dist * sphi * sth, z = ::fabs(dist * cphi);
+      z = z > (double)P.min_height ? z : (double)P.min_height;
+      T* tp = D.r + (size_t)(RF_TARGETS + 3 * i) * n + env;
+      tp[0] = (T)x; tp[n] = (T)y; tp[2 * n] = (T)z;
+    }
+  }
+  num_reached = 0;
+  // Aviary(): start pose + PyFlyt starting velocity, zero actuators; then the
+  // 10 warm-up Aviary steps with a zero setpoint (fixedwing_base_env.py:254-255).
+  if (P.warm_valid) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { S.p[k] = P.warm[k]; S.v[k] = P.warm[7 + k]; S.w[k] = P.warm[10 + k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) S.q[k] = P.warm[3 + k];
+#pragma unroll
+    for (int k = 0; k < FW_NUM_ACTUATORS; ++k) S.act[k] = P.warm[13 + k];
+    tick = P.warm_ticks;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { S.p[k] = P.start_pos[k]; S.v[k] = P.start_vel[k]; S.w[k] = (T)0; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) S.q[k] = P.start_quat[k];
+#pragma unroll
+    for (int k = 0; k < FW_NUM_ACTUATORS; ++k) S.act[k] = (T)0;
+    tick = 0;
+    T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
+#pragma unroll 1
+    for (int i = 0; i < P.warmup_aviary_steps; ++i) (void)aviary_step<T>(P, S, cmd0, tick, genv, ep, wb, wa, wphase);
+  }
+  // end_reset -> compute_state: WaypointHandler distances (old=0 -> new)
+  new_dist = (T)0;
+  if (P.task != FW_TASK_OBJLOCK && P.num_targets > 0) {
+    const T* tp = D.r + (size_t)RF_TARGETS * n + env;
+    T dx = tp[0] - S.p[0], dy = tp[n] - S.p[1], dz = tp[2 * n] - S.p[2];
+    new_dist = M<T>::sqrt_(dx * dx + dy * dy + dz * dz);
+  }
+}
+
+// ------------------------------------------------------------------------
+// LDS-staged, coalesced store of a [64 x D] observation tile
+// ------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void flush_obs_tile(const T* tile, int ld, T* obs, int blk_env0, int n, int D) {
+  // tile[lane*ld + k]; global rows [blk_env0, blk_env0+64) are one contiguous span of 64*D elements
+  const int rows = min(kWave, n - blk_env0);
+  const int total = rows * D;
+  T* dst = obs + (size_t)blk_env0 * D;
+  for (int e = threadIdx.x; e < total; e += kWave) {
+    int row = e / D, col = e - row * D;
+    dst[e] = tile[row * ld + col];
+  }
+}
+
+}  // namespace fwsim

@@ -1,0 +1,237 @@
+"""SB3-``VecEnv``-shaped host mirror of the reference's env stack for the hot path.
+
+In the reference the stack is ``SubprocVecEnv([make_env(i) ...])`` over
+``FlattenWaypointEnv(gym.make("PyFlyt/Fixedwing-Waypoints-v3", ...))``
+(train/train_Fixedwing_Waypoints_v3.py:82-121,251).  Here the N envs are one
+HIP kernel launch; this class only owns device tensors and forwards to the
+C ABI (include/fwsim.h).  Two surfaces:
+
+* numpy / SB3 ``VecEnv`` duck type: ``reset() -> obs[N,D]``,
+  ``step_async(actions)``, ``step_wait() -> (obs, rewards, dones, infos)``,
+  ``step``, ``close``, ``seed``, ``get_attr/set_attr/env_method/env_is_wrapped``
+  with the worker semantics SB3 implements (auto-reset, ``terminal_observation``,
+  ``TimeLimit.truncated``; info keys of
+  envs/fixedwing_envs/fixedwing_base_env.py:212-215 and ``num_targets_reached``).
+* device fast path: ``reset_tensor()`` / ``step_tensor(actions)`` return torch
+  tensors living on the GPU; nothing touches the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import config as K
+from .spaces import Box
+
+
+def _devptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class FixedwingVecEnv:
+    """N fixed-wing envs advanced in lockstep by ``fw_step`` on one MI355X."""
+
+    metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 30}
+
+    def __init__(self, cfg: K.FwConfig, num_envs: int, device: Optional[int | str | torch.device] = None,
+                 seed: int = 0, global_env_offset: int = 0):
+        _lib.validate(cfg)
+        if num_envs <= 0:
+            raise ValueError("num_envs must be positive")
+        if not torch.cuda.is_available():
+            raise RuntimeError("pyflyt_drone_amd needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        if device is None:
+            device = torch.cuda.current_device()
+        dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.cfg = cfg.copy()
+        self.num_envs = int(num_envs)
+        self.obs_dim = K.obs_dim(cfg)
+        self.np_dtype = np.float64 if cfg.dtype == K.FW_F64 else np.float32
+        self.torch_dtype = torch.float64 if cfg.dtype == K.FW_F64 else torch.float32
+        self.observation_space = Box(-np.inf, np.inf, (self.obs_dim,), self.np_dtype)
+        self.action_space = Box(-1.0, 1.0, (4,), self.np_dtype)
+        self.render_mode = None
+        self.reset_infos: List[dict] = [{} for _ in range(self.num_envs)]
+
+        h = C.c_void_p()
+        rc = _lib.lib().fw_create(C.byref(self.cfg), self.num_envs, int(dev.index), int(seed) & (2**64 - 1),
+                                  int(global_env_offset), C.byref(h))
+        _lib.check(rc, None)
+        self._h = h
+        n, d = self.num_envs, self.obs_dim
+        kw = dict(device=dev)
+        self.obs = torch.zeros((n, d), dtype=self.torch_dtype, **kw)
+        self.rewards = torch.zeros((n,), dtype=self.torch_dtype, **kw)
+        self.terminated = torch.zeros((n,), dtype=torch.uint8, **kw)
+        self.truncated = torch.zeros((n,), dtype=torch.uint8, **kw)
+        self.terminal_obs = torch.zeros((n, d), dtype=self.torch_dtype, **kw)
+        self.info = torch.zeros((n, K.FW_INFO_DIM), dtype=torch.int32, **kw)
+        self._actions_dev = torch.zeros((n, 4), dtype=self.torch_dtype, **kw)
+        self._pending = False
+
+    # ------------------------------------------------------------------ device fast path
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset_tensor(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Reset all envs (or those with ``mask != 0``) on the device; returns obs[N,D]."""
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            if mask.numel() != self.num_envs:
+                raise ValueError("mask must have num_envs elements")
+        rc = _lib.lib().fw_reset(self._h, _devptr(mask), _devptr(self.obs), self._stream())
+        _lib.check(rc, self._h)
+        return self.obs
+
+    def step_tensor(self, actions: torch.Tensor):
+        """One agent step.  ``actions``: device tensor [N,4] of the env dtype in [-1,1]
+        (the caller clips, as SB3's collector does).  Returns views of the env-owned
+        output tensors ``(obs, rewards, terminated, truncated)``; ``terminal_obs`` and
+        ``info`` are attributes.  No host synchronisation."""
+        if actions.device != self.device or actions.dtype != self.torch_dtype or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=self.torch_dtype).contiguous()
+        if actions.shape != (self.num_envs, 4):
+            raise ValueError(f"actions must have shape ({self.num_envs}, 4), got {tuple(actions.shape)}")
+        rc = _lib.lib().fw_step(self._h, _devptr(actions), _devptr(self.obs), _devptr(self.rewards),
+                                _devptr(self.terminated), _devptr(self.truncated), _devptr(self.terminal_obs),
+                                _devptr(self.info), self._stream())
+        _lib.check(rc, self._h)
+        return self.obs, self.rewards, self.terminated, self.truncated
+
+    def observe_tensor(self) -> torch.Tensor:
+        rc = _lib.lib().fw_observe(self._h, _devptr(self.obs), self._stream())
+        _lib.check(rc, self._h)
+        return self.obs
+
+    # ------------------------------------------------------------------ SB3 VecEnv surface (numpy)
+    def reset(self) -> np.ndarray:
+        obs = self.reset_tensor()
+        self.reset_infos = [{} for _ in range(self.num_envs)]
+        return obs.cpu().numpy()
+
+    def step_async(self, actions: np.ndarray) -> None:
+        a = torch.as_tensor(np.asarray(actions), dtype=self.torch_dtype).reshape(self.num_envs, 4)
+        self._actions_dev.copy_(a, non_blocking=False)
+        self.step_tensor(self._actions_dev)
+        self._pending = True
+
+    def step_wait(self):
+        if not self._pending:
+            raise RuntimeError("step_wait() called without step_async()")
+        self._pending = False
+        obs = self.obs.cpu().numpy()
+        rewards = self.rewards.cpu().numpy()
+        term = self.terminated.cpu().numpy().astype(bool)
+        trunc = self.truncated.cpu().numpy().astype(bool)
+        info = self.info.cpu().numpy()
+        dones = term | trunc
+        infos: List[dict] = []
+        tobs = self.terminal_obs.cpu().numpy() if dones.any() else None
+        for i in range(self.num_envs):
+            d = {
+                "out_of_bounds": bool(info[i, K.INFO_OUT_OF_BOUNDS]),
+                "collision": bool(info[i, K.INFO_COLLISION]),
+                "env_complete": bool(info[i, K.INFO_ENV_COMPLETE]),
+                "num_targets_reached": int(info[i, K.INFO_NUM_TARGETS_REACHED]),
+                "TimeLimit.truncated": bool(trunc[i] and not term[i]),
+            }
+            if self.cfg.task != K.FW_TASK_WAYPOINTS:
+                d["duck_strike"] = bool(info[i, K.INFO_DUCK_STRIKE])
+                d["is_success"] = bool(info[i, K.INFO_IS_SUCCESS])
+            if dones[i] and self.cfg.auto_reset:
+                d["terminal_observation"] = tobs[i].copy()
+                d["episode_length"] = int(info[i, K.INFO_EP_LEN])
+            infos.append(d)
+        return obs, rewards, dones, infos
+
+    def step(self, actions: np.ndarray):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def seed(self, seed: Optional[int] = None) -> Sequence[Optional[int]]:
+        s = 0 if seed is None else int(seed)
+        _lib.check(_lib.lib().fw_seed(self._h, s & (2**64 - 1)), self._h)
+        return [s + i for i in range(self.num_envs)]
+
+    def close(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().fw_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _indices(self, indices) -> List[int]:
+        if indices is None:
+            return list(range(self.num_envs))
+        if isinstance(indices, int):
+            return [indices]
+        return list(indices)
+
+    def get_attr(self, attr_name: str, indices=None) -> List[Any]:
+        return [getattr(self, attr_name) for _ in self._indices(indices)]
+
+    def set_attr(self, attr_name: str, value: Any, indices=None) -> None:
+        raise AttributeError("per-env attributes cannot be set on a fused device env; rebuild it with a new config")
+
+    def env_method(self, method_name: str, *args, indices=None, **kwargs) -> List[Any]:
+        raise AttributeError(f"env_method({method_name!r}) is not available on a fused device env")
+
+    def env_is_wrapped(self, wrapper_class, indices=None) -> List[bool]:
+        return [False for _ in self._indices(indices)]
+
+    def get_images(self):
+        return [None for _ in range(self.num_envs)]
+
+    def render(self, mode: Optional[str] = None):
+        return None
+
+    @property
+    def unwrapped(self):
+        return self
+
+    # ------------------------------------------------------------------ state access (parity tests / checkpoints)
+    def get_state(self) -> np.ndarray:
+        s = np.empty((self.num_envs, K.FW_STATE_DIM), dtype=np.float64)
+        _lib.check(_lib.lib().fw_get_state(self._h, s.ctypes.data_as(C.c_void_p)), self._h)
+        return s
+
+    def set_state(self, state: np.ndarray) -> None:
+        s = np.ascontiguousarray(state, dtype=np.float64).reshape(self.num_envs, K.FW_STATE_DIM)
+        _lib.check(_lib.lib().fw_set_state(self._h, s.ctypes.data_as(C.c_void_p)), self._h)
+
+
+class FixedwingWaypointsVecEnv(FixedwingVecEnv):
+    """``PyFlyt/Fixedwing-Waypoints-v3`` + ``FlattenWaypointEnv``, vectorised.
+
+    Keyword arguments are those of the upstream env constructor as passed at
+    train/train_Fixedwing_Waypoints_v3.py:100-110 plus the wrapper's
+    ``context_length`` (:117) and the wind dict of ``WindOnResetWrapper`` (:112-113).
+    """
+
+    def __init__(self, num_envs: int, *, sparse_reward: bool = False, num_targets: int = 4,
+                 goal_reach_distance: float = 2.0, flight_dome_size: float = 100.0,
+                 max_duration_seconds: float = 120.0, angle_representation: str = "quaternion",
+                 agent_hz: int = 30, context_length: int = 2, wind_config: Optional[dict] = None,
+                 render_mode: Optional[str] = None, dtype: str = "float64", motor_noise: bool = True,
+                 device=None, seed: int = 0, global_env_offset: int = 0):
+        if render_mode is not None:
+            raise ValueError(f"Invalid render mode {render_mode}, rendering is not part of the device env.")
+        cfg = K.waypoints_config(sparse_reward=sparse_reward, num_targets=num_targets,
+                                 goal_reach_distance=goal_reach_distance, flight_dome_size=flight_dome_size,
+                                 max_duration_seconds=max_duration_seconds,
+                                 angle_representation=angle_representation, agent_hz=agent_hz,
+                                 context_length=context_length, wind_config=wind_config, dtype=dtype,
+                                 motor_noise=motor_noise)
+        super().__init__(cfg, num_envs, device=device, seed=seed, global_env_offset=global_env_offset)
