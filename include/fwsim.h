@@ -209,11 +209,12 @@ enum {
   FW_S_VEL = 7,        /* 3  world-frame linear velocity */
   FW_S_OMEGA = 10,     /* 3  world-frame angular velocity */
   FW_S_ACT = 13,       /* 6  surface actuations (5) + throttle */
-  FW_S_ACTION = 19,    /* 4  raw action of the last step (obs[12:16]) */
+  FW_S_ACTION = 19,    /* 4  raw action as shown in the current observation (obs[12:16]) */
   FW_S_STEP_COUNT = 23,
   FW_S_TICK_COUNT = 24,/* physics ticks since reset (elapsed_time * physics_hz) */
   FW_S_EPISODE = 25,   /* episode index (RNG counter word) */
-  FW_S_FLAGS = 26,     /* bit0 termination, bit1 truncation, bit2 collision, bit3 oob, bit4 env_complete */
+  FW_S_FLAGS = 26,     /* bit0 termination, bit1 truncation, bit2 collision, bit3 oob, bit4 env_complete,
+                          bits 8-11: waypoint index seen by the last compute_state() (the returned obs) */
   FW_S_NUM_REACHED = 27,
   FW_S_NEW_DIST = 28,  /* WaypointHandler.new_distance */
   FW_S_WIND = 29,      /* 7  base[3], gust amp[3], phase */

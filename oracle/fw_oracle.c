@@ -24,6 +24,9 @@
  * HOST pointers everywhere.
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -162,6 +165,7 @@ typedef struct {
   int termination, truncation, collision, oob, env_complete;
   int contact;                                   /* Aviary.contact_array any() */
   int num_reached;
+  int obs_target_index;                          /* num_reached as seen by the last compute_state() */
   double new_distance, old_distance;
   double wind_base[3], wind_amp[3], wind_phase;
   double ep_return;
@@ -486,6 +490,7 @@ static void compute_state_waypoints(struct fw_env* h, oenv* e) {
   mat_from_quat(q, R);
   int nleft = n_targets_left(h, e);
   e->n_deltas = nleft;
+  e->obs_target_index = e->num_reached;
   for (int i = 0; i < nleft; ++i) {
     double d[3];
     for (int k = 0; k < 3; ++k) d[k] = e->targets[e->num_reached + i][k] - e->pos[k];
@@ -678,6 +683,8 @@ int32_t fwo_step(fw_handle h, const void* actions, void* obs, void* reward, uint
                  uint8_t* truncated, void* terminal_obs, int32_t* info, void* stream) {
   (void)stream;
   if (!h || !actions) return FW_EINVAL;
+  /* envs are independent: the multi-core CPU baseline just splits them over threads */
+#pragma omp parallel for schedule(static) if (h->n >= 64)
   for (int i = 0; i < h->n; ++i) {
     oenv* e = &h->e[i];
     uint32_t genv = (uint32_t)(h->env_offset + i);
@@ -714,6 +721,7 @@ int32_t fwo_observe(fw_handle h, void* obs_out, void* stream) {
   if (!h || !obs_out) return FW_EINVAL;
   for (int i = 0; i < h->n; ++i) {
     oenv tmp = h->e[i];
+    tmp.num_reached = tmp.obs_target_index;
     compute_state(h, &tmp);          /* on a copy: no new/old-distance side effect */
     write_obs(h, &tmp, obs_out, (size_t)i);
   }
@@ -734,11 +742,14 @@ int32_t fwo_get_state(fw_handle h, double* s) {
     double* r = s + (size_t)i * FW_STATE_DIM;
     memset(r, 0, sizeof(double) * FW_STATE_DIM);
     for (int k = 0; k < 3; ++k) { r[FW_S_POS + k] = e->pos[k]; r[FW_S_VEL + k] = e->vel[k]; r[FW_S_OMEGA + k] = e->omega[k]; }
-    for (int k = 0; k < 4; ++k) { r[FW_S_QUAT + k] = e->quat[k]; r[FW_S_ACTION + k] = e->action[k]; }
+    /* FW_S_ACTION is the action visible in the env's current observation: a done env in
+     * bare-Gymnasium mode keeps its stale self.state although self.action is overwritten (:328) */
+    const int aoff = (h->cfg.angle_representation == 0 ? 12 : 13);
+    for (int k = 0; k < 4; ++k) { r[FW_S_QUAT + k] = e->quat[k]; r[FW_S_ACTION + k] = e->attitude[aoff + k]; }
     for (int k = 0; k < FW_NUM_ACTUATORS; ++k) r[FW_S_ACT + k] = e->act[k];
     r[FW_S_STEP_COUNT] = (double)e->step_count; r[FW_S_TICK_COUNT] = (double)e->tick_count;
     r[FW_S_EPISODE] = (double)e->episode;
-    r[FW_S_FLAGS] = (double)(e->termination | (e->truncation << 1) | (e->collision << 2) | (e->oob << 3) | (e->env_complete << 4));
+    r[FW_S_FLAGS] = (double)(e->termination | (e->truncation << 1) | (e->collision << 2) | (e->oob << 3) | (e->env_complete << 4) | (e->obs_target_index << 8));
     r[FW_S_NUM_REACHED] = (double)e->num_reached; r[FW_S_NEW_DIST] = e->new_distance;
     for (int k = 0; k < 3; ++k) { r[FW_S_WIND + k] = e->wind_base[k]; r[FW_S_WIND + 3 + k] = e->wind_amp[k]; }
     r[FW_S_WIND + 6] = e->wind_phase;
@@ -761,6 +772,7 @@ int32_t fwo_set_state(fw_handle h, const double* s) {
     e->episode = (int64_t)r[FW_S_EPISODE];
     int fl = (int)r[FW_S_FLAGS];
     e->termination = fl & 1; e->truncation = (fl >> 1) & 1; e->collision = (fl >> 2) & 1; e->oob = (fl >> 3) & 1; e->env_complete = (fl >> 4) & 1;
+    e->obs_target_index = (fl >> 8) & 15;
     e->num_reached = (int)r[FW_S_NUM_REACHED]; e->new_distance = r[FW_S_NEW_DIST];
     for (int k = 0; k < 3; ++k) { e->wind_base[k] = r[FW_S_WIND + k]; e->wind_amp[k] = r[FW_S_WIND + 3 + k]; }
     e->wind_phase = r[FW_S_WIND + 6];
@@ -769,6 +781,7 @@ int32_t fwo_set_state(fw_handle h, const double* s) {
     for (int t = 0; t < FW_MAX_TARGETS; ++t) for (int k = 0; k < 3; ++k) e->targets[t][k] = r[FW_S_TARGETS + 3 * t + k];
     memcpy(e->task, r + FW_S_TASK, sizeof(e->task));
     oenv tmp = *e;                    /* refresh the cached observation without side effects */
+    tmp.num_reached = e->obs_target_index;
     compute_state(h, &tmp);
     memcpy(e->attitude, tmp.attitude, sizeof e->attitude);
     memcpy(e->target_deltas, tmp.target_deltas, sizeof e->target_deltas);
@@ -777,6 +790,14 @@ int32_t fwo_set_state(fw_handle h, const double* s) {
   return FW_OK;
 }
 
+int32_t fwo_set_threads(int32_t n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n; return 1;
+#endif
+}
 int32_t fwo_num_envs(fw_handle h) { return h ? h->n : FW_EINVAL; }
 const char* fwo_last_error(fw_handle h) { return h ? h->err : g_err; }
 int32_t fwo_destroy(fw_handle h) {
@@ -805,6 +826,15 @@ void fwo_mat_from_quat(const double q[4], double m[9]) { mat_from_quat(q, m); }
 void fwo_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
 double fwo_rng_uniform01(uint64_t seed, uint32_t env, uint32_t ep, uint32_t stream, uint32_t j) { return rng_uniform01(seed, env, ep, stream, j); }
 void fwo_rng_normal2(uint64_t seed, uint32_t env, uint32_t ep, uint32_t astep, double z[2]) { rng_normal2(seed, env, ep, astep, z); }
+/* wind field value at time t for explicit (base, amp, phase) */
+void fwo_wind_at(const fw_config* c, const double base[3], const double amp[3], double phase, double t, double w[3]) {
+  struct fw_env h; oenv e;
+  memset(&h, 0, sizeof h); memset(&e, 0, sizeof e);
+  h.cfg = *c;
+  for (int k = 0; k < 3; ++k) { e.wind_base[k] = base[k]; e.wind_amp[k] = amp[k]; }
+  e.wind_phase = phase;
+  wind_at(&h, &e, t, w);
+}
 /* camera depth-buffer -> metres (envs/fixedwing_objlock_env.py:691-696) */
 double fwo_depth_buffer_to_meters(double depth_buffer) {
   double near = 0.1, far = 255.0;

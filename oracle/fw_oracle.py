@@ -50,6 +50,7 @@ def lib() -> C.CDLL:
         L.fwo_seed.restype = i32; L.fwo_seed.argtypes = [vp, u64]
         L.fwo_get_state.restype = i32; L.fwo_get_state.argtypes = [vp, vp]
         L.fwo_set_state.restype = i32; L.fwo_set_state.argtypes = [vp, vp]
+        L.fwo_set_threads.restype = i32; L.fwo_set_threads.argtypes = [i32]
         L.fwo_num_envs.restype = i32; L.fwo_num_envs.argtypes = [vp]
         L.fwo_last_error.restype = C.c_char_p; L.fwo_last_error.argtypes = [vp]
         L.fwo_destroy.restype = i32; L.fwo_destroy.argtypes = [vp]
@@ -62,6 +63,7 @@ def lib() -> C.CDLL:
         L.fwo_philox.restype = None; L.fwo_philox.argtypes = [vp, vp, vp]
         L.fwo_rng_uniform01.restype = C.c_double; L.fwo_rng_uniform01.argtypes = [u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.fwo_rng_normal2.restype = None; L.fwo_rng_normal2.argtypes = [u64, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+        L.fwo_wind_at.restype = None; L.fwo_wind_at.argtypes = [vp, vp, vp, C.c_double, C.c_double, vp]
         L.fwo_depth_buffer_to_meters.restype = C.c_double; L.fwo_depth_buffer_to_meters.argtypes = [C.c_double]
         _lib = L
     return _lib
@@ -142,6 +144,11 @@ class OracleEnv:
         assert lib().fwo_set_state(self._h, _ptr(s)) == 0
 
 
+def set_threads(n: int) -> int:
+    """Set (n>0) / query (n<=0) the OpenMP thread count used by fwo_step."""
+    return int(lib().fwo_set_threads(int(n)))
+
+
 # ---- unit-level helpers for known-answer tests ----
 def aero_coeffs(surface_params, alpha: float, defl: float) -> np.ndarray:
     out = np.empty(3)
@@ -190,6 +197,12 @@ def rng_uniform01(seed, env, ep, stream, j) -> float:
 def rng_normal2(seed, env, ep, astep) -> np.ndarray:
     z = np.empty(2)
     lib().fwo_rng_normal2(int(seed), int(env), int(ep), int(astep), _ptr(z)); return z
+
+
+def wind_at(cfg, base, amp, phase: float, t: float) -> np.ndarray:
+    b = np.ascontiguousarray(base, dtype=np.float64); a = np.ascontiguousarray(amp, dtype=np.float64)
+    w = np.empty(3)
+    lib().fwo_wind_at(C.byref(cfg), _ptr(b), _ptr(a), float(phase), float(t), _ptr(w)); return w
 
 
 def depth_buffer_to_meters(d: float) -> float:

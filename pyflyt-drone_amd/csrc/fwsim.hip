@@ -96,7 +96,11 @@ __global__ __launch_bounds__(kWave, 4) void fw_step_kernel(const Params<T>* __re
       cmd[c] = P.mixer[c][0] * sp[0] + P.mixer[c][1] * sp[1] + P.mixer[c][2] * sp[2] + P.mixer[c][3] * sp[3];
 
     const uint32_t genv = (uint32_t)(P.env_offset + env);
-    int tgt_obs = num_reached;   // target index the last compute_state() saw
+    // An env that is already done (bare-Gymnasium mode) runs no sub-step: the reference
+    // then returns its stale self.state, i.e. the previous action and target view.
+    const bool done_at_entry = (flags & (FL_TERM | FL_TRUNC)) != 0;
+    int tgt_obs = (flags >> FL_TGT_SHIFT) & 15;   // target index the last compute_state() saw
+    flags &= FL_MASK;
 
 #pragma unroll 1
     for (int sub = 0; sub < P.step_ratio; ++sub) {              // :334
@@ -142,6 +146,10 @@ __global__ __launch_bounds__(kWave, 4) void fw_step_kernel(const Params<T>* __re
       ip[1] = make_int4(0, 0, step_count, 0);
     }
     T act_obs[4] = { a[0], a[1], a[2], a[3] };
+    if (done_at_entry) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) act_obs[k] = D.r[(RF_ACTION + k) * n + env];
+    }
     if (done && P.auto_reset) {
       if (terminal_obs) {
         T* row = terminal_obs + (size_t)env * Dobs;
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(kWave, 4) void fw_step_kernel(const Params<T>* __re
     D.i[IF_STEP * n + env] = step_count;
     D.i[IF_TICK * n + env] = tick;
     D.i[IF_EPISODE * n + env] = episode;
-    D.i[IF_FLAGS * n + env] = flags;
+    D.i[IF_FLAGS * n + env] = flags | (tgt_obs << FL_TGT_SHIFT);
     D.i[IF_NUM_REACHED * n + env] = num_reached;
   }
   __syncthreads();
@@ -188,6 +196,7 @@ __global__ __launch_bounds__(kWave, 4) void fw_reset_kernel(const Params<T>* __r
 #pragma unroll
     for (int k = 0; k < 4; ++k) action[k] = D.r[(RF_ACTION + k) * n + env];
     int32_t num_reached = D.i[IF_NUM_REACHED * n + env];
+    int tgt_obs = (D.i[IF_FLAGS * n + env] >> FL_TGT_SHIFT) & 15;
     if (do_reset && (!mask || mask[env])) {
       int32_t tick = 0, episode = D.i[IF_EPISODE * n + env];
       T new_dist, wb[3], wa[3], wphase;
@@ -203,8 +212,9 @@ __global__ __launch_bounds__(kWave, 4) void fw_reset_kernel(const Params<T>* __r
       D.i[IF_EPISODE * n + env] = episode;
       D.i[IF_FLAGS * n + env] = 0;
       D.i[IF_NUM_REACHED * n + env] = num_reached;
+      tgt_obs = 0;
     }
-    if (obs) write_obs<T>(P, D, env, S, action, num_reached, [&](int k, T v) { tile[lane * ld + k] = v; });
+    if (obs) write_obs<T>(P, D, env, S, action, tgt_obs, [&](int k, T v) { tile[lane * ld + k] = v; });
   }
   __syncthreads();
   if (obs) flush_obs_tile<T>(tile, ld, obs, env0, D.n, Dobs);

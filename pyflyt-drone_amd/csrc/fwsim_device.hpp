@@ -37,7 +37,7 @@ enum RF : int {
 // ---- SoA integer fields ----
 enum IF : int { IF_STEP = 0, IF_TICK = 1, IF_EPISODE = 2, IF_FLAGS = 3, IF_NUM_REACHED = 4, IF_COUNT = 5 };
 
-enum Flags : int { FL_TERM = 1, FL_TRUNC = 2, FL_COLLISION = 4, FL_OOB = 8, FL_COMPLETE = 16 };
+enum Flags : int { FL_TERM = 1, FL_TRUNC = 2, FL_COLLISION = 4, FL_OOB = 8, FL_COMPLETE = 16, FL_MASK = 0xFF, FL_TGT_SHIFT = 8 };
 
 template <typename T>
 struct SurfC {

@@ -1,0 +1,131 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every
+symbol include/fwsim.h declares, config validation mirrors the reference's
+ValueErrors, and the product fails loudly (no CPU fallback) without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pyflyt_drone_amd as P
+from pyflyt_drone_amd import _lib
+from pyflyt_drone_amd import config as K
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "fwsim.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fw_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared_functions()
+    assert set(names) == set(_lib.EXPORTS)
+    L = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), f"{n} is declared in include/fwsim.h but not exported"
+
+
+def test_config_layout_matches_header():
+    L = _lib.lib()
+    assert L.fw_sizeof_config() == C.sizeof(K.FwConfig)
+    assert L.fw_abi_version() == K.FW_ABI_VERSION
+    cfg = K.train_waypoints_v3_config()
+    assert L.fw_obs_dim(C.byref(cfg)) == 28 == K.obs_dim(cfg)
+    cfg = K.waypoints_config(angle_representation="quaternion", context_length=3)
+    assert L.fw_obs_dim(C.byref(cfg)) == 13 + 4 + 6 + 9
+
+
+def test_header_enums_match_python_mirror():
+    text = open(os.path.join(ROOT, "include", "fwsim.h")).read()
+    vals = dict((k, int(v)) for k, v in re.findall(r"\b(FW_[A-Z_0-9]+)\s*=\s*(-?\d+)", text))
+    vals.update((k, int(v)) for k, v in re.findall(r"#define\s+(FW_[A-Z_0-9]+)\s+(\d+)", text))
+    assert vals["FW_ABI_VERSION"] == K.FW_ABI_VERSION and vals["FW_STATE_DIM"] == K.FW_STATE_DIM
+    for py, h in [("S_POS", "FW_S_POS"), ("S_QUAT", "FW_S_QUAT"), ("S_VEL", "FW_S_VEL"), ("S_OMEGA", "FW_S_OMEGA"),
+                  ("S_ACT", "FW_S_ACT"), ("S_ACTION", "FW_S_ACTION"), ("S_STEP_COUNT", "FW_S_STEP_COUNT"),
+                  ("S_TICK_COUNT", "FW_S_TICK_COUNT"), ("S_EPISODE", "FW_S_EPISODE"), ("S_FLAGS", "FW_S_FLAGS"),
+                  ("S_NUM_REACHED", "FW_S_NUM_REACHED"), ("S_NEW_DIST", "FW_S_NEW_DIST"), ("S_WIND", "FW_S_WIND"),
+                  ("S_EP_RETURN", "FW_S_EP_RETURN"), ("S_TARGETS", "FW_S_TARGETS"), ("S_TASK", "FW_S_TASK"),
+                  ("INFO_NUM_TARGETS_REACHED", "FW_INFO_NUM_TARGETS_REACHED"), ("INFO_COLLISION", "FW_INFO_COLLISION"),
+                  ("INFO_OUT_OF_BOUNDS", "FW_INFO_OUT_OF_BOUNDS"), ("INFO_ENV_COMPLETE", "FW_INFO_ENV_COMPLETE"),
+                  ("INFO_EP_LEN", "FW_INFO_EP_LEN"), ("FW_INFO_DIM", "FW_INFO_DIM"),
+                  ("FW_MAX_TARGETS", "FW_MAX_TARGETS"), ("FW_EHIP", "FW_EHIP"), ("FW_EINVAL", "FW_EINVAL")]:
+        assert getattr(K, py) == vals[h], (py, h)
+
+
+def test_validate_config_through_the_abi():
+    cfg = K.train_waypoints_v3_config()
+    _lib.validate(cfg)
+    bad = cfg.copy(); bad.agent_hz = 50
+    with pytest.raises(ValueError, match="try 40 or 60"):
+        _lib.validate(bad)
+    bad = cfg.copy(); bad.angle_representation = 3
+    with pytest.raises(ValueError, match="euler"):
+        _lib.validate(bad)
+    bad = cfg.copy(); bad.wind_mode = 7
+    with pytest.raises(ValueError, match="Unsupported wind mode"):
+        _lib.validate(bad)
+    bad = cfg.copy(); bad.abi_version = 1
+    with pytest.raises(ValueError, match="abi_version"):
+        _lib.validate(bad)
+    bad = cfg.copy(); bad.num_targets = 99
+    with pytest.raises(ValueError, match="num_targets"):
+        _lib.validate(bad)
+
+
+def test_validation_messages_agree_with_oracle(oracle):
+    for mutate in (lambda c: setattr(c, "agent_hz", 7), lambda c: setattr(c, "angle_representation", 2),
+                   lambda c: setattr(c, "wind_mode", -1), lambda c: setattr(c, "mass", 0.0)):
+        c = K.train_waypoints_v3_config(); mutate(c)
+        buf_a, buf_b = C.create_string_buffer(256), C.create_string_buffer(256)
+        ra = _lib.lib().fw_validate_config(C.byref(c), buf_a, 256)
+        rb = oracle.lib().fwo_validate_config(C.byref(c), buf_b, 256)
+        assert ra == rb == K.FW_EINVAL and buf_a.value == buf_b.value
+
+
+def test_python_constructor_errors_mirror_reference():
+    with pytest.raises(ValueError, match="`agent_hz` must be round denominator of 120"):
+        K.waypoints_config(agent_hz=50)
+    with pytest.raises(ValueError, match="angle_representation must be either `euler` or `quaternion`"):
+        K.waypoints_config(angle_representation="rpy")
+    with pytest.raises(ValueError, match="num_targets"):
+        K.waypoints_config(num_targets=9)
+    with pytest.raises(ValueError, match="dtype"):
+        K.waypoints_config(dtype="bf16")
+
+
+def test_box_space():
+    b = P.Box(-1.0, 1.0, (4,), np.float64)
+    assert b.shape == (4,) and b.dtype == np.float64
+    assert b.contains(np.zeros(4)) and not b.contains(np.full(4, 2.0)) and not b.contains(np.zeros(3))
+    s = b.sample()
+    assert s.shape == (4,) and b.contains(s)
+    o = P.Box(-np.inf, np.inf, (28,), np.float64)
+    assert o.sample().shape == (28,)
+    assert b == P.Box(-1.0, 1.0, (4,), np.float64) and b != o
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a HIP device the product must refuse to run, not emulate."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        P.FixedwingWaypointsVecEnv(4)
+    cfg = K.train_waypoints_v3_config()
+    h = C.c_void_p()
+    rc = _lib.lib().fw_create(C.byref(cfg), 4, 0, 0, 0, C.byref(h))
+    assert rc == K.FW_EHIP and not h
+    assert b"no HIP device" in _lib.lib().fw_last_error(None)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pyflyt-drone_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "fw_oracle" not in text and "libfw_oracle" not in text and "fwo_" not in text, f
