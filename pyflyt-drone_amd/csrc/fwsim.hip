@@ -42,126 +42,208 @@ __global__ void fw_warm_kernel(Params<T>* Pm) {
   T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
   T wind0[3] = {(T)0, (T)0, (T)0};
   int ticks = P.warmup_aviary_steps * P.ticks_per_aviary;
-  for (int t = 0; t < ticks; ++t) (void)physics_tick<T>(P, S, cmd0, (T)0, wind0);
+  for (int t = 0; t < ticks; ++t) (void)physics_tick<T, false, 1>(P, S, cmd0, (T)0, wind0, P.s[0], (T)1);
   for (int k = 0; k < 3; ++k) { Pm->warm[k] = S.p[k]; Pm->warm[7 + k] = S.v[k]; Pm->warm[10 + k] = S.w[k]; }
   for (int k = 0; k < 4; ++k) Pm->warm[3 + k] = S.q[k];
   for (int k = 0; k < FW_NUM_ACTUATORS; ++k) Pm->warm[13 + k] = S.act[k];
   Pm->warm_ticks = ticks;
 }
 
-// K1: one agent step for 64 envs per workgroup (one wave), everything fused.
+// action shown in the observation: src 0 = this step's input, 1 = stored (stale), 2 = zeros
 template <typename T>
-__global__ __launch_bounds__(kWave, 4) void fw_step_kernel(const Params<T>* __restrict__ Pp, DevState<T> D,
-                                                        const T* __restrict__ actions, T* __restrict__ obs,
-                                                        T* __restrict__ reward, uint8_t* __restrict__ terminated,
-                                                        uint8_t* __restrict__ truncated, T* __restrict__ terminal_obs,
-                                                        int32_t* __restrict__ info) {
-  __shared__ T tile[kWave * (kMaxObs + 1)];
+__device__ __forceinline__ void load_action(const DevState<T>& D, const T* actions, int env, int src, T a[4]) {
+  const T* ap = actions + (size_t)env * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    T cur = ap[k], old = D.r[(size_t)(RF_ACTION + k) * D.npad + env];
+    a[k] = (src == 0) ? cur : (src == 1) ? old : (T)0;
+  }
+}
+
+// Per-lane phase of the fused step state machine.
+enum Phase : int { PH_STEP = 0, PH_WARM = 1, PH_DONE = 2 };
+
+// K1: one agent step, everything fused.  One wave per workgroup; the wave holds 64/G envs
+// (G lanes per env, see fwsim_device.hpp).
+//
+// The kernel is a per-env state machine around ONE inlined Aviary step:
+//   PH_STEP  the env runs its (<= step_ratio) sub-steps; after each one the
+//            reference's compute_state / compute_term_trunc_reward are applied;
+//   PH_WARM  the env finished its episode mid-launch and (wind acting on the
+//            dynamics) is integrating its reset warm-up with a zero setpoint --
+//            concurrently with neighbours that are still in PH_STEP;
+//   PH_DONE  results latched; the lanes idle until the wave-uniform exit.
+// Outputs are latched in registers and stored once at the end.
+// GENERAL = wind is on (per-env wind registers, and -- if it acts on the dynamics -- the
+// PH_WARM path).  The wind-free instantiation (the headline config) carries none of that.
+template <typename T, bool GENERAL, int G>
+__global__ __launch_bounds__(kWave)
+void fw_step_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restrict__ actions, T* __restrict__ obs,
+                    T* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
+                    T* __restrict__ terminal_obs, int32_t* __restrict__ info) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);
   const Params<T>& P = *Pp;
+  constexpr int EPW = kWave / G;                     // envs per wave
   const int lane = threadIdx.x;
-  const int env0 = blockIdx.x * kWave;
-  const int env = env0 + lane;
+  const int sub = (G == 1) ? 0 : (lane & (G - 1));   // my lane within the env's group
+  const int row = lane / G;                          // env slot within the wave
+  const bool leader = sub == 0;
+  const int env0 = blockIdx.x * EPW;
+  const int env = env0 + row;
   const bool active = env < D.n;
+  const int envc = active ? env : D.n - 1;           // inactive lanes shadow the last env and never store
   const size_t n = D.npad;
   const int Dobs = P.obs_dim;
   const int ld = Dobs + 1;
 
-  if (active) {
-    Rigid<T> S;
-    load_rigid<T>(D, env, S);
-    int32_t step_count = D.i[IF_STEP * n + env];
-    int32_t tick = D.i[IF_TICK * n + env];
-    int32_t episode = D.i[IF_EPISODE * n + env];
-    int32_t flags = D.i[IF_FLAGS * n + env];
-    int32_t num_reached = D.i[IF_NUM_REACHED * n + env];
-    T new_dist = D.r[RF_NEW_DIST * n + env];
-    T ep_return = D.r[RF_EP_RETURN * n + env];
-    T wb[3] = {(T)0, (T)0, (T)0}, wa[3] = {(T)0, (T)0, (T)0}, wphase = (T)0;
-    if (P.wind_mode != FW_WIND_OFF) {
+  // this lane's lifting surface (G = 8): constants live in VGPRs for the whole launch
+  const SurfC<T> mine = P.s[(G == 1) ? 0 : min(sub, FW_NUM_SURFACES - 1)];
+  const T wmask = (sub < FW_NUM_SURFACES) ? (T)1 : (T)0;
+
+  Rigid<T> S;
+  load_rigid<T>(D, envc, S);
+  int32_t step_count = D.i[IF_STEP * n + envc];
+  int32_t tick = D.i[IF_TICK * n + envc];
+  int32_t episode = D.i[IF_EPISODE * n + envc];
+  int32_t flags = D.i[IF_FLAGS * n + envc];
+  int32_t num_reached = D.i[IF_NUM_REACHED * n + envc];
+  T new_dist = D.r[RF_NEW_DIST * n + envc];
+  T ep_return = D.r[RF_EP_RETURN * n + envc];
+  T wb[3] = {(T)0, (T)0, (T)0}, wa[3] = {(T)0, (T)0, (T)0}, wphase = (T)0;
+  if (GENERAL) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { wb[k] = D.r[(RF_WIND + k) * n + env]; wa[k] = D.r[(RF_WIND + 3 + k) * n + env]; }
-      wphase = D.r[(RF_WIND + 6) * n + env];
-    }
-    T a[4];
-    {
-      const T* ap = actions + (size_t)env * 4;
-      a[0] = ap[0]; a[1] = ap[1]; a[2] = ap[2]; a[3] = ap[3];
-    }
-    // fixedwing_base_env.py:325-331
-    T rew = (T)-0.1;
-    T sp[4] = { a[0], a[1], a[2], a[3] / (T)2 + (T)0.5 };
-    T cmd[FW_NUM_ACTUATORS];
+    for (int k = 0; k < 3; ++k) { wb[k] = D.r[(RF_WIND + k) * n + envc]; wa[k] = D.r[(RF_WIND + 3 + k) * n + envc]; }
+    wphase = D.r[(RF_WIND + 6) * n + envc];
+  }
+  // fixedwing_base_env.py:325-331
+  T rew = (T)-0.1;
+  T cmd[FW_NUM_ACTUATORS];
+  {
+    const T* ap = actions + (size_t)envc * 4;
+    const T sp[4] = { ap[0], ap[1], ap[2], ap[3] * (T)0.5 + (T)0.5 };
 #pragma unroll
     for (int c = 0; c < FW_NUM_ACTUATORS; ++c)
       cmd[c] = P.mixer[c][0] * sp[0] + P.mixer[c][1] * sp[1] + P.mixer[c][2] * sp[2] + P.mixer[c][3] * sp[3];
+  }
 
-    const uint32_t genv = (uint32_t)(P.env_offset + env);
-    // An env that is already done (bare-Gymnasium mode) runs no sub-step: the reference
-    // then returns its stale self.state, i.e. the previous action and target view.
-    const bool done_at_entry = (flags & (FL_TERM | FL_TRUNC)) != 0;
-    int tgt_obs = (flags >> FL_TGT_SHIFT) & 15;   // target index the last compute_state() saw
-    flags &= FL_MASK;
+  const uint32_t genv = (uint32_t)(P.env_offset + envc);
+  // An env that is already done (bare-Gymnasium mode) runs no sub-step: the reference then
+  // returns its stale self.state, i.e. the previous action and target view.
+  const bool done_at_entry = (flags & (FL_TERM | FL_TRUNC)) != 0;
+  int tgt_obs = (flags >> FL_TGT_SHIFT) & 15;        // target index the last compute_state() saw
+  flags &= FL_MASK;
+  // which action the returned observation shows: 0 = this step's, 1 = the stored (stale) one,
+  // 2 = zeros (fresh reset).  Re-read at the end instead of held in registers across the loop.
+  int act_src = done_at_entry ? 1 : 0;
+
+  // Motor noise.  G = 8: lane j of the group draws the normals of the step's j-th Aviary
+  // step up front (8 lanes -> up to 8 sub-steps, in parallel); they are fetched by shuffle.
+  const uint32_t astep0 = (uint32_t)(tick / P.ticks_per_aviary);
+  const bool pre_noise = (G == 8) && P.has_noise && (P.step_ratio <= G);
+  T nz0 = (T)0, nz1 = (T)0;
+  if (pre_noise && !done_at_entry) rng_normal2<T>(P, genv, (uint32_t)episode, astep0 + (uint32_t)sub, nz0, nz1);
+
+  // latched outputs
+  T out_rew = (T)0;
+  int32_t out_flags = 0, out_reached = 0, out_steps = 0;
+  int phase = active ? PH_STEP : PH_DONE;
+  int it = 0, warm_left = 0;
+  bool step_over = active && done_at_entry;          // nothing to simulate: finalise immediately
 
 #pragma unroll 1
-    for (int sub = 0; sub < P.step_ratio; ++sub) {              // :334
-      if (flags & (FL_TERM | FL_TRUNC)) break;                  // :336
-      bool contact = aviary_step<T>(P, S, cmd, tick, genv, (uint32_t)episode, wb, wa, wphase);   // :339
-      // compute_state(): WaypointHandler.distance_to_targets side effects
-      const int nleft = P.num_targets - num_reached;
-      T old_dist = new_dist;
-      if (P.task != FW_TASK_OBJLOCK && nleft > 0) {
-        const T* tp = D.r + (size_t)(RF_TARGETS + 3 * num_reached) * n + env;
-        T dx = tp[0] - S.p[0], dy = tp[n] - S.p[1], dz = tp[2 * n] - S.p[2];
-        new_dist = M<T>::sqrt_(dx * dx + dy * dy + dz * dz);
-      }
-      tgt_obs = num_reached;
-      // compute_base_term_trunc_reward(): :296-312
-      if (step_count > P.max_steps) flags |= FL_TRUNC;
-      if (contact) { rew = (T)-100; flags |= FL_COLLISION | FL_TERM; }
-      if (M<T>::sqrt_(S.p[0] * S.p[0] + S.p[1] * S.p[1] + S.p[2] * S.p[2]) > P.dome) { rew = (T)-100; flags |= FL_OOB | FL_TERM; }
-      // waypoint reward (upstream FixedwingWaypointsEnv; mirrored at fixedwing_waypoint_objlock_env.py:286-294)
-      if (P.task != FW_TASK_OBJLOCK && nleft > 0) {
-        if (!P.sparse) {
-          T progress = (old_dist != (T)0) ? (old_dist - new_dist) : (T)0;
-          rew += M<T>::fmax_((T)3 * progress, (T)0);
-          rew += (T)1 / new_dist;
+  for (;;) {
+    if (phase == PH_STEP && step_over) {
+      // ---- end of env.step(): :346, outputs, SB3 worker auto-reset ----
+      step_count += 1;
+      ep_return += rew;
+      out_rew = rew; out_flags = flags; out_reached = num_reached; out_steps = step_count;
+      phase = PH_DONE;
+      if ((flags & (FL_TERM | FL_TRUNC)) && P.auto_reset) {
+        if (terminal_obs && leader) {
+          T* trow = terminal_obs + (size_t)env * Dobs;
+          T act_t[4];
+          load_action<T>(D, actions, env, act_src, act_t);
+          write_obs<T>(P, D, env, S, act_t, tgt_obs, [&](int k, T v) { trow[k] = v; });
         }
-        if (new_dist < P.reach) {
-          rew = (T)100;
-          num_reached += 1;
-          if (num_reached == P.num_targets) flags |= FL_TRUNC | FL_COMPLETE;
-        }
+        warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase);
+        step_count = 0; flags = 0; ep_return = (T)0; tgt_obs = 0;
+        act_src = 2;
+        if (GENERAL && warm_left > 0) phase = PH_WARM;
+        else new_dist = end_reset<T, G>(P, D, env, episode, S);
       }
     }
-    step_count += 1;                                            // :346
-    ep_return += rew;
+    if (__ballot(phase != PH_DONE) == 0ull) break;   // wave-uniform exit
+    // noise of this iteration's Aviary step (all stepping envs of the wave are at sub-step `it`)
+    T z0 = (T)0, z1 = (T)0;
+    if (pre_noise) {
+      const int src = (lane & ~(G - 1)) | (it & (G - 1));
+      z0 = __shfl(nz0, src, kWave); z1 = __shfl(nz1, src, kWave);
+    }
+    if (phase != PH_DONE) {
+      const bool stepping = !GENERAL || phase == PH_STEP;
+      if (P.has_noise && !pre_noise && stepping)
+        rng_normal2<T>(P, genv, (uint32_t)episode, (uint32_t)(tick / P.ticks_per_aviary), z0, z1);
+      bool contact;
+      if (GENERAL) {
+        T c_eff[FW_NUM_ACTUATORS];
+#pragma unroll
+        for (int c = 0; c < FW_NUM_ACTUATORS; ++c) c_eff[c] = stepping ? cmd[c] : (T)0;
+        z0 = stepping ? z0 : (T)0; z1 = stepping ? z1 : (T)0;
+        contact = aviary_step<T, true, G>(P, S, c_eff, tick, z0, z1, wb, wa, wphase, mine, wmask);   // :339
+      } else {
+        contact = aviary_step<T, false, G>(P, S, cmd, tick, z0, z1, wb, wa, wphase, mine, wmask);    // :339
+      }
+      if (stepping) {
+        // compute_state(): WaypointHandler.distance_to_targets side effects
+        const int nleft = P.num_targets - num_reached;
+        const T old_dist = new_dist;
+        if (P.task != FW_TASK_OBJLOCK && nleft > 0) {
+          const T* tp = D.r + (size_t)(RF_TARGETS + 3 * num_reached) * n + env;
+          T dx = tp[0] - S.p[0], dy = tp[n] - S.p[1], dz = tp[2 * n] - S.p[2];
+          new_dist = M<T>::sqrt_(dx * dx + dy * dy + dz * dz);
+        }
+        tgt_obs = num_reached;
+        // compute_base_term_trunc_reward(): :296-312
+        if (step_count > P.max_steps) flags |= FL_TRUNC;
+        if (contact) { rew = (T)-100; flags |= FL_COLLISION | FL_TERM; }
+        if (S.p[0] * S.p[0] + S.p[1] * S.p[1] + S.p[2] * S.p[2] > P.dome * P.dome) { rew = (T)-100; flags |= FL_OOB | FL_TERM; }
+        // waypoint reward (upstream FixedwingWaypointsEnv; mirrored at fixedwing_waypoint_objlock_env.py:286-294)
+        if (P.task != FW_TASK_OBJLOCK && nleft > 0) {
+          if (!P.sparse) {
+            T progress = (old_dist != (T)0) ? (old_dist - new_dist) : (T)0;
+            rew += M<T>::fmax_((T)3 * progress, (T)0);
+            rew += M<T>::rcp_(new_dist);
+          }
+          if (new_dist < P.reach) {
+            rew = (T)100;
+            num_reached += 1;
+            if (num_reached == P.num_targets) flags |= FL_TRUNC | FL_COMPLETE;
+          }
+        }
+        step_over = (it + 1 >= P.step_ratio) || (flags & (FL_TERM | FL_TRUNC));     // :334-337
+      } else {
+        warm_left -= 1;
+        if (warm_left == 0) { new_dist = end_reset<T, G>(P, D, env, episode, S); phase = PH_DONE; }
+      }
+    }
+    it += 1;
+  }
+  // G = 8: waypoints sampled by sibling lanes during an in-launch reset are read back below
+  if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 
-    const bool done = (flags & (FL_TERM | FL_TRUNC)) != 0;
-    reward[env] = rew;
-    terminated[env] = (uint8_t)((flags & FL_TERM) ? 1 : 0);
-    truncated[env] = (uint8_t)((flags & FL_TRUNC) ? 1 : 0);
+  if (active && leader) {
+    reward[env] = out_rew;
+    terminated[env] = (uint8_t)((out_flags & FL_TERM) ? 1 : 0);
+    truncated[env] = (uint8_t)((out_flags & FL_TRUNC) ? 1 : 0);
     if (info) {
       int4* ip = reinterpret_cast<int4*>(info + (size_t)env * FW_INFO_DIM);
-      ip[0] = make_int4(num_reached, (flags & FL_COLLISION) ? 1 : 0, (flags & FL_OOB) ? 1 : 0, (flags & FL_COMPLETE) ? 1 : 0);
-      ip[1] = make_int4(0, 0, step_count, 0);
+      ip[0] = make_int4(out_reached, (out_flags & FL_COLLISION) ? 1 : 0, (out_flags & FL_OOB) ? 1 : 0, (out_flags & FL_COMPLETE) ? 1 : 0);
+      ip[1] = make_int4(0, 0, out_steps, 0);
     }
-    T act_obs[4] = { a[0], a[1], a[2], a[3] };
-    if (done_at_entry) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) act_obs[k] = D.r[(RF_ACTION + k) * n + env];
-    }
-    if (done && P.auto_reset) {
-      if (terminal_obs) {
-        T* row = terminal_obs + (size_t)env * Dobs;
-        write_obs<T>(P, D, env, S, act_obs, tgt_obs, [&](int k, T v) { row[k] = v; });
-      }
-      reset_env<T>(P, D, env, S, tick, episode, num_reached, new_dist, wb, wa, wphase);
-      step_count = 0; flags = 0; ep_return = (T)0;
-      act_obs[0] = act_obs[1] = act_obs[2] = act_obs[3] = (T)0;
-      tgt_obs = 0;
-    }
-    write_obs<T>(P, D, env, S, act_obs, tgt_obs, [&](int k, T v) { tile[lane * ld + k] = v; });
-
+    T act_obs[4];
+    load_action<T>(D, actions, env, act_src, act_obs);
+    write_obs<T>(P, D, env, S, act_obs, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
     store_rigid<T>(D, env, S);
 #pragma unroll
     for (int k = 0; k < 4; ++k) D.r[(RF_ACTION + k) * n + env] = act_obs[k];
@@ -174,34 +256,61 @@ __global__ __launch_bounds__(kWave, 4) void fw_step_kernel(const Params<T>* __re
     D.i[IF_NUM_REACHED * n + env] = num_reached;
   }
   __syncthreads();
-  flush_obs_tile<T>(tile, ld, obs, env0, D.n, Dobs);
+  flush_obs_tile<T>(tile, ld, obs, env0, EPW, D.n, Dobs);
 }
 
-// K2: reset (masked) + observation.
-template <typename T>
-__global__ __launch_bounds__(kWave, 4) void fw_reset_kernel(const Params<T>* __restrict__ Pp, DevState<T> D,
-                                                         const uint8_t* __restrict__ mask, T* __restrict__ obs, int do_reset) {
-  __shared__ T tile[kWave * (kMaxObs + 1)];
+// K2: reset (masked) + observation.  Same single-tick-site structure (warm-up only).
+template <typename T, int G>
+__global__ __launch_bounds__(kWave)
+void fw_reset_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const uint8_t* __restrict__ mask,
+                     T* __restrict__ obs, int do_reset) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);
   const Params<T>& P = *Pp;
+  constexpr int EPW = kWave / G;
   const int lane = threadIdx.x;
-  const int env0 = blockIdx.x * kWave;
-  const int env = env0 + lane;
+  const int sub = (G == 1) ? 0 : (lane & (G - 1));
+  const int row = lane / G;
+  const bool leader = sub == 0;
+  const int env0 = blockIdx.x * EPW;
+  const int env = env0 + row;
+  const bool active = env < D.n;
+  const int envc = active ? env : D.n - 1;
   const size_t n = D.npad;
   const int Dobs = P.obs_dim;
   const int ld = Dobs + 1;
-  if (env < D.n) {
-    Rigid<T> S;
-    load_rigid<T>(D, env, S);
-    T action[4];
+  const SurfC<T> mine = P.s[(G == 1) ? 0 : min(sub, FW_NUM_SURFACES - 1)];
+  const T wmask = (sub < FW_NUM_SURFACES) ? (T)1 : (T)0;
+
+  Rigid<T> S;
+  load_rigid<T>(D, envc, S);
+  T action[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) action[k] = D.r[(RF_ACTION + k) * n + env];
-    int32_t num_reached = D.i[IF_NUM_REACHED * n + env];
-    int tgt_obs = (D.i[IF_FLAGS * n + env] >> FL_TGT_SHIFT) & 15;
-    if (do_reset && (!mask || mask[env])) {
-      int32_t tick = 0, episode = D.i[IF_EPISODE * n + env];
-      T new_dist, wb[3], wa[3], wphase;
-      reset_env<T>(P, D, env, S, tick, episode, num_reached, new_dist, wb, wa, wphase);
-      action[0] = action[1] = action[2] = action[3] = (T)0;
+  for (int k = 0; k < 4; ++k) action[k] = D.r[(RF_ACTION + k) * n + envc];
+  int32_t num_reached = D.i[IF_NUM_REACHED * n + envc];
+  int tgt_obs = (D.i[IF_FLAGS * n + envc] >> FL_TGT_SHIFT) & 15;
+  const bool resetting = active && do_reset && (!mask || mask[envc]);
+  int32_t tick = 0, episode = D.i[IF_EPISODE * n + envc];
+  T new_dist = (T)0, wb[3] = {(T)0, (T)0, (T)0}, wa[3] = {(T)0, (T)0, (T)0}, wphase = (T)0;
+  int warm_left = 0;
+  if (resetting) {
+    warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase);
+    if (warm_left == 0) new_dist = end_reset<T, G>(P, D, env, episode, S);
+  }
+  const T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
+#pragma unroll 1
+  while (__ballot(warm_left > 0) != 0ull) {
+    if (warm_left > 0) {
+      (void)aviary_step<T, true, G>(P, S, cmd0, tick, (T)0, (T)0, wb, wa, wphase, mine, wmask);
+      warm_left -= 1;
+      if (warm_left == 0) new_dist = end_reset<T, G>(P, D, env, episode, S);
+    }
+  }
+  if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  if (resetting) {
+    action[0] = action[1] = action[2] = action[3] = (T)0;
+    tgt_obs = 0;
+    if (leader) {
       store_rigid<T>(D, env, S);
 #pragma unroll
       for (int k = 0; k < 4; ++k) D.r[(RF_ACTION + k) * n + env] = (T)0;
@@ -212,12 +321,13 @@ __global__ __launch_bounds__(kWave, 4) void fw_reset_kernel(const Params<T>* __r
       D.i[IF_EPISODE * n + env] = episode;
       D.i[IF_FLAGS * n + env] = 0;
       D.i[IF_NUM_REACHED * n + env] = num_reached;
-      tgt_obs = 0;
     }
-    if (obs) write_obs<T>(P, D, env, S, action, tgt_obs, [&](int k, T v) { tile[lane * ld + k] = v; });
   }
-  __syncthreads();
-  if (obs) flush_obs_tile<T>(tile, ld, obs, env0, D.n, Dobs);
+  if (obs) {
+    if (active && leader) write_obs<T>(P, D, env, S, action, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
+    __syncthreads();
+    flush_obs_tile<T>(tile, ld, obs, env0, EPW, D.n, Dobs);
+  }
 }
 
 // ======================================================================
@@ -225,6 +335,7 @@ __global__ __launch_bounds__(kWave, 4) void fw_reset_kernel(const Params<T>* __r
 // ======================================================================
 namespace {
 
+constexpr int kG8MaxEnvs = 32768;
 thread_local std::string g_err;
 
 struct HostDerived {
@@ -326,7 +437,7 @@ bool build_params(const fw_config& c, uint64_t seed, int64_t env_offset, Params<
   for (int k = 0; k < 9; ++k) { P.I[k] = (T)m[k]; P.Iinv[k] = (T)mi[k]; }
   for (int i = 0; i < FW_MAX_COLLISION_PTS; ++i) for (int k = 0; k < 3; ++k) P.coll[i][k] = (T)c.collision_pts[i][k];
   P.n_coll = c.n_collision_pts; P.gyroscopic = c.gyroscopic;
-  P.dt = (T)dt; P.inv_physics_hz = (T)dt;
+  P.dt = (T)dt; P.inv_physics_hz = (T)dt; P.physics_hz_T = (T)c.physics_hz;
   P.dome = (T)c.flight_dome_size; P.reach = (T)c.goal_reach_distance;
   P.min_height = (T)c.waypoint_min_height; P.spawn_hi = (T)(c.waypoint_spawn_size * 0.9);
   {
@@ -365,6 +476,7 @@ bool build_params(const fw_config& c, uint64_t seed, int64_t env_offset, Params<
 struct fw_env {
   fw_config cfg;
   int32_t n = 0, npad = 0, device = 0;
+  int32_t lanes_per_env = 1;    // 1: throughput mapping, 8: latency mapping (see fwsim_device.hpp)
   uint64_t seed = 0;
   int64_t env_offset = 0;
   void* params_dev = nullptr;   // Params<T>
@@ -396,6 +508,12 @@ template <typename T> DevState<T> dev_state(fw_env* h) {
   DevState<T> D; D.r = (T*)h->r_dev; D.i = h->i_dev; D.n = h->n; D.npad = h->npad; return D;
 }
 
+// LDS bytes of the padded [64/G][D+1] observation tile
+template <typename T> size_t tile_bytes(const fw_env* h) {
+  return sizeof(T) * (size_t)(kWave / h->lanes_per_env) * (size_t)(obs_dim_of(&h->cfg) + 1);
+}
+inline dim3 grid_of(const fw_env* h) { return dim3((unsigned)(h->npad / (kWave / h->lanes_per_env))); }
+
 template <typename T>
 int upload_params(fw_env* h) {
   Params<T> P;
@@ -423,19 +541,35 @@ int create_T(fw_env* h) {
   return FW_OK;
 }
 
+template <typename T, bool GENERAL, int G>
+void launch_step(fw_env* h, const void* actions, void* obs, void* reward, uint8_t* term, uint8_t* trunc, void* tobs,
+                 int32_t* info, hipStream_t st) {
+  hipLaunchKernelGGL((fw_step_kernel<T, GENERAL, G>), grid_of(h), dim3(kWave), tile_bytes<T>(h), st,
+                     (const Params<T>*)h->params_dev, dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term,
+                     trunc, (T*)tobs, info);
+}
+
 template <typename T>
 int step_T(fw_env* h, const void* actions, void* obs, void* reward, uint8_t* term, uint8_t* trunc, void* tobs,
            int32_t* info, hipStream_t st) {
-  hipLaunchKernelGGL(fw_step_kernel<T>, dim3(h->npad / kWave), dim3(kWave), 0, st, (const Params<T>*)h->params_dev,
-                     dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term, trunc, (T*)tobs, info);
+  const bool general = h->cfg.wind_mode != FW_WIND_OFF;
+  const bool g8 = h->lanes_per_env == 8;
+  if (general) { if (g8) launch_step<T, true, 8>(h, actions, obs, reward, term, trunc, tobs, info, st);
+                 else    launch_step<T, true, 1>(h, actions, obs, reward, term, trunc, tobs, info, st); }
+  else         { if (g8) launch_step<T, false, 8>(h, actions, obs, reward, term, trunc, tobs, info, st);
+                 else    launch_step<T, false, 1>(h, actions, obs, reward, term, trunc, tobs, info, st); }
   HIP_TRY(h, hipGetLastError());
   return FW_OK;
 }
 
 template <typename T>
 int reset_T(fw_env* h, const uint8_t* mask, void* obs, int do_reset, hipStream_t st) {
-  hipLaunchKernelGGL(fw_reset_kernel<T>, dim3(h->npad / kWave), dim3(kWave), 0, st, (const Params<T>*)h->params_dev,
-                     dev_state<T>(h), mask, (T*)obs, do_reset);
+  if (h->lanes_per_env == 8)
+    hipLaunchKernelGGL((fw_reset_kernel<T, 8>), grid_of(h), dim3(kWave), tile_bytes<T>(h), st,
+                       (const Params<T>*)h->params_dev, dev_state<T>(h), mask, (T*)obs, do_reset);
+  else
+    hipLaunchKernelGGL((fw_reset_kernel<T, 1>), grid_of(h), dim3(kWave), tile_bytes<T>(h), st,
+                       (const Params<T>*)h->params_dev, dev_state<T>(h), mask, (T*)obs, do_reset);
   HIP_TRY(h, hipGetLastError());
   return FW_OK;
 }
@@ -517,6 +651,14 @@ int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64
   if (!h) return FW_ENOMEM;
   h->cfg = *cfg; h->n = num_envs; h->npad = (num_envs + kWave - 1) / kWave * kWave;
   h->device = device; h->seed = seed; h->env_offset = global_env_offset;
+  // Lane mapping: below ~1 wave per SIMD of env-per-lane work, split each env over 8 lanes
+  // (512 waves for 4096 envs) -- latency-bound regime; above, one lane per env.
+  // FWSIM_LANES_PER_ENV=1|8 overrides (used by the benchmark sweep).
+  h->lanes_per_env = (num_envs <= kG8MaxEnvs && cfg->num_targets <= 8 && cfg->n_collision_pts <= 8) ? 8 : 1;
+  if (const char* ev = getenv("FWSIM_LANES_PER_ENV")) {
+    int v = atoi(ev);
+    if (v == 1 || (v == 8 && cfg->num_targets <= 8 && cfg->n_collision_pts <= 8)) h->lanes_per_env = v;
+  }
   DeviceGuard g(device);
   rc = (cfg->dtype == FW_F64) ? create_T<double>(h) : create_T<float>(h);
   if (rc != FW_OK) {

@@ -1,21 +1,25 @@
 // fwsim_device.hpp -- gfx950 device code of the vectorised fixed-wing env step.
 //
-// One wavefront lane per env.  State is SoA in HBM ([field][Npad], coalesced
-// per field); wave-uniform vehicle/task constants live in one device-resident
-// `Params<T>` block that every lane addresses uniformly, so the compiler
-// fetches them with scalar loads (SGPRs / scalar cache) instead of burning
-// VGPRs or LDS bandwidth; LDS is used for the [64 x D] observation tile so that
-// the row-major obs[N,D] the policy GEMM wants is written with fully coalesced
-// stores.  All 8 physics ticks, the 4 reward/termination evaluations, the
-// observation and the SB3-style auto-reset of one agent step run in registers
-// inside a single launch.  No MFMA: this is element-wise physics.
+// Two lane mappings of the same physics (template parameter G = lanes per env):
+//   G = 1  one wavefront lane per env, the 5 lifting surfaces in a rolled loop whose
+//          constants arrive by scalar loads.  Throughput mapping for large N.
+//   G = 8  eight lanes per env: lanes 0-4 each evaluate ONE lifting surface with their
+//          constants resident in VGPRs, the wrench is summed with 3 DPP steps and the
+//          (cheap) rigid-body update is replicated in all 8 lanes.  Latency mapping for
+//          small N: 4096 envs become 512 waves instead of 64, and the dependent-issue
+//          chain per tick is ~5x shorter (one surface instead of five in series).
+// State is SoA in HBM ([field][Npad], coalesced per field); LDS holds the padded
+// observation tile so the row-major obs[N,D] the policy GEMM wants is written with
+// coalesced stores.  All 8 physics ticks, the 4 reward/termination evaluations, the
+// observation and the SB3-style auto-reset of one agent step run in registers inside
+// a single launch.  No MFMA: this is element-wise physics.
 //
 // Algorithm provenance (reference paths relative to the reference repo root):
 //   step loop / reward / termination : envs/fixedwing_envs/fixedwing_base_env.py:296-348
 //   observation layout               : envs/fixedwing_objlock_env.py:260-267, envs/flatten_waypoint_env.py:52-72
 //   wind                             : envs/fixedwing_envs/fixedwing_base_env.py:108-173
 //   aero / motor coefficients        : my_models/fixedwing/fixewing.yaml:1-71
-//   un-vendored PyFlyt/Bullet parts  : SURVEY.md appendix A (spec), DESIGN.md section 3
+//   un-vendored PyFlyt/Bullet parts  : SURVEY.md appendix A (spec), DESIGN.md section 2
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -64,7 +68,7 @@ struct Params {
   T inv_mass, gravity;
   T I[9], Iinv[9];
   T coll[FW_MAX_COLLISION_PTS][3];
-  T dt, inv_physics_hz;
+  T dt, inv_physics_hz, physics_hz_T;
   T dome, reach, min_height, spawn_hi;
   T start_pos[3], start_quat[4], start_vel[3];
   T wind_base[3], wind_amp[3], wind_phase, gust_omega, wind_force_coef;
@@ -88,34 +92,137 @@ struct DevState {
   int32_t n, npad;
 };
 
+constexpr double kPi = 3.14159265358979323846;
+
 // ------------------------------------------------------------------------
-// math helpers (T = double | float)
+// math building blocks
 // ------------------------------------------------------------------------
+// fp64: one wave per SIMD is bound by dependent-issue latency (~16 cycles per dependent
+// fp64 op, tools/microbench_math.hip), so what matters is the DEPTH of each function:
+// v_rcp/v_rsq seeds + Newton steps instead of the IEEE division / sqrt sequences,
+// bounded-range Cody-Waite sincos and a single-division atan2, all with Estrin-scheme
+// polynomials (log depth instead of Horner's linear chain).  Each is accurate to ~1 ulp
+// (prototyped against numpy: <= 4.5e-16 absolute).
 template <typename T> struct M;
 template <> struct M<double> {
-  static __device__ __forceinline__ double sqrt_(double x) { return ::sqrt(x); }
-  static __device__ __forceinline__ double atan2_(double y, double x) { return ::atan2(y, x); }
-  static __device__ __forceinline__ double asin_(double x) { return ::asin(x); }
-  static __device__ __forceinline__ void sincos_(double x, double* s, double* c) { ::sincos(x, s, c); }
-  static __device__ __forceinline__ double sin_(double x) { return ::sin(x); }
-  static __device__ __forceinline__ double cos_(double x) { return ::cos(x); }
+  static __device__ __forceinline__ double rcp_(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    x = fma(fma(-d, x, 1.0), x, x);
+    return x;
+  }
+  static __device__ __forceinline__ double div_(double n, double d) {
+    double x = rcp_(d);
+    double q = n * x;
+    return fma(fma(-d, q, n), x, q);
+  }
+  static __device__ __forceinline__ double sqrt_(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    double e = fma(-g, g, a);
+    g = fma(e, h, g);
+    return (a == 0.0) ? 0.0 : g;
+  }
+  // sin/cos kernels on |r| <= pi/4 (fdlibm coefficients), Estrin form
+  static __device__ __forceinline__ void sincos_kernel_(double r, double* sn, double* cs) {
+    double z = r * r, z2 = z * z, z4 = z2 * z2;
+    double s01 = fma(z, 8.33333333332248946124e-03, -1.66666666666666324348e-01);
+    double s23 = fma(z, 2.75573137070700676789e-06, -1.98412698298579493134e-04);
+    double s45 = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    double ps = fma(z4, s45, fma(z2, s23, s01));
+    *sn = fma(z * r, ps, r);
+    double c01 = fma(z, -1.38888888888741095749e-03, 4.16666666666666019037e-02);
+    double c23 = fma(z, -2.75573143513906633035e-07, 2.48015872894767294178e-05);
+    double c45 = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    double pc = fma(z4, c45, fma(z2, c23, c01));
+    *cs = fma(z2, pc, fma(z, -0.5, 1.0));
+  }
+  static __device__ __forceinline__ void sincos_(double x, double* s, double* c) {
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
+    double k = ::rint(x * INV_PIO2);
+    double r = fma(-k, PIO2_HI, x);
+    r = fma(-k, PIO2_LO, r);
+    double sn, cs;
+    sincos_kernel_(r, &sn, &cs);
+    int q = (int)k;
+    double s0 = (q & 1) ? cs : sn, c0 = (q & 1) ? sn : cs;
+    *s = (q & 2) ? -s0 : s0;
+    *c = ((q + 1) & 2) ? -c0 : c0;
+  }
+  static __device__ __forceinline__ double sin_(double x) { double s, c; sincos_(x, &s, &c); return s; }
+  // atan2 with ONE division: t = min/max in [0,1] is split at c in {0,1/4,1/2,3/4,1};
+  // atan(t) = atan(c) + atan((u - c v)/(v + c u)), |z| <= 1/8, 9-term odd series.
+  static __device__ __forceinline__ double atan2_(double y, double x) {
+    double ax = ::fabs(x), ay = ::fabs(y);
+    double u = ::fmin(ax, ay), v = ::fmax(ax, ay);
+    double c = 0.0, tc = 0.0;
+    c = (u > 0.125 * v) ? 0.25 : c;  tc = (u > 0.125 * v) ? 2.44978663126864143e-01 : tc;
+    c = (u > 0.375 * v) ? 0.50 : c;  tc = (u > 0.375 * v) ? 4.63647609000806094e-01 : tc;
+    c = (u > 0.625 * v) ? 0.75 : c;  tc = (u > 0.625 * v) ? 6.43501108793284371e-01 : tc;
+    c = (u > 0.875 * v) ? 1.00 : c;  tc = (u > 0.875 * v) ? 7.85398163397448279e-01 : tc;
+    double num = fma(-c, v, u), den = fma(c, u, v);
+    double z = (den == 0.0) ? 0.0 : div_(num, den);
+    double w = z * z, w2 = w * w, w4 = w2 * w2;
+    double p01 = fma(w, -1.0 / 3.0, 1.0), p23 = fma(w, -1.0 / 7.0, 1.0 / 5.0);
+    double p45 = fma(w, -1.0 / 11.0, 1.0 / 9.0), p67 = fma(w, -1.0 / 15.0, 1.0 / 13.0);
+    double lo = fma(w2, p23, p01), hi = fma(w2, p67, p45);
+    double p = fma(w4, fma(w4, 1.0 / 17.0, hi), lo);
+    double r = fma(z, p, tc);
+    r = (ay > ax) ? (0.5 * kPi - r) : r;
+    r = (x < 0.0) ? (kPi - r) : r;
+    return (y < 0.0) ? -r : r;
+  }
+  static __device__ __forceinline__ double asin_(double s) { return atan2_(s, sqrt_((1.0 - s) * (1.0 + s))); }
   static __device__ __forceinline__ double fabs_(double x) { return ::fabs(x); }
   static __device__ __forceinline__ double fmax_(double a, double b) { return ::fmax(a, b); }
   static __device__ __forceinline__ double log_(double x) { return ::log(x); }
 };
 template <> struct M<float> {
+  static __device__ __forceinline__ float rcp_(float d) { return 1.0f / d; }
+  static __device__ __forceinline__ float div_(float n, float d) { return n / d; }
   static __device__ __forceinline__ float sqrt_(float x) { return ::sqrtf(x); }
-  static __device__ __forceinline__ float atan2_(float y, float x) { return ::atan2f(y, x); }
-  static __device__ __forceinline__ float asin_(float x) { return ::asinf(x); }
   static __device__ __forceinline__ void sincos_(float x, float* s, float* c) { ::sincosf(x, s, c); }
   static __device__ __forceinline__ float sin_(float x) { return ::sinf(x); }
-  static __device__ __forceinline__ float cos_(float x) { return ::cosf(x); }
+  static __device__ __forceinline__ float atan2_(float y, float x) { return ::atan2f(y, x); }
+  static __device__ __forceinline__ float asin_(float x) { return ::asinf(x); }
   static __device__ __forceinline__ float fabs_(float x) { return ::fabsf(x); }
   static __device__ __forceinline__ float fmax_(float a, float b) { return ::fmaxf(a, b); }
   static __device__ __forceinline__ float log_(float x) { return ::logf(x); }
 };
 
-constexpr double kPi = 3.14159265358979323846;
+// ------------------------------------------------------------------------
+// cross-lane helpers for the 8-lanes-per-env mapping (DPP: no LDS round trip)
+// ------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL> __device__ __forceinline__ double dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(dpp_i32<CTRL>(hi), dpp_i32<CTRL>(lo));
+}
+template <int CTRL> __device__ __forceinline__ float dpp(float v) {
+  return __int_as_float(dpp_i32<CTRL>(__float_as_int(v)));
+}
+// sum over the 8 lanes of a group; every lane ends with the bit-identical total
+template <int G, typename T> __device__ __forceinline__ T group_sum(T v) {
+  if (G == 8) {
+    v += dpp<0xB1>(v);    // quad_perm [1,0,3,2]  (lane ^ 1)
+    v += dpp<0x4E>(v);    // quad_perm [2,3,0,1]  (lane ^ 2)
+    v += dpp<0x141>(v);   // row_half_mirror      (the other quad of the 8)
+  }
+  return v;
+}
+// does any lane of my group have `pred` set?
+template <int G> __device__ __forceinline__ bool group_any(bool pred) {
+  if (G == 1) return pred;
+  unsigned long long m = __ballot(pred);
+  return ((m >> (threadIdx.x & ~(G - 1))) & ((1ull << G) - 1)) != 0ull;
+}
 
 // ---- Philox4x32-10, identical counter/key convention to the spec in DESIGN.md ----
 enum { STREAM_SCENARIO = 0, STREAM_NOISE = 1 };
@@ -169,11 +276,20 @@ struct Rigid {
   T act[FW_NUM_ACTUATORS];
 };
 
+// 2/|q|^2: q is a unit quaternion up to rounding, so a 4-term series in eps = |q|^2 - 1
+// replaces the reciprocal; the exact path is kept for badly normalised input (set_state).
+template <typename T>
+__device__ __forceinline__ T two_over_norm2(T d) {
+  T e = d - (T)1;
+  T ser = (T)2 * ((T)1 + e * ((T)-1 + e * ((T)1 + e * ((T)-1 + e))));
+  return (M<T>::fabs_(e) < (T)1e-4) ? ser : (T)2 * M<T>::rcp_(d);
+}
+
 template <typename T>
 __device__ __forceinline__ void rot_from_quat(const T q[4], T m[9]) {
   T x = q[0], y = q[1], z = q[2], w = q[3];
   T d = x * x + y * y + z * z + w * w;
-  T s = (T)2 / d;
+  T s = two_over_norm2<T>(d);
   T xs = x * s, ys = y * s, zs = z * s;
   T wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
   m[0] = (T)1 - (yy + zz); m[1] = xy - wz;           m[2] = xz + wy;
@@ -196,7 +312,7 @@ template <typename T> __device__ __forceinline__ void cross(const T a[3], const 
 
 // np.interp(x,[x0,x1],[y0,y1]) with end clamping
 template <typename T> __device__ __forceinline__ T interp2(T x, T x0, T x1, T y0, T y1) {
-  T t = (x - x0) / (x1 - x0);
+  T t = M<T>::div_(x - x0, x1 - x0);
   T y = y0 + (y1 - y0) * t;
   y = (x <= x0) ? y0 : y;
   y = (x >= x1) ? y1 : y;
@@ -206,9 +322,10 @@ template <typename T> __device__ __forceinline__ T interp2(T x, T x0, T x1, T y0
 // One lifting surface: branch-free Khan&Nahon flat-plate model (pre- and post-stall
 // evaluated on the same sincos, selected per lane => no wave divergence).
 // cos(alpha), sin(alpha) are never formed: V*cos = v_f, V*sin = -v_l.
+// Returns the surface's force f and its torque about the COM (r x f + pitching moment).
 template <typename T>
 __device__ __forceinline__ void surface_wrench(const SurfC<T>& S, T act, const T v_b[3], const T w_b[3],
-                                               const T wind_b[3], T F[3], T Tq[3]) {
+                                               const T wind_b[3], T f[3], T tq[3]) {
   T wxr[3];
   cross(w_b, S.pos, wxr);
   T vl0 = v_b[0] + wxr[0] - wind_b[0], vl1 = v_b[1] + wxr[1] - wind_b[1], vl2 = v_b[2] + wxr[2] - wind_b[2];
@@ -232,21 +349,27 @@ __device__ __forceinline__ void surface_wrench(const SurfC<T>& S, T act, const T
   const T hpi = (T)(0.5 * kPi);
   T ai_stP = S.Cl3 * (asP - a0) * S.inv_piAR;
   T ai_stN = S.Cl3 * (asN - a0) * S.inv_piAR;
-  T ai_pos = interp2<T>(alpha, asP, hpi, ai_stP, (T)0);
-  T ai_neg = interp2<T>(alpha, -hpi, asN, (T)0, ai_stN);
-  T ai_st = (alpha > (T)0) ? ai_pos : ai_neg;
+  // np.interp on the active side only (one division): positive stall [asP, pi/2] -> [ai_stP, 0],
+  // negative stall [-pi/2, asN] -> [0, ai_stN]
+  const bool pos = alpha > (T)0;
+  T ix0 = pos ? asP : -hpi, ix1 = pos ? hpi : asN;
+  T iy0 = pos ? ai_stP : (T)0, iy1 = pos ? (T)0 : ai_stN;
+  T ai_st = interp2<T>(alpha, ix0, ix1, iy0, iy1);
   T ai = nostall ? ai_lin : ai_st;
   T ae = alpha - a0 - ai;
   T sn, cs;
   M<T>::sincos_(ae, &sn, &cs);
 
+  // one reciprocal serves both branches: 1/cos(ae) pre-stall, 1/(0.56+0.44|sin ae|) post-stall
+  T asn = M<T>::fabs_(sn);
+  T inv = M<T>::rcp_(nostall ? cs : ((T)0.56 + (T)0.44 * asn));
   // pre-stall
   T CT_a = S.Cd0 * cs;
-  T CN_a = (Cl_lin + CT_a * sn) / cs;
+  T CN_a = (Cl_lin + CT_a * sn) * inv;
   T CM_a = -CN_a * ((T)0.25 - (T)0.175 * ((T)1 - ((T)2 * ae) * (T)(1.0 / kPi)));
   // post-stall
   T Cd90 = ((T)-4.26e-2 * (defl * defl)) + ((T)2.1e-1 * defl) + (T)1.98;
-  T CN_b = Cd90 * sn * ((T)1 / ((T)0.56 + (T)0.44 * M<T>::fabs_(sn)) - S.k_exp);
+  T CN_b = Cd90 * sn * (inv - S.k_exp);
   T CT_b = (T)0.5 * S.Cd0 * cs;
   T CM_b = -CN_b * ((T)0.25 - (T)0.175 * ((T)1 - ((T)2 * M<T>::fabs_(ae)) * (T)(1.0 / kPi)));
 
@@ -261,11 +384,10 @@ __device__ __forceinline__ void surface_wrench(const SurfC<T>& S, T act, const T
   T Fn = hV * (Cl * v_f - Cd * v_l);
   T Fp = hV * (-Cl * v_l - Cd * v_f);
   T Mq = S.hra * V2 * CM * S.chord;
-  T f[3] = { S.lift[0] * Fn + S.fwd[0] * Fp, S.lift[1] * Fn + S.fwd[1] * Fp, S.lift[2] * Fn + S.fwd[2] * Fp };
+  f[0] = S.lift[0] * Fn + S.fwd[0] * Fp; f[1] = S.lift[1] * Fn + S.fwd[1] * Fp; f[2] = S.lift[2] * Fn + S.fwd[2] * Fp;
   T rxf[3];
   cross(S.pos, f, rxf);
-  F[0] += f[0]; F[1] += f[1]; F[2] += f[2];
-  Tq[0] += rxf[0] + Mq * S.tq[0]; Tq[1] += rxf[1] + Mq * S.tq[1]; Tq[2] += rxf[2] + Mq * S.tq[2];
+  tq[0] = rxf[0] + Mq * S.tq[0]; tq[1] = rxf[1] + Mq * S.tq[1]; tq[2] = rxf[2] + Mq * S.tq[2];
 }
 
 // wind vector at time t (envs/fixedwing_envs/fixedwing_base_env.py:145-171)
@@ -278,36 +400,61 @@ __device__ __forceinline__ void wind_at(const Params<T>& P, const T wb[3], const
   w[0] = wb[0] + wa[0] * s; w[1] = wb[1] + wa[1] * s; w[2] = wb[2] + wa[2] * s;
 }
 
-// One 1/240 s physics tick.  Returns true if a body-fixed collision point touched z<=0.
+// Exponential-map quaternion update (Bullet): q <- normalize(dq(w dt) (x) q).
+// sin(th)/th and cos(th), th = |w| dt / 2 <= pi/8, are even polynomials in th^2, so no
+// sqrt / sincos / division sits on the critical path; the angular-motion clamp
+// (|w| dt > pi/4, i.e. > 188 rad/s) takes the literal formula on a rare branch.
 template <typename T>
-__device__ __forceinline__ bool physics_tick(const Params<T>& P, Rigid<T>& S, const T cmd[FW_NUM_ACTUATORS], T noise_z,
-                                             const T wind[3]) {
+__device__ __forceinline__ void quat_integrate(const Params<T>& P, Rigid<T>& S) {
   const T dt = P.dt;
-  // actuator lags
+  T w2 = S.w[0] * S.w[0] + S.w[1] * S.w[1] + S.w[2] * S.w[2];
+  T hdt = (T)0.5 * dt;
+  T x = w2 * hdt * hdt;                         // th^2
+  T x2 = x * x, x4 = x2 * x2;
+  T s01 = (T)1 + x * (T)(-1.0 / 6.0), s23 = (T)(1.0 / 120.0) + x * (T)(-1.0 / 5040.0);
+  T s45 = (T)(1.0 / 362880.0) + x * (T)(-1.0 / 39916800.0), s67 = (T)(1.0 / 6227020800.0) + x * (T)(-1.0 / 1307674368000.0);
+  T sinc = (s01 + s23 * x2) + (s45 + s67 * x2) * x4;
+  T c01 = (T)1 + x * (T)-0.5, c23 = (T)(1.0 / 24.0) + x * (T)(-1.0 / 720.0);
+  T c45 = (T)(1.0 / 40320.0) + x * (T)(-1.0 / 3628800.0), c67 = (T)(1.0 / 479001600.0) + x * (T)(-1.0 / 87178291200.0);
+  T ch = (c01 + c23 * x2) + (c45 + c67 * x2 + (T)(1.0 / 20922789888000.0) * x4) * x4;
+  T k = sinc * hdt;                              // sin(th)/|w|
+  const T lim = (T)(0.25 * kPi);
+  if (w2 * dt * dt > lim * lim) {                // ANGULAR_MOTION_THRESHOLD clamp (rare)
+    T ang = lim * P.physics_hz_T;
+    T sh;
+    M<T>::sincos_((T)0.5 * ang * dt, &sh, &ch);
+    k = M<T>::div_(sh, ang);
+  }
+  T ax = S.w[0] * k, ay = S.w[1] * k, az = S.w[2] * k;
+  T qx = S.q[0], qy = S.q[1], qz = S.q[2], qw = S.q[3];
+  T nx = ch * qx + ax * qw + ay * qz - az * qy;
+  T ny = ch * qy + ay * qw + az * qx - ax * qz;
+  T nz = ch * qz + az * qw + ax * qy - ay * qx;
+  T nw = ch * qw - ax * qx - ay * qy - az * qz;
+  T n2 = nx * nx + ny * ny + nz * nz + nw * nw;
+  T e = n2 - (T)1;                               // 1/sqrt(1+e) series; exact path for un-normalised input
+  T inv = (T)1 + e * ((T)-0.5 + e * ((T)0.375 + e * ((T)-0.3125 + e * (T)0.2734375)));
+  if (M<T>::fabs_(e) >= (T)1e-4) inv = M<T>::rcp_(M<T>::sqrt_(n2));
+  S.q[0] = nx * inv; S.q[1] = ny * inv; S.q[2] = nz * inv; S.q[3] = nw * inv;
+}
+
+// ---- one 1/240 s physics tick, in three stages ----
+// (1) actuator lags
+template <typename T>
+__device__ __forceinline__ void tick_actuators(const Params<T>& P, Rigid<T>& S, const T cmd[FW_NUM_ACTUATORS], T noise_z) {
 #pragma unroll
   for (int s = 0; s < FW_NUM_SURFACES; ++s) S.act[s] += P.s[s].dt_tau * (cmd[s] - S.act[s]);
   T thr = S.act[FW_NUM_SURFACES];
   thr += P.motor_dt_tau * (cmd[FW_NUM_SURFACES] - thr);
   thr += noise_z * thr * P.noise_ratio;
   S.act[FW_NUM_SURFACES] = thr;
-
-  T R[9];
-  rot_from_quat(S.q, R);
-  T v_b[3], w_b[3], wind_b[3] = {(T)0, (T)0, (T)0};
-  mtv(R, S.v, v_b);
-  mtv(R, S.w, w_b);
-  if (P.wind_coupling == FW_WIND_COUPLE_AIRSPEED) mtv(R, wind, wind_b);
-
-  T F[3] = {(T)0, (T)0, (T)0}, Tq[3] = {(T)0, (T)0, (T)0};
-  // rolled on purpose: per-surface constants are fetched by scalar loads at a
-  // wave-uniform runtime index; unrolling makes hipcc hoist ~100 constants into
-  // SGPRs for the whole kernel and spill them (724 SGPR spills, 256 VGPRs).
-#pragma unroll 1
-  for (int s = 0; s < FW_NUM_SURFACES; ++s) {
-    T a_s = (s == 0) ? S.act[0] : (s == 1) ? S.act[1] : (s == 2) ? S.act[2] : (s == 3) ? S.act[3] : S.act[4];
-    surface_wrench(P.s[s], a_s, v_b, w_b, wind_b, F, Tq);
-  }
+}
+// (3) motor + integration + contacts, given the summed surface wrench (F, Tq) in the body frame
+template <typename T, bool WIND, int G>
+__device__ __forceinline__ bool tick_integrate(const Params<T>& P, Rigid<T>& S, const T w_b[3], T F[3], T Tq[3], const T wind[3]) {
+  const T dt = P.dt;
   {
+    T thr = S.act[FW_NUM_SURFACES];
     T t2 = thr * thr;
     T f[3] = { t2 * P.m_force[0], t2 * P.m_force[1], t2 * P.m_force[2] };
     T rxf[3];
@@ -315,13 +462,14 @@ __device__ __forceinline__ bool physics_tick(const Params<T>& P, Rigid<T>& S, co
     F[0] += f[0]; F[1] += f[1]; F[2] += f[2];
     Tq[0] += rxf[0] + t2 * P.m_torque[0]; Tq[1] += rxf[1] + t2 * P.m_torque[1]; Tq[2] += rxf[2] + t2 * P.m_torque[2];
   }
+  T R[9];
+  rot_from_quat(S.q, R);      // recomputed (30 flops) rather than kept live across the surface evaluation
   T Fw[3];
   mv(R, F, Fw);
-  if (P.wind_coupling == FW_WIND_COUPLE_FORCE) {
+  if (WIND && P.wind_coupling == FW_WIND_COUPLE_FORCE) {
     Fw[0] += P.wind_force_coef * wind[0]; Fw[1] += P.wind_force_coef * wind[1]; Fw[2] += P.wind_force_coef * wind[2];
   }
   T acc[3] = { Fw[0] * P.inv_mass, Fw[1] * P.inv_mass, Fw[2] * P.inv_mass - P.gravity };
-
   T Iw[3], rhs[3] = { Tq[0], Tq[1], Tq[2] }, al_b[3], al_w[3];
   mv(P.I, w_b, Iw);
   if (P.gyroscopic) {
@@ -331,37 +479,21 @@ __device__ __forceinline__ bool physics_tick(const Params<T>& P, Rigid<T>& S, co
   }
   mv(P.Iinv, rhs, al_b);
   mv(R, al_b, al_w);
-
 #pragma unroll
   for (int k = 0; k < 3; ++k) { S.v[k] += acc[k] * dt; S.w[k] += al_w[k] * dt; }
 #pragma unroll
   for (int k = 0; k < 3; ++k) S.p[k] += S.v[k] * dt;
-
-  // exponential-map quaternion update (Bullet), dq(w*dt) (x) q, renormalised
-  {
-    T ang = M<T>::sqrt_(S.w[0] * S.w[0] + S.w[1] * S.w[1] + S.w[2] * S.w[2]);
-    const T lim = (T)(0.25 * kPi);
-    ang = (ang * dt > lim) ? lim / dt : ang;
-    T sh, ch;
-    M<T>::sincos_((T)0.5 * ang * dt, &sh, &ch);
-    T k_small = (T)0.5 * dt - (dt * dt * dt) * (T)0.020833333333 * ang * ang;
-    T k = (ang < (T)0.001) ? k_small : sh / ang;
-    T ax = S.w[0] * k, ay = S.w[1] * k, az = S.w[2] * k;
-    T x = S.q[0], y = S.q[1], z = S.q[2], w = S.q[3];
-    T nx = ch * x + ax * w + ay * z - az * y;
-    T ny = ch * y + ay * w + az * x - ax * z;
-    T nz = ch * z + az * w + ax * y - ay * x;
-    T nw = ch * w - ax * x - ay * y - az * z;
-    T inv = (T)1 / M<T>::sqrt_(nx * nx + ny * ny + nz * nz + nw * nw);
-    S.q[0] = nx * inv; S.q[1] = ny * inv; S.q[2] = nz * inv; S.q[3] = nw * inv;
-  }
+  quat_integrate<T>(P, S);
   // contacts: third row of R(q_new) dotted with the body-fixed points
+  T x = S.q[0], y = S.q[1], z = S.q[2], w = S.q[3];
+  T s2 = two_over_norm2<T>(x * x + y * y + z * z + w * w);
+  T r6 = (x * z - w * y) * s2, r7 = (y * z + w * x) * s2, r8 = (T)1 - (x * x + y * y) * s2;
   bool contact = false;
-  {
-    T x = S.q[0], y = S.q[1], z = S.q[2], w = S.q[3];
-    T d = x * x + y * y + z * z + w * w;
-    T s2 = (T)2 / d;
-    T r6 = (x * z - w * y) * s2, r7 = (y * z + w * x) * s2, r8 = (T)1 - (x * x + y * y) * s2;
+  if (G == 8) {                // lane `sub` tests point `sub`; OR over the group
+    const int sub = threadIdx.x & 7;
+    T zc = S.p[2] + r6 * P.coll[sub][0] + r7 * P.coll[sub][1] + r8 * P.coll[sub][2];
+    contact = group_any<8>(sub < P.n_coll && zc <= (T)0);
+  } else {
     for (int i = 0; i < P.n_coll; ++i) {
       T zc = S.p[2] + r6 * P.coll[i][0] + r7 * P.coll[i][1] + r8 * P.coll[i][2];
       contact |= (zc <= (T)0);
@@ -370,18 +502,54 @@ __device__ __forceinline__ bool physics_tick(const Params<T>& P, Rigid<T>& S, co
   return contact;
 }
 
-// Aviary.step(): ticks_per_aviary ticks; returns any-contact
-template <typename T>
+// Full tick.  G = 1: rolled loop over the 5 surfaces (constants by scalar loads at a
+// wave-uniform index -- unrolling makes hipcc hoist ~100 constants into SGPRs and spill).
+// G = 8: `mine` holds this lane's surface constants in VGPRs, `wmask` zeroes lanes 5-7.
+template <typename T, bool WIND, int G>
+__device__ __forceinline__ bool physics_tick(const Params<T>& P, Rigid<T>& S, const T cmd[FW_NUM_ACTUATORS], T noise_z,
+                                             const T wind[3], const SurfC<T>& mine, T wmask) {
+  tick_actuators<T>(P, S, cmd, noise_z);
+  T R[9];
+  rot_from_quat(S.q, R);
+  T v_b[3], w_b[3], wind_b[3] = {(T)0, (T)0, (T)0};
+  mtv(R, S.v, v_b);
+  mtv(R, S.w, w_b);
+  if (WIND && P.wind_coupling == FW_WIND_COUPLE_AIRSPEED) mtv(R, wind, wind_b);
+  T F[3] = {(T)0, (T)0, (T)0}, Tq[3] = {(T)0, (T)0, (T)0};
+  if (G == 8) {
+    const int sub = threadIdx.x & 7;
+    T a_s = S.act[0];
+    a_s = (sub == 1) ? S.act[1] : a_s; a_s = (sub == 2) ? S.act[2] : a_s;
+    a_s = (sub == 3) ? S.act[3] : a_s; a_s = (sub >= 4) ? S.act[4] : a_s;
+    T f[3], tq[3];
+    surface_wrench<T>(mine, a_s, v_b, w_b, wind_b, f, tq);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { F[k] = group_sum<8, T>(f[k] * wmask); Tq[k] = group_sum<8, T>(tq[k] * wmask); }
+  } else {
+#pragma unroll 1
+    for (int s = 0; s < FW_NUM_SURFACES; ++s) {
+      T a_s = (s == 0) ? S.act[0] : (s == 1) ? S.act[1] : (s == 2) ? S.act[2] : (s == 3) ? S.act[3] : S.act[4];
+      T f[3], tq[3];
+      surface_wrench<T>(P.s[s], a_s, v_b, w_b, wind_b, f, tq);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { F[k] += f[k]; Tq[k] += tq[k]; }
+    }
+  }
+  return tick_integrate<T, WIND, G>(P, S, w_b, F, Tq, wind);
+}
+
+// Aviary.step(): ticks_per_aviary ticks; returns any-contact.  (z0, z1) are the two
+// ticks' motor-noise normals (zero for warm-up lanes: their throttle is exactly 0).
+template <typename T, bool WIND, int G>
 __device__ __forceinline__ bool aviary_step(const Params<T>& P, Rigid<T>& S, const T cmd[FW_NUM_ACTUATORS], int32_t& tick,
-                                            uint32_t genv, uint32_t ep, const T wb[3], const T wa[3], T wphase) {
-  T z0 = (T)0, z1 = (T)0;
-  if (P.has_noise) rng_normal2<T>(P, genv, ep, (uint32_t)(tick / P.ticks_per_aviary), z0, z1);
+                                            T z0, T z1, const T wb[3], const T wa[3], T wphase,
+                                            const SurfC<T>& mine, T wmask) {
   bool contact = false;
 #pragma unroll 1
   for (int t = 0; t < P.ticks_per_aviary; ++t) {
-    T wind[3];
-    wind_at<T>(P, wb, wa, wphase, tick, wind);
-    contact |= physics_tick<T>(P, S, cmd, (t & 1) ? z1 : z0, wind);
+    T wind[3] = {(T)0, (T)0, (T)0};
+    if (WIND) wind_at<T>(P, wb, wa, wphase, tick, wind);
+    contact |= physics_tick<T, WIND, G>(P, S, cmd, (t & 1) ? z1 : z0, wind, mine, wmask);
     tick += 1;
   }
   return contact;
@@ -484,15 +652,21 @@ __device__ __forceinline__ void store_rigid(const DevState<T>& D, int env, const
 }
 
 // ------------------------------------------------------------------------
-// reset of one env (begin_reset / scenario sampling / end_reset)
+// reset of one env, split like the reference: begin_reset (+ scenario sampling)
+// and end_reset; the warm-up Aviary steps in between are run by the caller's
+// single tick loop (so the tick is inlined exactly once per kernel).
 // ------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void reset_env(const Params<T>& P, const DevState<T>& D, int env, Rigid<T>& S, int32_t& tick,
-                                          int32_t& episode, int32_t& num_reached, T& new_dist, T wb[3], T wa[3], T& wphase) {
+// Returns the number of warm-up Aviary steps still to run (0 when the cached
+// env-independent warm state could be copied).  G = 8: lane `sub` samples waypoint
+// `sub` (num_targets <= 8 = group size); only the group leader stores wind.
+template <typename T, int G>
+__device__ __forceinline__ int begin_reset(const Params<T>& P, const DevState<T>& D, int env, Rigid<T>& S, int32_t& tick,
+                                           int32_t& episode, int32_t& num_reached, T wb[3], T wa[3], T& wphase) {
   episode += 1;
   const uint32_t ep = (uint32_t)episode;
   const uint32_t genv = (uint32_t)(P.env_offset + env);
   const size_t n = D.npad;
+  const int sub = (G == 1) ? 0 : (int)(threadIdx.x & (G - 1));
   // wind: base(3), gust amp(3), phase -- fixedwing_base_env.py:139-165
 #pragma unroll
   for (int k = 0; k < 3; ++k) { wb[k] = P.wind_base[k]; wa[k] = P.wind_amp[k]; }
@@ -506,20 +680,22 @@ __device__ __forceinline__ void reset_env(const Params<T>& P, const DevState<T>&
       if (P.wind_randomize_phase) wphase = (T)rng_uniform<T>(P, genv, ep, J_WIND_PHASE, 0.0, 2.0 * kPi);
     }
   }
-  if (P.wind_mode != FW_WIND_OFF) {
+  if (P.wind_mode != FW_WIND_OFF && sub == 0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) { D.r[(RF_WIND + k) * n + env] = wb[k]; D.r[(RF_WIND + 3 + k) * n + env] = wa[k]; }
     D.r[(RF_WIND + 6) * n + env] = wphase;
   }
   // WaypointHandler.reset: polar sampling (always in double, cast once)
   if (P.task != FW_TASK_OBJLOCK) {
-    for (int i = 0; i < P.num_targets; ++i) {
+    const int i0 = (G == 1) ? 0 : sub, i1 = (G == 1) ? P.num_targets : min(sub + 1, P.num_targets);
+#pragma unroll 1
+    for (int i = i0; i < i1; ++i) {
       double theta = rng_uniform<T>(P, genv, ep, J_THETA + i, 0.0, 2.0 * kPi);
       double phi = rng_uniform<T>(P, genv, ep, J_PHI + i, 0.0, 2.0 * kPi);
       double dist = rng_uniform<T>(P, genv, ep, J_DIST + i, 1.0, (double)P.spawn_hi);
       double sphi, cphi, sth, cth;
-      ::sincos(phi, &sphi, &cphi);
-      ::sincos(theta, &sth, &cth);
+      M<double>::sincos_(phi, &sphi, &cphi);
+      M<double>::sincos_(theta, &sth, &cth);
       double x = dist * sphi * cth, y = dist * sphi * sth, z = ::fabs(dist * cphi);
       z = z > (double)P.min_height ? z : (double)P.min_height;
       T* tp = D.r + (size_t)(RF_TARGETS + 3 * i) * n + env;
@@ -527,8 +703,7 @@ __device__ __forceinline__ void reset_env(const Params<T>& P, const DevState<T>&
     }
   }
   num_reached = 0;
-  // Aviary(): start pose + PyFlyt starting velocity, zero actuators; then the
-  // 10 warm-up Aviary steps with a zero setpoint (fixedwing_base_env.py:254-255).
+  // Aviary(): start pose + PyFlyt starting velocity, zero actuators
   if (P.warm_valid) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) { S.p[k] = P.warm[k]; S.v[k] = P.warm[7 + k]; S.w[k] = P.warm[10 + k]; }
@@ -537,34 +712,59 @@ __device__ __forceinline__ void reset_env(const Params<T>& P, const DevState<T>&
 #pragma unroll
     for (int k = 0; k < FW_NUM_ACTUATORS; ++k) S.act[k] = P.warm[13 + k];
     tick = P.warm_ticks;
-  } else {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { S.p[k] = P.start_pos[k]; S.v[k] = P.start_vel[k]; S.w[k] = (T)0; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) S.q[k] = P.start_quat[k];
-#pragma unroll
-    for (int k = 0; k < FW_NUM_ACTUATORS; ++k) S.act[k] = (T)0;
-    tick = 0;
-    T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
-#pragma unroll 1
-    for (int i = 0; i < P.warmup_aviary_steps; ++i) (void)aviary_step<T>(P, S, cmd0, tick, genv, ep, wb, wa, wphase);
+    return 0;
   }
-  // end_reset -> compute_state: WaypointHandler distances (old=0 -> new)
-  new_dist = (T)0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { S.p[k] = P.start_pos[k]; S.v[k] = P.start_vel[k]; S.w[k] = (T)0; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) S.q[k] = P.start_quat[k];
+#pragma unroll
+  for (int k = 0; k < FW_NUM_ACTUATORS; ++k) S.act[k] = (T)0;
+  tick = 0;
+  return P.warmup_aviary_steps;
+}
+
+// first waypoint of the episode that was just sampled (regenerated from the RNG so that
+// no lane has to read back what another lane has just stored)
+template <typename T>
+__device__ __forceinline__ void first_target(const Params<T>& P, uint32_t genv, uint32_t ep, T t0[3]) {
+  double theta = rng_uniform<T>(P, genv, ep, J_THETA, 0.0, 2.0 * kPi);
+  double phi = rng_uniform<T>(P, genv, ep, J_PHI, 0.0, 2.0 * kPi);
+  double dist = rng_uniform<T>(P, genv, ep, J_DIST, 1.0, (double)P.spawn_hi);
+  double sphi, cphi, sth, cth;
+  M<double>::sincos_(phi, &sphi, &cphi);
+  M<double>::sincos_(theta, &sth, &cth);
+  double z = ::fabs(dist * cphi);
+  t0[0] = (T)(dist * sphi * cth); t0[1] = (T)(dist * sphi * sth);
+  t0[2] = (T)(z > (double)P.min_height ? z : (double)P.min_height);
+}
+
+// end_reset -> compute_state: WaypointHandler distances (old = 0 -> new)
+template <typename T, int G>
+__device__ __forceinline__ T end_reset(const Params<T>& P, const DevState<T>& D, int env, int32_t episode, const Rigid<T>& S) {
+  T new_dist = (T)0;
   if (P.task != FW_TASK_OBJLOCK && P.num_targets > 0) {
-    const T* tp = D.r + (size_t)RF_TARGETS * n + env;
-    T dx = tp[0] - S.p[0], dy = tp[n] - S.p[1], dz = tp[2 * n] - S.p[2];
+    T t0[3];
+    if (G == 1) {
+      const size_t n = D.npad;
+      const T* tp = D.r + (size_t)RF_TARGETS * n + env;
+      t0[0] = tp[0]; t0[1] = tp[n]; t0[2] = tp[2 * n];
+    } else {
+      first_target<T>(P, (uint32_t)(P.env_offset + env), (uint32_t)episode, t0);
+    }
+    T dx = t0[0] - S.p[0], dy = t0[1] - S.p[1], dz = t0[2] - S.p[2];
     new_dist = M<T>::sqrt_(dx * dx + dy * dy + dz * dz);
   }
+  return new_dist;
 }
 
 // ------------------------------------------------------------------------
-// LDS-staged, coalesced store of a [64 x D] observation tile
+// LDS-staged, coalesced store of a [rows x D] observation tile
 // ------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void flush_obs_tile(const T* tile, int ld, T* obs, int blk_env0, int n, int D) {
-  // tile[lane*ld + k]; global rows [blk_env0, blk_env0+64) are one contiguous span of 64*D elements
-  const int rows = min(kWave, n - blk_env0);
+__device__ __forceinline__ void flush_obs_tile(const T* tile, int ld, T* obs, int blk_env0, int rows_max, int n, int D) {
+  // tile[row*ld + k]; global rows [blk_env0, blk_env0+rows) are one contiguous span of rows*D elements
+  const int rows = min(rows_max, n - blk_env0);
   const int total = rows * D;
   T* dst = obs + (size_t)blk_env0 * D;
   for (int e = threadIdx.x; e < total; e += kWave) {

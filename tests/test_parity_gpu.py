@@ -59,8 +59,15 @@ def _mutate(cfg, **kw):
 CASES = {name: (cfg, kind) for name, cfg, kind in lockstep_cases()}
 
 
+@pytest.fixture(params=[1, 8], ids=["lane_per_env", "8_lanes_per_env"])
+def lanes(request, monkeypatch):
+    """Both lane mappings of the kernel (fwsim_device.hpp) must pass every parity test."""
+    monkeypatch.setenv("FWSIM_LANES_PER_ENV", str(request.param))
+    return request.param
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_lockstep_f64(oracle, name):
+def test_lockstep_f64(oracle, name, lanes):
     cfg, kind = CASES[name]
     n = 192 + 7                                      # deliberately not a multiple of 64
     hip = P.FixedwingVecEnv(cfg, n, seed=1234)
@@ -71,7 +78,7 @@ def test_lockstep_f64(oracle, name):
         assert worst["dones"] > 0, "case was meant to exercise the auto-reset path"
 
 
-def test_baseline_size_4096_envs_against_oracle(oracle):
+def test_baseline_size_4096_envs_against_oracle(oracle, lanes):
     """configs[1] of BASELINE.json: 4096 envs; 24 steps is what the scalar oracle does in ~2 s."""
     cfg = K.train_waypoints_v3_config()
     hip = P.FixedwingVecEnv(cfg, 4096, seed=42)
@@ -79,7 +86,7 @@ def test_baseline_size_4096_envs_against_oracle(oracle):
     run_lockstep(hip, ora, 24, np.random.default_rng(0), kind="uniform", atol=1e-7, rtol=0)
 
 
-def test_gimbal_guard_branch(oracle):
+def test_gimbal_guard_branch(oracle, lanes):
     """pybullet's getEulerFromQuaternion switches formulas at |sin(pitch)| >= 0.99999; the
     kernel takes the Euler->quaternion round trip only there.  Force it."""
     cfg = K.waypoints_config(sparse_reward=False, num_targets=3, angle_representation="euler", motor_noise=False,
@@ -107,7 +114,7 @@ def test_gimbal_guard_branch(oracle):
     np.testing.assert_allclose(hip.obs.cpu().numpy(), o2[0], rtol=0, atol=1e-8)
 
 
-def test_truncation_timing_matches_reference_quirk():
+def test_truncation_timing_matches_reference_quirk(lanes):
     """strict '>' and a post-incremented counter => first truncation on call max_steps+2
     (envs/fixedwing_envs/fixedwing_base_env.py:299,346)."""
     import torch
@@ -127,7 +134,23 @@ def test_truncation_timing_matches_reference_quirk():
     assert first == 32
 
 
-def test_sharding_is_world_size_independent():
+def test_lane_mappings_agree_with_each_other(monkeypatch):
+    """The two lane mappings sum the surface wrench in a different order; they must still agree to rounding."""
+    import torch
+    cfg = K.train_waypoints_v3_config()
+    monkeypatch.setenv("FWSIM_LANES_PER_ENV", "1"); a = P.FixedwingVecEnv(cfg, 1000, seed=5)
+    monkeypatch.setenv("FWSIM_LANES_PER_ENV", "8"); b = P.FixedwingVecEnv(cfg, 1000, seed=5)
+    assert torch.equal(a.reset_tensor(), b.reset_tensor())
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for _ in range(100):
+        act = (torch.rand((1000, 4), generator=g, dtype=torch.float64) * 2 - 1).to(a.device)
+        a.step_tensor(act); b.step_tensor(act)
+        assert torch.equal(a.terminated, b.terminated) and torch.equal(a.truncated, b.truncated)
+        assert torch.equal(a.info, b.info)
+        assert (a.obs - b.obs).abs().max().item() < 1e-9 and torch.equal(a.rewards, b.rewards)
+
+
+def test_sharding_is_world_size_independent(lanes):
     """rank r of a sharded job (global_env_offset = r*N_local) reproduces envs [r*N_local, ...) of one big job, bit for bit."""
     import torch
     cfg = K.train_waypoints_v3_config()
@@ -143,7 +166,7 @@ def test_sharding_is_world_size_independent():
         assert torch.equal(big.terminated[3072:], shard.terminated) and torch.equal(big.info[3072:], shard.info)
 
 
-def test_properties_at_baseline_size():
+def test_properties_at_baseline_size(lanes):
     """Size-independent invariants at N=4096 over 300 steps of random actions."""
     import torch
     cfg = K.train_waypoints_v3_config()
@@ -178,7 +201,7 @@ def test_properties_at_baseline_size():
     np.testing.assert_array_equal(env.obs.cpu().numpy()[:, 16:22], s[:, K.S_ACT:K.S_ACT + 6])
 
 
-def test_reset_mask_and_seed(oracle):
+def test_reset_mask_and_seed(oracle, lanes):
     import torch
     cfg = K.train_waypoints_v3_config(motor_noise=False)
     n = 130
@@ -206,7 +229,7 @@ def test_reset_mask_and_seed(oracle):
     np.testing.assert_allclose(a1.cpu().numpy(), ora.reset(), rtol=0, atol=1e-9)
 
 
-def test_abi_writes_stay_inside_the_buffers():
+def test_abi_writes_stay_inside_the_buffers(lanes):
     """Call fw_step directly with sentinel-padded buffers for N not a multiple of the wave size."""
     import torch
     cfg = K.train_waypoints_v3_config()
