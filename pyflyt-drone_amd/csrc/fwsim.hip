@@ -42,7 +42,12 @@ __global__ void fw_warm_kernel(Params<T>* Pm) {
   T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
   T wind0[3] = {(T)0, (T)0, (T)0};
   int ticks = P.warmup_aviary_steps * P.ticks_per_aviary;
-  for (int t = 0; t < ticks; ++t) (void)physics_tick<T, false, 1>(P, S, cmd0, (T)0, wind0, P.s[0], (T)1);
+  TickC<T> C; SurfC<T> mine; T wmask;
+  load_tick_constants<T, 1>(Pm, C, mine, wmask);
+  T R[9];
+  normalize_quat<T>(S.q);
+  rot_from_unit_quat<T>(S.q, R);
+  for (int t = 0; t < ticks; ++t) (void)physics_tick<T, false, 1>(P, C, S, R, cmd0, (T)0, wind0, mine, wmask);
   for (int k = 0; k < 3; ++k) { Pm->warm[k] = S.p[k]; Pm->warm[7 + k] = S.v[k]; Pm->warm[10 + k] = S.w[k]; }
   for (int k = 0; k < 4; ++k) Pm->warm[3 + k] = S.q[k];
   for (int k = 0; k < FW_NUM_ACTUATORS; ++k) Pm->warm[13 + k] = S.act[k];
@@ -77,10 +82,10 @@ enum Phase : int { PH_STEP = 0, PH_WARM = 1, PH_DONE = 2 };
 // GENERAL = wind is on (per-env wind registers, and -- if it acts on the dynamics -- the
 // PH_WARM path).  The wind-free instantiation (the headline config) carries none of that.
 template <typename T, bool GENERAL, int G>
-__global__ __launch_bounds__(kWave)
-void fw_step_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restrict__ actions, T* __restrict__ obs,
-                    T* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
-                    T* __restrict__ terminal_obs, int32_t* __restrict__ info) {
+__device__ __forceinline__
+void step_body(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restrict__ actions, T* __restrict__ obs,
+               T* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
+               T* __restrict__ terminal_obs, int32_t* __restrict__ info) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
   const Params<T>& P = *Pp;
@@ -97,12 +102,15 @@ void fw_step_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __
   const int Dobs = P.obs_dim;
   const int ld = Dobs + 1;
 
-  // this lane's lifting surface (G = 8): constants live in VGPRs for the whole launch
-  const SurfC<T> mine = P.s[(G == 1) ? 0 : min(sub, FW_NUM_SURFACES - 1)];
-  const T wmask = (sub < FW_NUM_SURFACES) ? (T)1 : (T)0;
+  // tick constants + this lane's lifting surface (G = 8: resident in VGPRs for the whole launch)
+  TickC<T> C; SurfC<T> mine; T wmask;
+  load_tick_constants<T, G>(Pp, C, mine, wmask);
 
   Rigid<T> S;
   load_rigid<T>(D, envc, S);
+  normalize_quat<T>(S.q);
+  T R[9];
+  rot_from_unit_quat<T>(S.q, R);
   int32_t step_count = D.i[IF_STEP * n + envc];
   int32_t tick = D.i[IF_TICK * n + envc];
   int32_t episode = D.i[IF_EPISODE * n + envc];
@@ -125,6 +133,17 @@ void fw_step_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __
 #pragma unroll
     for (int c = 0; c < FW_NUM_ACTUATORS; ++c)
       cmd[c] = P.mixer[c][0] * sp[0] + P.mixer[c][1] * sp[1] + P.mixer[c][2] * sp[2] + P.mixer[c][3] * sp[3];
+  }
+
+  // current and next waypoint stay in registers (no L2 round trip per sub-step)
+  T tcur[3] = {(T)0, (T)0, (T)0}, tnext[3] = {(T)0, (T)0, (T)0};
+  if (P.task != FW_TASK_OBJLOCK) {
+    const int i0 = min(num_reached, FW_MAX_TARGETS - 1), i1 = min(num_reached + 1, FW_MAX_TARGETS - 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      tcur[k] = D.r[(size_t)(RF_TARGETS + 3 * i0 + k) * n + envc];
+      tnext[k] = D.r[(size_t)(RF_TARGETS + 3 * i1 + k) * n + envc];
+    }
   }
 
   const uint32_t genv = (uint32_t)(P.env_offset + envc);
@@ -169,6 +188,7 @@ void fw_step_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __
         warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase);
         step_count = 0; flags = 0; ep_return = (T)0; tgt_obs = 0;
         act_src = 2;
+        rot_from_unit_quat<T>(S.q, R);
         if (GENERAL && warm_left > 0) phase = PH_WARM;
         else new_dist = end_reset<T, G>(P, D, env, episode, S);
       }
@@ -190,17 +210,16 @@ void fw_step_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __
 #pragma unroll
         for (int c = 0; c < FW_NUM_ACTUATORS; ++c) c_eff[c] = stepping ? cmd[c] : (T)0;
         z0 = stepping ? z0 : (T)0; z1 = stepping ? z1 : (T)0;
-        contact = aviary_step<T, true, G>(P, S, c_eff, tick, z0, z1, wb, wa, wphase, mine, wmask);   // :339
+        contact = aviary_step<T, true, G>(P, C, S, R, c_eff, tick, z0, z1, wb, wa, wphase, mine, wmask);   // :339
       } else {
-        contact = aviary_step<T, false, G>(P, S, cmd, tick, z0, z1, wb, wa, wphase, mine, wmask);    // :339
+        contact = aviary_step<T, false, G>(P, C, S, R, cmd, tick, z0, z1, wb, wa, wphase, mine, wmask);    // :339
       }
       if (stepping) {
         // compute_state(): WaypointHandler.distance_to_targets side effects
         const int nleft = P.num_targets - num_reached;
         const T old_dist = new_dist;
         if (P.task != FW_TASK_OBJLOCK && nleft > 0) {
-          const T* tp = D.r + (size_t)(RF_TARGETS + 3 * num_reached) * n + env;
-          T dx = tp[0] - S.p[0], dy = tp[n] - S.p[1], dz = tp[2 * n] - S.p[2];
+          T dx = tcur[0] - S.p[0], dy = tcur[1] - S.p[1], dz = tcur[2] - S.p[2];
           new_dist = M<T>::sqrt_(dx * dx + dy * dy + dz * dz);
         }
         tgt_obs = num_reached;
@@ -219,6 +238,9 @@ void fw_step_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __
             rew = (T)100;
             num_reached += 1;
             if (num_reached == P.num_targets) flags |= FL_TRUNC | FL_COMPLETE;
+            const int i1 = min(num_reached + 1, FW_MAX_TARGETS - 1);       // advance_targets(): shift the register window
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { tcur[k] = tnext[k]; tnext[k] = D.r[(size_t)(RF_TARGETS + 3 * i1 + k) * n + env]; }
           }
         }
         step_over = (it + 1 >= P.step_ratio) || (flags & (FL_TERM | FL_TRUNC));     // :334-337
@@ -259,6 +281,26 @@ void fw_step_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __
   flush_obs_tile<T>(tile, ld, obs, env0, EPW, D.n, Dobs);
 }
 
+#ifndef FW_G1_WAVES
+#define FW_G1_WAVES 2   // env-per-lane mapping: cap registers for >= 2 waves/SIMD (TLP hides the scalar-load and fp64 latency)
+#endif
+// latency mapping (8 lanes per env): one wave per SIMD by construction, let the allocator use the whole file
+template <typename T, bool GENERAL>
+__global__ __launch_bounds__(kWave)
+void fw_step_kernel_g8(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restrict__ actions, T* __restrict__ obs,
+                       T* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
+                       T* __restrict__ terminal_obs, int32_t* __restrict__ info) {
+  step_body<T, GENERAL, 8>(Pp, D, actions, obs, reward, terminated, truncated, terminal_obs, info);
+}
+// throughput mapping (one lane per env)
+template <typename T, bool GENERAL>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(FW_G1_WAVES, FW_G1_WAVES)))
+void fw_step_kernel_g1(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restrict__ actions, T* __restrict__ obs,
+                       T* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
+                       T* __restrict__ terminal_obs, int32_t* __restrict__ info) {
+  step_body<T, GENERAL, 1>(Pp, D, actions, obs, reward, terminated, truncated, terminal_obs, info);
+}
+
 // K2: reset (masked) + observation.  Same single-tick-site structure (warm-up only).
 template <typename T, int G>
 __global__ __launch_bounds__(kWave)
@@ -279,8 +321,8 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const uint
   const size_t n = D.npad;
   const int Dobs = P.obs_dim;
   const int ld = Dobs + 1;
-  const SurfC<T> mine = P.s[(G == 1) ? 0 : min(sub, FW_NUM_SURFACES - 1)];
-  const T wmask = (sub < FW_NUM_SURFACES) ? (T)1 : (T)0;
+  TickC<T> C; SurfC<T> mine; T wmask;
+  load_tick_constants<T, G>(Pp, C, mine, wmask);
 
   Rigid<T> S;
   load_rigid<T>(D, envc, S);
@@ -298,10 +340,13 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const uint
     if (warm_left == 0) new_dist = end_reset<T, G>(P, D, env, episode, S);
   }
   const T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
+  T R[9];
+  normalize_quat<T>(S.q);
+  rot_from_unit_quat<T>(S.q, R);
 #pragma unroll 1
   while (__ballot(warm_left > 0) != 0ull) {
     if (warm_left > 0) {
-      (void)aviary_step<T, true, G>(P, S, cmd0, tick, (T)0, (T)0, wb, wa, wphase, mine, wmask);
+      (void)aviary_step<T, true, G>(P, C, S, R, cmd0, tick, (T)0, (T)0, wb, wa, wphase, mine, wmask);
       warm_left -= 1;
       if (warm_left == 0) new_dist = end_reset<T, G>(P, D, env, episode, S);
     }
@@ -335,7 +380,7 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const uint
 // ======================================================================
 namespace {
 
-constexpr int kG8MaxEnvs = 32768;
+constexpr int kG8MaxEnvs = 16384;   // measured crossover on MI355X: 8 lanes/env wins up to 2^14 envs (51 vs 70 us), loses at 2^15 (93 vs 76 us)
 thread_local std::string g_err;
 
 struct HostDerived {
@@ -428,6 +473,14 @@ bool build_params(const fw_config& c, uint64_t seed, int64_t env_offset, Params<
     P.m_force[k] = (T)(max_rpm * max_rpm * c.motor.thrust_coef * c.motor.thrust_unit[k]);
     P.m_torque[k] = (T)(max_rpm * max_rpm * c.motor.torque_coef * c.motor.thrust_unit[k]);
     P.m_pos[k] = (T)c.motor.pos[k];
+  }
+  {
+    const double f[3] = { max_rpm * max_rpm * c.motor.thrust_coef * c.motor.thrust_unit[0], max_rpm * max_rpm * c.motor.thrust_coef * c.motor.thrust_unit[1], max_rpm * max_rpm * c.motor.thrust_coef * c.motor.thrust_unit[2] };
+    const double* r = c.motor.pos;
+    const double tq[3] = { max_rpm * max_rpm * c.motor.torque_coef * c.motor.thrust_unit[0], max_rpm * max_rpm * c.motor.torque_coef * c.motor.thrust_unit[1], max_rpm * max_rpm * c.motor.torque_coef * c.motor.thrust_unit[2] };
+    P.m_wrench_t[0] = (T)(r[1] * f[2] - r[2] * f[1] + tq[0]);
+    P.m_wrench_t[1] = (T)(r[2] * f[0] - r[0] * f[2] + tq[1]);
+    P.m_wrench_t[2] = (T)(r[0] * f[1] - r[1] * f[0] + tq[2]);
   }
   for (int a = 0; a < FW_NUM_ACTUATORS; ++a) for (int k = 0; k < 4; ++k) P.mixer[a][k] = (T)c.mixer[a][k];
   P.inv_mass = (T)(1.0 / c.mass); P.gravity = (T)c.gravity;
@@ -544,9 +597,14 @@ int create_T(fw_env* h) {
 template <typename T, bool GENERAL, int G>
 void launch_step(fw_env* h, const void* actions, void* obs, void* reward, uint8_t* term, uint8_t* trunc, void* tobs,
                  int32_t* info, hipStream_t st) {
-  hipLaunchKernelGGL((fw_step_kernel<T, GENERAL, G>), grid_of(h), dim3(kWave), tile_bytes<T>(h), st,
-                     (const Params<T>*)h->params_dev, dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term,
-                     trunc, (T*)tobs, info);
+  if (G == 8)
+    hipLaunchKernelGGL((fw_step_kernel_g8<T, GENERAL>), grid_of(h), dim3(kWave), tile_bytes<T>(h), st,
+                       (const Params<T>*)h->params_dev, dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term,
+                       trunc, (T*)tobs, info);
+  else
+    hipLaunchKernelGGL((fw_step_kernel_g1<T, GENERAL>), grid_of(h), dim3(kWave), tile_bytes<T>(h), st,
+                       (const Params<T>*)h->params_dev, dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term,
+                       trunc, (T*)tobs, info);
 }
 
 template <typename T>

@@ -64,6 +64,7 @@ struct Params {
   SurfC<T> s[FW_NUM_SURFACES];
   T motor_dt_tau, noise_ratio;
   T m_force[3], m_torque[3], m_pos[3];   // thrust/torque at throttle=1 (max_rpm^2 * coef * unit)
+  T m_wrench_t[3];                       // m_pos x m_force + m_torque (motor torque about the COM at throttle=1)
   T mixer[FW_NUM_ACTUATORS][4];
   T inv_mass, gravity;
   T I[9], Iinv[9];
@@ -400,15 +401,94 @@ __device__ __forceinline__ void wind_at(const Params<T>& P, const T wb[3], const
   w[0] = wb[0] + wa[0] * s; w[1] = wb[1] + wa[1] * s; w[2] = wb[2] + wa[2] * s;
 }
 
+// ------------------------------------------------------------------------
+// Constants of the tick loop, gathered once per launch.
+//   G = 1: they stay wave-uniform (SGPRs / scalar cache).
+//   G = 8: loaded through a per-lane ("opaque") pointer so that they live in VGPRs for
+//          the whole launch.  rocprofv3 showed the uniform version spending ~30 % of the
+//          wave time in s_waitcnt behind in-loop scalar loads (98 SMEM per wave-step,
+//          SGPR file exhausted by fp64 pairs); with 512 VGPRs available and one wave
+//          per SIMD the vector file is the right home.
+// ------------------------------------------------------------------------
+template <typename T>
+struct TickC {
+  T dt_tau[FW_NUM_SURFACES];
+  T motor_dt_tau, noise_ratio;
+  T mF[3], mT[3];            // motor force / torque about the COM at throttle = 1
+  T inv_mass, gravity, dt, hdt;
+  T I[9], Iinv[9];
+  T wind_force_coef;
+  T cpt[3];                  // G = 8: this lane's collision point
+  T cvalid;                  // 1 if this lane's collision point exists
+};
+
+__device__ __forceinline__ int opaque_zero() {
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return z;
+}
+
+template <typename T, int G>
+__device__ __forceinline__ void load_tick_constants(const Params<T>* Pp, TickC<T>& C, SurfC<T>& mine, T& wmask) {
+  const int sub = (G == 1) ? 0 : (int)(threadIdx.x & (G - 1));
+  const Params<T>* Q = (G == 1) ? Pp : Pp + opaque_zero();     // per-lane address => vector loads => VGPR residency
+#pragma unroll
+  for (int s = 0; s < FW_NUM_SURFACES; ++s) C.dt_tau[s] = Q->s[s].dt_tau;
+  C.motor_dt_tau = Q->motor_dt_tau; C.noise_ratio = Q->noise_ratio;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { C.mF[k] = Q->m_force[k]; C.mT[k] = Q->m_wrench_t[k]; }
+  C.inv_mass = Q->inv_mass; C.gravity = Q->gravity; C.dt = Q->dt; C.hdt = (T)0.5 * Q->dt;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { C.I[k] = Q->I[k]; C.Iinv[k] = Q->Iinv[k]; }
+  C.wind_force_coef = Q->wind_force_coef;
+  const int ci = (G == 1) ? 0 : sub;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) C.cpt[k] = Q->coll[ci][k];
+  C.cvalid = (ci < Q->n_coll) ? (T)1 : (T)0;
+  mine = Q->s[(G == 1) ? 0 : min(sub, FW_NUM_SURFACES - 1)];
+  wmask = (sub < FW_NUM_SURFACES) ? (T)1 : (T)0;
+}
+
+// rotation matrix of a UNIT quaternion (s = 2 exactly); the tick keeps q normalised
+template <typename T>
+__device__ __forceinline__ void rot_from_unit_quat(const T q[4], T m[9]) {
+  T x = q[0], y = q[1], z = q[2], w = q[3];
+  T xs = x + x, ys = y + y, zs = z + z;
+  T wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+  m[0] = (T)1 - (yy + zz); m[1] = xy - wz;           m[2] = xz + wy;
+  m[3] = xy + wz;           m[4] = (T)1 - (xx + zz); m[5] = yz - wx;
+  m[6] = xz - wy;           m[7] = yz + wx;           m[8] = (T)1 - (xx + yy);
+}
+// bring an externally supplied quaternion (set_state) onto the unit sphere
+template <typename T>
+__device__ __forceinline__ void normalize_quat(T q[4]) {
+  T d = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (M<T>::fabs_(d - (T)1) > (T)1e-12) {
+    T inv = M<T>::rcp_(M<T>::sqrt_(d));
+    q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+  }
+}
+
+// ---- one 1/240 s physics tick, in three stages ----
+// (1) actuator lags
+template <typename T>
+__device__ __forceinline__ void tick_actuators(const TickC<T>& C, Rigid<T>& S, const T cmd[FW_NUM_ACTUATORS], T noise_z) {
+#pragma unroll
+  for (int s = 0; s < FW_NUM_SURFACES; ++s) S.act[s] += C.dt_tau[s] * (cmd[s] - S.act[s]);
+  T thr = S.act[FW_NUM_SURFACES];
+  thr += C.motor_dt_tau * (cmd[FW_NUM_SURFACES] - thr);
+  thr += noise_z * thr * C.noise_ratio;
+  S.act[FW_NUM_SURFACES] = thr;
+}
+
 // Exponential-map quaternion update (Bullet): q <- normalize(dq(w dt) (x) q).
 // sin(th)/th and cos(th), th = |w| dt / 2 <= pi/8, are even polynomials in th^2, so no
 // sqrt / sincos / division sits on the critical path; the angular-motion clamp
 // (|w| dt > pi/4, i.e. > 188 rad/s) takes the literal formula on a rare branch.
 template <typename T>
-__device__ __forceinline__ void quat_integrate(const Params<T>& P, Rigid<T>& S) {
-  const T dt = P.dt;
+__device__ __forceinline__ void quat_integrate(const TickC<T>& C, Rigid<T>& S) {
+  const T dt = C.dt, hdt = C.hdt;
   T w2 = S.w[0] * S.w[0] + S.w[1] * S.w[1] + S.w[2] * S.w[2];
-  T hdt = (T)0.5 * dt;
   T x = w2 * hdt * hdt;                         // th^2
   T x2 = x * x, x4 = x2 * x2;
   T s01 = (T)1 + x * (T)(-1.0 / 6.0), s23 = (T)(1.0 / 120.0) + x * (T)(-1.0 / 5040.0);
@@ -420,7 +500,7 @@ __device__ __forceinline__ void quat_integrate(const Params<T>& P, Rigid<T>& S) 
   T k = sinc * hdt;                              // sin(th)/|w|
   const T lim = (T)(0.25 * kPi);
   if (w2 * dt * dt > lim * lim) {                // ANGULAR_MOTION_THRESHOLD clamp (rare)
-    T ang = lim * P.physics_hz_T;
+    T ang = M<T>::div_(lim, dt);
     T sh;
     M<T>::sincos_((T)0.5 * ang * dt, &sh, &ch);
     k = M<T>::div_(sh, ang);
@@ -431,86 +511,24 @@ __device__ __forceinline__ void quat_integrate(const Params<T>& P, Rigid<T>& S) 
   T ny = ch * qy + ay * qw + az * qx - ax * qz;
   T nz = ch * qz + az * qw + ax * qy - ay * qx;
   T nw = ch * qw - ax * qx - ay * qy - az * qz;
-  T n2 = nx * nx + ny * ny + nz * nz + nw * nw;
+  T n2 = (nx * nx + ny * ny) + (nz * nz + nw * nw);
   T e = n2 - (T)1;                               // 1/sqrt(1+e) series; exact path for un-normalised input
-  T inv = (T)1 + e * ((T)-0.5 + e * ((T)0.375 + e * ((T)-0.3125 + e * (T)0.2734375)));
+  T e2 = e * e;
+  T inv = ((T)1 + e * (T)-0.5) + e2 * (((T)0.375 + e * (T)-0.3125) + e2 * (T)0.2734375);
   if (M<T>::fabs_(e) >= (T)1e-4) inv = M<T>::rcp_(M<T>::sqrt_(n2));
   S.q[0] = nx * inv; S.q[1] = ny * inv; S.q[2] = nz * inv; S.q[3] = nw * inv;
 }
 
-// ---- one 1/240 s physics tick, in three stages ----
-// (1) actuator lags
-template <typename T>
-__device__ __forceinline__ void tick_actuators(const Params<T>& P, Rigid<T>& S, const T cmd[FW_NUM_ACTUATORS], T noise_z) {
-#pragma unroll
-  for (int s = 0; s < FW_NUM_SURFACES; ++s) S.act[s] += P.s[s].dt_tau * (cmd[s] - S.act[s]);
-  T thr = S.act[FW_NUM_SURFACES];
-  thr += P.motor_dt_tau * (cmd[FW_NUM_SURFACES] - thr);
-  thr += noise_z * thr * P.noise_ratio;
-  S.act[FW_NUM_SURFACES] = thr;
-}
-// (3) motor + integration + contacts, given the summed surface wrench (F, Tq) in the body frame
-template <typename T, bool WIND, int G>
-__device__ __forceinline__ bool tick_integrate(const Params<T>& P, Rigid<T>& S, const T w_b[3], T F[3], T Tq[3], const T wind[3]) {
-  const T dt = P.dt;
-  {
-    T thr = S.act[FW_NUM_SURFACES];
-    T t2 = thr * thr;
-    T f[3] = { t2 * P.m_force[0], t2 * P.m_force[1], t2 * P.m_force[2] };
-    T rxf[3];
-    cross(P.m_pos, f, rxf);
-    F[0] += f[0]; F[1] += f[1]; F[2] += f[2];
-    Tq[0] += rxf[0] + t2 * P.m_torque[0]; Tq[1] += rxf[1] + t2 * P.m_torque[1]; Tq[2] += rxf[2] + t2 * P.m_torque[2];
-  }
-  T R[9];
-  rot_from_quat(S.q, R);      // recomputed (30 flops) rather than kept live across the surface evaluation
-  T Fw[3];
-  mv(R, F, Fw);
-  if (WIND && P.wind_coupling == FW_WIND_COUPLE_FORCE) {
-    Fw[0] += P.wind_force_coef * wind[0]; Fw[1] += P.wind_force_coef * wind[1]; Fw[2] += P.wind_force_coef * wind[2];
-  }
-  T acc[3] = { Fw[0] * P.inv_mass, Fw[1] * P.inv_mass, Fw[2] * P.inv_mass - P.gravity };
-  T Iw[3], rhs[3] = { Tq[0], Tq[1], Tq[2] }, al_b[3], al_w[3];
-  mv(P.I, w_b, Iw);
-  if (P.gyroscopic) {
-    T g[3];
-    cross(w_b, Iw, g);
-    rhs[0] -= g[0]; rhs[1] -= g[1]; rhs[2] -= g[2];
-  }
-  mv(P.Iinv, rhs, al_b);
-  mv(R, al_b, al_w);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { S.v[k] += acc[k] * dt; S.w[k] += al_w[k] * dt; }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) S.p[k] += S.v[k] * dt;
-  quat_integrate<T>(P, S);
-  // contacts: third row of R(q_new) dotted with the body-fixed points
-  T x = S.q[0], y = S.q[1], z = S.q[2], w = S.q[3];
-  T s2 = two_over_norm2<T>(x * x + y * y + z * z + w * w);
-  T r6 = (x * z - w * y) * s2, r7 = (y * z + w * x) * s2, r8 = (T)1 - (x * x + y * y) * s2;
-  bool contact = false;
-  if (G == 8) {                // lane `sub` tests point `sub`; OR over the group
-    const int sub = threadIdx.x & 7;
-    T zc = S.p[2] + r6 * P.coll[sub][0] + r7 * P.coll[sub][1] + r8 * P.coll[sub][2];
-    contact = group_any<8>(sub < P.n_coll && zc <= (T)0);
-  } else {
-    for (int i = 0; i < P.n_coll; ++i) {
-      T zc = S.p[2] + r6 * P.coll[i][0] + r7 * P.coll[i][1] + r8 * P.coll[i][2];
-      contact |= (zc <= (T)0);
-    }
-  }
-  return contact;
-}
-
-// Full tick.  G = 1: rolled loop over the 5 surfaces (constants by scalar loads at a
-// wave-uniform index -- unrolling makes hipcc hoist ~100 constants into SGPRs and spill).
+// Full tick.  R = R(S.q) on entry and on exit (carried across ticks: it is needed for the
+// contact test of this tick and the body-frame velocities of the next one).
+// G = 1: rolled loop over the 5 surfaces (constants by scalar loads at a wave-uniform index
+//        -- unrolling makes hipcc hoist ~100 constants into SGPRs and spill).
 // G = 8: `mine` holds this lane's surface constants in VGPRs, `wmask` zeroes lanes 5-7.
 template <typename T, bool WIND, int G>
-__device__ __forceinline__ bool physics_tick(const Params<T>& P, Rigid<T>& S, const T cmd[FW_NUM_ACTUATORS], T noise_z,
-                                             const T wind[3], const SurfC<T>& mine, T wmask) {
-  tick_actuators<T>(P, S, cmd, noise_z);
-  T R[9];
-  rot_from_quat(S.q, R);
+__device__ __forceinline__ bool physics_tick(const Params<T>& P, const TickC<T>& C, Rigid<T>& S, T R[9],
+                                             const T cmd[FW_NUM_ACTUATORS], T noise_z, const T wind[3],
+                                             const SurfC<T>& mine, T wmask) {
+  tick_actuators<T>(C, S, cmd, noise_z);
   T v_b[3], w_b[3], wind_b[3] = {(T)0, (T)0, (T)0};
   mtv(R, S.v, v_b);
   mtv(R, S.w, w_b);
@@ -535,21 +553,61 @@ __device__ __forceinline__ bool physics_tick(const Params<T>& P, Rigid<T>& S, co
       for (int k = 0; k < 3; ++k) { F[k] += f[k]; Tq[k] += tq[k]; }
     }
   }
-  return tick_integrate<T, WIND, G>(P, S, w_b, F, Tq, wind);
+  // motor
+  {
+    T thr = S.act[FW_NUM_SURFACES];
+    T t2 = thr * thr;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { F[k] += t2 * C.mF[k]; Tq[k] += t2 * C.mT[k]; }
+  }
+  const T dt = C.dt;
+  T Fw[3];
+  mv(R, F, Fw);
+  if (WIND && P.wind_coupling == FW_WIND_COUPLE_FORCE) {
+    Fw[0] += C.wind_force_coef * wind[0]; Fw[1] += C.wind_force_coef * wind[1]; Fw[2] += C.wind_force_coef * wind[2];
+  }
+  T acc[3] = { Fw[0] * C.inv_mass, Fw[1] * C.inv_mass, Fw[2] * C.inv_mass - C.gravity };
+  T Iw[3], rhs[3] = { Tq[0], Tq[1], Tq[2] }, al_b[3], al_w[3];
+  mv(C.I, w_b, Iw);
+  if (P.gyroscopic) {
+    T g[3];
+    cross(w_b, Iw, g);
+    rhs[0] -= g[0]; rhs[1] -= g[1]; rhs[2] -= g[2];
+  }
+  mv(C.Iinv, rhs, al_b);
+  mv(R, al_b, al_w);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { S.v[k] += acc[k] * dt; S.w[k] += al_w[k] * dt; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) S.p[k] += S.v[k] * dt;
+  quat_integrate<T>(C, S);
+  rot_from_unit_quat<T>(S.q, R);
+  // contacts: third row of R(q_new) dotted with the body-fixed points
+  bool contact = false;
+  if (G == 8) {                // lane `sub` tests point `sub`; OR over the group
+    T zc = S.p[2] + R[6] * C.cpt[0] + R[7] * C.cpt[1] + R[8] * C.cpt[2];
+    contact = group_any<8>(C.cvalid != (T)0 && zc <= (T)0);
+  } else {
+    for (int i = 0; i < P.n_coll; ++i) {
+      T zc = S.p[2] + R[6] * P.coll[i][0] + R[7] * P.coll[i][1] + R[8] * P.coll[i][2];
+      contact |= (zc <= (T)0);
+    }
+  }
+  return contact;
 }
 
 // Aviary.step(): ticks_per_aviary ticks; returns any-contact.  (z0, z1) are the two
 // ticks' motor-noise normals (zero for warm-up lanes: their throttle is exactly 0).
 template <typename T, bool WIND, int G>
-__device__ __forceinline__ bool aviary_step(const Params<T>& P, Rigid<T>& S, const T cmd[FW_NUM_ACTUATORS], int32_t& tick,
-                                            T z0, T z1, const T wb[3], const T wa[3], T wphase,
-                                            const SurfC<T>& mine, T wmask) {
+__device__ __forceinline__ bool aviary_step(const Params<T>& P, const TickC<T>& C, Rigid<T>& S, T R[9],
+                                            const T cmd[FW_NUM_ACTUATORS], int32_t& tick, T z0, T z1, const T wb[3],
+                                            const T wa[3], T wphase, const SurfC<T>& mine, T wmask) {
   bool contact = false;
 #pragma unroll 1
   for (int t = 0; t < P.ticks_per_aviary; ++t) {
     T wind[3] = {(T)0, (T)0, (T)0};
     if (WIND) wind_at<T>(P, wb, wa, wphase, tick, wind);
-    contact |= physics_tick<T, WIND, G>(P, S, cmd, (t & 1) ? z1 : z0, wind, mine, wmask);
+    contact |= physics_tick<T, WIND, G>(P, C, S, R, cmd, (t & 1) ? z1 : z0, wind, mine, wmask);
     tick += 1;
   }
   return contact;
