@@ -303,6 +303,28 @@ int32_t fw_set_state(fw_handle h, const double* state_in);
 /* Recompute the observation from the current state (no dynamics), device T[N,D]. */
 int32_t fw_observe(fw_handle h, void* obs_out, void* hip_stream);
 
+/* ---- rollout-collector helpers (the caller side of the path: SB3's OnPolicyAlgorithm /
+ * RolloutBuffer / VecNormalize as driven by train/train_Fixedwing_Waypoints_v3.py:260,293-337).
+ * Stateless, float32 device buffers laid out [T, N] (time-major, env contiguous). ---- */
+
+/* Generalised advantage estimation, SB3 RolloutBuffer.compute_returns_and_advantage:
+ *   delta_t = r_t + gamma * V_{t+1} * (1 - start_{t+1}) - V_t
+ *   A_t     = delta_t + gamma * lambda * (1 - start_{t+1}) * A_{t+1},   returns = A + V
+ * with V_T = last_values, start_T = last_dones.  episode_starts[t,n] = 1 iff step t is the
+ * first of an episode.  One lane per env, T sequential steps, coalesced across envs. */
+int32_t fw_gae(const float* rewards, const float* values, const float* episode_starts,
+               const float* last_values, const float* last_dones, float* advantages, float* returns,
+               int32_t T, int32_t N, float gamma, float gae_lambda, void* hip_stream);
+
+/* VecNormalize step (SB3 VecNormalize.step_wait + RunningMeanStd.update, Chan et al. merge),
+ * fused: one pass over obs[N,D] (env dtype T_in = double|float per `in_is_f64`) that
+ *   (a) if `update` != 0 merges the batch moments into (mean[D], var[D], count[1]) (double),
+ *   (b) writes clip((obs - mean) / sqrt(var + eps), +-clip) as float32 to obs_out[N,D]
+ *       using the UPDATED statistics, as SB3 does.
+ * mean/var/count are device double buffers owned by the caller (checkpointable). */
+int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t D, double* mean, double* var,
+                         double* count, int32_t update, float clip, float eps, float* obs_out, void* hip_stream);
+
 int32_t fw_num_envs(fw_handle h);
 const char* fw_last_error(fw_handle h); /* h may be NULL: last create/validate error */
 int32_t fw_destroy(fw_handle h);

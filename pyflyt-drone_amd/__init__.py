@@ -9,6 +9,7 @@ from . import config
 from .config import (FwConfig, train_waypoints_v3_config, waypoints_config)
 from .spaces import Box
 from .vec_env import FixedwingVecEnv, FixedwingWaypointsVecEnv
+from . import rollout
 
 __all__ = ["config", "FwConfig", "Box", "FixedwingVecEnv", "FixedwingWaypointsVecEnv",
            "waypoints_config", "train_waypoints_v3_config"]

@@ -20,7 +20,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 EXPORTS = (
     "fw_sizeof_config", "fw_abi_version", "fw_obs_dim", "fw_validate_config", "fw_create", "fw_reset",
     "fw_step", "fw_seed", "fw_get_state", "fw_set_state", "fw_observe", "fw_num_envs", "fw_last_error",
-    "fw_destroy",
+    "fw_destroy", "fw_gae", "fw_normalize_obs",
 )
 
 
@@ -65,6 +65,10 @@ def lib() -> C.CDLL:
         L.fw_num_envs.restype = i32; L.fw_num_envs.argtypes = [vp]
         L.fw_last_error.restype = C.c_char_p; L.fw_last_error.argtypes = [vp]
         L.fw_destroy.restype = i32; L.fw_destroy.argtypes = [vp]
+        L.fw_gae.restype = i32
+        L.fw_gae.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_float, vp]
+        L.fw_normalize_obs.restype = i32
+        L.fw_normalize_obs.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, C.c_float, C.c_float, vp, vp]
         if L.fw_abi_version() != K.FW_ABI_VERSION:
             raise RuntimeError("libfwsim_hip.so ABI version does not match the Python binding; rebuild")
         if L.fw_sizeof_config() != C.sizeof(K.FwConfig):

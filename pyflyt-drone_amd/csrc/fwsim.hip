@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "fwsim_device.hpp"
+#include "fwsim_rollout.hpp"
 
 using namespace fwsim;
 
@@ -778,6 +779,49 @@ int32_t fw_set_state(fw_handle h, const double* state_in) {
   if (!h || !state_in) return FW_EINVAL;
   DeviceGuard g(h->device);
   return (h->cfg.dtype == FW_F64) ? set_state_T<double>(h, state_in) : set_state_T<float>(h, state_in);
+}
+
+int32_t fw_gae(const float* rewards, const float* values, const float* episode_starts, const float* last_values,
+               const float* last_dones, float* advantages, float* returns, int32_t T, int32_t N, float gamma,
+               float gae_lambda, void* hip_stream) {
+  if (!rewards || !values || !episode_starts || !last_values || !last_dones || !advantages || !returns || T <= 0 || N <= 0) {
+    g_err = "fw_gae: bad arguments"; return FW_EINVAL;
+  }
+  hipLaunchKernelGGL(fw_gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, rewards, values,
+                     episode_starts, last_values, last_dones, advantages, returns, T, N, gamma, gae_lambda);
+  HIP_TRY((fw_env*)nullptr, hipGetLastError());
+  return FW_OK;
+}
+
+int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t D, double* mean, double* var,
+                         double* count, int32_t update, float clip, float eps, float* obs_out, void* hip_stream) {
+  if (!obs || !mean || !var || !count || !obs_out || N <= 0 || D <= 0 || D > 4096) { g_err = "fw_normalize_obs: bad arguments"; return FW_EINVAL; }
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (update) {
+    // partial sums live in a small per-device scratch buffer (allocated once; never freed in a launch path)
+    // (first use per device allocates: call once outside hipGraph capture)
+    static double* scratch_dev[64] = {nullptr};
+    static size_t scratch_elems_dev[64] = {0};
+    int dev = 0;
+    HIP_TRY((fw_env*)nullptr, hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { g_err = "device index out of range"; return FW_EINVAL; }
+    const int nblocks = 64;
+    const size_t need = (size_t)nblocks * 2 * D;
+    if (scratch_elems_dev[dev] < need) {
+      if (scratch_dev[dev]) (void)hipFree(scratch_dev[dev]);
+      HIP_TRY((fw_env*)nullptr, hipMalloc((void**)&scratch_dev[dev], sizeof(double) * need));
+      scratch_elems_dev[dev] = need;
+    }
+    double* scratch = scratch_dev[dev];
+    if (in_is_f64) hipLaunchKernelGGL(fw_obs_moments_kernel<double>, dim3(nblocks), dim3(256), 8 * sizeof(double), st, (const double*)obs, N, D, scratch);
+    else hipLaunchKernelGGL(fw_obs_moments_kernel<float>, dim3(nblocks), dim3(256), 8 * sizeof(double), st, (const float*)obs, N, D, scratch);
+    hipLaunchKernelGGL(fw_obs_merge_kernel, dim3((D + 63) / 64), dim3(64), 0, st, scratch, nblocks, N, D, mean, var, count);
+  }
+  const int total = N * D;
+  if (in_is_f64) hipLaunchKernelGGL(fw_obs_normalize_kernel<double>, dim3((total + 255) / 256), dim3(256), 0, st, (const double*)obs, total, D, mean, var, clip, eps, obs_out);
+  else hipLaunchKernelGGL(fw_obs_normalize_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)obs, total, D, mean, var, clip, eps, obs_out);
+  HIP_TRY((fw_env*)nullptr, hipGetLastError());
+  return FW_OK;
 }
 
 int32_t fw_num_envs(fw_handle h) { return h ? h->n : FW_EINVAL; }

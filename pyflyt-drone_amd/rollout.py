@@ -1,0 +1,477 @@
+"""Device-resident PPO rollout collector -- the caller side of the env step.
+
+Mirrors what the reference gets from Stable-Baselines3 in
+train/train_Fixedwing_Waypoints_v3.py:251-337 (SB3 itself is not a dependency and is
+not shipped): ``VecNormalize(norm_obs, norm_reward, clip_obs=10)`` (:260),
+``PPO("MlpPolicy", n_steps, batch_size, n_epochs, gamma, gae_lambda, clip_range,
+ent_coef, vf_coef, max_grad_norm)`` (:293-310) and its collect/GAE/update cycle.
+Everything lives on the GPU: the env step (fw_step), the normaliser (fw_normalize_obs),
+the policy MLP (torch-ROCm), the rollout buffer and the GAE scan (fw_gae); nothing makes
+a host round trip inside the rollout loop.
+
+Multi-GPU (one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI):
+envs are sharded by rank; collectives happen only at update time --
+  * all-gather of the advantages (north_star) for the global normalisation statistics,
+  * all-reduce of one flattened gradient bucket per minibatch,
+  * all-reduce of the normaliser's batch sums.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _dist():
+    import torch.distributed as td
+    return td if (td.is_available() and td.is_initialized() and td.get_world_size() > 1) else None
+
+
+# ---------------------------------------------------------------------------------------------
+# running statistics (SB3 common/running_mean_std.py): mean 0, var 1, count = epsilon = 1e-4
+# ---------------------------------------------------------------------------------------------
+class RunningMeanStd:
+    def __init__(self, shape, device, epsilon: float = 1e-4):
+        self.mean = torch.zeros(shape, dtype=torch.float64, device=device)
+        self.var = torch.ones(shape, dtype=torch.float64, device=device)
+        self.count = torch.full((1,), epsilon, dtype=torch.float64, device=device)
+
+    def update(self, x: torch.Tensor) -> None:
+        """Chan et al. merge of the batch moments of x[B, ...]; in a multi-GPU job the batch is
+        the union of every rank's rows (one all-reduce of [sum, sum of squares, rows])."""
+        x = x.to(torch.float64).reshape(x.shape[0], -1)
+        s, s2 = x.sum(0), (x * x).sum(0)
+        n = torch.full((1,), float(x.shape[0]), dtype=torch.float64, device=x.device)   # fill kernel: graph-capturable
+        td = _dist()
+        if td is not None:
+            buf = torch.cat([s, s2, n])
+            td.all_reduce(buf)
+            d = s.numel()
+            s, s2, n = buf[:d], buf[d:2 * d], buf[2 * d:]
+        bm = s / n
+        bv = (s2 / n - bm * bm).clamp_min(0.0)
+        self.update_from_moments(bm.reshape(self.mean.shape), bv.reshape(self.var.shape), n)
+
+    def update_from_moments(self, bm, bv, bn) -> None:
+        bn, cnt = bn.reshape(-1)[0], self.count[0]          # 0-dim, so scalar statistics keep shape ()
+        delta = bm - self.mean
+        tot = cnt + bn
+        new_mean = self.mean + delta * bn / tot
+        m2 = self.var * cnt + bv * bn + delta * delta * cnt * bn / tot
+        self.mean, self.var = new_mean, m2 / tot
+        self.count = tot.reshape(1)
+
+    def state_dict(self):
+        return {"mean": self.mean.cpu(), "var": self.var.cpu(), "count": self.count.cpu()}
+
+    def load_state_dict(self, sd):
+        self.mean.copy_(sd["mean"]); self.var.copy_(sd["var"]); self.count.copy_(sd["count"])
+
+
+class VecNormalizeDevice:
+    """SB3 ``VecNormalize`` on device tensors (train/train_Fixedwing_Waypoints_v3.py:260).
+
+    ``step(actions)`` returns ``(obs_f32, reward_f32, dones, terminal_obs_f32)`` all normalised
+    exactly like ``VecNormalize.step_wait``: statistics are updated *before* normalising, the
+    reward is divided by the std of the discounted return, terminal observations are
+    normalised with the same statistics, and ``returns[dones] = 0``."""
+
+    def __init__(self, venv, training: bool = True, norm_obs: bool = True, norm_reward: bool = True,
+                 clip_obs: float = 10.0, clip_reward: float = 10.0, gamma: float = 0.99, epsilon: float = 1e-8,
+                 use_fused_kernel: Optional[bool] = None):
+        self.venv = venv
+        self.device = venv.device
+        self.num_envs, self.obs_dim = venv.num_envs, venv.obs_dim
+        self.training, self.norm_obs, self.norm_reward = training, norm_obs, norm_reward
+        self.clip_obs, self.clip_reward, self.gamma, self.epsilon = clip_obs, clip_reward, gamma, epsilon
+        self.obs_rms = RunningMeanStd((self.obs_dim,), self.device)
+        self.ret_rms = RunningMeanStd((), self.device)
+        self.returns = torch.zeros(self.num_envs, dtype=torch.float64, device=self.device)
+        self.obs_out = torch.zeros((self.num_envs, self.obs_dim), dtype=torch.float32, device=self.device)
+        self.tobs_out = torch.zeros_like(self.obs_out)
+        # single-GPU: one fused HIP pass (moments + merge + normalise); multi-GPU: torch ops + all-reduce
+        self.use_fused = (_dist() is None) if use_fused_kernel is None else use_fused_kernel
+
+    # -- observation ---------------------------------------------------------------------------
+    def _norm_obs_torch(self, obs, out):
+        z = (obs.to(torch.float64) - self.obs_rms.mean) / torch.sqrt(self.obs_rms.var + self.epsilon)
+        out.copy_(z.to(torch.float32).clamp_(-self.clip_obs, self.clip_obs))
+        return out
+
+    def _process_obs(self, obs, update: bool):
+        if not self.norm_obs:
+            self.obs_out.copy_(obs.to(torch.float32))
+            return self.obs_out
+        if self.use_fused:
+            rc = _lib.lib().fw_normalize_obs(_p(obs), int(obs.dtype == torch.float64), self.num_envs, self.obs_dim,
+                                             _p(self.obs_rms.mean), _p(self.obs_rms.var), _p(self.obs_rms.count),
+                                             int(update), float(self.clip_obs), float(self.epsilon), _p(self.obs_out),
+                                             _stream(self.device))
+            _lib.check(rc)
+            return self.obs_out
+        if update:
+            self.obs_rms.update(obs)
+        return self._norm_obs_torch(obs, self.obs_out)
+
+    def normalize_obs(self, obs, out=None):
+        """Normalise with the current statistics without updating them."""
+        out = torch.empty(obs.shape, dtype=torch.float32, device=obs.device) if out is None else out
+        if not self.norm_obs:
+            out.copy_(obs.to(torch.float32)); return out
+        return self._norm_obs_torch(obs, out)
+
+    # -- API -----------------------------------------------------------------------------------
+    def reset(self):
+        obs = self.venv.reset_tensor()
+        self.returns.zero_()
+        return self._process_obs(obs, update=self.training)
+
+    def step(self, actions):
+        obs, rew, term, trunc = self.venv.step_tensor(actions)
+        dones = (term | trunc).bool()
+        obs_n = self._process_obs(obs, update=self.training)
+        rew64 = rew.to(torch.float64)
+        if self.training and self.norm_reward:
+            self.returns = self.returns * self.gamma + rew64
+            self.ret_rms.update(self.returns)
+        if self.norm_reward:
+            rew_n = (rew64 / torch.sqrt(self.ret_rms.var + self.epsilon)).clamp(-self.clip_reward, self.clip_reward)
+        else:
+            rew_n = rew64
+        tobs_n = self.normalize_obs(self.venv.terminal_obs, self.tobs_out)
+        self.returns = torch.where(dones, torch.zeros_like(self.returns), self.returns)
+        return obs_n, rew_n.to(torch.float32), dones, trunc.bool() & ~term.bool(), tobs_n
+
+    def state_dict(self):
+        return {"obs_rms": self.obs_rms.state_dict(), "ret_rms": self.ret_rms.state_dict(),
+                "clip_obs": self.clip_obs, "clip_reward": self.clip_reward, "gamma": self.gamma,
+                "epsilon": self.epsilon, "norm_obs": self.norm_obs, "norm_reward": self.norm_reward}
+
+    def load_state_dict(self, sd):
+        self.obs_rms.load_state_dict(sd["obs_rms"]); self.ret_rms.load_state_dict(sd["ret_rms"])
+        for k in ("clip_obs", "clip_reward", "gamma", "epsilon", "norm_obs", "norm_reward"):
+            setattr(self, k, sd[k])
+
+
+# ---------------------------------------------------------------------------------------------
+# policy: SB3 "MlpPolicy" (ActorCriticPolicy defaults)
+# ---------------------------------------------------------------------------------------------
+class MlpPolicy(nn.Module):
+    """Separate 64-64 tanh networks for pi and V, orthogonal init (gain sqrt(2) hidden, 0.01
+    action head, 1 value head), state-independent log_std initialised to 0, diagonal Gaussian."""
+
+    def __init__(self, obs_dim: int, act_dim: int = 4, hidden=(64, 64)):
+        super().__init__()
+
+        def mlp():
+            layers, d = [], obs_dim
+            for h in hidden:
+                layers += [nn.Linear(d, h), nn.Tanh()]
+                d = h
+            return nn.Sequential(*layers), d
+
+        self.pi_net, dpi = mlp()
+        self.vf_net, dvf = mlp()
+        self.action_net = nn.Linear(dpi, act_dim)
+        self.value_net = nn.Linear(dvf, 1)
+        self.log_std = nn.Parameter(torch.zeros(act_dim))
+        for net in (self.pi_net, self.vf_net):
+            for m in net:
+                if isinstance(m, nn.Linear):
+                    nn.init.orthogonal_(m.weight, gain=math.sqrt(2)); nn.init.zeros_(m.bias)
+        nn.init.orthogonal_(self.action_net.weight, gain=0.01); nn.init.zeros_(self.action_net.bias)
+        nn.init.orthogonal_(self.value_net.weight, gain=1.0); nn.init.zeros_(self.value_net.bias)
+
+    def _dist_params(self, obs):
+        return self.action_net(self.pi_net(obs)), self.log_std
+
+    @staticmethod
+    def _log_prob(actions, mean, log_std):
+        var = torch.exp(2 * log_std)
+        return (-((actions - mean) ** 2) / (2 * var) - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+
+    def forward(self, obs, deterministic: bool = False, generator=None):
+        mean, log_std = self._dist_params(obs)
+        if deterministic:
+            actions = mean
+        else:
+            noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+            actions = mean + noise * torch.exp(log_std)
+        values = self.value_net(self.vf_net(obs)).squeeze(-1)
+        return actions, values, self._log_prob(actions, mean, log_std)
+
+    def predict_values(self, obs):
+        return self.value_net(self.vf_net(obs)).squeeze(-1)
+
+    def evaluate_actions(self, obs, actions):
+        mean, log_std = self._dist_params(obs)
+        values = self.value_net(self.vf_net(obs)).squeeze(-1)
+        entropy = (0.5 + 0.5 * math.log(2 * math.pi) + log_std).sum(-1).expand(obs.shape[0])
+        return values, self._log_prob(actions, mean, log_std), entropy
+
+
+# ---------------------------------------------------------------------------------------------
+# GAE
+# ---------------------------------------------------------------------------------------------
+def gae_reference(rewards, values, episode_starts, last_values, last_dones, gamma, lam):
+    """Plain-torch restatement of SB3 RolloutBuffer.compute_returns_and_advantage (checker for fw_gae)."""
+    T = rewards.shape[0]
+    adv = torch.zeros_like(rewards)
+    last = torch.zeros_like(last_values)
+    for t in reversed(range(T)):
+        if t == T - 1:
+            nnt, nv = 1.0 - last_dones, last_values
+        else:
+            nnt, nv = 1.0 - episode_starts[t + 1], values[t + 1]
+        delta = rewards[t] + gamma * nv * nnt - values[t]
+        last = delta + gamma * lam * nnt * last
+        adv[t] = last
+    return adv, adv + values
+
+
+def gae_device(rewards, values, episode_starts, last_values, last_dones, gamma, lam):
+    """fw_gae: one lane per env, time loop in registers, [T, N] float32 device buffers."""
+    if not rewards.is_cuda:
+        raise RuntimeError("fw_gae needs device tensors (no CPU fallback); tests use gae_reference as the checker")
+    T, N = rewards.shape
+    adv, ret = torch.empty_like(rewards), torch.empty_like(rewards)
+    rc = _lib.lib().fw_gae(_p(rewards), _p(values), _p(episode_starts), _p(last_values.contiguous()),
+                           _p(last_dones.contiguous()), _p(adv), _p(ret), T, N, float(gamma), float(lam),
+                           _stream(rewards.device))
+    _lib.check(rc)
+    return adv, ret
+
+
+# ---------------------------------------------------------------------------------------------
+# distributed helpers (update time only)
+# ---------------------------------------------------------------------------------------------
+def global_advantage_stats(adv: torch.Tensor):
+    """Mean / std (unbiased, as torch.std) of the advantages of ALL ranks.
+
+    north_star: an all-gather of the advantages over RCCL.  The payload is small
+    (N_local x T x 4 B); the gathered tensor is also what a global minibatch sampler needs."""
+    td = _dist()
+    flat = adv.reshape(-1)
+    if td is None:
+        return flat.mean(), flat.std(), flat
+    parts = [torch.empty_like(flat) for _ in range(td.get_world_size())]
+    td.all_gather(parts, flat.contiguous())
+    allv = torch.cat(parts)
+    return allv.mean(), allv.std(), allv
+
+
+def allreduce_grads_(params) -> None:
+    """Average gradients over ranks with ONE flattened bucket (the MLP has ~1.2e4 parameters:
+    latency-bound, so a single collective per minibatch)."""
+    td = _dist()
+    if td is None:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    td.all_reduce(flat)
+    flat /= td.get_world_size()
+    o = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[o:o + n].view_as(g)); o += n
+
+
+# ---------------------------------------------------------------------------------------------
+# PPO
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class PPOConfig:
+    """TRAIN_CONFIG of train/train_Fixedwing_Waypoints_v3.py:27-55.  With thousands of envs
+    ``n_steps`` is what shrinks: 4096 envs x 16 steps = the reference's 32 x 2048 = 65 536
+    samples per update."""
+    n_steps: int = 16
+    batch_size: int = 128
+    n_epochs: int = 20
+    learning_rate: float = 3e-4
+    gamma: float = 0.99
+    gae_lambda: float = 0.95
+    clip_range: float = 0.2
+    ent_coef: float = 0.001
+    vf_coef: float = 0.5
+    max_grad_norm: float = 0.5
+    normalize_advantage: bool = True
+    adv_norm_scope: str = "minibatch"      # "minibatch" (SB3) | "global" (all-gathered statistics)
+    seed: int = 42
+    use_graphs: bool = True                # replay the rollout / minibatch update as hipGraphs (single-GPU, device envs)
+
+
+class PPO:
+    def __init__(self, env: VecNormalizeDevice, cfg: PPOConfig = PPOConfig(), policy: Optional[MlpPolicy] = None,
+                 gae_fn=gae_device):
+        self.env, self.cfg, self.device = env, cfg, env.device
+        self._gae = gae_fn
+        torch.manual_seed(cfg.seed)
+        self.policy = (policy or MlpPolicy(env.obs_dim)).to(self.device)
+        td = _dist()
+        if td is not None:                 # identical initial weights on every rank
+            for p in self.policy.parameters():
+                td.broadcast(p.data, src=0)
+        self._graphs = bool(cfg.use_graphs) and self.device.type == "cuda" and td is None
+        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5,
+                                          capturable=self._graphs)
+        self._g_rollout = self._g_update = None
+        self._warm_rollouts = 0
+        self._loss_acc = torch.zeros(3, device=self.device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(cfg.seed + (td.get_rank() if td is not None else 0))
+        T, N, D = cfg.n_steps, env.num_envs, env.obs_dim
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.buf_obs = torch.zeros((T, N, D), **f32)
+        self.buf_act = torch.zeros((T, N, 4), **f32)
+        self.buf_rew = torch.zeros((T, N), **f32)
+        self.buf_start = torch.zeros((T, N), **f32)
+        self.buf_val = torch.zeros((T, N), **f32)
+        self.buf_logp = torch.zeros((T, N), **f32)
+        self.last_obs = None
+        self.last_starts = torch.ones(N, **f32)
+        self.num_timesteps = 0
+        self.logs: Dict[str, float] = {}
+
+    # ---- SB3 OnPolicyAlgorithm.collect_rollouts ---------------------------------------------
+    def _rollout_body(self):
+        cfg, env = self.cfg, self.env
+        act_dtype = env.venv.torch_dtype
+        for t in range(cfg.n_steps):
+            actions, values, logp = self.policy(self.last_obs, generator=self.gen)
+            clipped = actions.clamp(-1.0, 1.0).to(act_dtype)
+            obs_n, rew_n, dones, timeouts, tobs_n = env.step(clipped)
+            # bootstrap truncated episodes with V(terminal_observation)
+            tv = self.policy.predict_values(tobs_n)
+            rew_n = rew_n + cfg.gamma * tv * timeouts.to(torch.float32)
+            self.buf_obs[t].copy_(self.last_obs); self.buf_act[t].copy_(actions); self.buf_rew[t].copy_(rew_n)
+            self.buf_start[t].copy_(self.last_starts); self.buf_val[t].copy_(values); self.buf_logp[t].copy_(logp)
+            self.last_obs.copy_(obs_n)
+            self.last_starts.copy_(dones.to(torch.float32))
+        self.last_values.copy_(self.policy.predict_values(self.last_obs))
+
+    @torch.no_grad()
+    def collect_rollouts(self):
+        cfg, env = self.cfg, self.env
+        if self.last_obs is None:
+            self.last_obs = env.reset().clone()
+            self.last_starts.fill_(1.0)
+            self.last_values = torch.zeros(env.num_envs, dtype=torch.float32, device=self.device)
+        if self._graphs and self._warm_rollouts >= 1:
+            # the n_steps x (policy forward, fw_step, fw_normalize_obs, buffer writes) chain is one
+            # hipGraph: ~40 tiny launches per vec-step are otherwise host-bound (0.75 ms vs 27 us of physics).
+            # The first rollout runs eagerly (it doubles as the allocator warm-up); capture happens on the second.
+            if self._g_rollout is None:
+                torch.cuda.synchronize()
+                self._g_rollout = torch.cuda.CUDAGraph()
+                if hasattr(self._g_rollout, "register_generator_state"):
+                    self._g_rollout.register_generator_state(self.gen)
+                with torch.cuda.graph(self._g_rollout):
+                    self._rollout_body()
+            self._g_rollout.replay()
+        else:
+            self._rollout_body()
+        self._warm_rollouts += 1
+        self.adv, self.ret = self._gae(self.buf_rew, self.buf_val, self.buf_start, self.last_values, self.last_starts,
+                                       cfg.gamma, cfg.gae_lambda)
+        td = _dist()
+        self.num_timesteps += cfg.n_steps * env.num_envs * (td.get_world_size() if td is not None else 1)
+
+    # ---- SB3 PPO.train ------------------------------------------------------------------------
+    def _minibatch_step(self, obs, act, old_logp, adv, ret, idx, g_mean, g_std, params):
+        cfg = self.cfg
+        a = adv[idx]
+        if cfg.normalize_advantage and a.numel() > 1:
+            a = (a - g_mean) / (g_std + 1e-8) if cfg.adv_norm_scope == "global" else (a - a.mean()) / (a.std() + 1e-8)
+        values, logp, entropy = self.policy.evaluate_actions(obs[idx], act[idx])
+        ratio = torch.exp(logp - old_logp[idx])
+        policy_loss = -torch.min(a * ratio, a * ratio.clamp(1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
+        value_loss = torch.nn.functional.mse_loss(ret[idx], values)
+        entropy_loss = -entropy.mean()
+        loss = policy_loss + cfg.ent_coef * entropy_loss + cfg.vf_coef * value_loss
+        self.optimizer.zero_grad(set_to_none=False)
+        loss.backward()
+        allreduce_grads_(params)
+        torch.nn.utils.clip_grad_norm_(params, cfg.max_grad_norm)
+        self.optimizer.step()
+        self._loss_acc += torch.stack([policy_loss.detach(), value_loss.detach(), entropy_loss.detach()])
+
+    def train(self):
+        cfg = self.cfg
+        T, N = cfg.n_steps, self.env.num_envs
+        B = T * N
+        obs = self.buf_obs.reshape(B, -1); act = self.buf_act.reshape(B, -1)
+        old_logp = self.buf_logp.reshape(B); adv = self.adv.reshape(B); ret = self.ret.reshape(B)
+        g_mean, g_std, _ = global_advantage_stats(adv)           # RCCL all-gather at update time
+        params = list(self.policy.parameters())
+        self._loss_acc.zero_()          # persistent buffer: the captured update graph holds its address
+        nb = 0
+        bs = cfg.batch_size
+        use_graph = self._graphs and B % bs == 0
+        if use_graph and self._g_update is None:
+            self._idx = torch.zeros(bs, dtype=torch.long, device=self.device)
+            self._gm = torch.zeros((), device=self.device); self._gs = torch.ones((), device=self.device)
+            self._adv_s, self._ret_s = torch.zeros(B, device=self.device), torch.zeros(B, device=self.device)
+            self._adv_s.copy_(adv); self._ret_s.copy_(ret); self._gm.copy_(g_mean); self._gs.copy_(g_std)
+            self._idx.copy_(torch.randperm(B, device=self.device)[:bs])
+            sd_p = [p.detach().clone() for p in params]
+            sd_o = self.optimizer.state_dict()
+            st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                for _ in range(3):                               # warm-up on the side stream, then undone below
+                    self._minibatch_step(obs, act, old_logp, self._adv_s, self._ret_s, self._idx, self._gm, self._gs, params)
+            torch.cuda.current_stream().wait_stream(st); torch.cuda.synchronize()
+            self._g_update = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_update):
+                self._minibatch_step(obs, act, old_logp, self._adv_s, self._ret_s, self._idx, self._gm, self._gs, params)
+            with torch.no_grad():                                # restore weights; zero the Adam moments the warm-up touched
+                for p, q in zip(params, sd_p):
+                    p.copy_(q)
+                for stt in self.optimizer.state.values():
+                    for k, v in stt.items():
+                        if torch.is_tensor(v):
+                            v.zero_()
+            self._loss_acc.zero_()
+        if use_graph:
+            self._adv_s.copy_(adv); self._ret_s.copy_(ret); self._gm.copy_(g_mean); self._gs.copy_(g_std)
+        for _ in range(cfg.n_epochs):
+            perm = torch.randperm(B, device=self.device, generator=self.gen)
+            for s in range(0, B, bs):
+                if use_graph:
+                    self._idx.copy_(perm[s:s + bs])
+                    self._g_update.replay()
+                else:
+                    self._minibatch_step(obs, act, old_logp, adv, ret, perm[s:s + bs], g_mean, g_std, params)
+                nb += 1
+        la = (self._loss_acc / nb).tolist()                      # the only host sync of the update
+        self.logs = {"policy_loss": la[0], "value_loss": la[1], "entropy_loss": la[2],
+                     "adv_mean": float(g_mean), "adv_std": float(g_std)}
+
+    def learn(self, total_timesteps: int):
+        while self.num_timesteps < total_timesteps:
+            self.collect_rollouts()
+            self.train()
+        return self
+
+    # ---- checkpoint (model + normaliser), train/train_Fixedwing_Waypoints_v3.py:340-347 ----------
+    def state_dict(self):
+        return {"policy": self.policy.state_dict(), "optimizer": self.optimizer.state_dict(),
+                "vecnormalize": self.env.state_dict(), "num_timesteps": self.num_timesteps}
+
+    def load_state_dict(self, sd, reset_num_timesteps: bool = True):
+        self.policy.load_state_dict(sd["policy"]); self.optimizer.load_state_dict(sd["optimizer"])
+        self.env.load_state_dict(sd["vecnormalize"])
+        self.num_timesteps = 0 if reset_num_timesteps else int(sd["num_timesteps"])

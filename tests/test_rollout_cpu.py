@@ -1,0 +1,229 @@
+"""CPU checks of the rollout-collector host logic against literal restatements of the SB3
+algorithms the reference's train scripts rely on (train/train_Fixedwing_Waypoints_v3.py:260,
+293-310), plus world_size-2 gloo tests of the update-time collectives."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from pyflyt_drone_amd import rollout as R
+
+
+# ---------------------------------------------------------------- literal numpy restatements (checkers)
+class NpRunningMeanStd:                      # SB3 common/running_mean_std.py
+    def __init__(self, shape=(), epsilon=1e-4):
+        self.mean, self.var, self.count = np.zeros(shape), np.ones(shape), epsilon
+
+    def update(self, arr):
+        bm, bv, bc = arr.mean(axis=0), arr.var(axis=0), arr.shape[0]
+        delta = bm - self.mean
+        tot = self.count + bc
+        new_mean = self.mean + delta * bc / tot
+        m2 = self.var * self.count + bv * bc + np.square(delta) * self.count * bc / tot
+        self.mean, self.var, self.count = new_mean, m2 / tot, tot
+
+
+def np_gae(rewards, values, episode_starts, last_values, dones, gamma, lam):   # RolloutBuffer.compute_returns_and_advantage
+    T = rewards.shape[0]
+    adv = np.zeros_like(rewards)
+    last = 0
+    for step in reversed(range(T)):
+        if step == T - 1:
+            nnt, nv = 1.0 - dones, last_values
+        else:
+            nnt, nv = 1.0 - episode_starts[step + 1], values[step + 1]
+        delta = rewards[step] + gamma * nv * nnt - values[step]
+        last = delta + gamma * lam * nnt * last
+        adv[step] = last
+    return adv, adv + values
+
+
+class FakeVenv:
+    """CPU stand-in with the device-env surface VecNormalizeDevice consumes (tests only)."""
+
+    def __init__(self, n=16, d=6, seed=0, horizon=7):
+        self.device = torch.device("cpu"); self.num_envs, self.obs_dim = n, d
+        self.torch_dtype = torch.float64
+        self.g = torch.Generator().manual_seed(seed)
+        self.t = torch.zeros(n, dtype=torch.long); self.horizon = horizon
+        self.terminal_obs = torch.zeros((n, d), dtype=torch.float64)
+        self.obs = torch.zeros((n, d), dtype=torch.float64)
+
+    def _draw(self):
+        return torch.randn((self.num_envs, self.obs_dim), generator=self.g, dtype=torch.float64) * 3.0 + 1.5
+
+    def reset_tensor(self):
+        self.t.zero_(); self.obs = self._draw(); return self.obs
+
+    def step_tensor(self, actions):
+        self.t += 1
+        nxt = self._draw()
+        rew = -(actions.to(torch.float64) ** 2).sum(-1) + 0.1 * nxt[:, 0]
+        trunc = (self.t >= self.horizon + (torch.arange(self.num_envs) % 3))
+        term = (nxt[:, 1] > 7.0) & ~trunc
+        done = term | trunc
+        self.terminal_obs = torch.where(done[:, None], nxt, self.terminal_obs)
+        fresh = self._draw()
+        self.obs = torch.where(done[:, None], fresh, nxt)
+        self.t = torch.where(done, torch.zeros_like(self.t), self.t)
+        return self.obs, rew, term.to(torch.uint8), trunc.to(torch.uint8)
+
+
+# ---------------------------------------------------------------- tests
+def test_running_mean_std_matches_sb3_formula():
+    rng = np.random.default_rng(0)
+    a, b = NpRunningMeanStd((5,)), R.RunningMeanStd((5,), "cpu")
+    for n in (7, 1, 64, 300):
+        x = rng.normal(2.0, 3.0, size=(n, 5))
+        a.update(x); b.update(torch.as_tensor(x))
+        np.testing.assert_allclose(b.mean.numpy(), a.mean, rtol=1e-12)
+        np.testing.assert_allclose(b.var.numpy(), a.var, rtol=1e-11)
+        assert float(b.count) == pytest.approx(a.count)
+    s = R.RunningMeanStd((), "cpu"); s.update(torch.as_tensor(rng.normal(size=100)))
+    assert s.mean.shape == ()
+
+
+def test_gae_reference_matches_sb3_loop():
+    rng = np.random.default_rng(1)
+    T, N = 37, 11
+    r, v = rng.normal(size=(T, N)).astype(np.float32), rng.normal(size=(T, N)).astype(np.float32)
+    es = (rng.uniform(size=(T, N)) < 0.1).astype(np.float32)
+    lv, d = rng.normal(size=N).astype(np.float32), (rng.uniform(size=N) < 0.3).astype(np.float32)
+    a0, r0 = np_gae(r, v, es, lv, d, 0.99, 0.95)
+    a1, r1 = R.gae_reference(*(torch.as_tensor(x) for x in (r, v, es, lv, d)), 0.99, 0.95)
+    np.testing.assert_allclose(a1.numpy(), a0, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r1.numpy(), r0, rtol=1e-5, atol=1e-6)
+
+
+def test_policy_distribution_matches_torch_normal():
+    torch.manual_seed(0)
+    pol = R.MlpPolicy(9)
+    assert sum(p.numel() for p in pol.parameters()) == 2 * (9 * 64 + 64 + 64 * 64 + 64) + 64 * 4 + 4 + 64 + 1 + 4
+    obs = torch.randn(13, 9)
+    with torch.no_grad():
+        pol.log_std.copy_(torch.tensor([0.1, -0.3, 0.0, 0.5]))
+        act, val, logp = pol(obs)
+        mean = pol.action_net(pol.pi_net(obs))
+        dist = torch.distributions.Normal(mean, pol.log_std.exp())
+        torch.testing.assert_close(logp, dist.log_prob(act).sum(-1))
+        v2, lp2, ent = pol.evaluate_actions(obs, act)
+        torch.testing.assert_close(lp2, logp); torch.testing.assert_close(v2, val)
+        torch.testing.assert_close(ent, dist.entropy().sum(-1))
+        a_det, _, _ = pol(obs, deterministic=True)
+        torch.testing.assert_close(a_det, mean)
+    # SB3 init: action head gain 0.01 => near-zero mean actions, log_std 0
+    fresh = R.MlpPolicy(9)
+    assert fresh.action_net.weight.abs().max() < 0.05 and float(fresh.log_std.abs().max()) == 0.0
+
+
+def test_vecnormalize_semantics_match_sb3():
+    venv = FakeVenv(n=8, d=4, seed=3)
+    vn = R.VecNormalizeDevice(venv, gamma=0.99, use_fused_kernel=False)
+    obs_rms, ret_rms, returns = NpRunningMeanStd((4,)), NpRunningMeanStd(()), np.zeros(8)
+    twin = FakeVenv(n=8, d=4, seed=3)
+    o = twin.reset_tensor().numpy(); obs_rms.update(o)
+    got = vn.reset()
+    np.testing.assert_allclose(got.numpy(), np.clip((o - obs_rms.mean) / np.sqrt(obs_rms.var + 1e-8), -10, 10), rtol=1e-5, atol=1e-6)
+    g = torch.Generator().manual_seed(9)
+    for _ in range(25):
+        a = torch.randn((8, 4), generator=g)
+        o, r, te, tr = twin.step_tensor(a)
+        o, r = o.numpy(), r.numpy(); done = (te | tr).numpy().astype(bool)
+        obs_rms.update(o)
+        returns = returns * 0.99 + r; ret_rms.update(returns)
+        want_r = np.clip(r / np.sqrt(ret_rms.var + 1e-8), -10, 10)
+        returns[done] = 0
+        on, rn, dn, to, tobs = vn.step(a)
+        np.testing.assert_allclose(on.numpy(), np.clip((o - obs_rms.mean) / np.sqrt(obs_rms.var + 1e-8), -10, 10), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(rn.numpy(), want_r, rtol=1e-5, atol=1e-6)
+        assert np.array_equal(dn.numpy(), done) and np.array_equal(to.numpy(), (tr.numpy() == 1) & (te.numpy() == 0))
+        want_t = np.clip((twin.terminal_obs.numpy() - obs_rms.mean) / np.sqrt(obs_rms.var + 1e-8), -10, 10)
+        np.testing.assert_allclose(tobs.numpy()[done], want_t[done], rtol=1e-5, atol=1e-5)
+    # eval mode: statistics frozen, reward untouched (eval env of the train script: training=False, norm_reward=False)
+    ev = R.VecNormalizeDevice(FakeVenv(n=8, d=4, seed=5), training=False, norm_reward=False, use_fused_kernel=False)
+    ev.load_state_dict(vn.state_dict()); ev.training, ev.norm_reward = False, False
+    before = ev.obs_rms.mean.clone(); ev.reset(); _, r2, *_ = ev.step(torch.zeros(8, 4))
+    assert torch.equal(before, ev.obs_rms.mean) and r2.abs().max() < 3.0
+
+
+def test_ppo_runs_on_fake_env_and_improves_objective():
+    venv = FakeVenv(n=32, d=5, seed=1)
+    env = R.VecNormalizeDevice(venv, use_fused_kernel=False)
+    cfg = R.PPOConfig(n_steps=8, batch_size=64, n_epochs=4, seed=7)
+    ppo = R.PPO(env, cfg, policy=R.MlpPolicy(5), gae_fn=R.gae_reference)
+    w0 = [p.detach().clone() for p in ppo.policy.parameters()]
+    ppo.learn(total_timesteps=3 * 8 * 32)
+    assert ppo.num_timesteps == 3 * 8 * 32
+    assert all(math.isfinite(v) for v in ppo.logs.values())
+    assert any(not torch.equal(a, b) for a, b in zip(w0, ppo.policy.parameters()))
+    # truncation bootstrap: reward of a timed-out step includes gamma * V(terminal_obs)
+    sd = ppo.state_dict()
+    ppo2 = R.PPO(R.VecNormalizeDevice(FakeVenv(n=32, d=5, seed=1), use_fused_kernel=False), cfg, policy=R.MlpPolicy(5), gae_fn=R.gae_reference)
+    ppo2.load_state_dict(sd)
+    assert ppo2.num_timesteps == 0                      # the reference restarts the counter on resume (:313-327)
+    for a, b in zip(ppo.policy.parameters(), ppo2.policy.parameters()):
+        assert torch.equal(a, b)
+    assert torch.equal(ppo.env.obs_rms.mean, ppo2.env.obs_rms.mean)
+
+
+# ---------------------------------------------------------------- gloo, world_size 2
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(123)
+        full = torch.randn((40, 6), generator=g, dtype=torch.float64) * 2 + 1
+        mine = full[rank * 20:(rank + 1) * 20]
+        # (1) normaliser moments: merged statistics == single-process statistics of the union
+        rms = R.RunningMeanStd((6,), "cpu"); rms.update(mine)
+        ref = NpRunningMeanStd((6,)); ref.update(full.numpy())
+        ok1 = np.allclose(rms.mean.numpy(), ref.mean, rtol=1e-12) and np.allclose(rms.var.numpy(), ref.var, rtol=1e-11)
+        # (2) advantage all-gather == statistics of the union == the 2-scalar all-reduce formula
+        adv_full = torch.randn(64, generator=g); adv = adv_full[rank * 32:(rank + 1) * 32]
+        m, s, allv = R.global_advantage_stats(adv)
+        buf = torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(adv.numel()))]); td.all_reduce(buf)
+        m2 = buf[0] / buf[2]; s2 = torch.sqrt((buf[1] - buf[2] * m2 * m2) / (buf[2] - 1))
+        ok2 = (torch.allclose(m, adv_full.mean()) and torch.allclose(s, adv_full.std()) and torch.equal(allv, adv_full)
+               and torch.allclose(m, m2, atol=1e-6) and torch.allclose(s, s2, atol=1e-5))
+        # (3) one flattened gradient bucket: every rank ends with the mean gradient
+        lin = torch.nn.Linear(3, 2)
+        for p in lin.parameters():
+            p.grad = torch.full_like(p, float(rank + 1))
+        R.allreduce_grads_(list(lin.parameters()))
+        ok3 = all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in lin.parameters())
+        # (4) a sharded PPO job keeps its replicas identical and counts global timesteps
+        venv = FakeVenv(n=8, d=5, seed=100 + rank)
+        ppo = R.PPO(R.VecNormalizeDevice(venv, use_fused_kernel=False), R.PPOConfig(n_steps=4, batch_size=16, n_epochs=2, seed=3),
+                    policy=R.MlpPolicy(5), gae_fn=R.gae_reference)
+        ppo.learn(total_timesteps=2 * 4 * 8 * world)
+        flat = torch.cat([p.detach().reshape(-1) for p in ppo.policy.parameters()])
+        others = [torch.empty_like(flat) for _ in range(world)]; td.all_gather(others, flat)
+        ok4 = all(torch.allclose(o, flat, atol=1e-7) for o in others) and ppo.num_timesteps == 2 * 4 * 8 * world
+        stats = torch.cat([ppo.env.obs_rms.mean, ppo.env.obs_rms.var]); so = [torch.empty_like(stats) for _ in range(world)]
+        td.all_gather(so, stats)
+        ok5 = all(torch.allclose(o, stats) for o in so)
+        q.put((rank, ok1, ok2, ok3, ok4, ok5))
+    finally:
+        td.destroy_process_group()
+
+
+def test_update_time_collectives_world_size_2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60); assert p.exitcode == 0
+    for rank, *oks in sorted(res):
+        assert all(oks), (rank, oks)
