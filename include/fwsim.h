@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 3
+#define FW_ABI_VERSION 4
 
 #define FW_NUM_SURFACES 5         /* left aileron, right aileron, h-tail, v-tail, main wing */
 #define FW_NUM_ACTUATORS 6        /* 5 surfaces + throttle (aux_state order) */
@@ -221,10 +221,11 @@ enum {
   FW_S_EP_RETURN = 36,
   FW_S_TARGETS = 37,   /* FW_MAX_TARGETS x 3 (world) */
   FW_S_TASK = 61,      /* task-specific tail, see FW_ST_* */
-  FW_STATE_DIM = 128
+  FW_STATE_DIM = 176
 };
 
-/* objlock tail (offsets from FW_S_TASK) */
+/* objlock tail (offsets from FW_S_TASK); mirrors the private fields of
+ * envs/fixedwing_objlock_env.py:143-156 plus the latest analytic camera frame */
 enum {
   FW_ST_DUCK_POS = 0,      /* 3 */
   FW_ST_LOCK_STEPS = 3,
@@ -235,11 +236,14 @@ enum {
   FW_ST_LAST_DEPTH = 8,
   FW_ST_SINCE_SEEN = 9,
   FW_ST_HIST_FILLED = 10,
-  FW_ST_CAM = 11,          /* 5 latest camera frame: visible,d_left,d_center,d_right, has_frame */
-  FW_ST_HIST = 16,         /* FW_VISION_HIST x FW_VISION_FEATS = 27 */
-  FW_ST_DUCK_PHASE = 43,   /* combined env: bit0 duck_phase, bit1 post_waypoints */
-  FW_ST_SEEN_CONSEC = 44,
-  FW_ST_OBST = 45          /* FW_MAX_OBSTACLES x 3 (x,y,h) = 60 -> 105 <= 128-61 */
+  FW_ST_FRAME_HAS = 11,    /* 1 once the camera has captured a frame this episode */
+  FW_ST_FRAME = 12,        /* 8: visible, cx, cy, area, depth_m, d_left, d_center, d_right of the latest frame */
+  FW_ST_HIST = 20,         /* FW_VISION_HIST x FW_VISION_FEATS = 27, newest first */
+  FW_ST_DUCK_PHASE = 47,   /* combined env: bit0 duck_phase, bit1 post_waypoints */
+  FW_ST_SEEN_CONSEC = 48,
+  FW_ST_NUM_OBST = 49,
+  FW_ST_OBST = 50,         /* FW_MAX_OBSTACLES x 3 (x, y, height) -> 110 of the 115 tail slots */
+  FW_ST_DIM = 110
 };
 
 /* info_i32 columns written by fw_step (info of the step that just ran, i.e. of
@@ -261,6 +265,7 @@ typedef struct fw_env* fw_handle;
 /* Size of fw_config as compiled into the library (binding self-check). */
 int32_t fw_sizeof_config(void);
 int32_t fw_abi_version(void);
+int32_t fw_state_dim(void);      /* FW_STATE_DIM of the canonical state record */
 
 /* Observation width D for a config (22/23 attitude + task part); <0 on error. */
 int32_t fw_obs_dim(const fw_config* cfg);

@@ -178,6 +178,8 @@ typedef struct {
   int n_deltas;
   /* objlock tail (kept in canonical-record order, see FW_ST_*) */
   double task[FW_STATE_DIM - FW_S_TASK];
+  double obj_target_vector[3], obj_duck_vision[FW_VISION_HIST * FW_VISION_FEATS + 4];
+  int duck_strike;
 } oenv;
 
 typedef struct {
@@ -195,6 +197,9 @@ struct fw_env {            /* the opaque handle type of fwsim.h, oracle flavour 
   double max_rpm;
   double inertia[9], inertia_inv[9];
   int obs_dim, att_dim;
+  /* analytic camera (objlock tasks): body-frame axes, focal length [px], image size, duck radius */
+  double cam_f[3], cam_r[3], cam_d[3], cam_focal, duck_radius;
+  int cam_w, cam_h, camera_ratio_ticks;
   int64_t max_steps;
   int env_step_ratio, ticks_per_aviary;
   char err[256];
@@ -242,6 +247,7 @@ static int obs_dim_of(const fw_config* c) {
 
 int32_t fwo_sizeof_config(void) { return (int32_t)sizeof(fw_config); }
 int32_t fwo_abi_version(void) { return FW_ABI_VERSION; }
+int32_t fwo_state_dim(void) { return FW_STATE_DIM; }
 int32_t fwo_obs_dim(const fw_config* c) { return c ? obs_dim_of(c) : FW_EINVAL; }
 int32_t fwo_validate_config(const fw_config* c, char* msg, int32_t n) { return validate(c, msg, n); }
 
@@ -450,13 +456,21 @@ static void physics_tick(struct fw_env* h, oenv* e, uint32_t genv, int tick_in_a
   }
 }
 
+static void object_contacts(const struct fw_env* h, oenv* e);
+static void camera_capture(const struct fw_env* h, oenv* e);
 /* Aviary.step(): contact_array &= False; updates_per_step ticks */
 static void aviary_step(struct fw_env* h, oenv* e, uint32_t genv) {
   e->contact = 0;
   double z2[2] = {0.0, 0.0};
   if (h->cfg.motor.noise_ratio != 0.0)
     rng_normal2(h->seed, genv, (uint32_t)e->episode, (uint32_t)(e->tick_count / h->ticks_per_aviary), z2);
-  for (int t = 0; t < h->ticks_per_aviary; ++t) physics_tick(h, e, genv, t & 1, z2);
+  for (int t = 0; t < h->ticks_per_aviary; ++t) {
+    physics_tick(h, e, genv, t & 1, z2);
+    if (h->cfg.task != FW_TASK_WAYPOINTS) object_contacts(h, e);
+  }
+  /* update_last(): the camera captures every physics_camera_ratio ticks (:631-641) */
+  if (h->cfg.task != FW_TASK_WAYPOINTS && h->camera_ratio_ticks > 0 && (e->tick_count % h->camera_ratio_ticks) == 0)
+    camera_capture(h, e);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -528,13 +542,283 @@ static void compute_term_trunc_reward_waypoints(struct fw_env* h, oenv* e) {
   }
 }
 
+
+/* ========================================================================= */
+/* ObjLock task (envs/fixedwing_objlock_env.py).                              */
+/* The reference derives its vision features from PyBullet's rendered          */
+/* segmentation / depth images (:643-761).  Rendering is replaced by an        */
+/* ANALYTIC camera (build-owned): the duck is a sphere,   */
+/* obstacles are vertical cylinders, the ground is the plane z = 0; a "frame"   */
+/* is the 8 numbers the reference extracts from the images.  Everything         */
+/* downstream of the frame follows the reference line by line.                  */
+/* ========================================================================= */
+#define TK(e, k) ((e)->task[(k)])
+static double f32r(double x) { return (double)(float)x; }
+
+/* _reset_duck_state :409-419 */
+static void reset_duck_state(oenv* e) {
+  TK(e, FW_ST_LOCK_STEPS) = 0.0; TK(e, FW_ST_PREV_EST) = -1.0;
+  TK(e, FW_ST_LAST_CX) = 0.5; TK(e, FW_ST_LAST_CY) = 0.5; TK(e, FW_ST_LAST_AREA) = 0.0; TK(e, FW_ST_LAST_DEPTH) = 0.0;
+  TK(e, FW_ST_SINCE_SEEN) = 60.0; TK(e, FW_ST_HIST_FILLED) = 0.0; TK(e, FW_ST_FRAME_HAS) = 0.0;
+  for (int k = 0; k < 8; ++k) TK(e, FW_ST_FRAME + k) = 0.0;
+  for (int k = 0; k < FW_VISION_HIST * FW_VISION_FEATS; ++k) TK(e, FW_ST_HIST + k) = 0.0;
+  TK(e, FW_ST_DUCK_PHASE) = 0.0; TK(e, FW_ST_SEEN_CONSEC) = 0.0;
+}
+
+/* _spawn_duck :461-491 and _spawn_obstacles :507-565 (draw order: x, y, yaw; then per attempt h, x, y) */
+static void objlock_spawn(struct fw_env* h, oenv* e, uint32_t genv, uint32_t ep) {
+  const fw_config* c = &h->cfg;
+  const double r = c->flight_dome_size / 2.0;
+  TK(e, FW_ST_DUCK_POS + 0) = rng_uniform(h->seed, genv, ep, J_DUCK_X, -r, r);
+  TK(e, FW_ST_DUCK_POS + 1) = rng_uniform(h->seed, genv, ep, J_DUCK_Y, -r, r);
+  TK(e, FW_ST_DUCK_POS + 2) = 0.05;
+  (void)rng_uniform(h->seed, genv, ep, J_DUCK_YAW, -FWO_PI, FWO_PI);      /* yaw: drawn, irrelevant for a sphere */
+  int n = 0;
+  for (int i = 0; i < c->num_obstacles; ++i) {
+    double hh = rng_uniform(h->seed, genv, ep, J_OBST + 3 * i + 0, c->obstacle_height_range[0], c->obstacle_height_range[1]);
+    double x = rng_uniform(h->seed, genv, ep, J_OBST + 3 * i + 1, -r, r);
+    double y = rng_uniform(h->seed, genv, ep, J_OBST + 3 * i + 2, -r, r);
+    double dx = x - TK(e, FW_ST_DUCK_POS), dy = y - TK(e, FW_ST_DUCK_POS + 1);
+    if (sqrt(dx * dx + dy * dy) < 10.0) continue;                          /* :536-539 */
+    if (x * x + y * y < 100.0) continue;                                   /* :542-543 */
+    TK(e, FW_ST_OBST + 3 * n + 0) = x; TK(e, FW_ST_OBST + 3 * n + 1) = y; TK(e, FW_ST_OBST + 3 * n + 2) = hh;
+    ++n;
+  }
+  for (int i = n; i < FW_MAX_OBSTACLES; ++i) for (int k = 0; k < 3; ++k) TK(e, FW_ST_OBST + 3 * i + k) = 0.0;
+  TK(e, FW_ST_NUM_OBST) = (double)n;
+}
+
+/* contacts with the duck sphere and the obstacle cylinders (Aviary.contact_array) */
+static void object_contacts(const struct fw_env* h, oenv* e) {
+  const fw_config* c = &h->cfg;
+  double R[9];
+  mat_from_quat(e->quat, R);
+  const double cx = TK(e, FW_ST_DUCK_POS), cy = TK(e, FW_ST_DUCK_POS + 1), cz = TK(e, FW_ST_DUCK_POS + 2) + h->duck_radius;
+  const int nob = (int)TK(e, FW_ST_NUM_OBST);
+  for (int i = 0; i < c->n_collision_pts; ++i) {
+    double pb[3] = { c->collision_pts[i][0], c->collision_pts[i][1], c->collision_pts[i][2] }, pw[3];
+    mat_vec(R, pb, pw);
+    for (int k = 0; k < 3; ++k) pw[k] += e->pos[k];
+    double dx = pw[0] - cx, dy = pw[1] - cy, dz = pw[2] - cz;
+    if (dx * dx + dy * dy + dz * dz <= h->duck_radius * h->duck_radius) e->contact = 1;
+    for (int o = 0; o < nob; ++o) {
+      double ox = pw[0] - TK(e, FW_ST_OBST + 3 * o), oy = pw[1] - TK(e, FW_ST_OBST + 3 * o + 1);
+      if (ox * ox + oy * oy <= c->obstacle_radius * c->obstacle_radius && pw[2] <= TK(e, FW_ST_OBST + 3 * o + 2)) e->contact = 1;
+    }
+  }
+}
+
+/* depth along the view axis of the first thing a camera ray hits (ground or cylinder), clamped to [near, far] */
+static double ray_depth(const struct fw_env* h, const oenv* e, const double cam[3], const double dw[3]) {
+  const fw_config* c = &h->cfg;
+  double best = c->camera_far;
+  if (dw[2] < 0.0) { double t = -cam[2] / dw[2]; if (t > 0.0 && t < best) best = t; }
+  const int nob = (int)TK(e, FW_ST_NUM_OBST);
+  for (int o = 0; o < nob; ++o) {
+    double ox = cam[0] - TK(e, FW_ST_OBST + 3 * o), oy = cam[1] - TK(e, FW_ST_OBST + 3 * o + 1), hh = TK(e, FW_ST_OBST + 3 * o + 2);
+    double a = dw[0] * dw[0] + dw[1] * dw[1], b = 2.0 * (ox * dw[0] + oy * dw[1]), cc = ox * ox + oy * oy - c->obstacle_radius * c->obstacle_radius;
+    if (a <= 0.0) continue;
+    double disc = b * b - 4.0 * a * cc;
+    if (disc < 0.0) continue;
+    double t = (-b - sqrt(disc)) / (2.0 * a);
+    if (t <= 0.0) continue;
+    double z = cam[2] + t * dw[2];
+    if (z < 0.0 || z > hh) continue;
+    if (t < best) best = t;
+  }
+  return best < c->camera_near ? c->camera_near : best;
+}
+
+/* does the segment cam -> P pass through an obstacle cylinder? (occlusion of the duck) */
+static int occluded(const struct fw_env* h, const oenv* e, const double cam[3], const double P[3]) {
+  const fw_config* c = &h->cfg;
+  double dw[3] = { P[0] - cam[0], P[1] - cam[1], P[2] - cam[2] };
+  const int nob = (int)TK(e, FW_ST_NUM_OBST);
+  for (int o = 0; o < nob; ++o) {
+    double ox = cam[0] - TK(e, FW_ST_OBST + 3 * o), oy = cam[1] - TK(e, FW_ST_OBST + 3 * o + 1), hh = TK(e, FW_ST_OBST + 3 * o + 2);
+    double a = dw[0] * dw[0] + dw[1] * dw[1], b = 2.0 * (ox * dw[0] + oy * dw[1]), cc = ox * ox + oy * oy - c->obstacle_radius * c->obstacle_radius;
+    if (a <= 0.0) continue;
+    double disc = b * b - 4.0 * a * cc;
+    if (disc < 0.0) continue;
+    double t = (-b - sqrt(disc)) / (2.0 * a);
+    if (t <= 0.0 || t >= 1.0) continue;
+    double z = cam[2] + t * dw[2];
+    if (z >= 0.0 && z <= hh) return 1;
+  }
+  return 0;
+}
+
+/* Camera.capture_image() replaced: fills the frame (visible, cx, cy, area, depth_m, d_left, d_center, d_right) */
+static void camera_capture(const struct fw_env* h, oenv* e) {
+  const fw_config* c = &h->cfg;
+  double R[9], cam[3], off_w[3];
+  mat_from_quat(e->quat, R);
+  mat_vec(R, c->camera_offset, off_w);
+  for (int k = 0; k < 3; ++k) cam[k] = e->pos[k] + off_w[k];
+  const double W = (double)h->cam_w, H = (double)h->cam_h, F = h->cam_focal;
+  const double u0 = 0.5 * (W - 1.0), v0 = 0.5 * (H - 1.0);
+  double* fr = &TK(e, FW_ST_FRAME);
+  /* --- duck --- */
+  double C[3] = { TK(e, FW_ST_DUCK_POS), TK(e, FW_ST_DUCK_POS + 1), TK(e, FW_ST_DUCK_POS + 2) + h->duck_radius };
+  double relw[3] = { C[0] - cam[0], C[1] - cam[1], C[2] - cam[2] }, relb[3];
+  matT_vec(R, relw, relb);
+  double zc = dot3(relb, h->cam_f), xc = dot3(relb, h->cam_r), yc = dot3(relb, h->cam_d);
+  double visible = 0.0, cx = 0.0, cy = 0.0, area = 0.0, depth = 0.0;
+  if (zc - h->duck_radius > c->camera_near && zc - h->duck_radius < c->camera_far) {
+    double u = u0 + F * xc / zc, v = v0 + F * yc / zc, rho = F * h->duck_radius / zc;
+    double x0 = fmax(u - rho, 0.0), x1 = fmin(u + rho, W - 1.0), y0 = fmax(v - rho, 0.0), y1 = fmin(v + rho, H - 1.0);
+    if (x1 > x0 && y1 > y0) {
+      double a = 0.25 * FWO_PI * (x1 - x0) * (y1 - y0);
+      if (a >= 1.0 && !occluded(h, e, cam, C)) {
+        visible = 1.0;
+        cx = 0.5 * (x0 + x1) / fmax(1.0, W - 1.0);        /* mean(xs)/(w-1) :673 */
+        cy = 0.5 * (y0 + y1) / fmax(1.0, H - 1.0);
+        area = fmin(a / (W * H), 1.0);                    /* count/(h*w)   :675 */
+        depth = zc - h->duck_radius;                      /* min depth over the mask, in metres :731-743 */
+      }
+    }
+  }
+  fr[0] = visible; fr[1] = cx; fr[2] = cy; fr[3] = area; fr[4] = depth;
+  /* --- obstacle zones: centre column of each third of the middle row :698-729 --- */
+  const double vmid = (double)(h->cam_h / 2);
+  for (int zid = 0; zid < 3; ++zid) {
+    double ucol = (2.0 * zid + 1.0) * W / 6.0 - 0.5;
+    double a = (ucol - u0) / F, b = (vmid - v0) / F, db[3], dw[3];
+    for (int k = 0; k < 3; ++k) db[k] = h->cam_f[k] + a * h->cam_r[k] + b * h->cam_d[k];
+    mat_vec(R, db, dw);
+    fr[5 + zid] = ray_depth(h, e, cam, dw);
+  }
+  TK(e, FW_ST_FRAME_HAS) = 1.0;
+}
+
+/* _compute_vision_features :643-689 on the latest frame; returns the 9 float32 features */
+static void vision_features(oenv* e, double out[FW_VISION_FEATS]) {
+  double visible = 0.0, dl = 0.0, dc = 0.0, dr = 0.0;
+  if (TK(e, FW_ST_FRAME_HAS) != 0.0) {
+    const double* fr = &TK(e, FW_ST_FRAME);
+    dl = fr[5]; dc = fr[6]; dr = fr[7];
+    if (fr[0] == 0.0) {
+      TK(e, FW_ST_SINCE_SEEN) = fmin(TK(e, FW_ST_SINCE_SEEN) + 1.0, 60.0);            /* :664 */
+    } else {
+      TK(e, FW_ST_LAST_CX) = fr[1]; TK(e, FW_ST_LAST_CY) = fr[2]; TK(e, FW_ST_LAST_AREA) = fr[3];
+      TK(e, FW_ST_LAST_DEPTH) = fr[4]; TK(e, FW_ST_SINCE_SEEN) = 0.0; visible = 1.0;   /* :673-681 */
+    }
+  }
+  /* _build_vision_vector :745-761 (np.float32) */
+  out[0] = visible; out[1] = f32r(TK(e, FW_ST_LAST_CX)); out[2] = f32r(TK(e, FW_ST_LAST_CY));
+  out[3] = f32r(TK(e, FW_ST_LAST_AREA)); out[4] = f32r(TK(e, FW_ST_LAST_DEPTH));
+  out[5] = f32r(TK(e, FW_ST_SINCE_SEEN) / 60.0); out[6] = f32r(dl); out[7] = f32r(dc); out[8] = f32r(dr);
+}
+
+/* the 31-float duck_vision observation as a pure function of the stored history:
+ * after the shift of :437-442, base = hist[0] and prev = hist[1] */
+static void duck_vision_from_hist(const oenv* e, double out[FW_VISION_HIST * FW_VISION_FEATS + 4]) {
+  const double* hist = &e->task[FW_ST_HIST];
+  for (int k = 0; k < FW_VISION_HIST * FW_VISION_FEATS; ++k) out[k] = hist[k];
+  double* dl = out + FW_VISION_HIST * FW_VISION_FEATS;
+  dl[0] = dl[1] = dl[2] = dl[3] = 0.0;
+  if (e->task[FW_ST_HIST_FILLED] >= 2.0 && hist[0] > 0.5 && hist[FW_VISION_FEATS] > 0.5)
+    for (int k = 0; k < 4; ++k) dl[k] = (double)((float)hist[1 + k] - (float)hist[FW_VISION_FEATS + 1 + k]);   /* float32 arithmetic :454-457 */
+}
+
+/* per-env scratch of the objlock observation */
+typedef struct { double target_vector[3]; double duck_vision[FW_VISION_HIST * FW_VISION_FEATS + 4]; } oobj;
+
+/* compute_state :253-287 (+ _build_duck_vision_observation :421-459) */
+static void compute_state_objlock(struct fw_env* h, oenv* e, oobj* ob) {
+  double ang_pos[3], q[4], R[9], diff[3];
+  compute_attitude(h, e, ang_pos, q);
+  mat_from_quat(q, R);
+  for (int k = 0; k < 3; ++k) diff[k] = TK(e, FW_ST_DUCK_POS + k) - e->pos[k];
+  matT_vec(R, diff, ob->target_vector);                                   /* rot.T @ diff :277 */
+  double base[FW_VISION_FEATS];
+  vision_features(e, base);
+  double* hist = &TK(e, FW_ST_HIST);
+  for (int r = FW_VISION_HIST - 1; r >= 1; --r) for (int k = 0; k < FW_VISION_FEATS; ++k) hist[r * FW_VISION_FEATS + k] = hist[(r - 1) * FW_VISION_FEATS + k];
+  for (int k = 0; k < FW_VISION_FEATS; ++k) hist[k] = base[k];
+  TK(e, FW_ST_HIST_FILLED) = fmin(TK(e, FW_ST_HIST_FILLED) + 1.0, (double)FW_VISION_HIST);
+  duck_vision_from_hist(e, ob->duck_vision);
+  e->n_deltas = 0;
+  e->obs_target_index = 0;
+}
+
+/* _apply_obstacle_avoidance_reward :376-407 */
+static void obstacle_penalty(const struct fw_env* h, oenv* e, const double vis[FW_VISION_FEATS], double scale_mult) {
+  double d_obs = INFINITY; int any = 0;
+  for (int k = 6; k < 9; ++k) if (vis[k] > 0.0 && isfinite(vis[k])) { if (vis[k] < d_obs) d_obs = vis[k]; any = 1; }
+  if (!any) return;
+  double d_safe = h->cfg.obstacle_safe_distance_m;
+  if (d_safe <= 0.0 || d_obs >= d_safe) return;
+  double penalty = h->cfg.obstacle_avoid_reward_scale * scale_mult * (d_safe - d_obs) / d_safe;
+  if (penalty > h->cfg.obstacle_avoid_max_penalty) penalty = h->cfg.obstacle_avoid_max_penalty;
+  e->reward -= penalty;
+}
+
+/* compute_term_trunc_reward :289-372 */
+static void compute_term_trunc_reward_objlock(struct fw_env* h, oenv* e, const oobj* ob, int* duck_strike) {
+  const fw_config* c = &h->cfg;
+  compute_base_term_trunc_reward(h, e);
+  if (e->collision || e->oob) return;                                      /* :293-294 */
+  const double* vis = ob->duck_vision;                                     /* newest frame = first 9 entries */
+  obstacle_penalty(h, e, vis, 0.5);                                        /* :403 */
+  const double dist_to_duck = norm3(ob->target_vector);
+  if (!c->sparse_reward) {
+    e->reward += c->duck_distance_reward_scale / fmax(dist_to_duck, 2.0);  /* :303 */
+    if (vis[0] > 0.5) {
+      double cx = vis[1], cy = vis[2], area = vis[3], est_dist = vis[4];
+      e->reward += c->duck_visible_step_reward;
+      e->reward += c->duck_area_reward_scale * fmax(0.0, area);
+      double dist_to_center = sqrt((cx - 0.5) * (cx - 0.5) + (cy - 0.5) * (cy - 0.5));
+      double r_lock = fmax(c->duck_lock_center_radius, 1e-6);
+      double center_score = fmax(0.0, (r_lock - dist_to_center) / r_lock);
+      e->reward += c->duck_centering_reward_scale * center_score;
+      if (dist_to_center < r_lock) {
+        TK(e, FW_ST_LOCK_STEPS) = fmin(TK(e, FW_ST_LOCK_STEPS) + 1.0, (double)c->duck_lock_hold_steps);
+        e->reward += c->duck_lock_step_reward;
+      } else {
+        TK(e, FW_ST_LOCK_STEPS) = fmax(TK(e, FW_ST_LOCK_STEPS) - (double)c->duck_lock_decay_steps, 0.0);
+      }
+      if (TK(e, FW_ST_PREV_EST) >= 0.0 && est_dist > 0.0 && isfinite(est_dist)) {
+        double diff = TK(e, FW_ST_PREV_EST) - est_dist, clip_m = c->duck_approach_reward_clip_m;
+        if (clip_m > 0.0) diff = fmax(-clip_m, fmin(diff, clip_m));
+        e->reward += diff * c->duck_approach_reward_scale;
+      }
+      TK(e, FW_ST_PREV_EST) = (est_dist > 0.0 && isfinite(est_dist)) ? est_dist : -1.0;
+    } else {
+      if (TK(e, FW_ST_LOCK_STEPS) > 0.0) e->reward -= c->duck_lock_lost_penalty;
+      TK(e, FW_ST_LOCK_STEPS) = fmax(TK(e, FW_ST_LOCK_STEPS) - (double)c->duck_lock_decay_steps, 0.0);
+      TK(e, FW_ST_PREV_EST) = -1.0;
+    }
+  }
+  if (TK(e, FW_ST_LOCK_STEPS) >= (double)c->duck_lock_hold_steps && dist_to_duck <= c->duck_strike_distance_m) {   /* :366-372 */
+    e->termination = 1;
+    e->reward += c->duck_strike_reward;
+    e->env_complete = 1;
+    *duck_strike = 1;
+  }
+}
+
 static void compute_state(struct fw_env* h, oenv* e) {
   switch (h->cfg.task) {
+    case FW_TASK_OBJLOCK: {
+      oobj ob;
+      compute_state_objlock(h, e, &ob);
+      memcpy(e->obj_target_vector, ob.target_vector, sizeof ob.target_vector);
+      memcpy(e->obj_duck_vision, ob.duck_vision, sizeof ob.duck_vision);
+      break;
+    }
     case FW_TASK_WAYPOINTS: default: compute_state_waypoints(h, e); break;
   }
 }
 static void compute_term_trunc_reward(struct fw_env* h, oenv* e) {
   switch (h->cfg.task) {
+    case FW_TASK_OBJLOCK: {
+      oobj ob;
+      memcpy(ob.target_vector, e->obj_target_vector, sizeof ob.target_vector);
+      memcpy(ob.duck_vision, e->obj_duck_vision, sizeof ob.duck_vision);
+      compute_term_trunc_reward_objlock(h, e, &ob, &e->duck_strike);
+      break;
+    }
     case FW_TASK_WAYPOINTS: default: compute_term_trunc_reward_waypoints(h, e); break;
   }
 }
@@ -542,6 +826,12 @@ static void compute_term_trunc_reward(struct fw_env* h, oenv* e) {
 /* flatten: envs/flatten_waypoint_env.py:52-72 */
 static void flatten_obs(const struct fw_env* h, const oenv* e, double* out) {
   int att = h->att_dim, o = 0;
+  if (h->cfg.task == FW_TASK_OBJLOCK) {          /* envs/flatten_objlock_env.py:41-46: concat(...).astype(np.float32) */
+    for (int k = 0; k < att; ++k) out[o++] = (double)(float)e->attitude[k];
+    for (int k = 0; k < 3; ++k) out[o++] = (double)(float)e->obj_target_vector[k];
+    for (int k = 0; k < FW_VISION_HIST * FW_VISION_FEATS + 4; ++k) out[o++] = e->obj_duck_vision[k];
+    return;
+  }
   for (int k = 0; k < att; ++k) out[o++] = e->attitude[k];
   int ctx = h->cfg.context_length;
   for (int i = 0; i < ctx; ++i)
@@ -551,6 +841,8 @@ static void flatten_obs(const struct fw_env* h, const oenv* e, double* out) {
 /* ------------------------------------------------------------------------- */
 /* reset: begin_reset / scenario / end_reset (fixedwing_base_env.py:193-257)  */
 /* ------------------------------------------------------------------------- */
+static void reset_duck_state(oenv* e);
+static void objlock_spawn(struct fw_env* h, oenv* e, uint32_t genv, uint32_t ep);
 static void env_reset(struct fw_env* h, oenv* e, uint32_t genv) {
   const fw_config* c = &h->cfg;
   e->episode += 1;                       /* index of the episode that starts now */
@@ -595,6 +887,8 @@ static void env_reset(struct fw_env* h, oenv* e, uint32_t genv) {
     }
   }
   memset(e->task, 0, sizeof(e->task));
+  e->duck_strike = 0;
+  if (c->task != FW_TASK_WAYPOINTS) { reset_duck_state(e); objlock_spawn(h, e, genv, ep); }   /* :240-245 */
   /* end_reset: 10 warm-up Aviary steps with a zero setpoint, then compute_state */
   for (int i = 0; i < c->warmup_aviary_steps; ++i) aviary_step(h, e, genv);
   compute_state(h, e);
@@ -635,6 +929,7 @@ int32_t fwo_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint6
   if (!cfg || !out || num_envs <= 0) { snprintf(g_err, sizeof g_err, "bad arguments"); return FW_EINVAL; }
   int rc = validate(cfg, g_err, (int)sizeof g_err);
   if (rc != FW_OK) return rc;
+  if (cfg->task == FW_TASK_WAYPOINT_OBJLOCK) { snprintf(g_err, sizeof g_err, "FW_TASK_WAYPOINT_OBJLOCK is not built yet"); return FW_EUNSUPPORTED; }
   struct fw_env* h = (struct fw_env*)calloc(1, sizeof *h);
   if (!h) return FW_ENOMEM;
   h->cfg = *cfg; h->n = num_envs; h->seed = seed; h->env_offset = global_env_offset;
@@ -651,6 +946,16 @@ int32_t fwo_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint6
   h->max_steps = (int64_t)(cfg->agent_hz * cfg->max_duration_seconds);   /* int(agent_hz*max_duration) :101 */
   h->env_step_ratio = (int)(120 / cfg->agent_hz);                        /* :102 */
   h->ticks_per_aviary = cfg->physics_hz / cfg->control_hz;
+  {
+    double th = cfg->camera_angle_deg * (FWO_PI / 180.0);
+    h->cam_f[0] = cos(th); h->cam_f[1] = 0.0; h->cam_f[2] = sin(th);      /* tilt about body y; negative = looking down */
+    h->cam_r[0] = 0.0; h->cam_r[1] = -1.0; h->cam_r[2] = 0.0;             /* body y is LEFT => image x grows to the right */
+    cross3(h->cam_f, h->cam_r, h->cam_d);                                 /* image y grows downwards */
+    h->cam_w = h->cam_h = cfg->camera_resolution > 0 ? cfg->camera_resolution : 128;
+    h->cam_focal = 0.5 * h->cam_w / tan(0.5 * cfg->camera_fov_deg * (FWO_PI / 180.0));
+    h->duck_radius = cfg->duck_radius_per_scale * cfg->duck_global_scaling;
+    h->camera_ratio_ticks = h->ticks_per_aviary * cfg->duck_camera_capture_interval_steps;
+  }
   /* envs start un-reset: a terminated shell so that step() before reset() is inert */
   for (int i = 0; i < num_envs; ++i) { h->e[i].termination = 1; h->e[i].quat[3] = 1.0; h->e[i].episode = -1; }
   *out = h;
@@ -702,8 +1007,8 @@ int32_t fwo_step(fw_handle h, const void* actions, void* obs, void* reward, uint
       r[FW_INFO_COLLISION] = e->collision;
       r[FW_INFO_OUT_OF_BOUNDS] = e->oob;
       r[FW_INFO_ENV_COMPLETE] = e->env_complete;
-      r[FW_INFO_DUCK_STRIKE] = 0;
-      r[FW_INFO_IS_SUCCESS] = 0;
+      r[FW_INFO_DUCK_STRIKE] = e->duck_strike;
+      r[FW_INFO_IS_SUCCESS] = e->duck_strike;
       r[FW_INFO_EP_LEN] = (int32_t)e->ep_len;
       r[FW_INFO_RESERVED] = 0;
     }
@@ -722,7 +1027,8 @@ int32_t fwo_observe(fw_handle h, void* obs_out, void* stream) {
   for (int i = 0; i < h->n; ++i) {
     oenv tmp = h->e[i];
     tmp.num_reached = tmp.obs_target_index;
-    compute_state(h, &tmp);          /* on a copy: no new/old-distance side effect */
+    if (h->cfg.task != FW_TASK_OBJLOCK)
+      compute_state(h, &tmp);        /* on a copy: no new/old-distance side effect */
     write_obs(h, &tmp, obs_out, (size_t)i);
   }
   return FW_OK;
@@ -782,6 +1088,16 @@ int32_t fwo_set_state(fw_handle h, const double* s) {
     memcpy(e->task, r + FW_S_TASK, sizeof(e->task));
     oenv tmp = *e;                    /* refresh the cached observation without side effects */
     tmp.num_reached = e->obs_target_index;
+    if (h->cfg.task == FW_TASK_OBJLOCK) {   /* vision history is state: rebuild obs from it without shifting */
+      double ap[3], q[4], R[9], diff[3];
+      compute_attitude(h, &tmp, ap, q);
+      mat_from_quat(q, R);
+      for (int k = 0; k < 3; ++k) diff[k] = tmp.task[FW_ST_DUCK_POS + k] - tmp.pos[k];
+      matT_vec(R, diff, tmp.obj_target_vector);
+      duck_vision_from_hist(&tmp, tmp.obj_duck_vision);
+      memcpy(e->obj_target_vector, tmp.obj_target_vector, sizeof tmp.obj_target_vector);
+      memcpy(e->obj_duck_vision, tmp.obj_duck_vision, sizeof tmp.obj_duck_vision);
+    } else
     compute_state(h, &tmp);
     memcpy(e->attitude, tmp.attitude, sizeof e->attitude);
     memcpy(e->target_deltas, tmp.target_deltas, sizeof e->target_deltas);

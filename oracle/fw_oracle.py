@@ -15,7 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libfw_oracle.so")
-FW_STATE_DIM = 128
+FW_STATE_DIM = 176
 FW_INFO_DIM = 8
 
 
@@ -41,6 +41,7 @@ def lib() -> C.CDLL:
         vp, i32, u64, i64 = C.c_void_p, C.c_int32, C.c_uint64, C.c_int64
         L.fwo_sizeof_config.restype = i32
         L.fwo_abi_version.restype = i32
+        L.fwo_state_dim.restype = i32
         L.fwo_obs_dim.restype = i32; L.fwo_obs_dim.argtypes = [vp]
         L.fwo_validate_config.restype = i32; L.fwo_validate_config.argtypes = [vp, C.c_char_p, i32]
         L.fwo_create.restype = i32; L.fwo_create.argtypes = [vp, i32, i32, u64, i64, C.POINTER(vp)]
@@ -65,6 +66,8 @@ def lib() -> C.CDLL:
         L.fwo_rng_normal2.restype = None; L.fwo_rng_normal2.argtypes = [u64, C.c_uint32, C.c_uint32, C.c_uint32, vp]
         L.fwo_wind_at.restype = None; L.fwo_wind_at.argtypes = [vp, vp, vp, C.c_double, C.c_double, vp]
         L.fwo_depth_buffer_to_meters.restype = C.c_double; L.fwo_depth_buffer_to_meters.argtypes = [C.c_double]
+        if L.fwo_state_dim() != FW_STATE_DIM:
+            raise RuntimeError("oracle FW_STATE_DIM does not match the Python wrapper")
         _lib = L
     return _lib
 

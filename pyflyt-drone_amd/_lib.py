@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(CSRC, "libfwsim_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 EXPORTS = (
-    "fw_sizeof_config", "fw_abi_version", "fw_obs_dim", "fw_validate_config", "fw_create", "fw_reset",
+    "fw_sizeof_config", "fw_abi_version", "fw_state_dim", "fw_obs_dim", "fw_validate_config", "fw_create", "fw_reset",
     "fw_step", "fw_seed", "fw_get_state", "fw_set_state", "fw_observe", "fw_num_envs", "fw_last_error",
     "fw_destroy", "fw_gae", "fw_normalize_obs",
 )
@@ -53,6 +53,7 @@ def lib() -> C.CDLL:
         vp, i32, u64, i64 = C.c_void_p, C.c_int32, C.c_uint64, C.c_int64
         L.fw_sizeof_config.restype = i32; L.fw_sizeof_config.argtypes = []
         L.fw_abi_version.restype = i32; L.fw_abi_version.argtypes = []
+        L.fw_state_dim.restype = i32; L.fw_state_dim.argtypes = []
         L.fw_obs_dim.restype = i32; L.fw_obs_dim.argtypes = [vp]
         L.fw_validate_config.restype = i32; L.fw_validate_config.argtypes = [vp, C.c_char_p, i32]
         L.fw_create.restype = i32; L.fw_create.argtypes = [vp, i32, i32, u64, i64, C.POINTER(vp)]
@@ -71,6 +72,8 @@ def lib() -> C.CDLL:
         L.fw_normalize_obs.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, C.c_float, C.c_float, vp, vp]
         if L.fw_abi_version() != K.FW_ABI_VERSION:
             raise RuntimeError("libfwsim_hip.so ABI version does not match the Python binding; rebuild")
+        if L.fw_state_dim() != K.FW_STATE_DIM:
+            raise RuntimeError("FW_STATE_DIM mismatch between include/fwsim.h and config.py")
         if L.fw_sizeof_config() != C.sizeof(K.FwConfig):
             raise RuntimeError("fw_config layout mismatch between include/fwsim.h and config.FwConfig")
         _lib = L

@@ -18,7 +18,7 @@ import ctypes as C
 import math
 from typing import Any, Mapping, Optional
 
-FW_ABI_VERSION = 3
+FW_ABI_VERSION = 4
 FW_NUM_SURFACES = 5
 FW_NUM_ACTUATORS = 6
 FW_MAX_TARGETS = 8
@@ -26,7 +26,7 @@ FW_MAX_COLLISION_PTS = 8
 FW_MAX_OBSTACLES = 20
 FW_VISION_FEATS = 9
 FW_VISION_HIST = 3
-FW_STATE_DIM = 128
+FW_STATE_DIM = 176
 FW_INFO_DIM = 8
 
 FW_OK, FW_EINVAL, FW_EHIP, FW_ENOMEM, FW_EVERSION, FW_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
@@ -41,8 +41,8 @@ S_STEP_COUNT, S_TICK_COUNT, S_EPISODE, S_FLAGS, S_NUM_REACHED, S_NEW_DIST = 23, 
 S_WIND, S_EP_RETURN, S_TARGETS, S_TASK = 29, 36, 37, 61
 # objlock tail (offsets from S_TASK)
 ST_DUCK_POS, ST_LOCK_STEPS, ST_PREV_EST, ST_LAST_CX, ST_LAST_CY = 0, 3, 4, 5, 6
-ST_LAST_AREA, ST_LAST_DEPTH, ST_SINCE_SEEN, ST_HIST_FILLED, ST_CAM, ST_HIST = 7, 8, 9, 10, 11, 16
-ST_DUCK_PHASE, ST_SEEN_CONSEC, ST_OBST = 43, 44, 45
+ST_LAST_AREA, ST_LAST_DEPTH, ST_SINCE_SEEN, ST_HIST_FILLED, ST_FRAME_HAS, ST_FRAME, ST_HIST = 7, 8, 9, 10, 11, 12, 20
+ST_DUCK_PHASE, ST_SEEN_CONSEC, ST_NUM_OBST, ST_OBST, ST_DIM = 47, 48, 49, 50, 110
 
 INFO_NUM_TARGETS_REACHED, INFO_COLLISION, INFO_OUT_OF_BOUNDS, INFO_ENV_COMPLETE = 0, 1, 2, 3
 INFO_DUCK_STRIKE, INFO_IS_SUCCESS, INFO_EP_LEN = 4, 5, 6
@@ -316,6 +316,104 @@ def train_waypoints_v3_config(**overrides) -> FwConfig:
               wind_config={"enabled": False, "mode": "constant", "wind_enu_mps": [0.0, 0.0, 0.0]})
     kw.update(overrides)
     return waypoints_config(**kw)
+
+
+def _fill_objlock(c: FwConfig, *, num_obstacles, obstacle_radius, obstacle_height_range, obstacle_safe_distance_m,
+                  obstacle_avoid_reward_scale, obstacle_avoid_max_penalty, duck_camera_capture_interval_steps,
+                  duck_lock_hold_steps, duck_strike_distance_m, duck_strike_reward, duck_lock_step_reward,
+                  duck_approach_reward_scale, duck_global_scaling, duck_distance_reward_scale=1.0,
+                  duck_lock_center_radius=0.55, duck_centering_reward_scale=3.0, duck_visible_step_reward=2.0,
+                  duck_area_reward_scale=5.0, duck_lock_decay_steps=1, duck_lock_lost_penalty=0.5,
+                  duck_approach_reward_clip_m=2.0, camera_resolution=128) -> None:
+    if not 0 <= int(num_obstacles) <= FW_MAX_OBSTACLES:
+        raise ValueError(f"num_obstacles must be in [0, {FW_MAX_OBSTACLES}]")
+    c.num_obstacles = int(num_obstacles)
+    c.obstacle_radius = float(obstacle_radius)
+    lo, hi = float(obstacle_height_range[0]), float(obstacle_height_range[1])
+    if hi < lo:                                   # envs/fixedwing_objlock_env.py:525-526
+        lo, hi = hi, lo
+    c.obstacle_height_range[0], c.obstacle_height_range[1] = lo, hi
+    c.obstacle_safe_distance_m = float(obstacle_safe_distance_m)
+    c.obstacle_avoid_reward_scale = float(obstacle_avoid_reward_scale)
+    c.obstacle_avoid_max_penalty = float(obstacle_avoid_max_penalty)
+    c.duck_camera_capture_interval_steps = int(duck_camera_capture_interval_steps)
+    c.duck_lock_hold_steps = int(duck_lock_hold_steps)
+    c.duck_lock_decay_steps = int(max(1, duck_lock_decay_steps))            # :116
+    c.duck_strike_distance_m = float(duck_strike_distance_m)
+    c.duck_strike_reward = float(duck_strike_reward)
+    c.duck_lock_step_reward = float(duck_lock_step_reward)
+    c.duck_approach_reward_scale = float(duck_approach_reward_scale)
+    c.duck_global_scaling = float(duck_global_scaling)
+    c.duck_distance_reward_scale = float(duck_distance_reward_scale)
+    c.duck_lock_center_radius = float(duck_lock_center_radius)
+    c.duck_centering_reward_scale = float(duck_centering_reward_scale)
+    c.duck_visible_step_reward = float(duck_visible_step_reward)
+    c.duck_area_reward_scale = float(duck_area_reward_scale)
+    c.duck_lock_lost_penalty = float(duck_lock_lost_penalty)
+    c.duck_approach_reward_clip_m = float(max(0.0, duck_approach_reward_clip_m))   # :118
+    c.duck_radius_per_scale = 0.05           # build-owned: analytic duck = sphere of radius scale * 0.05 m
+    c.camera_resolution = int(camera_resolution)
+
+
+def objlock_config(*, sparse_reward: bool = False, flight_dome_size: float = 100.0, max_duration_seconds: float = 120.0,
+                   angle_representation: str = "quaternion", agent_hz: int = 30,
+                   num_obstacles: int = 5, obstacle_radius: float = 2.0, obstacle_height_range=(10.0, 30.0),
+                   obstacle_safe_distance_m: float = 20.0, obstacle_avoid_reward_scale: float = 1.0,
+                   obstacle_avoid_max_penalty: float = 2.0, duck_camera_capture_interval_steps: int = 12,
+                   duck_lock_hold_steps: int = 10, duck_strike_distance_m: float = 2.0, duck_strike_reward: float = 200.0,
+                   duck_lock_step_reward: float = 0.1, duck_approach_reward_scale: float = 0.05,
+                   duck_global_scaling: float = 20.0, duck_distance_reward_scale: float = 1.0,
+                   duck_lock_center_radius: float = 0.55, duck_centering_reward_scale: float = 3.0,
+                   duck_visible_step_reward: float = 2.0, duck_area_reward_scale: float = 5.0,
+                   duck_lock_decay_steps: int = 1, duck_lock_lost_penalty: float = 0.5,
+                   duck_approach_reward_clip_m: float = 2.0, camera_resolution: int = 128,
+                   wind_config: Optional[Mapping[str, Any]] = None, dtype: str = "float64",
+                   motor_noise: bool = True, auto_reset: bool = True) -> FwConfig:
+    """``FixedwingObjLockEnv`` + ``FlattenObjLockEnv``: keyword names and defaults of
+    envs/fixedwing_objlock_env.py:37-81 (start position [0,0,100] :83)."""
+    c = base_config(task=FW_TASK_OBJLOCK, dtype=dtype, angle_representation=angle_representation, agent_hz=agent_hz,
+                    flight_dome_size=flight_dome_size, max_duration_seconds=max_duration_seconds,
+                    start_pos=(0.0, 0.0, 100.0), wind_config=wind_config, motor_noise=motor_noise, auto_reset=auto_reset)
+    c.sparse_reward = int(bool(sparse_reward))
+    c.num_targets = 0
+    c.context_length = 0
+    _fill_objlock(c, num_obstacles=num_obstacles, obstacle_radius=obstacle_radius,
+                  obstacle_height_range=obstacle_height_range, obstacle_safe_distance_m=obstacle_safe_distance_m,
+                  obstacle_avoid_reward_scale=obstacle_avoid_reward_scale,
+                  obstacle_avoid_max_penalty=obstacle_avoid_max_penalty,
+                  duck_camera_capture_interval_steps=duck_camera_capture_interval_steps,
+                  duck_lock_hold_steps=duck_lock_hold_steps, duck_strike_distance_m=duck_strike_distance_m,
+                  duck_strike_reward=duck_strike_reward, duck_lock_step_reward=duck_lock_step_reward,
+                  duck_approach_reward_scale=duck_approach_reward_scale, duck_global_scaling=duck_global_scaling,
+                  duck_distance_reward_scale=duck_distance_reward_scale, duck_lock_center_radius=duck_lock_center_radius,
+                  duck_centering_reward_scale=duck_centering_reward_scale,
+                  duck_visible_step_reward=duck_visible_step_reward, duck_area_reward_scale=duck_area_reward_scale,
+                  duck_lock_decay_steps=duck_lock_decay_steps, duck_lock_lost_penalty=duck_lock_lost_penalty,
+                  duck_approach_reward_clip_m=duck_approach_reward_clip_m, camera_resolution=camera_resolution)
+    return c
+
+
+TRAIN_OBJLOCK_WIND = {      # train/train_objlock.py:74-85
+    "enabled": True, "mode": "gust_sine", "wind_enu_mps": [0.0, 0.0, 0.0], "gust_amp_enu_mps": [0.0, 0.0, 0.0],
+    "gust_freq_hz": 0.2, "gust_phase_rad": 0.0, "randomize_on_reset": True, "randomize_gust_phase": True,
+    "wind_enu_mps_range": [[-10.0, 10.0], [-10.0, 10.0], [-0.1, 0.1]],
+    "gust_amp_enu_mps_range": [[0.0, 3.0], [0.0, 3.0], [0.0, 0.3]],
+}
+
+
+def train_objlock_config(**overrides) -> FwConfig:
+    """ENV_CONFIG of train/train_objlock.py:27-86,113-153 (config 3 of BASELINE.json):
+    dome 200 m, 60 s, euler, duck scale 60, hold 5, strike 10 m / +400, lock step 0.2,
+    approach 0.1, capture interval 12, no obstacles, gust wind; render_mode="rgb_array"
+    makes the camera 480 x 480 (envs/fixedwing_objlock_env.py:213-218)."""
+    kw = dict(sparse_reward=False, flight_dome_size=200.0, max_duration_seconds=60.0, angle_representation="euler",
+              agent_hz=30, num_obstacles=0, obstacle_radius=2.0, obstacle_height_range=(10.0, 30.0),
+              obstacle_safe_distance_m=10.0, obstacle_avoid_reward_scale=1.0, obstacle_avoid_max_penalty=5.0,
+              duck_camera_capture_interval_steps=12, duck_lock_hold_steps=5, duck_strike_distance_m=10.0,
+              duck_strike_reward=400.0, duck_lock_step_reward=0.2, duck_approach_reward_scale=0.1,
+              duck_global_scaling=60.0, camera_resolution=480, wind_config=TRAIN_OBJLOCK_WIND)
+    kw.update(overrides)
+    return objlock_config(**kw)
 
 
 def obs_dim(c: FwConfig) -> int:

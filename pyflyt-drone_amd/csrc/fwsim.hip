@@ -12,6 +12,7 @@
 
 #include "fwsim_device.hpp"
 #include "fwsim_rollout.hpp"
+#include "fwsim_objlock.hpp"
 
 using namespace fwsim;
 
@@ -82,11 +83,13 @@ enum Phase : int { PH_STEP = 0, PH_WARM = 1, PH_DONE = 2 };
 // Outputs are latched in registers and stored once at the end.
 // GENERAL = wind is on (per-env wind registers, and -- if it acts on the dynamics -- the
 // PH_WARM path).  The wind-free instantiation (the headline config) carries none of that.
-template <typename T, bool GENERAL, int G>
+// OBJ = the ObjLock task (duck / analytic camera / vision shaping, fwsim_objlock.hpp); its state rides in registers.
+template <typename T, bool GENERAL, int G, bool OBJ>
 __device__ __forceinline__
-void step_body(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restrict__ actions, T* __restrict__ obs,
-               T* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
-               T* __restrict__ terminal_obs, int32_t* __restrict__ info) {
+void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> D,
+               const T* __restrict__ actions, T* __restrict__ obs, T* __restrict__ reward,
+               uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated, T* __restrict__ terminal_obs,
+               int32_t* __restrict__ info) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
   const Params<T>& P = *Pp;
@@ -112,6 +115,10 @@ void step_body(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restr
   normalize_quat<T>(S.q);
   T R[9];
   rot_from_unit_quat<T>(S.q, R);
+  ObjState<T> O;
+  const ObjC<T>& OC = *OCp;
+  if (OBJ) obj_load<T>(D, envc, O);
+  int32_t out_strike = 0;
   int32_t step_count = D.i[IF_STEP * n + envc];
   int32_t tick = D.i[IF_TICK * n + envc];
   int32_t episode = D.i[IF_EPISODE * n + envc];
@@ -138,7 +145,7 @@ void step_body(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restr
 
   // current and next waypoint stay in registers (no L2 round trip per sub-step)
   T tcur[3] = {(T)0, (T)0, (T)0}, tnext[3] = {(T)0, (T)0, (T)0};
-  if (P.task != FW_TASK_OBJLOCK) {
+  if (!OBJ) {
     const int i0 = min(num_reached, FW_MAX_TARGETS - 1), i1 = min(num_reached + 1, FW_MAX_TARGETS - 1);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -166,7 +173,7 @@ void step_body(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restr
 
   // latched outputs
   T out_rew = (T)0;
-  int32_t out_flags = 0, out_reached = 0, out_steps = 0;
+  int32_t out_flags = 0, out_reached = 0, out_steps = 0, out_strike_latched = 0;
   int phase = active ? PH_STEP : PH_DONE;
   int it = 0, warm_left = 0;
   bool step_over = active && done_at_entry;          // nothing to simulate: finalise immediately
@@ -177,20 +184,26 @@ void step_body(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restr
       // ---- end of env.step(): :346, outputs, SB3 worker auto-reset ----
       step_count += 1;
       ep_return += rew;
-      out_rew = rew; out_flags = flags; out_reached = num_reached; out_steps = step_count;
+      out_rew = rew; out_flags = flags; out_reached = num_reached; out_steps = step_count; out_strike_latched = out_strike;
       phase = PH_DONE;
       if ((flags & (FL_TERM | FL_TRUNC)) && P.auto_reset) {
         if (terminal_obs && leader) {
           T* trow = terminal_obs + (size_t)env * Dobs;
           T act_t[4];
           load_action<T>(D, actions, env, act_src, act_t);
-          write_obs<T>(P, D, env, S, act_t, tgt_obs, [&](int k, T v) { trow[k] = v; });
+          if (OBJ) obj_write_obs<T>(P, O, S, act_t, [&](int k, T v) { trow[k] = v; });
+          else write_obs<T>(P, D, env, S, act_t, tgt_obs, [&](int k, T v) { trow[k] = v; });
         }
         warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase);
+        if (OBJ) {
+          obj_reset_state<T>(O); obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
+          if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        }
         step_count = 0; flags = 0; ep_return = (T)0; tgt_obs = 0;
         act_src = 2;
         rot_from_unit_quat<T>(S.q, R);
         if (GENERAL && warm_left > 0) phase = PH_WARM;
+        else if (OBJ) obj_compute_state<T>(O);                 // end_reset(): first compute_state of the episode
         else new_dist = end_reset<T, G>(P, D, env, episode, S);
       }
     }
@@ -211,11 +224,24 @@ void step_body(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restr
 #pragma unroll
         for (int c = 0; c < FW_NUM_ACTUATORS; ++c) c_eff[c] = stepping ? cmd[c] : (T)0;
         z0 = stepping ? z0 : (T)0; z1 = stepping ? z1 : (T)0;
-        contact = aviary_step<T, true, G>(P, C, S, R, c_eff, tick, z0, z1, wb, wa, wphase, mine, wmask);   // :339
+        contact = aviary_step<T, true, G, OBJ>(P, C, OC, D, env, O, S, R, c_eff, tick, z0, z1, wb, wa, wphase, mine, wmask);   // :339
       } else {
-        contact = aviary_step<T, false, G>(P, C, S, R, cmd, tick, z0, z1, wb, wa, wphase, mine, wmask);    // :339
+        contact = aviary_step<T, false, G, OBJ>(P, C, OC, D, env, O, S, R, cmd, tick, z0, z1, wb, wa, wphase, mine, wmask);    // :339
       }
-      if (stepping) {
+      if (stepping && OBJ) {
+        obj_compute_state<T>(O);                                                                   // :342
+        // compute_base_term_trunc_reward(): :296-312
+        if (step_count > P.max_steps) flags |= FL_TRUNC;
+        if (contact) { rew = (T)-100; flags |= FL_COLLISION | FL_TERM; }
+        if (S.p[0] * S.p[0] + S.p[1] * S.p[1] + S.p[2] * S.p[2] > P.dome * P.dome) { rew = (T)-100; flags |= FL_OOB | FL_TERM; }
+        if (!(flags & (FL_COLLISION | FL_OOB))) {                                                  // :293-294
+          T dx = O.duck[0] - S.p[0], dy = O.duck[1] - S.p[1], dz = O.duck[2] - S.p[2];
+          if (obj_reward<T>(OC, P.sparse, O, M<T>::sqrt_(dx * dx + dy * dy + dz * dz), rew)) {
+            flags |= FL_TERM | FL_COMPLETE; out_strike = 1;
+          }
+        }
+        step_over = (it + 1 >= P.step_ratio) || (flags & (FL_TERM | FL_TRUNC));
+      } else if (stepping) {
         // compute_state(): WaypointHandler.distance_to_targets side effects
         const int nleft = P.num_targets - num_reached;
         const T old_dist = new_dist;
@@ -247,7 +273,10 @@ void step_body(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restr
         step_over = (it + 1 >= P.step_ratio) || (flags & (FL_TERM | FL_TRUNC));     // :334-337
       } else {
         warm_left -= 1;
-        if (warm_left == 0) { new_dist = end_reset<T, G>(P, D, env, episode, S); phase = PH_DONE; }
+        if (warm_left == 0) {
+          if (OBJ) obj_compute_state<T>(O); else new_dist = end_reset<T, G>(P, D, env, episode, S);
+          phase = PH_DONE;
+        }
       }
     }
     it += 1;
@@ -262,12 +291,14 @@ void step_body(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restr
     if (info) {
       int4* ip = reinterpret_cast<int4*>(info + (size_t)env * FW_INFO_DIM);
       ip[0] = make_int4(out_reached, (out_flags & FL_COLLISION) ? 1 : 0, (out_flags & FL_OOB) ? 1 : 0, (out_flags & FL_COMPLETE) ? 1 : 0);
-      ip[1] = make_int4(0, 0, out_steps, 0);
+      ip[1] = make_int4(out_strike_latched, out_strike_latched, out_steps, 0);
     }
     T act_obs[4];
     load_action<T>(D, actions, env, act_src, act_obs);
-    write_obs<T>(P, D, env, S, act_obs, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
+    if (OBJ) obj_write_obs<T>(P, O, S, act_obs, [&](int k, T v) { tile[row * ld + k] = v; });
+    else write_obs<T>(P, D, env, S, act_obs, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
     store_rigid<T>(D, env, S);
+    if (OBJ) obj_store<T>(D, env, O);
 #pragma unroll
     for (int k = 0; k < 4; ++k) D.r[(RF_ACTION + k) * n + env] = act_obs[k];
     D.r[RF_NEW_DIST * n + env] = new_dist;
@@ -285,28 +316,28 @@ void step_body(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restr
 #ifndef FW_G1_WAVES
 #define FW_G1_WAVES 2   // env-per-lane mapping: cap registers for >= 2 waves/SIMD (TLP hides the scalar-load and fp64 latency)
 #endif
+#define FW_STEP_ARGS const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> D,                  \
+    const T* __restrict__ actions, T* __restrict__ obs, T* __restrict__ reward, uint8_t* __restrict__ terminated,        \
+    uint8_t* __restrict__ truncated, T* __restrict__ terminal_obs, int32_t* __restrict__ info
+#define FW_STEP_PASS Pp, OCp, D, actions, obs, reward, terminated, truncated, terminal_obs, info
 // latency mapping (8 lanes per env): one wave per SIMD by construction, let the allocator use the whole file
 template <typename T, bool GENERAL>
-__global__ __launch_bounds__(kWave)
-void fw_step_kernel_g8(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restrict__ actions, T* __restrict__ obs,
-                       T* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
-                       T* __restrict__ terminal_obs, int32_t* __restrict__ info) {
-  step_body<T, GENERAL, 8>(Pp, D, actions, obs, reward, terminated, truncated, terminal_obs, info);
-}
+__global__ __launch_bounds__(kWave) void fw_step_kernel_g8(FW_STEP_ARGS) { step_body<T, GENERAL, 8, false>(FW_STEP_PASS); }
 // throughput mapping (one lane per env)
 template <typename T, bool GENERAL>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(FW_G1_WAVES, FW_G1_WAVES)))
-void fw_step_kernel_g1(const Params<T>* __restrict__ Pp, DevState<T> D, const T* __restrict__ actions, T* __restrict__ obs,
-                       T* __restrict__ reward, uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
-                       T* __restrict__ terminal_obs, int32_t* __restrict__ info) {
-  step_body<T, GENERAL, 1>(Pp, D, actions, obs, reward, terminated, truncated, terminal_obs, info);
-}
+void fw_step_kernel_g1(FW_STEP_ARGS) { step_body<T, GENERAL, 1, false>(FW_STEP_PASS); }
+// ObjLock task (always the GENERAL path: its training config has wind)
+template <typename T>
+__global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g8(FW_STEP_ARGS) { step_body<T, true, 8, true>(FW_STEP_PASS); }
+template <typename T>
+__global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g1(FW_STEP_ARGS) { step_body<T, true, 1, true>(FW_STEP_PASS); }
 
 // K2: reset (masked) + observation.  Same single-tick-site structure (warm-up only).
-template <typename T, int G>
+template <typename T, int G, bool OBJ>
 __global__ __launch_bounds__(kWave)
-void fw_reset_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const uint8_t* __restrict__ mask,
-                     T* __restrict__ obs, int do_reset) {
+void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> D,
+                     const uint8_t* __restrict__ mask, T* __restrict__ obs, int do_reset) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
   const Params<T>& P = *Pp;
@@ -327,6 +358,9 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const uint
 
   Rigid<T> S;
   load_rigid<T>(D, envc, S);
+  ObjState<T> O;
+  const ObjC<T>& OC = *OCp;
+  if (OBJ) obj_load<T>(D, envc, O);
   T action[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) action[k] = D.r[(RF_ACTION + k) * n + envc];
@@ -338,7 +372,11 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const uint
   int warm_left = 0;
   if (resetting) {
     warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase);
-    if (warm_left == 0) new_dist = end_reset<T, G>(P, D, env, episode, S);
+    if (OBJ) {
+      obj_reset_state<T>(O); obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
+      if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    if (warm_left == 0) { if (OBJ) obj_compute_state<T>(O); else new_dist = end_reset<T, G>(P, D, env, episode, S); }
   }
   const T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
   T R[9];
@@ -347,9 +385,9 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const uint
 #pragma unroll 1
   while (__ballot(warm_left > 0) != 0ull) {
     if (warm_left > 0) {
-      (void)aviary_step<T, true, G>(P, C, S, R, cmd0, tick, (T)0, (T)0, wb, wa, wphase, mine, wmask);
+      (void)aviary_step<T, true, G, OBJ>(P, C, OC, D, env, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, wphase, mine, wmask);
       warm_left -= 1;
-      if (warm_left == 0) new_dist = end_reset<T, G>(P, D, env, episode, S);
+      if (warm_left == 0) { if (OBJ) obj_compute_state<T>(O); else new_dist = end_reset<T, G>(P, D, env, episode, S); }
     }
   }
   if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -367,10 +405,14 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, DevState<T> D, const uint
       D.i[IF_EPISODE * n + env] = episode;
       D.i[IF_FLAGS * n + env] = 0;
       D.i[IF_NUM_REACHED * n + env] = num_reached;
+      if (OBJ) obj_store<T>(D, env, O);
     }
   }
   if (obs) {
-    if (active && leader) write_obs<T>(P, D, env, S, action, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
+    if (active && leader) {
+      if (OBJ) obj_write_obs<T>(P, O, S, action, [&](int k, T v) { tile[row * ld + k] = v; });
+      else write_obs<T>(P, D, env, S, action, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
+    }
     __syncthreads();
     flush_obs_tile<T>(tile, ld, obs, env0, EPW, D.n, Dobs);
   }
@@ -518,7 +560,8 @@ bool build_params(const fw_config& c, uint64_t seed, int64_t env_offset, Params<
   P.warmup_aviary_steps = c.warmup_aviary_steps;
   // The warm-up is env-independent iff wind cannot act on the dynamics (throttle
   // stays exactly 0 under a zero setpoint, so motor noise multiplies 0).
-  P.warm_valid = (P.wind_coupling == FW_WIND_COUPLE_NONE) ? 1 : 0;
+  // ObjLock: the camera may capture during the warm-up (cadence), so it is always integrated in-kernel.
+  P.warm_valid = (P.wind_coupling == FW_WIND_COUPLE_NONE && c.task == FW_TASK_WAYPOINTS) ? 1 : 0;   // (the duck cannot be in contact during warm-up: it spawns >= start height away only by chance; contacts there are ignored by the reference too)
   P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
   P.env_offset = env_offset;
   if (P.obs_dim > kMaxObs) { err = "obs_dim exceeds kMaxObs"; return false; }
@@ -534,6 +577,7 @@ struct fw_env {
   uint64_t seed = 0;
   int64_t env_offset = 0;
   void* params_dev = nullptr;   // Params<T>
+  void* objc_dev = nullptr;     // ObjC<T>
   void* r_dev = nullptr;        // T[RF_COUNT][npad]
   int32_t* i_dev = nullptr;     // i32[IF_COUNT][npad]
   std::string err;
@@ -568,12 +612,39 @@ template <typename T> size_t tile_bytes(const fw_env* h) {
 }
 inline dim3 grid_of(const fw_env* h) { return dim3((unsigned)(h->npad / (kWave / h->lanes_per_env))); }
 
+// ObjLock task constants (analytic camera axes, shaping coefficients of envs/fixedwing_objlock_env.py:54-80)
+template <typename T>
+void build_objc(const fw_config& c, ObjC<T>& O) {
+  std::memset(&O, 0, sizeof O);
+  const double th = c.camera_angle_deg * kPi / 180.0;
+  const double f[3] = { std::cos(th), 0.0, std::sin(th) }, r[3] = { 0.0, -1.0, 0.0 };
+  const double d[3] = { f[1] * r[2] - f[2] * r[1], f[2] * r[0] - f[0] * r[2], f[0] * r[1] - f[1] * r[0] };
+  for (int k = 0; k < 3; ++k) { O.cam_f[k] = (T)f[k]; O.cam_r[k] = (T)r[k]; O.cam_d[k] = (T)d[k]; O.cam_off[k] = (T)c.camera_offset[k]; }
+  const int res = c.camera_resolution > 0 ? c.camera_resolution : 128;
+  O.W = O.H = (T)res; O.vmid = (T)(res / 2);
+  O.focal = (T)(0.5 * res / std::tan(0.5 * c.camera_fov_deg * kPi / 180.0));
+  O.near_ = (T)c.camera_near; O.far_ = (T)c.camera_far;
+  O.duck_radius = (T)(c.duck_radius_per_scale * c.duck_global_scaling); O.half_dome = (T)(c.flight_dome_size / 2.0);
+  O.obst_radius = (T)c.obstacle_radius; O.obst_hmin = (T)c.obstacle_height_range[0]; O.obst_hmax = (T)c.obstacle_height_range[1];
+  O.safe_dist = (T)c.obstacle_safe_distance_m; O.avoid_scale = (T)c.obstacle_avoid_reward_scale; O.avoid_max = (T)c.obstacle_avoid_max_penalty;
+  O.k_dist = (T)c.duck_distance_reward_scale; O.lock_radius = (T)c.duck_lock_center_radius; O.k_center = (T)c.duck_centering_reward_scale;
+  O.k_visible = (T)c.duck_visible_step_reward; O.k_area = (T)c.duck_area_reward_scale; O.lost_penalty = (T)c.duck_lock_lost_penalty;
+  O.approach_clip = (T)c.duck_approach_reward_clip_m; O.k_approach = (T)c.duck_approach_reward_scale;
+  O.strike_dist = (T)c.duck_strike_distance_m; O.strike_reward = (T)c.duck_strike_reward; O.lock_step_reward = (T)c.duck_lock_step_reward;
+  O.hold_steps = c.duck_lock_hold_steps; O.decay_steps = c.duck_lock_decay_steps; O.num_obstacles = c.num_obstacles;
+  O.camera_ratio_ticks = (c.physics_hz / c.control_hz) * c.duck_camera_capture_interval_steps;
+}
+
 template <typename T>
 int upload_params(fw_env* h) {
   Params<T> P;
   if (!build_params<T>(h->cfg, h->seed, h->env_offset, P, h->err)) return FW_EINVAL;
   if (!h->params_dev) HIP_TRY(h, hipMalloc(&h->params_dev, sizeof(Params<T>)));
   HIP_TRY(h, hipMemcpy(h->params_dev, &P, sizeof P, hipMemcpyHostToDevice));
+  ObjC<T> OC;
+  build_objc<T>(h->cfg, OC);
+  if (!h->objc_dev) HIP_TRY(h, hipMalloc(&h->objc_dev, sizeof(ObjC<T>)));
+  HIP_TRY(h, hipMemcpy(h->objc_dev, &OC, sizeof OC, hipMemcpyHostToDevice));
   if (P.warm_valid) {
     hipLaunchKernelGGL(fw_warm_kernel<T>, dim3(1), dim3(kWave), 0, 0, (Params<T>*)h->params_dev);
     HIP_TRY(h, hipGetLastError());
@@ -595,40 +666,39 @@ int create_T(fw_env* h) {
   return FW_OK;
 }
 
-template <typename T, bool GENERAL, int G>
-void launch_step(fw_env* h, const void* actions, void* obs, void* reward, uint8_t* term, uint8_t* trunc, void* tobs,
-                 int32_t* info, hipStream_t st) {
-  if (G == 8)
-    hipLaunchKernelGGL((fw_step_kernel_g8<T, GENERAL>), grid_of(h), dim3(kWave), tile_bytes<T>(h), st,
-                       (const Params<T>*)h->params_dev, dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term,
-                       trunc, (T*)tobs, info);
-  else
-    hipLaunchKernelGGL((fw_step_kernel_g1<T, GENERAL>), grid_of(h), dim3(kWave), tile_bytes<T>(h), st,
-                       (const Params<T>*)h->params_dev, dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term,
-                       trunc, (T*)tobs, info);
-}
+#define FW_LAUNCH_STEP(KERNEL)                                                                                   \
+  hipLaunchKernelGGL((KERNEL), grid_of(h), dim3(kWave), tile_bytes<T>(h), st, (const Params<T>*)h->params_dev,   \
+                     (const ObjC<T>*)h->objc_dev, dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term,  \
+                     trunc, (T*)tobs, info)
 
 template <typename T>
 int step_T(fw_env* h, const void* actions, void* obs, void* reward, uint8_t* term, uint8_t* trunc, void* tobs,
            int32_t* info, hipStream_t st) {
   const bool general = h->cfg.wind_mode != FW_WIND_OFF;
   const bool g8 = h->lanes_per_env == 8;
-  if (general) { if (g8) launch_step<T, true, 8>(h, actions, obs, reward, term, trunc, tobs, info, st);
-                 else    launch_step<T, true, 1>(h, actions, obs, reward, term, trunc, tobs, info, st); }
-  else         { if (g8) launch_step<T, false, 8>(h, actions, obs, reward, term, trunc, tobs, info, st);
-                 else    launch_step<T, false, 1>(h, actions, obs, reward, term, trunc, tobs, info, st); }
+  if (h->cfg.task == FW_TASK_OBJLOCK) {
+    if (g8) FW_LAUNCH_STEP(fw_step_kernel_obj_g8<T>); else FW_LAUNCH_STEP(fw_step_kernel_obj_g1<T>);
+  } else if (general) {
+    if (g8) FW_LAUNCH_STEP((fw_step_kernel_g8<T, true>)); else FW_LAUNCH_STEP((fw_step_kernel_g1<T, true>));
+  } else {
+    if (g8) FW_LAUNCH_STEP((fw_step_kernel_g8<T, false>)); else FW_LAUNCH_STEP((fw_step_kernel_g1<T, false>));
+  }
   HIP_TRY(h, hipGetLastError());
   return FW_OK;
 }
 
+#define FW_LAUNCH_RESET(KERNEL)                                                                                   \
+  hipLaunchKernelGGL((KERNEL), grid_of(h), dim3(kWave), tile_bytes<T>(h), st, (const Params<T>*)h->params_dev,    \
+                     (const ObjC<T>*)h->objc_dev, dev_state<T>(h), mask, (T*)obs, do_reset)
+
 template <typename T>
 int reset_T(fw_env* h, const uint8_t* mask, void* obs, int do_reset, hipStream_t st) {
-  if (h->lanes_per_env == 8)
-    hipLaunchKernelGGL((fw_reset_kernel<T, 8>), grid_of(h), dim3(kWave), tile_bytes<T>(h), st,
-                       (const Params<T>*)h->params_dev, dev_state<T>(h), mask, (T*)obs, do_reset);
-  else
-    hipLaunchKernelGGL((fw_reset_kernel<T, 1>), grid_of(h), dim3(kWave), tile_bytes<T>(h), st,
-                       (const Params<T>*)h->params_dev, dev_state<T>(h), mask, (T*)obs, do_reset);
+  const bool g8 = h->lanes_per_env == 8;
+  if (h->cfg.task == FW_TASK_OBJLOCK) {
+    if (g8) FW_LAUNCH_RESET((fw_reset_kernel<T, 8, true>)); else FW_LAUNCH_RESET((fw_reset_kernel<T, 1, true>));
+  } else {
+    if (g8) FW_LAUNCH_RESET((fw_reset_kernel<T, 8, false>)); else FW_LAUNCH_RESET((fw_reset_kernel<T, 1, false>));
+  }
   HIP_TRY(h, hipGetLastError());
   return FW_OK;
 }
@@ -689,6 +759,7 @@ extern "C" {
 
 int32_t fw_sizeof_config(void) { return (int32_t)sizeof(fw_config); }
 int32_t fw_abi_version(void) { return FW_ABI_VERSION; }
+int32_t fw_state_dim(void) { return FW_STATE_DIM; }
 int32_t fw_obs_dim(const fw_config* cfg) { return cfg ? obs_dim_of(cfg) : FW_EINVAL; }
 
 int32_t fw_validate_config(const fw_config* cfg, char* msg, int32_t msg_len) {
@@ -703,6 +774,7 @@ int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64
   if (!cfg || !out || num_envs <= 0) { g_err = "bad arguments"; return FW_EINVAL; }
   int rc = validate(cfg, g_err);
   if (rc != FW_OK) return rc;
+  if (cfg->task == FW_TASK_WAYPOINT_OBJLOCK) { g_err = "FW_TASK_WAYPOINT_OBJLOCK is not built yet"; return FW_EUNSUPPORTED; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device available (this library has no CPU fallback)"; return FW_EHIP; }
   if (device < 0 || device >= ndev) { g_err = "device index out of range"; return FW_EINVAL; }
@@ -723,6 +795,7 @@ int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64
   if (rc != FW_OK) {
     g_err = h->err;
     if (h->params_dev) (void)hipFree(h->params_dev);
+    if (h->objc_dev) (void)hipFree(h->objc_dev);
     if (h->r_dev) (void)hipFree(h->r_dev);
     if (h->i_dev) (void)hipFree(h->i_dev);
     delete h;
@@ -833,6 +906,7 @@ int32_t fw_destroy(fw_handle h) {
   DeviceGuard g(h->device);
   (void)hipDeviceSynchronize();
   if (h->params_dev) (void)hipFree(h->params_dev);
+  if (h->objc_dev) (void)hipFree(h->objc_dev);
   if (h->r_dev) (void)hipFree(h->r_dev);
   if (h->i_dev) (void)hipFree(h->i_dev);
   delete h;

@@ -596,22 +596,7 @@ __device__ __forceinline__ bool physics_tick(const Params<T>& P, const TickC<T>&
   return contact;
 }
 
-// Aviary.step(): ticks_per_aviary ticks; returns any-contact.  (z0, z1) are the two
-// ticks' motor-noise normals (zero for warm-up lanes: their throttle is exactly 0).
-template <typename T, bool WIND, int G>
-__device__ __forceinline__ bool aviary_step(const Params<T>& P, const TickC<T>& C, Rigid<T>& S, T R[9],
-                                            const T cmd[FW_NUM_ACTUATORS], int32_t& tick, T z0, T z1, const T wb[3],
-                                            const T wa[3], T wphase, const SurfC<T>& mine, T wmask) {
-  bool contact = false;
-#pragma unroll 1
-  for (int t = 0; t < P.ticks_per_aviary; ++t) {
-    T wind[3] = {(T)0, (T)0, (T)0};
-    if (WIND) wind_at<T>(P, wb, wa, wphase, tick, wind);
-    contact |= physics_tick<T, WIND, G>(P, C, S, R, cmd, (t & 1) ? z1 : z0, wind, mine, wmask);
-    tick += 1;
-  }
-  return contact;
-}
+// Aviary.step() lives in fwsim_objlock.hpp (it also drives the ObjLock contacts / camera cadence).
 
 // pybullet.getEulerFromQuaternion incl. the gimbal guard
 template <typename T>

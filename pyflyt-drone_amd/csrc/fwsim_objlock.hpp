@@ -1,0 +1,350 @@
+// fwsim_objlock.hpp -- device side of the ObjLock task (envs/fixedwing_objlock_env.py).
+//
+// The reference derives its vision features from PyBullet's rendered segmentation /
+// depth images (:643-761).  Rendering is replaced by an ANALYTIC camera (build-owned,
+// DESIGN.md section 2b): duck = sphere, obstacles = vertical cylinders, ground = plane
+// z = 0; a "frame" is the 8 numbers the reference extracts from the images.  Everything
+// downstream of the frame (feature vector, 3-deep history with float32 deltas, obstacle
+// penalty, dense lock / approach shaping, strike) follows the reference line by line.
+// The task state of one env lives in registers for the whole launch.
+#pragma once
+#include "fwsim_device.hpp"
+
+namespace fwsim {
+
+constexpr int kHist = FW_VISION_HIST * FW_VISION_FEATS;   // 27
+
+template <typename T>
+struct ObjC {          // wave-uniform task constants
+  T cam_f[3], cam_r[3], cam_d[3], cam_off[3];
+  T focal, W, H, vmid, near_, far_;
+  T duck_radius, half_dome;
+  T obst_radius, obst_hmin, obst_hmax, safe_dist, avoid_scale, avoid_max;
+  T k_dist, lock_radius, k_center, k_visible, k_area, lost_penalty, approach_clip, k_approach;
+  T strike_dist, strike_reward, lock_step_reward;
+  int32_t hold_steps, decay_steps, num_obstacles, camera_ratio_ticks;
+};
+
+template <typename T>
+struct ObjState {
+  T duck[3];
+  T lock_steps, prev_est, last_cx, last_cy, last_area, last_depth, since_seen, filled, frame_has;
+  T frame[8];          // visible, cx, cy, area, depth_m, d_left, d_center, d_right
+  float hist[kHist];   // float32 by construction (np.float32 feature vectors)
+  int32_t nob;
+};
+
+template <typename T> __device__ __forceinline__ T f32r(T x) { return (T)(float)x; }
+
+template <typename T>
+__device__ __forceinline__ void obj_load(const DevState<T>& D, int env, ObjState<T>& O) {
+  const T* b = D.r + (size_t)RF_TASK * D.npad + env;
+  const size_t n = D.npad;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) O.duck[k] = b[(FW_ST_DUCK_POS + k) * n];
+  O.lock_steps = b[FW_ST_LOCK_STEPS * n]; O.prev_est = b[FW_ST_PREV_EST * n];
+  O.last_cx = b[FW_ST_LAST_CX * n]; O.last_cy = b[FW_ST_LAST_CY * n]; O.last_area = b[FW_ST_LAST_AREA * n];
+  O.last_depth = b[FW_ST_LAST_DEPTH * n]; O.since_seen = b[FW_ST_SINCE_SEEN * n]; O.filled = b[FW_ST_HIST_FILLED * n];
+  O.frame_has = b[FW_ST_FRAME_HAS * n];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) O.frame[k] = b[(FW_ST_FRAME + k) * n];
+#pragma unroll
+  for (int k = 0; k < kHist; ++k) O.hist[k] = (float)b[(FW_ST_HIST + k) * n];
+  O.nob = (int32_t)b[FW_ST_NUM_OBST * n];
+}
+template <typename T>
+__device__ __forceinline__ void obj_store(const DevState<T>& D, int env, const ObjState<T>& O) {
+  T* b = D.r + (size_t)RF_TASK * D.npad + env;
+  const size_t n = D.npad;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) b[(FW_ST_DUCK_POS + k) * n] = O.duck[k];
+  b[FW_ST_LOCK_STEPS * n] = O.lock_steps; b[FW_ST_PREV_EST * n] = O.prev_est;
+  b[FW_ST_LAST_CX * n] = O.last_cx; b[FW_ST_LAST_CY * n] = O.last_cy; b[FW_ST_LAST_AREA * n] = O.last_area;
+  b[FW_ST_LAST_DEPTH * n] = O.last_depth; b[FW_ST_SINCE_SEEN * n] = O.since_seen; b[FW_ST_HIST_FILLED * n] = O.filled;
+  b[FW_ST_FRAME_HAS * n] = O.frame_has;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) b[(FW_ST_FRAME + k) * n] = O.frame[k];
+#pragma unroll
+  for (int k = 0; k < kHist; ++k) b[(FW_ST_HIST + k) * n] = (T)O.hist[k];
+  b[FW_ST_NUM_OBST * n] = (T)O.nob;
+}
+
+// _reset_duck_state :409-419
+template <typename T>
+__device__ __forceinline__ void obj_reset_state(ObjState<T>& O) {
+  O.lock_steps = (T)0; O.prev_est = (T)-1; O.last_cx = (T)0.5; O.last_cy = (T)0.5; O.last_area = (T)0; O.last_depth = (T)0;
+  O.since_seen = (T)60; O.filled = (T)0; O.frame_has = (T)0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) O.frame[k] = (T)0;
+#pragma unroll
+  for (int k = 0; k < kHist; ++k) O.hist[k] = 0.0f;
+}
+
+// _spawn_duck :461-491, _spawn_obstacles :507-565.  Every lane computes the scenario; only the
+// leader writes the obstacle list to HBM.
+template <typename T>
+__device__ __forceinline__ void obj_spawn(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env, uint32_t ep,
+                                          bool leader, ObjState<T>& O) {
+  const uint32_t genv = (uint32_t)(P.env_offset + env);
+  const double r = (double)OC.half_dome;
+  const double dx = rng_uniform<T>(P, genv, ep, J_DUCK_X, -r, r), dy = rng_uniform<T>(P, genv, ep, J_DUCK_Y, -r, r);
+  O.duck[0] = (T)dx; O.duck[1] = (T)dy; O.duck[2] = (T)0.05;
+  int nob = 0;
+  T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
+  const size_t n = D.npad;
+#pragma unroll 1
+  for (int i = 0; i < OC.num_obstacles; ++i) {
+    double hh = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 0, (double)OC.obst_hmin, (double)OC.obst_hmax);
+    double x = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 1, -r, r);
+    double y = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 2, -r, r);
+    double ex = x - dx, ey = y - dy;
+    if (M<double>::sqrt_(ex * ex + ey * ey) < 10.0) continue;
+    if (x * x + y * y < 100.0) continue;
+    if (leader) { ob[(3 * nob + 0) * n] = (T)x; ob[(3 * nob + 1) * n] = (T)y; ob[(3 * nob + 2) * n] = (T)hh; }
+    ++nob;
+  }
+  if (leader)
+    for (int i = nob; i < FW_MAX_OBSTACLES; ++i) { ob[(3 * i + 0) * n] = (T)0; ob[(3 * i + 1) * n] = (T)0; ob[(3 * i + 2) * n] = (T)0; }
+  O.nob = nob;
+}
+
+// is world point pw inside the duck sphere or an obstacle cylinder?
+template <typename T>
+__device__ __forceinline__ bool obj_point_hit(const ObjC<T>& OC, const DevState<T>& D, int env, const ObjState<T>& O, const T pw[3]) {
+  T dx = pw[0] - O.duck[0], dy = pw[1] - O.duck[1], dz = pw[2] - (O.duck[2] + OC.duck_radius);
+  bool hit = dx * dx + dy * dy + dz * dz <= OC.duck_radius * OC.duck_radius;
+  const T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
+  const size_t n = D.npad;
+  for (int o = 0; o < O.nob; ++o) {
+    T ox = pw[0] - ob[(3 * o) * n], oy = pw[1] - ob[(3 * o + 1) * n];
+    hit |= (ox * ox + oy * oy <= OC.obst_radius * OC.obst_radius) && (pw[2] <= ob[(3 * o + 2) * n]);
+  }
+  return hit;
+}
+
+// contacts of the body-fixed points with duck / cylinders (G = 8: lane `sub` owns point `sub`)
+template <typename T, int G>
+__device__ __forceinline__ bool obj_contacts(const Params<T>& P, const TickC<T>& C, const ObjC<T>& OC, const DevState<T>& D, int env,
+                                             const ObjState<T>& O, const Rigid<T>& S, const T R[9]) {
+  if (G == 8) {
+    T pw[3];
+    mv(R, C.cpt, pw);
+    pw[0] += S.p[0]; pw[1] += S.p[1]; pw[2] += S.p[2];
+    return group_any<8>(C.cvalid != (T)0 && obj_point_hit<T>(OC, D, env, O, pw));
+  }
+  bool hit = false;
+  for (int i = 0; i < P.n_coll; ++i) {
+    T pb[3] = { P.coll[i][0], P.coll[i][1], P.coll[i][2] }, pw[3];
+    mv(R, pb, pw);
+    pw[0] += S.p[0]; pw[1] += S.p[1]; pw[2] += S.p[2];
+    hit |= obj_point_hit<T>(OC, D, env, O, pw);
+  }
+  return hit;
+}
+
+// first hit of a camera ray with the ground / a cylinder, as depth along the view axis, clamped to [near, far]
+template <typename T>
+__device__ __forceinline__ T obj_ray_depth(const ObjC<T>& OC, const DevState<T>& D, int env, const ObjState<T>& O, const T cam[3], const T dw[3]) {
+  T best = OC.far_;
+  if (dw[2] < (T)0) { T t = M<T>::div_(-cam[2], dw[2]); if (t > (T)0 && t < best) best = t; }
+  const T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
+  const size_t n = D.npad;
+  for (int o = 0; o < O.nob; ++o) {
+    T ox = cam[0] - ob[(3 * o) * n], oy = cam[1] - ob[(3 * o + 1) * n], hh = ob[(3 * o + 2) * n];
+    T a = dw[0] * dw[0] + dw[1] * dw[1], b = (T)2 * (ox * dw[0] + oy * dw[1]), cc = ox * ox + oy * oy - OC.obst_radius * OC.obst_radius;
+    if (a <= (T)0) continue;
+    T disc = b * b - (T)4 * a * cc;
+    if (disc < (T)0) continue;
+    T t = M<T>::div_(-b - M<T>::sqrt_(disc), (T)2 * a);
+    if (t <= (T)0) continue;
+    T z = cam[2] + t * dw[2];
+    if (z < (T)0 || z > hh) continue;
+    if (t < best) best = t;
+  }
+  return best < OC.near_ ? OC.near_ : best;
+}
+template <typename T>
+__device__ __forceinline__ bool obj_occluded(const ObjC<T>& OC, const DevState<T>& D, int env, const ObjState<T>& O, const T cam[3], const T Pt[3]) {
+  T dw[3] = { Pt[0] - cam[0], Pt[1] - cam[1], Pt[2] - cam[2] };
+  const T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
+  const size_t n = D.npad;
+  bool occ = false;
+  for (int o = 0; o < O.nob; ++o) {
+    T ox = cam[0] - ob[(3 * o) * n], oy = cam[1] - ob[(3 * o + 1) * n], hh = ob[(3 * o + 2) * n];
+    T a = dw[0] * dw[0] + dw[1] * dw[1], b = (T)2 * (ox * dw[0] + oy * dw[1]), cc = ox * ox + oy * oy - OC.obst_radius * OC.obst_radius;
+    if (a <= (T)0) continue;
+    T disc = b * b - (T)4 * a * cc;
+    if (disc < (T)0) continue;
+    T t = M<T>::div_(-b - M<T>::sqrt_(disc), (T)2 * a);
+    if (t <= (T)0 || t >= (T)1) continue;
+    T z = cam[2] + t * dw[2];
+    occ |= (z >= (T)0 && z <= hh);
+  }
+  return occ;
+}
+
+// Camera.capture_image() replaced by the analytic frame
+template <typename T>
+__device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevState<T>& D, int env, ObjState<T>& O,
+                                                   const Rigid<T>& S, const T R[9]) {
+  T cam[3], offw[3];
+  mv(R, OC.cam_off, offw);
+  cam[0] = S.p[0] + offw[0]; cam[1] = S.p[1] + offw[1]; cam[2] = S.p[2] + offw[2];
+  const T W = OC.W, H = OC.H, F = OC.focal;
+  const T u0 = (T)0.5 * (W - (T)1), v0 = (T)0.5 * (H - (T)1);
+  T Cc[3] = { O.duck[0], O.duck[1], O.duck[2] + OC.duck_radius };
+  T relw[3] = { Cc[0] - cam[0], Cc[1] - cam[1], Cc[2] - cam[2] }, relb[3];
+  mtv(R, relw, relb);
+  T zc = relb[0] * OC.cam_f[0] + relb[1] * OC.cam_f[1] + relb[2] * OC.cam_f[2];
+  T xc = relb[0] * OC.cam_r[0] + relb[1] * OC.cam_r[1] + relb[2] * OC.cam_r[2];
+  T yc = relb[0] * OC.cam_d[0] + relb[1] * OC.cam_d[1] + relb[2] * OC.cam_d[2];
+  T visible = (T)0, cx = (T)0, cy = (T)0, area = (T)0, depth = (T)0;
+  if (zc - OC.duck_radius > OC.near_ && zc - OC.duck_radius < OC.far_) {
+    T u = u0 + M<T>::div_(F * xc, zc), v = v0 + M<T>::div_(F * yc, zc), rho = M<T>::div_(F * OC.duck_radius, zc);
+    T x0 = M<T>::fmax_(u - rho, (T)0), x1 = -M<T>::fmax_(-(u + rho), -(W - (T)1));
+    T y0 = M<T>::fmax_(v - rho, (T)0), y1 = -M<T>::fmax_(-(v + rho), -(H - (T)1));
+    if (x1 > x0 && y1 > y0) {
+      T a = (T)(0.25 * kPi) * (x1 - x0) * (y1 - y0);
+      if (a >= (T)1 && !obj_occluded<T>(OC, D, env, O, cam, Cc)) {
+        visible = (T)1;
+        cx = M<T>::div_((T)0.5 * (x0 + x1), M<T>::fmax_((T)1, W - (T)1));
+        cy = M<T>::div_((T)0.5 * (y0 + y1), M<T>::fmax_((T)1, H - (T)1));
+        T af = M<T>::div_(a, W * H);
+        area = af < (T)1 ? af : (T)1;
+        depth = zc - OC.duck_radius;
+      }
+    }
+  }
+  O.frame[0] = visible; O.frame[1] = cx; O.frame[2] = cy; O.frame[3] = area; O.frame[4] = depth;
+#pragma unroll 1
+  for (int zid = 0; zid < 3; ++zid) {
+    T ucol = M<T>::div_((T)(2 * zid + 1) * W, (T)6) - (T)0.5;
+    T a = M<T>::div_(ucol - u0, F), b = M<T>::div_(OC.vmid - v0, F), db[3], dw[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) db[k] = OC.cam_f[k] + a * OC.cam_r[k] + b * OC.cam_d[k];
+    mv(R, db, dw);
+    O.frame[5 + zid] = obj_ray_depth<T>(OC, D, env, O, cam, dw);
+  }
+  O.frame_has = (T)1;
+}
+
+// compute_state (:253-287) side effects: _compute_vision_features (:643-689) on the latest frame,
+// then the history shift of _build_duck_vision_observation (:421-442)
+template <typename T>
+__device__ __forceinline__ void obj_compute_state(ObjState<T>& O) {
+  T visible = (T)0, dl = (T)0, dc = (T)0, dr = (T)0;
+  if (O.frame_has != (T)0) {
+    dl = O.frame[5]; dc = O.frame[6]; dr = O.frame[7];
+    if (O.frame[0] == (T)0) {
+      O.since_seen = O.since_seen + (T)1 < (T)60 ? O.since_seen + (T)1 : (T)60;
+    } else {
+      O.last_cx = O.frame[1]; O.last_cy = O.frame[2]; O.last_area = O.frame[3]; O.last_depth = O.frame[4];
+      O.since_seen = (T)0; visible = (T)1;
+    }
+  }
+#pragma unroll
+  for (int k = kHist - 1; k >= FW_VISION_FEATS; --k) O.hist[k] = O.hist[k - FW_VISION_FEATS];
+  O.hist[0] = (float)visible; O.hist[1] = (float)O.last_cx; O.hist[2] = (float)O.last_cy; O.hist[3] = (float)O.last_area;
+  O.hist[4] = (float)O.last_depth; O.hist[5] = (float)(O.since_seen / (T)60);
+  O.hist[6] = (float)dl; O.hist[7] = (float)dc; O.hist[8] = (float)dr;
+  O.filled = O.filled + (T)1 < (T)FW_VISION_HIST ? O.filled + (T)1 : (T)FW_VISION_HIST;
+}
+
+// compute_term_trunc_reward (:296-372) after the base checks; returns true on a strike
+template <typename T>
+__device__ __forceinline__ bool obj_reward(const ObjC<T>& OC, int sparse, ObjState<T>& O, T dist_to_duck, T& rew) {
+  const float* vis = O.hist;                      // newest feature vector
+  {  // _apply_obstacle_avoidance_reward :376-407
+    T d_obs = (T)1e300; bool any = false;
+#pragma unroll
+    for (int k = 6; k < 9; ++k) { T d = (T)vis[k]; if (d > (T)0 && d < (T)3.0e38) { any = true; d_obs = d < d_obs ? d : d_obs; } }
+    if (any && OC.safe_dist > (T)0 && d_obs < OC.safe_dist) {
+      T pen = M<T>::div_(OC.avoid_scale * (T)0.5 * (OC.safe_dist - d_obs), OC.safe_dist);
+      rew -= pen < OC.avoid_max ? pen : OC.avoid_max;
+    }
+  }
+  if (!sparse) {
+    rew += M<T>::div_(OC.k_dist, M<T>::fmax_(dist_to_duck, (T)2));
+    if (vis[0] > 0.5f) {
+      T cx = (T)vis[1], cy = (T)vis[2], area = (T)vis[3], est = (T)vis[4];
+      rew += OC.k_visible;
+      rew += OC.k_area * M<T>::fmax_((T)0, area);
+      T dcen = M<T>::sqrt_((cx - (T)0.5) * (cx - (T)0.5) + (cy - (T)0.5) * (cy - (T)0.5));
+      T r_lock = M<T>::fmax_(OC.lock_radius, (T)1e-6);
+      rew += OC.k_center * M<T>::fmax_((T)0, M<T>::div_(r_lock - dcen, r_lock));
+      if (dcen < r_lock) {
+        O.lock_steps = O.lock_steps + (T)1 < (T)OC.hold_steps ? O.lock_steps + (T)1 : (T)OC.hold_steps;
+        rew += OC.lock_step_reward;
+      } else {
+        O.lock_steps = M<T>::fmax_(O.lock_steps - (T)OC.decay_steps, (T)0);
+      }
+      if (O.prev_est >= (T)0 && est > (T)0) {
+        T diff = O.prev_est - est;
+        if (OC.approach_clip > (T)0) { diff = diff > OC.approach_clip ? OC.approach_clip : diff; diff = diff < -OC.approach_clip ? -OC.approach_clip : diff; }
+        rew += diff * OC.k_approach;
+      }
+      O.prev_est = est > (T)0 ? est : (T)-1;
+    } else {
+      if (O.lock_steps > (T)0) rew -= OC.lost_penalty;
+      O.lock_steps = M<T>::fmax_(O.lock_steps - (T)OC.decay_steps, (T)0);
+      O.prev_est = (T)-1;
+    }
+  }
+  if (O.lock_steps >= (T)OC.hold_steps && dist_to_duck <= OC.strike_dist) { rew += OC.strike_reward; return true; }
+  return false;
+}
+
+// FlattenObjLockEnv (envs/flatten_objlock_env.py:41-46): attitude ++ target_vector ++ duck_vision, all float32
+template <typename T, typename W>
+__device__ __forceinline__ void obj_write_obs(const Params<T>& P, const ObjState<T>& O, const Rigid<T>& S, const T action[4], W&& put) {
+  T R[9];
+  rot_from_quat(S.q, R);
+  T ang_vel[3], lin_vel[3], eul[3];
+  mtv(R, S.w, ang_vel);
+  mtv(R, S.v, lin_vel);
+  bool lock = euler_from_quat(S.q, eul);
+  T qrt[4] = { S.q[0], S.q[1], S.q[2], S.q[3] };
+  if (lock || P.angle_repr == 1) { quat_from_euler(eul, qrt); rot_from_quat(qrt, R); }
+  int o = 0;
+  put(o++, f32r(ang_vel[0])); put(o++, f32r(ang_vel[1])); put(o++, f32r(ang_vel[2]));
+  if (P.angle_repr == 0) { put(o++, f32r(eul[0])); put(o++, f32r(eul[1])); put(o++, f32r(eul[2])); }
+  else { put(o++, f32r(qrt[0])); put(o++, f32r(qrt[1])); put(o++, f32r(qrt[2])); put(o++, f32r(qrt[3])); }
+  put(o++, f32r(lin_vel[0])); put(o++, f32r(lin_vel[1])); put(o++, f32r(lin_vel[2]));
+  put(o++, f32r(S.p[0])); put(o++, f32r(S.p[1])); put(o++, f32r(S.p[2]));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) put(o++, f32r(action[k]));
+#pragma unroll
+  for (int k = 0; k < FW_NUM_ACTUATORS; ++k) put(o++, f32r(S.act[k]));
+  T d[3] = { O.duck[0] - S.p[0], O.duck[1] - S.p[1], O.duck[2] - S.p[2] }, tv[3];
+  mtv(R, d, tv);
+  put(o++, f32r(tv[0])); put(o++, f32r(tv[1])); put(o++, f32r(tv[2]));
+#pragma unroll
+  for (int k = 0; k < kHist; ++k) put(o++, (T)O.hist[k]);
+  const bool both = O.filled >= (T)2 && O.hist[0] > 0.5f && O.hist[FW_VISION_FEATS] > 0.5f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) put(o++, both ? (T)(O.hist[1 + k] - O.hist[FW_VISION_FEATS + 1 + k]) : (T)0);
+}
+
+// Aviary.step(): ticks_per_aviary ticks; returns any-contact.  (z0, z1) are the two ticks'
+// motor-noise normals (zero for warm-up lanes: their throttle is exactly 0).  OBJ adds the
+// duck / cylinder contacts per tick and the camera capture every physics_camera_ratio ticks
+// (envs/fixedwing_objlock_env.py:631-641).
+template <typename T, bool WIND, int G, bool OBJ>
+__device__ __forceinline__ bool aviary_step(const Params<T>& P, const TickC<T>& C, const ObjC<T>& OC, const DevState<T>& D,
+                                            int env, ObjState<T>& O, Rigid<T>& S, T R[9], const T cmd[FW_NUM_ACTUATORS],
+                                            int32_t& tick, T z0, T z1, const T wb[3], const T wa[3], T wphase,
+                                            const SurfC<T>& mine, T wmask) {
+  bool contact = false;
+#pragma unroll 1
+  for (int t = 0; t < P.ticks_per_aviary; ++t) {
+    T wind[3] = {(T)0, (T)0, (T)0};
+    if (WIND) wind_at<T>(P, wb, wa, wphase, tick, wind);
+    contact |= physics_tick<T, WIND, G>(P, C, S, R, cmd, (t & 1) ? z1 : z0, wind, mine, wmask);
+    if (OBJ) contact |= obj_contacts<T, G>(P, C, OC, D, env, O, S, R);
+    tick += 1;
+  }
+  if (OBJ && OC.camera_ratio_ticks > 0 && (tick % OC.camera_ratio_ticks) == 0) obj_camera_capture<T>(OC, D, env, O, S, R);
+  return contact;
+}
+
+}  // namespace fwsim

@@ -235,3 +235,20 @@ class FixedwingWaypointsVecEnv(FixedwingVecEnv):
                                  context_length=context_length, wind_config=wind_config, dtype=dtype,
                                  motor_noise=motor_noise)
         super().__init__(cfg, num_envs, device=device, seed=seed, global_env_offset=global_env_offset)
+
+
+class FixedwingObjLockVecEnv(FixedwingVecEnv):
+    """``FlattenObjLockEnv(FixedwingObjLockEnv(...))`` vectorised (envs/fixedwing_objlock_env.py:37-81,
+    envs/flatten_objlock_env.py; constructed at train/train_objlock.py:113-153).  Observations are
+    the reference's 56 float32 values (22 attitude + 3 target vector + 31 duck vision); with
+    ``dtype="float64"`` they are stored in float64 tensors but already rounded to float32."""
+
+    def __init__(self, num_envs: int, *, render_mode: Optional[str] = None, dtype: str = "float64",
+                 motor_noise: bool = True, device=None, seed: int = 0, global_env_offset: int = 0, **env_kwargs):
+        if render_mode not in (None, "rgb_array"):
+            raise ValueError(f"Invalid render mode {render_mode}, only [None, 'rgb_array'] have a device counterpart.")
+        if render_mode == "rgb_array":          # camera_resolution = render_resolution (:213-218)
+            env_kwargs.setdefault("camera_resolution", int(env_kwargs.pop("render_resolution", (480, 480))[0]))
+        cfg = K.objlock_config(dtype=dtype, motor_noise=motor_noise, **env_kwargs)
+        super().__init__(cfg, num_envs, device=device, seed=seed, global_env_offset=global_env_offset)
+        self.observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float32)

@@ -34,6 +34,8 @@ def cases():
     yield "dense_euler_const_airspeed_nonoise", K.waypoints_config(
         sparse_reward=False, num_targets=2, goal_reach_distance=6.0, angle_representation="euler",
         context_length=1, wind_config=CONST_AIR, motor_noise=False, max_duration_seconds=2.0), "gentle", 4, 100, 11
+    yield "objlock_train_config", K.train_objlock_config(duck_camera_capture_interval_steps=3, num_obstacles=6,
+                                                         obstacle_safe_distance_m=60.0), "gentle", 4, 100, 21
 
 
 def main():

@@ -10,7 +10,7 @@ def seeded_actions(rng, n, kind="uniform"):
     return a
 
 
-def run_lockstep(hip_env, ora_env, steps, rng, kind="uniform", atol=1e-6, rtol=1e-9, check_state=True):
+def run_lockstep(hip_env, ora_env, steps, rng, kind="uniform", atol=1e-6, rtol=1e-9, check_state=True, state_atol=None):
     """Step both implementations with the same actions; assert per-step agreement.
     Returns a dict of the worst deviations seen."""
     import torch
@@ -40,6 +40,6 @@ def run_lockstep(hip_env, ora_env, steps, rng, kind="uniform", atol=1e-6, rtol=1
         worst["dones"] += int(done.sum())
     if check_state:
         sh, so = hip_env.get_state(), ora_env.get_state()
-        np.testing.assert_allclose(sh, so, rtol=rtol, atol=atol, err_msg="final canonical state")
+        np.testing.assert_allclose(sh, so, rtol=rtol, atol=atol if state_atol is None else state_atol, err_msg="final canonical state")
         worst["state"] = float(np.abs(sh - so).max())
     return worst

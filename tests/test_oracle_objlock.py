@@ -1,0 +1,245 @@
+"""Known-answer tests of the oracle's ObjLock task against the reference text
+(envs/fixedwing_objlock_env.py, envs/flatten_objlock_env.py).  The rendered camera is
+replaced by an analytic one (build-owned); everything downstream of the frame is the
+reference's arithmetic and is pinned here."""
+import math
+
+import numpy as np
+import pytest
+
+from pyflyt_drone_amd import config as K
+
+T0 = K.S_TASK
+
+
+def quiet(**kw):
+    """120 Hz agent (one sub-step per step), no camera captures unless asked, no noise, no auto-reset."""
+    base = dict(agent_hz=120, motor_noise=False, auto_reset=False, angle_representation="euler",
+                duck_camera_capture_interval_steps=10 ** 6, flight_dome_size=1e5, num_obstacles=0,
+                duck_lock_hold_steps=5, duck_strike_distance_m=10.0, duck_strike_reward=400.0,
+                duck_lock_step_reward=0.2, duck_approach_reward_scale=0.1, duck_global_scaling=60.0)
+    base.update(kw)
+    return K.objlock_config(**base)
+
+
+def make(oracle, cfg, n=1, seed=3):
+    env = oracle.OracleEnv(cfg, n, seed=seed)
+    env.reset()
+    return env
+
+
+def set_frame(env, visible, cx=0.5, cy=0.5, area=0.01, depth=50.0, zones=(255.0, 255.0, 255.0), **extra):
+    s = env.get_state()
+    s[0, T0 + K.ST_FRAME_HAS] = 1.0
+    s[0, T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8] = [visible, cx, cy, area, depth, *zones]
+    for k, v in extra.items():
+        s[0, T0 + getattr(K, k)] = v
+    env.set_state(s)
+    return s
+
+
+def step0(env):
+    return env.step(np.zeros((1, 4)))
+
+
+def test_shapes_and_dtype():
+    cfg = K.train_objlock_config()
+    assert K.obs_dim(cfg) == 56 and K.max_steps(cfg) == 1800 and cfg.camera_resolution == 480
+    assert list(cfg.start_pos) == [0.0, 0.0, 100.0]
+
+
+def test_flat_obs_is_float32_rounded(oracle):
+    env = make(oracle, K.train_objlock_config(motor_noise=False), n=3)
+    obs, *_ = env.step(np.full((3, 4), 0.123456789))
+    np.testing.assert_array_equal(obs, obs.astype(np.float32).astype(np.float64))      # flatten_objlock_env.py:46
+    assert obs.shape == (3, 56)
+    np.testing.assert_array_equal(obs[:, 12:16], np.float32(0.123456789))
+
+
+def test_duck_spawn_distribution_and_obstacle_rejection(oracle):
+    cfg = K.objlock_config(flight_dome_size=200.0, num_obstacles=20, motor_noise=False)
+    env = make(oracle, cfg, n=256, seed=9)
+    s = env.get_state()
+    duck = s[:, T0:T0 + 3]
+    assert np.all(np.abs(duck[:, :2]) <= 100.0) and np.all(duck[:, 2] == 0.05) and duck[:, 0].std() > 40     # :476-481
+    nob = s[:, T0 + K.ST_NUM_OBST].astype(int)
+    assert nob.max() <= 20 and nob.min() >= 10 and (nob < 20).any()          # some attempts are rejected
+    for i in range(256):
+        ob = s[i, T0 + K.ST_OBST:T0 + K.ST_OBST + 3 * nob[i]].reshape(-1, 3)
+        assert np.all(np.hypot(ob[:, 0] - duck[i, 0], ob[:, 1] - duck[i, 1]) >= 10.0)          # :536-539
+        assert np.all(ob[:, 0] ** 2 + ob[:, 1] ** 2 >= 100.0)                                      # :542-543
+        assert np.all((ob[:, 2] >= 10.0) & (ob[:, 2] <= 30.0))
+    # rejected attempts still consume their draws: obstacle k of env 0 is attempt >= k
+    h0 = oracle.rng_uniform01(9, 0, 0, 0, 40) * 20 + 10
+    assert s[0, T0 + K.ST_OBST + 2] == pytest.approx(h0) or nob[0] < 20
+
+
+def test_reset_state_and_no_frame_features(oracle):
+    env = make(oracle, quiet())
+    s = env.get_state()[0]
+    assert s[T0 + K.ST_LOCK_STEPS] == 0 and s[T0 + K.ST_PREV_EST] == -1 and s[T0 + K.ST_SINCE_SEEN] == 60
+    assert s[T0 + K.ST_LAST_CX] == 0.5 and s[T0 + K.ST_LAST_CY] == 0.5 and s[T0 + K.ST_HIST_FILLED] == 1    # end_reset compute_state
+    obs = env.observe()[0]
+    # no frame yet: visible 0, cx=cy=.5, area=depth=0, steps_norm 1, zones 0 ; older history rows zero ; deltas zero
+    np.testing.assert_allclose(obs[25:34], [0, .5, .5, 0, 0, 1, 0, 0, 0])
+    assert np.all(obs[34:56] == 0)
+    _, r, *_ = step0(env)
+    assert env.get_state()[0, T0 + K.ST_SINCE_SEEN] == 60                      # not incremented without a frame (:650-651)
+
+
+def test_dense_reward_visible_inside_lock_radius(oracle):
+    cfg = quiet()
+    env = make(oracle, cfg)
+    set_frame(env, 1.0, cx=0.6, cy=0.45, area=0.02, depth=80.0, ST_PREV_EST=83.5)
+    _, r, term, trunc, _, info = step0(env)
+    s = env.get_state()[0]
+    dist = np.linalg.norm(s[T0:T0 + 3] - s[K.S_POS:K.S_POS + 3])
+    f = np.float32
+    dc = math.sqrt((float(f(0.6)) - 0.5) ** 2 + (float(f(0.45)) - 0.5) ** 2)
+    want = (-0.1 + 1.0 / max(dist, 2.0) + 2.0 + 5.0 * float(f(0.02)) + 3.0 * max(0.0, (0.55 - dc) / 0.55) + 0.2
+            + 0.1 * min(max(83.5 - 80.0, -2.0), 2.0))                            # approach clipped to +2 m (:344-347)
+    assert r[0] == pytest.approx(want, rel=1e-12)
+    assert s[T0 + K.ST_LOCK_STEPS] == 1 and s[T0 + K.ST_PREV_EST] == 80.0 and s[T0 + K.ST_SINCE_SEEN] == 0
+    assert not term[0] and info[0, K.INFO_DUCK_STRIKE] == 0
+
+
+def test_outside_lock_radius_decays_and_negative_approach_clip(oracle):
+    env = make(oracle, quiet())
+    set_frame(env, 1.0, cx=0.02, cy=0.98, area=0.001, depth=120.0, ST_PREV_EST=100.0, ST_LOCK_STEPS=3.0)
+    _, r, *_ = step0(env)
+    s = env.get_state()[0]
+    dist = np.linalg.norm(s[T0:T0 + 3] - s[K.S_POS:K.S_POS + 3])
+    want = -0.1 + 1.0 / max(dist, 2.0) + 2.0 + 5.0 * float(np.float32(0.001)) + 0.0 + 0.1 * (-2.0)
+    assert r[0] == pytest.approx(want, rel=1e-12)
+    assert s[T0 + K.ST_LOCK_STEPS] == 2                                          # decay by duck_lock_decay_steps (:336)
+
+
+def test_not_visible_lost_lock_penalty(oracle):
+    env = make(oracle, quiet())
+    set_frame(env, 0.0, ST_LOCK_STEPS=2.0, ST_PREV_EST=40.0, ST_SINCE_SEEN=7.0)
+    _, r, *_ = step0(env)
+    s = env.get_state()[0]
+    dist = np.linalg.norm(s[T0:T0 + 3] - s[K.S_POS:K.S_POS + 3])
+    assert r[0] == pytest.approx(-0.1 + 1.0 / max(dist, 2.0) - 0.5, rel=1e-12)      # :352-353
+    assert s[T0 + K.ST_LOCK_STEPS] == 1 and s[T0 + K.ST_PREV_EST] == -1 and s[T0 + K.ST_SINCE_SEEN] == 8
+    # saturates at 60 (:664)
+    set_frame(env, 0.0, ST_SINCE_SEEN=60.0)
+    step0(env)
+    assert env.get_state()[0, T0 + K.ST_SINCE_SEEN] == 60
+
+
+def test_strike_needs_lock_and_distance(oracle):
+    cfg = quiet()
+    env = make(oracle, cfg)
+    s = env.get_state()
+    s[0, T0:T0 + 3] = s[0, K.S_POS:K.S_POS + 3] + [6.0, 0.0, 0.0]                  # 6 m ahead (<= 10 m)
+    env.set_state(s)
+    set_frame(env, 1.0, cx=0.5, cy=0.5, area=0.3, depth=3.0, ST_LOCK_STEPS=4.0)     # this step makes it 5 = hold
+    _, r, term, trunc, _, info = step0(env)
+    assert term[0] == 1 and info[0, K.INFO_DUCK_STRIKE] == 1 and info[0, K.INFO_IS_SUCCESS] == 1 and info[0, K.INFO_ENV_COMPLETE] == 1
+    assert r[0] > 400.0
+    # same geometry but lock not yet held: no strike
+    env2 = make(oracle, cfg)
+    s2 = env2.get_state(); s2[0, T0:T0 + 3] = s2[0, K.S_POS:K.S_POS + 3] + [6.0, 0.0, 0.0]; env2.set_state(s2)
+    set_frame(env2, 1.0, cx=0.5, cy=0.5, area=0.3, depth=3.0, ST_LOCK_STEPS=2.0)
+    _, r2, term2, *_ = step0(env2)
+    assert term2[0] == 0 and r2[0] < 50
+
+
+def test_sparse_mode_can_never_strike(oracle):
+    """The lock counter only advances in the dense branch (:300-356), SURVEY quirk 8."""
+    env = make(oracle, quiet(sparse_reward=True))
+    s = env.get_state(); s[0, T0:T0 + 3] = s[0, K.S_POS:K.S_POS + 3] + [6.0, 0.0, 0.0]; env.set_state(s)
+    for _ in range(12):
+        set_frame(env, 1.0, cx=0.5, cy=0.5, area=0.3, depth=3.0)
+        _, r, term, *_ = step0(env)
+        assert term[0] == 0 and r[0] == pytest.approx(-0.1)
+    assert env.get_state()[0, T0 + K.ST_LOCK_STEPS] == 0
+
+
+def test_obstacle_penalty_formula(oracle):
+    cfg = quiet(obstacle_safe_distance_m=10.0, obstacle_avoid_reward_scale=1.0, obstacle_avoid_max_penalty=0.3, sparse_reward=True)
+    for zones, want in (((255.0, 4.0, 255.0), min(0.5 * (10 - 4) / 10, 0.3)), ((255.0, 9.0, 8.0), 0.5 * (10 - 8) / 10),
+                        ((0.0, 0.0, 0.0), 0.0), ((12.0, 255.0, 0.0), 0.0)):
+        env = make(oracle, cfg)
+        set_frame(env, 0.0, zones=zones)
+        _, r, *_ = step0(env)
+        assert r[0] == pytest.approx(-0.1 - want, rel=1e-9), zones
+
+
+def test_vision_history_shift_fill_and_deltas(oracle):
+    env = make(oracle, quiet())
+    set_frame(env, 1.0, cx=0.4, cy=0.6, area=0.01, depth=90.0)
+    o1, *_ = step0(env)
+    set_frame(env, 1.0, cx=0.45, cy=0.55, area=0.02, depth=85.0)
+    o2, *_ = step0(env)
+    f = lambda x: float(np.float32(x))
+    np.testing.assert_allclose(o2[0, 25:30], [1, f(0.45), f(0.55), f(0.02), 85.0])
+    np.testing.assert_allclose(o2[0, 34:39], [1, f(0.4), f(0.6), f(0.01), 90.0])           # previous frame shifted down
+    want = [np.float32(0.45) - np.float32(0.4), np.float32(0.55) - np.float32(0.6), np.float32(0.02) - np.float32(0.01), np.float32(85) - np.float32(90)]
+    np.testing.assert_array_equal(o2[0, 52:56], np.array(want, dtype=np.float64))         # float32 arithmetic (:454-457)
+    assert env.get_state()[0, T0 + K.ST_HIST_FILLED] == 3                                  # saturates at history_len
+    set_frame(env, 0.0)
+    o3, *_ = step0(env)
+    assert np.all(o3[0, 52:56] == 0) and o3[0, 25] == 0 and o3[0, 34] == 1                # deltas only if both visible
+
+
+def test_analytic_camera_geometry(oracle):
+    """Level flight straight at the duck: centred, depth = range - radius, area = pi rho^2 / (W H)."""
+    cfg = quiet(duck_camera_capture_interval_steps=1, camera_resolution=480, flight_dome_size=1e5)
+    env = make(oracle, cfg)
+    s = env.get_state()
+    s[0, K.S_POS:K.S_POS + 3] = [0.0, 0.0, 3.05]; s[0, K.S_QUAT:K.S_QUAT + 4] = [0, 0, 0, 1]
+    s[0, K.S_VEL:K.S_VEL + 3] = [20, 0, 0]; s[0, K.S_OMEGA:K.S_OMEGA + 3] = 0
+    s[0, T0:T0 + 3] = [150.0, 0.0, 0.05]
+    env.set_state(s)
+    step0(env)                                                                             # 2 ticks, then a capture
+    st = env.get_state()[0]
+    fr = st[T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
+    R_d = 0.05 * 60.0
+    cam = st[K.S_POS:K.S_POS + 3] + oracle.mat_from_quat(st[K.S_QUAT:K.S_QUAT + 4]) @ np.array([0.8, 0, 0.12])
+    assert st[T0 + K.ST_FRAME_HAS] == 1 and fr[0] == 1
+    zc_approx = 150.0 - cam[0]
+    assert fr[4] == pytest.approx(zc_approx * math.cos(math.radians(5)) - R_d, rel=2e-2)
+    assert fr[1] == pytest.approx(0.5, abs=0.01) and 0.3 < fr[2] < 0.6
+    rho = 240.0 * R_d / (zc_approx * math.cos(math.radians(5)))
+    assert fr[3] == pytest.approx(math.pi * rho ** 2 / 480 ** 2, rel=5e-2)
+    # obstacle zones see the ground ahead: the centre ray from ~3 m height, pitched 5 deg down
+    assert 20.0 < fr[6] < 60.0 and fr[5] == pytest.approx(fr[7], rel=0.2)
+    # duck behind the aircraft -> not visible
+    s2 = env.get_state(); s2[0, T0:T0 + 3] = [-150.0, 0.0, 0.05]; env.set_state(s2)
+    step0(env)
+    assert env.get_state()[0, T0 + K.ST_FRAME] == 0
+
+
+def test_obstacle_occludes_and_collides(oracle):
+    cfg = quiet(duck_camera_capture_interval_steps=1, num_obstacles=1, obstacle_radius=2.0, sparse_reward=True)
+    env = make(oracle, cfg)
+    s = env.get_state()
+    s[0, K.S_POS:K.S_POS + 3] = [0.0, 0.0, 12.0]; s[0, K.S_QUAT:K.S_QUAT + 4] = [0, 0, 0, 1]
+    s[0, K.S_VEL:K.S_VEL + 3] = [20, 0, 0]; s[0, K.S_OMEGA:K.S_OMEGA + 3] = 0
+    s[0, T0:T0 + 3] = [200.0, 0.0, 0.05]
+    s[0, T0 + K.ST_NUM_OBST] = 1; s[0, T0 + K.ST_OBST:T0 + K.ST_OBST + 3] = [60.0, 0.0, 30.0]     # cylinder on the line of sight
+    env.set_state(s)
+    _, r, term, *_ = step0(env)
+    fr = env.get_state()[0, T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
+    assert fr[0] == 0 and fr[6] == pytest.approx(60.0 - 2.0 - 0.8 - 20 * 2 / 240, abs=0.5) and not term[0]
+    # fly into it: -100 and collision
+    s = env.get_state(); s[0, K.S_POS] = 57.0; env.set_state(s)
+    for _ in range(20):
+        _, r, term, _, _, info = step0(env)
+        if term[0]:
+            break
+    assert term[0] == 1 and r[0] == -100.0 and info[0, K.INFO_COLLISION] == 1
+
+
+def test_depth_buffer_conversion_constants():
+    c = K.train_objlock_config()
+    assert c.camera_near == 0.1 and c.camera_far == 255.0 and c.camera_fov_deg == 90.0 and c.camera_angle_deg == -5.0
+    assert list(c.camera_offset) == [0.8, 0.0, 0.12]                                      # cockpit_fpv :185-186
+
+
+def test_unsupported_combined_task_is_refused(oracle):
+    c = K.train_objlock_config(); c.task = K.FW_TASK_WAYPOINT_OBJLOCK
+    with pytest.raises(RuntimeError, match="not built yet"):
+        oracle.OracleEnv(c, 1)

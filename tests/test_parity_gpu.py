@@ -48,6 +48,16 @@ def lockstep_cases():
                                       gyroscopic=0), "uniform"
     yield "no_autoreset", K.waypoints_config(sparse_reward=False, num_targets=2, goal_reach_distance=20.0,
                                              angle_representation="euler", auto_reset=False), "uniform"
+    # ---- ObjLock task (envs/fixedwing_objlock_env.py), analytic camera
+    yield "objlock_train", K.train_objlock_config(), "gentle"
+    yield "objlock_train_uniform", K.train_objlock_config(), "uniform"
+    yield "objlock_obstacles_quat", K.objlock_config(flight_dome_size=150.0, max_duration_seconds=20.0, num_obstacles=20,
+                                                     obstacle_safe_distance_m=40.0, duck_camera_capture_interval_steps=2,
+                                                     angle_representation="quaternion", camera_resolution=128,
+                                                     wind_config=CONST_AIRSPEED), "gentle"
+    yield "objlock_sparse_nowind", K.objlock_config(sparse_reward=True, flight_dome_size=120.0, num_obstacles=3,
+                                                    duck_camera_capture_interval_steps=1, angle_representation="euler",
+                                                    motor_noise=False), "uniform"
 
 
 def _mutate(cfg, **kw):
@@ -72,10 +82,50 @@ def test_lockstep_f64(oracle, name, lanes):
     n = 192 + 7                                      # deliberately not a multiple of 64
     hip = P.FixedwingVecEnv(cfg, n, seed=1234)
     ora = oracle.OracleEnv(cfg, n, seed=1234)
-    worst = run_lockstep(hip, ora, 240, np.random.default_rng(5), kind=kind, atol=1e-7, rtol=0)
-    assert worst["obs"] < 1e-7 and worst["state"] < 1e-7
+    obj = cfg.task == K.FW_TASK_OBJLOCK
+    # ObjLock observations are float32-rounded (flatten_objlock_env.py:46): a 1e-13 difference can flip one f32 ulp
+    worst = run_lockstep(hip, ora, 240, np.random.default_rng(5), kind=kind, atol=2e-5 if obj else 1e-7, rtol=0,
+                         state_atol=1e-7)
+    assert worst["obs"] < (2e-5 if obj else 1e-7) and worst["state"] < 1e-7
     if name in ("train_v3", "short_episodes_trunc", "dense_big_reach"):
         assert worst["dones"] > 0, "case was meant to exercise the auto-reset path"
+
+
+def test_objlock_aimed_flights_lock_and_strike(oracle, lanes):
+    """Aircraft aimed at their duck from 60-200 m: frames become visible, the lock counter runs,
+    strikes (+400, is_success) happen -- identically in the kernel and the oracle."""
+    import torch
+    cfg = K.train_objlock_config(duck_camera_capture_interval_steps=2, wind_config=None)
+    n = 256
+    hip = P.FixedwingVecEnv(cfg, n, seed=77); ora = oracle.OracleEnv(cfg, n, seed=77)
+    hip.reset_tensor(); ora.reset()
+    s = ora.get_state()
+    rng = np.random.default_rng(8)
+    T0 = K.S_TASK
+    for i in range(n):
+        rng_d = rng.uniform(60.0, 200.0); yaw = rng.uniform(-np.pi, np.pi)
+        height = rng.uniform(8.0, 30.0)
+        duck = s[i, T0:T0 + 3]
+        # glide slope towards the duck: nose down by atan(height / range)  (positive pitch = nose down)
+        pitch = np.arctan2(height, rng_d) * rng.uniform(0.6, 1.1)
+        s[i, K.S_POS:K.S_POS + 3] = [duck[0] - rng_d * np.cos(yaw), duck[1] - rng_d * np.sin(yaw), height]
+        s[i, K.S_QUAT:K.S_QUAT + 4] = oracle.quat_from_euler([0.0, pitch, yaw])
+        v = oracle.mat_from_quat(s[i, K.S_QUAT:K.S_QUAT + 4]) @ np.array([20.0, 0, 0])
+        s[i, K.S_VEL:K.S_VEL + 3] = v; s[i, K.S_OMEGA:K.S_OMEGA + 3] = 0
+    hip.set_state(s); ora.set_state(s)
+    np.testing.assert_allclose(hip.observe_tensor().cpu().numpy(), ora.observe(), rtol=0, atol=1e-6)
+    strikes = visible = 0
+    for t in range(150):
+        a = seeded_actions(rng, n, "gentle") * 0.3
+        o_obs, o_rew, o_term, o_trunc, o_tobs, o_info = ora.step(a)
+        hip.step_tensor(torch.as_tensor(a, device=hip.device))
+        assert np.array_equal(hip.terminated.cpu().numpy(), o_term) and np.array_equal(hip.truncated.cpu().numpy(), o_trunc), t
+        assert np.array_equal(hip.info.cpu().numpy(), o_info), t
+        np.testing.assert_allclose(hip.obs.cpu().numpy(), o_obs, rtol=0, atol=2e-5, err_msg=f"obs {t}")   # float32-rounded obs
+        np.testing.assert_allclose(hip.rewards.cpu().numpy(), o_rew, rtol=0, atol=1e-6, err_msg=f"reward {t}")
+        strikes += int(o_info[:, K.INFO_DUCK_STRIKE].sum()); visible += int((o_obs[:, 25] > 0.5).sum())
+    assert visible > 500 and strikes >= 3, (visible, strikes)
+    np.testing.assert_allclose(hip.get_state(), ora.get_state(), rtol=0, atol=1e-6)
 
 
 def test_baseline_size_4096_envs_against_oracle(oracle, lanes):
