@@ -798,6 +798,116 @@ static void compute_term_trunc_reward_objlock(struct fw_env* h, oenv* e, const o
   }
 }
 
+
+/* ========================================================================= */
+/* Combined task (envs/fixedwing_waypoint_objlock_env.py): N waypoints, then   */
+/* the duck.  Same analytic camera; no vision history in the observation.       */
+/* ========================================================================= */
+/* _spawn_duck :394-436 (at the last waypoint's x,y, on the ground) and _spawn_obstacles :452-503 */
+static void combined_spawn(struct fw_env* h, oenv* e, uint32_t genv, uint32_t ep) {
+  const fw_config* c = &h->cfg;
+  if (c->num_targets > 0) {
+    TK(e, FW_ST_DUCK_POS + 0) = e->targets[c->num_targets - 1][0];
+    TK(e, FW_ST_DUCK_POS + 1) = e->targets[c->num_targets - 1][1];
+  } else { TK(e, FW_ST_DUCK_POS + 0) = 10.0; TK(e, FW_ST_DUCK_POS + 1) = 0.0; }       /* :417 */
+  TK(e, FW_ST_DUCK_POS + 2) = 0.05;
+  (void)rng_uniform(h->seed, genv, ep, J_DUCK_YAW, -FWO_PI, FWO_PI);
+  const double r = c->flight_dome_size / 2.0;
+  int n = 0;
+  for (int i = 0; i < c->num_obstacles; ++i) {
+    double hh = rng_uniform(h->seed, genv, ep, J_OBST + 3 * i + 0, c->obstacle_height_range[0], c->obstacle_height_range[1]);
+    double x = rng_uniform(h->seed, genv, ep, J_OBST + 3 * i + 1, -r, r);
+    double y = rng_uniform(h->seed, genv, ep, J_OBST + 3 * i + 2, -r, r);
+    if (x * x + y * y < 100.0) continue;                                   /* :480-481 (no duck-distance rejection here) */
+    TK(e, FW_ST_OBST + 3 * n + 0) = x; TK(e, FW_ST_OBST + 3 * n + 1) = y; TK(e, FW_ST_OBST + 3 * n + 2) = hh;
+    ++n;
+  }
+  for (int i = n; i < FW_MAX_OBSTACLES; ++i) for (int k = 0; k < 3; ++k) TK(e, FW_ST_OBST + 3 * i + k) = 0.0;
+  TK(e, FW_ST_NUM_OBST) = (double)n;
+}
+
+/* compute_state :197-276 */
+static void compute_state_combined(struct fw_env* h, oenv* e) {
+  double ang_pos[3], q[4], R[9];
+  compute_attitude(h, e, ang_pos, q);
+  mat_from_quat(q, R);
+  const int nleft = n_targets_left(h, e);
+  e->obs_target_index = e->num_reached;
+  for (int i = 0; i < nleft; ++i) {
+    double d[3];
+    for (int k = 0; k < 3; ++k) d[k] = e->targets[e->num_reached + i][k] - e->pos[k];
+    matT_vec(R, d, e->target_deltas[i]);
+  }
+  if (nleft > 0) { e->old_distance = e->new_distance; e->new_distance = norm3(e->target_deltas[0]); }
+  {                                                                        /* duck delta appended as the last row :234-246 */
+    double d[3];
+    for (int k = 0; k < 3; ++k) d[k] = TK(e, FW_ST_DUCK_POS + k) - e->pos[k];
+    matT_vec(R, d, e->target_deltas[nleft]);
+  }
+  e->n_deltas = nleft + 1;
+  double feature[FW_VISION_FEATS];
+  vision_features(e, feature);
+  for (int k = 0; k < FW_VISION_FEATS; ++k) e->obj_duck_vision[k] = feature[k];
+  int phase = (int)TK(e, FW_ST_DUCK_PHASE);
+  if (nleft == 0) {                                                        /* all_targets_reached :255-270 */
+    phase |= 2;
+    if (!(phase & 1)) {
+      int visible = feature[0] > 0.5 && TK(e, FW_ST_LAST_AREA) >= h->cfg.duck_switch_min_area;
+      TK(e, FW_ST_SEEN_CONSEC) = visible ? TK(e, FW_ST_SEEN_CONSEC) + 1.0 : 0.0;
+      if (TK(e, FW_ST_SEEN_CONSEC) >= (double)h->cfg.duck_switch_min_consecutive_seen) phase |= 1;
+    }
+  } else {
+    phase = 0;                                                             /* :271-273 */
+  }
+  TK(e, FW_ST_DUCK_PHASE) = (double)phase;
+}
+
+/* compute_term_trunc_reward :278-343 */
+static void compute_term_trunc_reward_combined(struct fw_env* h, oenv* e) {
+  const fw_config* c = &h->cfg;
+  compute_base_term_trunc_reward(h, e);
+  if (e->collision || e->oob) return;                                      /* :282-283 */
+  if (n_targets_left(h, e) > 0) {                                          /* waypoint phase :286-302 */
+    if (!c->sparse_reward) {
+      double progress = (e->old_distance != 0.0) ? (e->old_distance - e->new_distance) : 0.0;
+      e->reward += fmax(3.0 * progress, 0.0);
+      e->reward += 1.0 / e->new_distance;
+    }
+    if (e->new_distance < c->goal_reach_distance) {
+      e->reward = 100.0;
+      e->num_reached += 1;
+      if (n_targets_left(h, e) == 0) { e->termination = 0; e->truncation = 0; }   /* :297-300 */
+    }
+    obstacle_penalty(h, e, e->obj_duck_vision, 1.0);
+  } else {                                                                 /* duck phase :305-343 */
+    e->termination = 0;
+    obstacle_penalty(h, e, e->obj_duck_vision, 0.5);
+    if (((int)TK(e, FW_ST_DUCK_PHASE)) & 1) {
+      const double last_depth = TK(e, FW_ST_LAST_DEPTH), cx = TK(e, FW_ST_LAST_CX), cy = TK(e, FW_ST_LAST_CY);
+      if (!c->sparse_reward && last_depth > 0.0) e->reward += 1.0 / fmax(last_depth, 2.0);
+      if (cx > 0.0) {
+        double dc = sqrt((cx - 0.5) * (cx - 0.5) + (cy - 0.5) * (cy - 0.5));
+        if (dc < 0.35) { TK(e, FW_ST_LOCK_STEPS) += 1.0; e->reward += c->duck_lock_step_reward; }
+        else TK(e, FW_ST_LOCK_STEPS) = 0.0;
+      } else {
+        TK(e, FW_ST_LOCK_STEPS) = 0.0;
+      }
+      const double est = last_depth;
+      if (TK(e, FW_ST_PREV_EST) >= 0.0 && est > 0.0) {
+        double diff = TK(e, FW_ST_PREV_EST) - est;
+        if (diff > 0.0) e->reward += diff * c->duck_approach_reward_scale;
+      }
+      TK(e, FW_ST_PREV_EST) = est;
+      if (TK(e, FW_ST_LOCK_STEPS) >= (double)c->duck_lock_hold_steps && est > 0.0 && est <= c->duck_strike_distance_m) {
+        e->termination = 1;
+        e->reward += c->duck_strike_reward;
+        e->env_complete = 1;
+        e->duck_strike = 1;
+      }
+    }
+  }
+}
+
 static void compute_state(struct fw_env* h, oenv* e) {
   switch (h->cfg.task) {
     case FW_TASK_OBJLOCK: {
@@ -807,6 +917,7 @@ static void compute_state(struct fw_env* h, oenv* e) {
       memcpy(e->obj_duck_vision, ob.duck_vision, sizeof ob.duck_vision);
       break;
     }
+    case FW_TASK_WAYPOINT_OBJLOCK: compute_state_combined(h, e); break;
     case FW_TASK_WAYPOINTS: default: compute_state_waypoints(h, e); break;
   }
 }
@@ -819,6 +930,7 @@ static void compute_term_trunc_reward(struct fw_env* h, oenv* e) {
       compute_term_trunc_reward_objlock(h, e, &ob, &e->duck_strike);
       break;
     }
+    case FW_TASK_WAYPOINT_OBJLOCK: compute_term_trunc_reward_combined(h, e); break;
     case FW_TASK_WAYPOINTS: default: compute_term_trunc_reward_waypoints(h, e); break;
   }
 }
@@ -843,6 +955,7 @@ static void flatten_obs(const struct fw_env* h, const oenv* e, double* out) {
 /* ------------------------------------------------------------------------- */
 static void reset_duck_state(oenv* e);
 static void objlock_spawn(struct fw_env* h, oenv* e, uint32_t genv, uint32_t ep);
+static void combined_spawn(struct fw_env* h, oenv* e, uint32_t genv, uint32_t ep);
 static void env_reset(struct fw_env* h, oenv* e, uint32_t genv) {
   const fw_config* c = &h->cfg;
   e->episode += 1;                       /* index of the episode that starts now */
@@ -888,7 +1001,8 @@ static void env_reset(struct fw_env* h, oenv* e, uint32_t genv) {
   }
   memset(e->task, 0, sizeof(e->task));
   e->duck_strike = 0;
-  if (c->task != FW_TASK_WAYPOINTS) { reset_duck_state(e); objlock_spawn(h, e, genv, ep); }   /* :240-245 */
+  if (c->task == FW_TASK_OBJLOCK) { reset_duck_state(e); objlock_spawn(h, e, genv, ep); }   /* :240-245 */
+  if (c->task == FW_TASK_WAYPOINT_OBJLOCK) { reset_duck_state(e); combined_spawn(h, e, genv, ep); }
   /* end_reset: 10 warm-up Aviary steps with a zero setpoint, then compute_state */
   for (int i = 0; i < c->warmup_aviary_steps; ++i) aviary_step(h, e, genv);
   compute_state(h, e);
@@ -929,7 +1043,6 @@ int32_t fwo_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint6
   if (!cfg || !out || num_envs <= 0) { snprintf(g_err, sizeof g_err, "bad arguments"); return FW_EINVAL; }
   int rc = validate(cfg, g_err, (int)sizeof g_err);
   if (rc != FW_OK) return rc;
-  if (cfg->task == FW_TASK_WAYPOINT_OBJLOCK) { snprintf(g_err, sizeof g_err, "FW_TASK_WAYPOINT_OBJLOCK is not built yet"); return FW_EUNSUPPORTED; }
   struct fw_env* h = (struct fw_env*)calloc(1, sizeof *h);
   if (!h) return FW_ENOMEM;
   h->cfg = *cfg; h->n = num_envs; h->seed = seed; h->env_offset = global_env_offset;
@@ -1008,7 +1121,7 @@ int32_t fwo_step(fw_handle h, const void* actions, void* obs, void* reward, uint
       r[FW_INFO_OUT_OF_BOUNDS] = e->oob;
       r[FW_INFO_ENV_COMPLETE] = e->env_complete;
       r[FW_INFO_DUCK_STRIKE] = e->duck_strike;
-      r[FW_INFO_IS_SUCCESS] = e->duck_strike;
+      r[FW_INFO_IS_SUCCESS] = (h->cfg.task == FW_TASK_OBJLOCK) ? e->duck_strike : 0;
       r[FW_INFO_EP_LEN] = (int32_t)e->ep_len;
       r[FW_INFO_RESERVED] = 0;
     }
@@ -1027,7 +1140,7 @@ int32_t fwo_observe(fw_handle h, void* obs_out, void* stream) {
   for (int i = 0; i < h->n; ++i) {
     oenv tmp = h->e[i];
     tmp.num_reached = tmp.obs_target_index;
-    if (h->cfg.task != FW_TASK_OBJLOCK)
+    if (h->cfg.task == FW_TASK_WAYPOINTS)
       compute_state(h, &tmp);        /* on a copy: no new/old-distance side effect */
     write_obs(h, &tmp, obs_out, (size_t)i);
   }
@@ -1097,6 +1210,17 @@ int32_t fwo_set_state(fw_handle h, const double* s) {
       duck_vision_from_hist(&tmp, tmp.obj_duck_vision);
       memcpy(e->obj_target_vector, tmp.obj_target_vector, sizeof tmp.obj_target_vector);
       memcpy(e->obj_duck_vision, tmp.obj_duck_vision, sizeof tmp.obj_duck_vision);
+    } else if (h->cfg.task == FW_TASK_WAYPOINT_OBJLOCK) {
+      double ap[3], q[4], R[9];
+      compute_attitude(h, &tmp, ap, q);
+      mat_from_quat(q, R);
+      const int nl = h->cfg.num_targets - tmp.num_reached;
+      for (int t = 0; t <= nl; ++t) {
+        double d[3];
+        for (int k = 0; k < 3; ++k) d[k] = (t < nl ? tmp.targets[tmp.num_reached + t][k] : tmp.task[FW_ST_DUCK_POS + k]) - tmp.pos[k];
+        matT_vec(R, d, tmp.target_deltas[t]);
+      }
+      tmp.n_deltas = nl + 1;
     } else
     compute_state(h, &tmp);
     memcpy(e->attitude, tmp.attitude, sizeof e->attitude);

@@ -8,8 +8,9 @@ SB3 ``VecEnv`` surface the reference's training scripts consume.
 from . import config
 from .config import (FwConfig, train_waypoints_v3_config, waypoints_config)
 from .spaces import Box
-from .vec_env import FixedwingObjLockVecEnv, FixedwingVecEnv, FixedwingWaypointsVecEnv
+from .vec_env import (FixedwingObjLockVecEnv, FixedwingVecEnv, FixedwingWaypointObjLockVecEnv,
+                      FixedwingWaypointsVecEnv)
 from . import rollout
 
-__all__ = ["config", "FwConfig", "Box", "FixedwingVecEnv", "FixedwingWaypointsVecEnv", "FixedwingObjLockVecEnv",
+__all__ = ["config", "FwConfig", "Box", "FixedwingVecEnv", "FixedwingWaypointsVecEnv", "FixedwingObjLockVecEnv", "FixedwingWaypointObjLockVecEnv",
            "waypoints_config", "train_waypoints_v3_config"]

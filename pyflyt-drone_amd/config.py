@@ -416,6 +416,66 @@ def train_objlock_config(**overrides) -> FwConfig:
     return objlock_config(**kw)
 
 
+def waypoint_objlock_config(*, sparse_reward: bool = False, num_targets: int = 4, goal_reach_distance: float = 2.0,
+                            flight_dome_size: float = 100.0, max_duration_seconds: float = 120.0,
+                            angle_representation: str = "quaternion", agent_hz: int = 30, context_length: int = 2,
+                            num_obstacles: int = 5, obstacle_radius: float = 2.0, obstacle_height_range=(10.0, 30.0),
+                            obstacle_safe_distance_m: float = 20.0, obstacle_avoid_reward_scale: float = 1.0,
+                            obstacle_avoid_max_penalty: float = 2.0, duck_camera_capture_interval_steps: int = 6,
+                            duck_lock_hold_steps: int = 10, duck_strike_distance_m: float = 2.0,
+                            duck_strike_reward: float = 200.0, duck_lock_step_reward: float = 0.1,
+                            duck_approach_reward_scale: float = 0.05, duck_switch_min_consecutive_seen: int = 2,
+                            duck_switch_min_area: float = 0.0005, duck_global_scaling: float = 20.0,
+                            waypoint_spawn_size: Optional[float] = None, camera_resolution: int = 128,
+                            wind_config: Optional[Mapping[str, Any]] = None, dtype: str = "float64",
+                            motor_noise: bool = True, auto_reset: bool = True) -> FwConfig:
+    """``FlattenWaypointEnv(FixedwingWaypointObjLockEnv(...))``: keyword names and defaults of
+    envs/fixedwing_waypoint_objlock_env.py:42-76 (start position [0,0,10] :78)."""
+    if not 0 <= int(num_targets) <= FW_MAX_TARGETS:
+        raise ValueError(f"num_targets must be in [0, {FW_MAX_TARGETS}]")
+    c = base_config(task=FW_TASK_WAYPOINT_OBJLOCK, dtype=dtype, angle_representation=angle_representation,
+                    agent_hz=agent_hz, flight_dome_size=flight_dome_size, max_duration_seconds=max_duration_seconds,
+                    start_pos=(0.0, 0.0, 10.0), wind_config=wind_config, motor_noise=motor_noise, auto_reset=auto_reset)
+    c.sparse_reward = int(bool(sparse_reward))
+    c.num_targets = int(num_targets)
+    c.goal_reach_distance = float(goal_reach_distance)
+    c.context_length = int(context_length)
+    c.waypoint_spawn_size = float(flight_dome_size if waypoint_spawn_size is None else waypoint_spawn_size)   # :94
+    _fill_objlock(c, num_obstacles=num_obstacles, obstacle_radius=obstacle_radius,
+                  obstacle_height_range=obstacle_height_range, obstacle_safe_distance_m=obstacle_safe_distance_m,
+                  obstacle_avoid_reward_scale=obstacle_avoid_reward_scale,
+                  obstacle_avoid_max_penalty=obstacle_avoid_max_penalty,
+                  duck_camera_capture_interval_steps=duck_camera_capture_interval_steps,
+                  duck_lock_hold_steps=duck_lock_hold_steps, duck_strike_distance_m=duck_strike_distance_m,
+                  duck_strike_reward=duck_strike_reward, duck_lock_step_reward=duck_lock_step_reward,
+                  duck_approach_reward_scale=duck_approach_reward_scale, duck_global_scaling=duck_global_scaling,
+                  camera_resolution=camera_resolution)
+    c.duck_switch_min_consecutive_seen = int(duck_switch_min_consecutive_seen)
+    c.duck_switch_min_area = float(duck_switch_min_area)
+    return c
+
+
+TRAIN_COMBINED_WIND = {     # train/train_Fixedwing_Waypoints_ObjLock.py:59-70
+    "enabled": True, "mode": "gust_sine", "wind_enu_mps": [0.0, 0.0, 0.0], "gust_amp_enu_mps": [0.0, 0.0, 0.0],
+    "gust_freq_hz": 0.2, "gust_phase_rad": 0.0, "randomize_on_reset": True, "randomize_gust_phase": True,
+    "wind_enu_mps_range": [[-5.0, 5.0], [-5.0, 5.0], [-0.5, 0.5]],
+    "gust_amp_enu_mps_range": [[0.0, 3.0], [0.0, 3.0], [0.0, 0.3]],
+}
+
+
+def train_waypoint_objlock_config(**overrides) -> FwConfig:
+    """TRAIN_CONFIG of train/train_Fixedwing_Waypoints_ObjLock.py:35-92,119-165 (config 5 of BASELINE.json)."""
+    kw = dict(sparse_reward=False, num_targets=8, goal_reach_distance=8.0, flight_dome_size=100.0,
+              max_duration_seconds=120.0, angle_representation="euler", agent_hz=30, context_length=2,
+              num_obstacles=20, obstacle_radius=2.0, obstacle_height_range=(10.0, 30.0), obstacle_safe_distance_m=5.0,
+              obstacle_avoid_reward_scale=1.0, obstacle_avoid_max_penalty=2.0, duck_camera_capture_interval_steps=6,
+              duck_lock_hold_steps=10, duck_strike_distance_m=8.0, duck_strike_reward=200.0, duck_lock_step_reward=0.1,
+              duck_approach_reward_scale=0.05, duck_switch_min_consecutive_seen=2, duck_switch_min_area=0.0005,
+              duck_global_scaling=30.0, camera_resolution=480, wind_config=TRAIN_COMBINED_WIND)
+    kw.update(overrides)
+    return waypoint_objlock_config(**kw)
+
+
 def obs_dim(c: FwConfig) -> int:
     att = (12 if c.angle_representation == 0 else 13) + 4 + 6
     if c.task == FW_TASK_OBJLOCK:

@@ -84,7 +84,7 @@ enum Phase : int { PH_STEP = 0, PH_WARM = 1, PH_DONE = 2 };
 // GENERAL = wind is on (per-env wind registers, and -- if it acts on the dynamics -- the
 // PH_WARM path).  The wind-free instantiation (the headline config) carries none of that.
 // OBJ = the ObjLock task (duck / analytic camera / vision shaping, fwsim_objlock.hpp); its state rides in registers.
-template <typename T, bool GENERAL, int G, bool OBJ>
+template <typename T, bool GENERAL, int G, int TKIND>
 __device__ __forceinline__
 void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> D,
                const T* __restrict__ actions, T* __restrict__ obs, T* __restrict__ reward,
@@ -93,6 +93,9 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
   const Params<T>& P = *Pp;
+  constexpr bool OBJ = TKIND == FW_TASK_OBJLOCK;              // duck only
+  constexpr bool COMB = TKIND == FW_TASK_WAYPOINT_OBJLOCK;    // waypoints, then the duck
+  constexpr bool HASOBJ = OBJ || COMB;
   constexpr int EPW = kWave / G;                     // envs per wave
   const int lane = threadIdx.x;
   const int sub = (G == 1) ? 0 : (lane & (G - 1));   // my lane within the env's group
@@ -117,7 +120,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   rot_from_unit_quat<T>(S.q, R);
   ObjState<T> O;
   const ObjC<T>& OC = *OCp;
-  if (OBJ) obj_load<T>(D, envc, O);
+  if (HASOBJ) obj_load<T>(D, envc, O);
   int32_t out_strike = 0;
   int32_t step_count = D.i[IF_STEP * n + envc];
   int32_t tick = D.i[IF_TICK * n + envc];
@@ -192,11 +195,14 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
           T act_t[4];
           load_action<T>(D, actions, env, act_src, act_t);
           if (OBJ) obj_write_obs<T>(P, O, S, act_t, [&](int k, T v) { trow[k] = v; });
+          else if (COMB) comb_write_obs<T>(P, D, env, O, S, act_t, tgt_obs, [&](int k, T v) { trow[k] = v; });
           else write_obs<T>(P, D, env, S, act_t, tgt_obs, [&](int k, T v) { trow[k] = v; });
         }
         warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase);
-        if (OBJ) {
-          obj_reset_state<T>(O); obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
+        if (HASOBJ) {
+          obj_reset_state<T>(O);
+          if (OBJ) obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
+          else comb_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
           if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         }
         step_count = 0; flags = 0; ep_return = (T)0; tgt_obs = 0;
@@ -204,7 +210,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
         rot_from_unit_quat<T>(S.q, R);
         if (GENERAL && warm_left > 0) phase = PH_WARM;
         else if (OBJ) obj_compute_state<T>(O);                 // end_reset(): first compute_state of the episode
-        else new_dist = end_reset<T, G>(P, D, env, episode, S);
+        else { new_dist = end_reset<T, G>(P, D, env, episode, S); if (COMB) comb_compute_state<T>(OC, O, P.num_targets == 0); }
       }
     }
     if (__ballot(phase != PH_DONE) == 0ull) break;   // wave-uniform exit
@@ -224,9 +230,9 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
 #pragma unroll
         for (int c = 0; c < FW_NUM_ACTUATORS; ++c) c_eff[c] = stepping ? cmd[c] : (T)0;
         z0 = stepping ? z0 : (T)0; z1 = stepping ? z1 : (T)0;
-        contact = aviary_step<T, true, G, OBJ>(P, C, OC, D, env, O, S, R, c_eff, tick, z0, z1, wb, wa, wphase, mine, wmask);   // :339
+        contact = aviary_step<T, true, G, HASOBJ>(P, C, OC, D, env, O, S, R, c_eff, tick, z0, z1, wb, wa, wphase, mine, wmask);   // :339
       } else {
-        contact = aviary_step<T, false, G, OBJ>(P, C, OC, D, env, O, S, R, cmd, tick, z0, z1, wb, wa, wphase, mine, wmask);    // :339
+        contact = aviary_step<T, false, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd, tick, z0, z1, wb, wa, wphase, mine, wmask);    // :339
       }
       if (stepping && OBJ) {
         obj_compute_state<T>(O);                                                                   // :342
@@ -238,6 +244,43 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
           T dx = O.duck[0] - S.p[0], dy = O.duck[1] - S.p[1], dz = O.duck[2] - S.p[2];
           if (obj_reward<T>(OC, P.sparse, O, M<T>::sqrt_(dx * dx + dy * dy + dz * dz), rew)) {
             flags |= FL_TERM | FL_COMPLETE; out_strike = 1;
+          }
+        }
+        step_over = (it + 1 >= P.step_ratio) || (flags & (FL_TERM | FL_TRUNC));
+      } else if (stepping && COMB) {
+        // compute_state() :197-276
+        const int nleft = P.num_targets - num_reached;
+        const T old_dist = new_dist;
+        if (nleft > 0) {
+          T dx = tcur[0] - S.p[0], dy = tcur[1] - S.p[1], dz = tcur[2] - S.p[2];
+          new_dist = M<T>::sqrt_(dx * dx + dy * dy + dz * dz);
+        }
+        tgt_obs = num_reached;
+        comb_compute_state<T>(OC, O, nleft == 0);
+        // compute_term_trunc_reward() :278-343
+        if (step_count > P.max_steps) flags |= FL_TRUNC;
+        if (contact) { rew = (T)-100; flags |= FL_COLLISION | FL_TERM; }
+        if (S.p[0] * S.p[0] + S.p[1] * S.p[1] + S.p[2] * S.p[2] > P.dome * P.dome) { rew = (T)-100; flags |= FL_OOB | FL_TERM; }
+        if (!(flags & (FL_COLLISION | FL_OOB))) {
+          if (nleft > 0) {
+            if (!P.sparse) {
+              T progress = (old_dist != (T)0) ? (old_dist - new_dist) : (T)0;
+              rew += M<T>::fmax_((T)3 * progress, (T)0);
+              rew += M<T>::rcp_(new_dist);
+            }
+            if (new_dist < P.reach) {
+              rew = (T)100;
+              num_reached += 1;
+              if (num_reached == P.num_targets) flags &= ~(FL_TERM | FL_TRUNC);          // :297-300
+              const int i1 = min(num_reached + 1, FW_MAX_TARGETS - 1);
+#pragma unroll
+              for (int k = 0; k < 3; ++k) { tcur[k] = tnext[k]; tnext[k] = D.r[(size_t)(RF_TARGETS + 3 * i1 + k) * n + env]; }
+            }
+            comb_obstacle_penalty<T>(OC, O, (T)1, rew);
+          } else {
+            flags &= ~FL_TERM;                                                            // :306
+            comb_obstacle_penalty<T>(OC, O, (T)0.5, rew);
+            if (comb_duck_reward<T>(OC, P.sparse, O, rew)) { flags |= FL_TERM | FL_COMPLETE; out_strike = 1; }
           }
         }
         step_over = (it + 1 >= P.step_ratio) || (flags & (FL_TERM | FL_TRUNC));
@@ -274,7 +317,8 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       } else {
         warm_left -= 1;
         if (warm_left == 0) {
-          if (OBJ) obj_compute_state<T>(O); else new_dist = end_reset<T, G>(P, D, env, episode, S);
+          if (OBJ) obj_compute_state<T>(O);
+          else { new_dist = end_reset<T, G>(P, D, env, episode, S); if (COMB) comb_compute_state<T>(OC, O, P.num_targets == 0); }
           phase = PH_DONE;
         }
       }
@@ -291,14 +335,15 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     if (info) {
       int4* ip = reinterpret_cast<int4*>(info + (size_t)env * FW_INFO_DIM);
       ip[0] = make_int4(out_reached, (out_flags & FL_COLLISION) ? 1 : 0, (out_flags & FL_OOB) ? 1 : 0, (out_flags & FL_COMPLETE) ? 1 : 0);
-      ip[1] = make_int4(out_strike_latched, out_strike_latched, out_steps, 0);
+      ip[1] = make_int4(out_strike_latched, OBJ ? out_strike_latched : 0, out_steps, 0);
     }
     T act_obs[4];
     load_action<T>(D, actions, env, act_src, act_obs);
     if (OBJ) obj_write_obs<T>(P, O, S, act_obs, [&](int k, T v) { tile[row * ld + k] = v; });
+    else if (COMB) comb_write_obs<T>(P, D, env, O, S, act_obs, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
     else write_obs<T>(P, D, env, S, act_obs, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
     store_rigid<T>(D, env, S);
-    if (OBJ) obj_store<T>(D, env, O);
+    if (HASOBJ) obj_store<T>(D, env, O);
 #pragma unroll
     for (int k = 0; k < 4; ++k) D.r[(RF_ACTION + k) * n + env] = act_obs[k];
     D.r[RF_NEW_DIST * n + env] = new_dist;
@@ -322,25 +367,28 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
 #define FW_STEP_PASS Pp, OCp, D, actions, obs, reward, terminated, truncated, terminal_obs, info
 // latency mapping (8 lanes per env): one wave per SIMD by construction, let the allocator use the whole file
 template <typename T, bool GENERAL>
-__global__ __launch_bounds__(kWave) void fw_step_kernel_g8(FW_STEP_ARGS) { step_body<T, GENERAL, 8, false>(FW_STEP_PASS); }
+__global__ __launch_bounds__(kWave) void fw_step_kernel_g8(FW_STEP_ARGS) { step_body<T, GENERAL, 8, FW_TASK_WAYPOINTS>(FW_STEP_PASS); }
 // throughput mapping (one lane per env)
 template <typename T, bool GENERAL>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(FW_G1_WAVES, FW_G1_WAVES)))
-void fw_step_kernel_g1(FW_STEP_ARGS) { step_body<T, GENERAL, 1, false>(FW_STEP_PASS); }
+void fw_step_kernel_g1(FW_STEP_ARGS) { step_body<T, GENERAL, 1, FW_TASK_WAYPOINTS>(FW_STEP_PASS); }
 // ObjLock task (always the GENERAL path: its training config has wind)
-template <typename T>
-__global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g8(FW_STEP_ARGS) { step_body<T, true, 8, true>(FW_STEP_PASS); }
-template <typename T>
-__global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g1(FW_STEP_ARGS) { step_body<T, true, 1, true>(FW_STEP_PASS); }
+template <typename T, int TKIND>
+__global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g8(FW_STEP_ARGS) { step_body<T, true, 8, TKIND>(FW_STEP_PASS); }
+template <typename T, int TKIND>
+__global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g1(FW_STEP_ARGS) { step_body<T, true, 1, TKIND>(FW_STEP_PASS); }
 
 // K2: reset (masked) + observation.  Same single-tick-site structure (warm-up only).
-template <typename T, int G, bool OBJ>
+template <typename T, int G, int TKIND>
 __global__ __launch_bounds__(kWave)
 void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> D,
                      const uint8_t* __restrict__ mask, T* __restrict__ obs, int do_reset) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
   const Params<T>& P = *Pp;
+  constexpr bool OBJ = TKIND == FW_TASK_OBJLOCK;
+  constexpr bool COMB = TKIND == FW_TASK_WAYPOINT_OBJLOCK;
+  constexpr bool HASOBJ = OBJ || COMB;
   constexpr int EPW = kWave / G;
   const int lane = threadIdx.x;
   const int sub = (G == 1) ? 0 : (lane & (G - 1));
@@ -360,7 +408,7 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
   load_rigid<T>(D, envc, S);
   ObjState<T> O;
   const ObjC<T>& OC = *OCp;
-  if (OBJ) obj_load<T>(D, envc, O);
+  if (HASOBJ) obj_load<T>(D, envc, O);
   T action[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) action[k] = D.r[(RF_ACTION + k) * n + envc];
@@ -372,11 +420,15 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
   int warm_left = 0;
   if (resetting) {
     warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase);
-    if (OBJ) {
-      obj_reset_state<T>(O); obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
+    if (HASOBJ) {
+      obj_reset_state<T>(O);
+      if (OBJ) obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O); else comb_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
       if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
-    if (warm_left == 0) { if (OBJ) obj_compute_state<T>(O); else new_dist = end_reset<T, G>(P, D, env, episode, S); }
+    if (warm_left == 0) {
+      if (OBJ) obj_compute_state<T>(O);
+      else { new_dist = end_reset<T, G>(P, D, env, episode, S); if (COMB) comb_compute_state<T>(OC, O, P.num_targets == 0); }
+    }
   }
   const T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
   T R[9];
@@ -385,9 +437,12 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
 #pragma unroll 1
   while (__ballot(warm_left > 0) != 0ull) {
     if (warm_left > 0) {
-      (void)aviary_step<T, true, G, OBJ>(P, C, OC, D, env, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, wphase, mine, wmask);
+      (void)aviary_step<T, true, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, wphase, mine, wmask);
       warm_left -= 1;
-      if (warm_left == 0) { if (OBJ) obj_compute_state<T>(O); else new_dist = end_reset<T, G>(P, D, env, episode, S); }
+      if (warm_left == 0) {
+        if (OBJ) obj_compute_state<T>(O);
+        else { new_dist = end_reset<T, G>(P, D, env, episode, S); if (COMB) comb_compute_state<T>(OC, O, P.num_targets == 0); }
+      }
     }
   }
   if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -405,12 +460,13 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
       D.i[IF_EPISODE * n + env] = episode;
       D.i[IF_FLAGS * n + env] = 0;
       D.i[IF_NUM_REACHED * n + env] = num_reached;
-      if (OBJ) obj_store<T>(D, env, O);
+      if (HASOBJ) obj_store<T>(D, env, O);
     }
   }
   if (obs) {
     if (active && leader) {
       if (OBJ) obj_write_obs<T>(P, O, S, action, [&](int k, T v) { tile[row * ld + k] = v; });
+      else if (COMB) comb_write_obs<T>(P, D, env, O, S, action, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
       else write_obs<T>(P, D, env, S, action, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
     }
     __syncthreads();
@@ -633,6 +689,7 @@ void build_objc(const fw_config& c, ObjC<T>& O) {
   O.strike_dist = (T)c.duck_strike_distance_m; O.strike_reward = (T)c.duck_strike_reward; O.lock_step_reward = (T)c.duck_lock_step_reward;
   O.hold_steps = c.duck_lock_hold_steps; O.decay_steps = c.duck_lock_decay_steps; O.num_obstacles = c.num_obstacles;
   O.camera_ratio_ticks = (c.physics_hz / c.control_hz) * c.duck_camera_capture_interval_steps;
+  O.switch_min_area = (T)c.duck_switch_min_area; O.switch_min_seen = c.duck_switch_min_consecutive_seen;
 }
 
 template <typename T>
@@ -677,7 +734,9 @@ int step_T(fw_env* h, const void* actions, void* obs, void* reward, uint8_t* ter
   const bool general = h->cfg.wind_mode != FW_WIND_OFF;
   const bool g8 = h->lanes_per_env == 8;
   if (h->cfg.task == FW_TASK_OBJLOCK) {
-    if (g8) FW_LAUNCH_STEP(fw_step_kernel_obj_g8<T>); else FW_LAUNCH_STEP(fw_step_kernel_obj_g1<T>);
+    if (g8) FW_LAUNCH_STEP((fw_step_kernel_obj_g8<T, FW_TASK_OBJLOCK>)); else FW_LAUNCH_STEP((fw_step_kernel_obj_g1<T, FW_TASK_OBJLOCK>));
+  } else if (h->cfg.task == FW_TASK_WAYPOINT_OBJLOCK) {
+    if (g8) FW_LAUNCH_STEP((fw_step_kernel_obj_g8<T, FW_TASK_WAYPOINT_OBJLOCK>)); else FW_LAUNCH_STEP((fw_step_kernel_obj_g1<T, FW_TASK_WAYPOINT_OBJLOCK>));
   } else if (general) {
     if (g8) FW_LAUNCH_STEP((fw_step_kernel_g8<T, true>)); else FW_LAUNCH_STEP((fw_step_kernel_g1<T, true>));
   } else {
@@ -695,9 +754,11 @@ template <typename T>
 int reset_T(fw_env* h, const uint8_t* mask, void* obs, int do_reset, hipStream_t st) {
   const bool g8 = h->lanes_per_env == 8;
   if (h->cfg.task == FW_TASK_OBJLOCK) {
-    if (g8) FW_LAUNCH_RESET((fw_reset_kernel<T, 8, true>)); else FW_LAUNCH_RESET((fw_reset_kernel<T, 1, true>));
+    if (g8) FW_LAUNCH_RESET((fw_reset_kernel<T, 8, FW_TASK_OBJLOCK>)); else FW_LAUNCH_RESET((fw_reset_kernel<T, 1, FW_TASK_OBJLOCK>));
+  } else if (h->cfg.task == FW_TASK_WAYPOINT_OBJLOCK) {
+    if (g8) FW_LAUNCH_RESET((fw_reset_kernel<T, 8, FW_TASK_WAYPOINT_OBJLOCK>)); else FW_LAUNCH_RESET((fw_reset_kernel<T, 1, FW_TASK_WAYPOINT_OBJLOCK>));
   } else {
-    if (g8) FW_LAUNCH_RESET((fw_reset_kernel<T, 8, false>)); else FW_LAUNCH_RESET((fw_reset_kernel<T, 1, false>));
+    if (g8) FW_LAUNCH_RESET((fw_reset_kernel<T, 8, FW_TASK_WAYPOINTS>)); else FW_LAUNCH_RESET((fw_reset_kernel<T, 1, FW_TASK_WAYPOINTS>));
   }
   HIP_TRY(h, hipGetLastError());
   return FW_OK;
@@ -774,7 +835,6 @@ int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64
   if (!cfg || !out || num_envs <= 0) { g_err = "bad arguments"; return FW_EINVAL; }
   int rc = validate(cfg, g_err);
   if (rc != FW_OK) return rc;
-  if (cfg->task == FW_TASK_WAYPOINT_OBJLOCK) { g_err = "FW_TASK_WAYPOINT_OBJLOCK is not built yet"; return FW_EUNSUPPORTED; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device available (this library has no CPU fallback)"; return FW_EHIP; }
   if (device < 0 || device >= ndev) { g_err = "device index out of range"; return FW_EINVAL; }

@@ -22,7 +22,8 @@ struct ObjC {          // wave-uniform task constants
   T obst_radius, obst_hmin, obst_hmax, safe_dist, avoid_scale, avoid_max;
   T k_dist, lock_radius, k_center, k_visible, k_area, lost_penalty, approach_clip, k_approach;
   T strike_dist, strike_reward, lock_step_reward;
-  int32_t hold_steps, decay_steps, num_obstacles, camera_ratio_ticks;
+  T switch_min_area;
+  int32_t hold_steps, decay_steps, num_obstacles, camera_ratio_ticks, switch_min_seen;
 };
 
 template <typename T>
@@ -31,7 +32,10 @@ struct ObjState {
   T lock_steps, prev_est, last_cx, last_cy, last_area, last_depth, since_seen, filled, frame_has;
   T frame[8];          // visible, cx, cy, area, depth_m, d_left, d_center, d_right
   float hist[kHist];   // float32 by construction (np.float32 feature vectors)
+  float cur_z[3];      // combined task: obstacle-zone depths of the current feature vector (transient)
   int32_t nob;
+  int32_t phase;       // combined task: bit0 duck_phase, bit1 post_waypoints
+  T seen_consec;
 };
 
 template <typename T> __device__ __forceinline__ T f32r(T x) { return (T)(float)x; }
@@ -51,6 +55,7 @@ __device__ __forceinline__ void obj_load(const DevState<T>& D, int env, ObjState
 #pragma unroll
   for (int k = 0; k < kHist; ++k) O.hist[k] = (float)b[(FW_ST_HIST + k) * n];
   O.nob = (int32_t)b[FW_ST_NUM_OBST * n];
+  O.phase = (int32_t)b[FW_ST_DUCK_PHASE * n]; O.seen_consec = b[FW_ST_SEEN_CONSEC * n];
 }
 template <typename T>
 __device__ __forceinline__ void obj_store(const DevState<T>& D, int env, const ObjState<T>& O) {
@@ -67,6 +72,7 @@ __device__ __forceinline__ void obj_store(const DevState<T>& D, int env, const O
 #pragma unroll
   for (int k = 0; k < kHist; ++k) b[(FW_ST_HIST + k) * n] = (T)O.hist[k];
   b[FW_ST_NUM_OBST * n] = (T)O.nob;
+  b[FW_ST_DUCK_PHASE * n] = (T)O.phase; b[FW_ST_SEEN_CONSEC * n] = O.seen_consec;
 }
 
 // _reset_duck_state :409-419
@@ -78,6 +84,7 @@ __device__ __forceinline__ void obj_reset_state(ObjState<T>& O) {
   for (int k = 0; k < 8; ++k) O.frame[k] = (T)0;
 #pragma unroll
   for (int k = 0; k < kHist; ++k) O.hist[k] = 0.0f;
+  O.phase = 0; O.seen_consec = (T)0;
 }
 
 // _spawn_duck :461-491, _spawn_obstacles :507-565.  Every lane computes the scenario; only the
@@ -99,6 +106,50 @@ __device__ __forceinline__ void obj_spawn(const Params<T>& P, const ObjC<T>& OC,
     double y = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 2, -r, r);
     double ex = x - dx, ey = y - dy;
     if (M<double>::sqrt_(ex * ex + ey * ey) < 10.0) continue;
+    if (x * x + y * y < 100.0) continue;
+    if (leader) { ob[(3 * nob + 0) * n] = (T)x; ob[(3 * nob + 1) * n] = (T)y; ob[(3 * nob + 2) * n] = (T)hh; }
+    ++nob;
+  }
+  if (leader)
+    for (int i = nob; i < FW_MAX_OBSTACLES; ++i) { ob[(3 * i + 0) * n] = (T)0; ob[(3 * i + 1) * n] = (T)0; ob[(3 * i + 2) * n] = (T)0; }
+  O.nob = nob;
+}
+
+// i-th waypoint of episode `ep`, regenerated from the RNG (WaypointHandler.reset polar sampling)
+template <typename T>
+__device__ __forceinline__ void nth_target(const Params<T>& P, uint32_t genv, uint32_t ep, int i, T t[3]) {
+  double theta = rng_uniform<T>(P, genv, ep, J_THETA + i, 0.0, 2.0 * kPi);
+  double phi = rng_uniform<T>(P, genv, ep, J_PHI + i, 0.0, 2.0 * kPi);
+  double dist = rng_uniform<T>(P, genv, ep, J_DIST + i, 1.0, (double)P.spawn_hi);
+  double sphi, cphi, sth, cth;
+  M<double>::sincos_(phi, &sphi, &cphi);
+  M<double>::sincos_(theta, &sth, &cth);
+  double z = ::fabs(dist * cphi);
+  t[0] = (T)(dist * sphi * cth); t[1] = (T)(dist * sphi * sth);
+  t[2] = (T)(z > (double)P.min_height ? z : (double)P.min_height);
+}
+
+// combined task: duck at the last waypoint's x,y (envs/fixedwing_waypoint_objlock_env.py:394-436), obstacles
+// with the origin rejection only (:452-503)
+template <typename T>
+__device__ __forceinline__ void comb_spawn(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env, uint32_t ep,
+                                           bool leader, ObjState<T>& O) {
+  const uint32_t genv = (uint32_t)(P.env_offset + env);
+  if (P.num_targets > 0) {
+    T tl[3];
+    nth_target<T>(P, genv, ep, P.num_targets - 1, tl);
+    O.duck[0] = tl[0]; O.duck[1] = tl[1];
+  } else { O.duck[0] = (T)10; O.duck[1] = (T)0; }
+  O.duck[2] = (T)0.05;
+  const double r = (double)OC.half_dome;
+  int nob = 0;
+  T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
+  const size_t n = D.npad;
+#pragma unroll 1
+  for (int i = 0; i < OC.num_obstacles; ++i) {
+    double hh = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 0, (double)OC.obst_hmin, (double)OC.obst_hmax);
+    double x = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 1, -r, r);
+    double y = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 2, -r, r);
     if (x * x + y * y < 100.0) continue;
     if (leader) { ob[(3 * nob + 0) * n] = (T)x; ob[(3 * nob + 1) * n] = (T)y; ob[(3 * nob + 2) * n] = (T)hh; }
     ++nob;
@@ -248,6 +299,101 @@ __device__ __forceinline__ void obj_compute_state(ObjState<T>& O) {
   O.hist[4] = (float)O.last_depth; O.hist[5] = (float)(O.since_seen / (T)60);
   O.hist[6] = (float)dl; O.hist[7] = (float)dc; O.hist[8] = (float)dr;
   O.filled = O.filled + (T)1 < (T)FW_VISION_HIST ? O.filled + (T)1 : (T)FW_VISION_HIST;
+}
+
+// combined task compute_state (:248-274): current feature vector (kept in hist[0..8]) + phase switching
+template <typename T>
+__device__ __forceinline__ void comb_compute_state(const ObjC<T>& OC, ObjState<T>& O, bool all_reached) {
+  T visible = (T)0, dl = (T)0, dc = (T)0, dr = (T)0;
+  if (O.frame_has != (T)0) {
+    dl = O.frame[5]; dc = O.frame[6]; dr = O.frame[7];
+    if (O.frame[0] == (T)0) {
+      O.since_seen = O.since_seen + (T)1 < (T)60 ? O.since_seen + (T)1 : (T)60;
+    } else {
+      O.last_cx = O.frame[1]; O.last_cy = O.frame[2]; O.last_area = O.frame[3]; O.last_depth = O.frame[4];
+      O.since_seen = (T)0; visible = (T)1;
+    }
+  }
+  O.cur_z[0] = (float)dl; O.cur_z[1] = (float)dc; O.cur_z[2] = (float)dr;
+  if (all_reached) {
+    O.phase |= 2;
+    if (!(O.phase & 1)) {
+      const bool vis = visible > (T)0.5 && O.last_area >= OC.switch_min_area;
+      O.seen_consec = vis ? O.seen_consec + (T)1 : (T)0;
+      if (O.seen_consec >= (T)OC.switch_min_seen) O.phase |= 1;
+    }
+  } else {
+    O.phase = 0;
+  }
+}
+
+// obstacle penalty of the combined task (:347-380): full scale in the waypoint phase, half in the duck phase
+template <typename T>
+__device__ __forceinline__ void comb_obstacle_penalty(const ObjC<T>& OC, const ObjState<T>& O, T mult, T& rew) {
+  T d_obs = (T)1e300; bool any = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { T d = (T)O.cur_z[k]; if (d > (T)0 && d < (T)3.0e38) { any = true; d_obs = d < d_obs ? d : d_obs; } }
+  if (any && OC.safe_dist > (T)0 && d_obs < OC.safe_dist) {
+    T pen = M<T>::div_(OC.avoid_scale * mult * (OC.safe_dist - d_obs), OC.safe_dist);
+    rew -= pen < OC.avoid_max ? pen : OC.avoid_max;
+  }
+}
+
+// duck phase reward (:310-343); returns true on a strike
+template <typename T>
+__device__ __forceinline__ bool comb_duck_reward(const ObjC<T>& OC, int sparse, ObjState<T>& O, T& rew) {
+  if (!(O.phase & 1)) return false;
+  const T est = O.last_depth;
+  if (!sparse && est > (T)0) rew += M<T>::rcp_(M<T>::fmax_(est, (T)2));
+  if (O.last_cx > (T)0) {
+    T dc = M<T>::sqrt_((O.last_cx - (T)0.5) * (O.last_cx - (T)0.5) + (O.last_cy - (T)0.5) * (O.last_cy - (T)0.5));
+    if (dc < (T)0.35) { O.lock_steps += (T)1; rew += OC.lock_step_reward; } else O.lock_steps = (T)0;
+  } else {
+    O.lock_steps = (T)0;
+  }
+  if (O.prev_est >= (T)0 && est > (T)0) {
+    T diff = O.prev_est - est;
+    if (diff > (T)0) rew += diff * OC.k_approach;
+  }
+  O.prev_est = est;
+  if (O.lock_steps >= (T)OC.hold_steps && est > (T)0 && est <= OC.strike_dist) { rew += OC.strike_reward; return true; }
+  return false;
+}
+
+// combined task observation (local FlattenWaypointEnv over [remaining waypoints ..., duck], float64)
+template <typename T, typename W>
+__device__ __forceinline__ void comb_write_obs(const Params<T>& P, const DevState<T>& D, int env, const ObjState<T>& O,
+                                               const Rigid<T>& S, const T action[4], int tgt_idx, W&& put) {
+  T R[9];
+  rot_from_quat(S.q, R);
+  T ang_vel[3], lin_vel[3], eul[3];
+  mtv(R, S.w, ang_vel);
+  mtv(R, S.v, lin_vel);
+  bool lock = euler_from_quat(S.q, eul);
+  T qrt[4] = { S.q[0], S.q[1], S.q[2], S.q[3] };
+  if (lock || P.angle_repr == 1) { quat_from_euler(eul, qrt); rot_from_quat(qrt, R); }
+  int o = 0;
+  put(o++, ang_vel[0]); put(o++, ang_vel[1]); put(o++, ang_vel[2]);
+  if (P.angle_repr == 0) { put(o++, eul[0]); put(o++, eul[1]); put(o++, eul[2]); }
+  else { put(o++, qrt[0]); put(o++, qrt[1]); put(o++, qrt[2]); put(o++, qrt[3]); }
+  put(o++, lin_vel[0]); put(o++, lin_vel[1]); put(o++, lin_vel[2]);
+  put(o++, S.p[0]); put(o++, S.p[1]); put(o++, S.p[2]);
+  put(o++, action[0]); put(o++, action[1]); put(o++, action[2]); put(o++, action[3]);
+#pragma unroll
+  for (int k = 0; k < FW_NUM_ACTUATORS; ++k) put(o++, S.act[k]);
+  for (int i = 0; i < P.ctx; ++i) {
+    const int t = tgt_idx + i;
+    T d[3] = {(T)0, (T)0, (T)0}, b[3] = {(T)0, (T)0, (T)0};
+    if (t < P.num_targets) {
+      const T* tp = D.r + (size_t)(RF_TARGETS + 3 * t) * D.npad + env;
+      d[0] = tp[0] - S.p[0]; d[1] = tp[D.npad] - S.p[1]; d[2] = tp[2 * (size_t)D.npad] - S.p[2];
+      mtv(R, d, b);
+    } else if (t == P.num_targets) {          // the duck is the row after the last remaining waypoint (:234-246)
+      d[0] = O.duck[0] - S.p[0]; d[1] = O.duck[1] - S.p[1]; d[2] = O.duck[2] - S.p[2];
+      mtv(R, d, b);
+    }
+    put(o++, b[0]); put(o++, b[1]); put(o++, b[2]);
+  }
 }
 
 // compute_term_trunc_reward (:296-372) after the base checks; returns true on a strike

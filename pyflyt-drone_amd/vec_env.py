@@ -252,3 +252,20 @@ class FixedwingObjLockVecEnv(FixedwingVecEnv):
         cfg = K.objlock_config(dtype=dtype, motor_noise=motor_noise, **env_kwargs)
         super().__init__(cfg, num_envs, device=device, seed=seed, global_env_offset=global_env_offset)
         self.observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float32)
+
+
+class FixedwingWaypointObjLockVecEnv(FixedwingVecEnv):
+    """``FlattenWaypointEnv(FixedwingWaypointObjLockEnv(...), context_length)`` vectorised
+    (envs/fixedwing_waypoint_objlock_env.py:42-76; constructed at
+    train/train_Fixedwing_Waypoints_ObjLock.py:119-165).  Observation = attitude ++ the first
+    ``context_length`` rows of [remaining waypoints ..., duck] in the body frame (float64)."""
+
+    def __init__(self, num_envs: int, *, render_mode: Optional[str] = None, context_length: int = 2,
+                 dtype: str = "float64", motor_noise: bool = True, device=None, seed: int = 0,
+                 global_env_offset: int = 0, **env_kwargs):
+        if render_mode not in (None, "rgb_array"):
+            raise ValueError(f"Invalid render mode {render_mode}, only [None, 'rgb_array'] have a device counterpart.")
+        if render_mode == "rgb_array":
+            env_kwargs.setdefault("camera_resolution", int(env_kwargs.pop("render_resolution", (480, 480))[0]))
+        cfg = K.waypoint_objlock_config(dtype=dtype, motor_noise=motor_noise, context_length=context_length, **env_kwargs)
+        super().__init__(cfg, num_envs, device=device, seed=seed, global_env_offset=global_env_offset)

@@ -36,6 +36,8 @@ def cases():
         context_length=1, wind_config=CONST_AIR, motor_noise=False, max_duration_seconds=2.0), "gentle", 4, 100, 11
     yield "objlock_train_config", K.train_objlock_config(duck_camera_capture_interval_steps=3, num_obstacles=6,
                                                          obstacle_safe_distance_m=60.0), "gentle", 4, 100, 21
+    yield "combined_train_config", K.train_waypoint_objlock_config(goal_reach_distance=30.0, duck_camera_capture_interval_steps=2,
+                                                                   obstacle_safe_distance_m=40.0), "gentle", 4, 100, 31
 
 
 def main():

@@ -239,7 +239,90 @@ def test_depth_buffer_conversion_constants():
     assert list(c.camera_offset) == [0.8, 0.0, 0.12]                                      # cockpit_fpv :185-186
 
 
-def test_unsupported_combined_task_is_refused(oracle):
-    c = K.train_objlock_config(); c.task = K.FW_TASK_WAYPOINT_OBJLOCK
-    with pytest.raises(RuntimeError, match="not built yet"):
-        oracle.OracleEnv(c, 1)
+# ---------------------------------------------------------------- combined task (envs/fixedwing_waypoint_objlock_env.py)
+def cquiet(**kw):
+    base = dict(agent_hz=120, motor_noise=False, auto_reset=False, angle_representation="euler", num_targets=2,
+                goal_reach_distance=8.0, duck_camera_capture_interval_steps=10 ** 6, flight_dome_size=1e5,
+                waypoint_spawn_size=100.0, num_obstacles=0, duck_lock_hold_steps=3, duck_strike_distance_m=8.0,
+                duck_strike_reward=200.0, duck_lock_step_reward=0.1, duck_approach_reward_scale=0.05)
+    base.update(kw)
+    return K.waypoint_objlock_config(**base)
+
+
+def test_combined_reset_places_duck_under_last_waypoint_and_obs_rows(oracle):
+    cfg = K.train_waypoint_objlock_config(motor_noise=False)
+    assert K.obs_dim(cfg) == 28 and list(cfg.start_pos) == [0.0, 0.0, 10.0]
+    env = make(oracle, cfg, n=32, seed=4)
+    s = env.get_state()
+    tg = s[:, K.S_TARGETS:K.S_TARGETS + 24].reshape(32, 8, 3)
+    np.testing.assert_array_equal(s[:, T0:T0 + 2], tg[:, 7, :2])                          # :411-415
+    assert np.all(s[:, T0 + 2] == 0.05)
+    nob = s[:, T0 + K.ST_NUM_OBST].astype(int)
+    assert nob.max() <= 20 and nob.min() >= 10
+    for i in range(32):
+        ob = s[i, T0 + K.ST_OBST:T0 + K.ST_OBST + 3 * nob[i]].reshape(-1, 3)
+        assert np.all(ob[:, 0] ** 2 + ob[:, 1] ** 2 >= 100.0)                               # only the origin rejection (:480)
+    # with one waypoint left the duck is the second context row; with none it is the first
+    env1 = make(oracle, cquiet(num_targets=1))
+    s1 = env1.get_state()[0]
+    R = oracle.mat_from_quat(s1[K.S_QUAT:K.S_QUAT + 4])
+    o = env1.observe()[0]
+    np.testing.assert_allclose(o[25:28], R.T @ (s1[T0:T0 + 3] - s1[K.S_POS:K.S_POS + 3]), atol=1e-9)
+    env0 = make(oracle, cquiet(num_targets=0))
+    s0 = env0.get_state()[0]
+    assert list(s0[T0:T0 + 3]) == [10.0, 0.0, 0.05]                                          # fallback :417
+    o0 = env0.observe()[0]
+    R0 = oracle.mat_from_quat(s0[K.S_QUAT:K.S_QUAT + 4])
+    np.testing.assert_allclose(o0[22:25], R0.T @ (s0[T0:T0 + 3] - s0[K.S_POS:K.S_POS + 3]), atol=1e-9)
+    assert np.all(o0[25:28] == 0)
+
+
+def test_combined_last_waypoint_does_not_end_the_episode_and_phase_switch(oracle):
+    cfg = cquiet(num_targets=1, sparse_reward=True)
+    env = make(oracle, cfg)
+    s = env.get_state()
+    s[0, K.S_TARGETS:K.S_TARGETS + 3] = s[0, K.S_POS:K.S_POS + 3] + [3.0, 0, 0]; s[0, K.S_NEW_DIST] = 3.0
+    env.set_state(s)
+    _, r, term, trunc, _, info = step0(env)
+    assert r[0] == 100.0 and not term[0] and not trunc[0] and info[0, K.INFO_NUM_TARGETS_REACHED] == 1      # :291-300
+    assert info[0, K.INFO_ENV_COMPLETE] == 0
+    # duck phase needs 2 consecutive visible frames with area >= 5e-4 (:255-270)
+    set_frame(env, 1.0, cx=0.5, cy=0.5, area=0.0004, depth=50.0); step0(env)
+    assert int(env.get_state()[0, T0 + K.ST_DUCK_PHASE]) == 2 and env.get_state()[0, T0 + K.ST_SEEN_CONSEC] == 0
+    set_frame(env, 1.0, cx=0.5, cy=0.5, area=0.01, depth=50.0); step0(env)
+    assert int(env.get_state()[0, T0 + K.ST_DUCK_PHASE]) == 2 and env.get_state()[0, T0 + K.ST_SEEN_CONSEC] == 1
+    _, r, *_ = step0(env)
+    assert int(env.get_state()[0, T0 + K.ST_DUCK_PHASE]) == 3
+    # first duck-phase reward: sparse => only the lock step reward (fixed radius 0.35 :320), no approach yet
+    assert r[0] == pytest.approx(-0.1 + 0.1)
+    assert env.get_state()[0, T0 + K.ST_LOCK_STEPS] == 1 and env.get_state()[0, T0 + K.ST_PREV_EST] == 50.0
+
+
+def test_combined_duck_phase_reward_and_visual_depth_strike(oracle):
+    cfg = cquiet(num_targets=0, sparse_reward=False)
+    env = make(oracle, cfg)
+    set_frame(env, 1.0, cx=0.5, cy=0.5, area=0.01, depth=20.0, ST_DUCK_PHASE=3.0, ST_PREV_EST=23.0, ST_LOCK_STEPS=1.0)
+    _, r, term, *_ = step0(env)
+    assert r[0] == pytest.approx(-0.1 + 1.0 / 20.0 + 0.1 + 0.05 * 3.0, rel=1e-12) and not term[0]      # :312-333
+    # off-centre frame resets the lock to zero (no decay) and only positive approach counts
+    set_frame(env, 1.0, cx=0.95, cy=0.5, area=0.01, depth=25.0)
+    _, r, *_ = step0(env)
+    assert r[0] == pytest.approx(-0.1 + 1.0 / 25.0, rel=1e-12) and env.get_state()[0, T0 + K.ST_LOCK_STEPS] == 0
+    # strike on the VISUAL depth estimate (:337-338), not on the geometric distance
+    set_frame(env, 1.0, cx=0.5, cy=0.5, area=0.2, depth=7.5, ST_LOCK_STEPS=2.0)
+    _, r, term, trunc, _, info = step0(env)
+    assert term[0] == 1 and info[0, K.INFO_DUCK_STRIKE] == 1 and info[0, K.INFO_ENV_COMPLETE] == 1 and info[0, K.INFO_IS_SUCCESS] == 0
+    assert r[0] == pytest.approx(-0.1 + 1.0 / 7.5 + 0.1 + 0.05 * 17.5 + 200.0, rel=1e-12)
+
+
+def test_combined_obstacle_penalty_full_scale_in_waypoint_phase(oracle):
+    cfg = cquiet(num_targets=2, sparse_reward=True, obstacle_safe_distance_m=5.0, obstacle_avoid_max_penalty=2.0)
+    env = make(oracle, cfg)
+    set_frame(env, 0.0, zones=(255.0, 2.0, 255.0))
+    _, r, _, _, _, info = step0(env)
+    base = 100.0 if info[0, K.INFO_NUM_TARGETS_REACHED] else -0.1          # the penalty is applied AFTER the =100 assignment (:291-302)
+    assert r[0] == pytest.approx(base - 1.0 * (5 - 2) / 5, rel=1e-12)                      # :374-380 scale 1.0
+    env2 = make(oracle, cquiet(num_targets=0, sparse_reward=True, obstacle_safe_distance_m=5.0))
+    set_frame(env2, 0.0, zones=(255.0, 2.0, 255.0))
+    _, r2, *_ = step0(env2)
+    assert r2[0] == pytest.approx(-0.1 - 0.5 * (5 - 2) / 5, rel=1e-12)                     # duck phase: x0.5

@@ -55,6 +55,17 @@ def lockstep_cases():
                                                      obstacle_safe_distance_m=40.0, duck_camera_capture_interval_steps=2,
                                                      angle_representation="quaternion", camera_resolution=128,
                                                      wind_config=CONST_AIRSPEED), "gentle"
+    # ---- combined task (envs/fixedwing_waypoint_objlock_env.py)
+    yield "combined_train", K.train_waypoint_objlock_config(), "gentle"
+    yield "combined_big_reach", K.waypoint_objlock_config(num_targets=3, goal_reach_distance=40.0, angle_representation="euler",
+                                                          duck_camera_capture_interval_steps=1, num_obstacles=8,
+                                                          obstacle_safe_distance_m=50.0, duck_strike_distance_m=30.0,
+                                                          duck_lock_hold_steps=3, duck_global_scaling=60.0,
+                                                          wind_config=CONST_RANDOM), "gentle"
+    yield "combined_sparse_quat_ctx3", K.waypoint_objlock_config(sparse_reward=True, num_targets=2, goal_reach_distance=25.0,
+                                                                  angle_representation="quaternion", context_length=3,
+                                                                  duck_camera_capture_interval_steps=2, num_obstacles=0,
+                                                                  motor_noise=False), "uniform"
     yield "objlock_sparse_nowind", K.objlock_config(sparse_reward=True, flight_dome_size=120.0, num_obstacles=3,
                                                     duck_camera_capture_interval_steps=1, angle_representation="euler",
                                                     motor_noise=False), "uniform"
@@ -83,6 +94,7 @@ def test_lockstep_f64(oracle, name, lanes):
     hip = P.FixedwingVecEnv(cfg, n, seed=1234)
     ora = oracle.OracleEnv(cfg, n, seed=1234)
     obj = cfg.task == K.FW_TASK_OBJLOCK
+    assert name.split('_')[0] in ('objlock', 'combined') or cfg.task == K.FW_TASK_WAYPOINTS
     # ObjLock observations are float32-rounded (flatten_objlock_env.py:46): a 1e-13 difference can flip one f32 ulp
     worst = run_lockstep(hip, ora, 240, np.random.default_rng(5), kind=kind, atol=2e-5 if obj else 1e-7, rtol=0,
                          state_atol=1e-7)
