@@ -2,6 +2,7 @@
 // See include/fwsim.h for the contract and fwsim_device.hpp for the device code.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -67,6 +68,98 @@ __device__ __forceinline__ void load_action(const DevState<T>& D, const T* actio
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Background warm-up ("shadow") -- used when the reset warm-up cannot be cached (wind acts on
+// the dynamics, or the task has a camera).  In the latency regime the launch time is the time
+// of its slowest wave, and a wave that has to sample a scenario and integrate the 10 warm-up
+// Aviary steps of a reset in-kernel takes several times as long as its neighbours -- with
+// thousands of envs most launches contain one (rocprofv3: 27 us min, 96 us max, 61 us mean).
+// Instead every env owns a shadow copy of its state holding the START of its NEXT episode.
+// Extra workgroups of the same launch (blocks >= the step blocks; they land on SIMDs the
+// latency mapping leaves idle) build it in chunks no longer than a stepping wave -- launch 1:
+// scenario sampling, launches 2-4: <= step_ratio warm-up Aviary steps each -- and a reset
+// swaps the finished shadow in (a copy).  An episode is a pure function of (seed, env,
+// episode), so the result equals the in-kernel path (to rounding: the compiler contracts
+// FMAs differently at the two inlining sites), which stays as the fallback while a shadow is
+// not ready (episodes shorter than ~5 steps).
+// Protocol (kernel-boundary visibility only, one writer per word, 8-byte words so nothing
+// tears): the env's own lanes never touch the shadow arrays; they post `sreq` = (episode
+// wanted, launch index).  The worker ignores a request carrying the current launch index
+// (it may be half a launch old), owns the shadow arrays and `sdone` = (episode built, launch
+// index, progress); the env's lanes accept a finished shadow only if it was finished in an
+// EARLIER launch.
+// ------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ DevState<T> shadow_view(const DevState<T>& D) {
+  DevState<T> V = D; V.r = D.rs; V.i = nullptr; return V;
+}
+__device__ __forceinline__ unsigned long long pack_done(uint32_t ep, uint32_t epoch, int done) {
+  return ((unsigned long long)ep << 32) | ((unsigned long long)(epoch & 0xFFFFFFu) << 8) | (unsigned long long)(done & 0xFF);
+}
+
+// worker: one chunk of work on the shadows of the envs of block `blk`
+template <typename T, int G, int TKIND>
+__device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> D, int blk) {
+  constexpr bool OBJ = TKIND == FW_TASK_OBJLOCK, COMB = TKIND == FW_TASK_WAYPOINT_OBJLOCK, HASOBJ = OBJ || COMB;
+  constexpr int EPW = kWave / G;
+  const Params<T>& P = *Pp;
+  const ObjC<T>& OC = *OCp;
+  const int lane = threadIdx.x, sub = (G == 1) ? 0 : (lane & (G - 1)), row = lane / G;
+  const bool leader = sub == 0;
+  const int env = blk * EPW + row;
+  const bool active = env < D.n;
+  const int envc = active ? env : D.n - 1;
+  const size_t n = D.npad;
+  const int total = P.warmup_aviary_steps + 1;                  // progress 1 = scenario sampled, then one per warm-up step
+  const unsigned long long req = D.sreq[envc], dn = D.sdone[envc];
+  const uint32_t target = (uint32_t)(req >> 32);
+  const bool fresh = active && (uint32_t)req != D.epoch && req != ~0ull;     // a request of an earlier launch
+  int done = (int)(dn & 0xFF);
+  const bool begin = fresh && (uint32_t)(dn >> 32) != target;   // new episode wanted: (re)start
+  int left = (fresh && !begin) ? min(total - done, P.step_ratio) : 0;
+  if (__ballot(begin || left > 0) == 0ull) return;              // nothing to do in this wave: the common case
+  const DevState<T> V = shadow_view<T>(D);
+  if (begin) {
+    Rigid<T> S0; int32_t tick0 = 0, episode = (int32_t)target - 1, nr = 0; T wb0[3], wa0[3], wph0;
+    (void)begin_reset<T, G>(P, V, env, S0, tick0, episode, nr, wb0, wa0, wph0);     // shadow_on implies !warm_valid
+    if (HASOBJ) {
+      ObjState<T> O0;
+      obj_reset_state<T>(O0);
+      if (OBJ) obj_spawn<T>(P, OC, V, env, target, leader, O0); else comb_spawn<T>(P, OC, V, env, target, leader, O0);
+      if (leader) obj_store<T>(V, env, O0);
+    }
+    if (leader) { store_rigid<T>(V, env, S0); D.is[env] = 0; D.sdone[env] = pack_done(target, D.epoch, 1); }
+  }
+  if (__ballot(left > 0) == 0ull) return;
+  TickC<T> C; SurfC<T> mine; T wmask;
+  load_tick_constants<T, G>(Pp, C, mine, wmask);
+  Rigid<T> S;
+  load_rigid<T>(V, envc, S);
+  T R[9];
+  rot_from_unit_quat<T>(S.q, R);
+  int32_t tick = D.is[envc];
+  T wb[3], wa[3], wph;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { wb[k] = V.r[(RF_WIND + k) * n + envc]; wa[k] = V.r[(RF_WIND + 3 + k) * n + envc]; }
+  wph = V.r[(RF_WIND + 6) * n + envc];
+  ObjState<T> O;
+  if (HASOBJ) { obj_load<T>(V, envc, O); O.near_mask = 0u; }
+  const T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
+  const int chunk = left;
+#pragma unroll 1
+  while (__ballot(left > 0) != 0ull) {
+    if (left > 0) {
+      (void)aviary_step<T, true, G, HASOBJ>(P, C, OC, V, envc, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, wph, mine, wmask);
+      left -= 1;
+    }
+  }
+  if (chunk > 0 && leader) {
+    store_rigid<T>(V, env, S);
+    D.is[env] = tick;
+    if (HASOBJ) obj_store<T>(V, env, O);
+    D.sdone[env] = pack_done(target, D.epoch, done + chunk);
+  }
+}
+
 // Per-lane phase of the fused step state machine.
 enum Phase : int { PH_STEP = 0, PH_WARM = 1, PH_DONE = 2 };
 
@@ -97,6 +190,8 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   constexpr bool COMB = TKIND == FW_TASK_WAYPOINT_OBJLOCK;    // waypoints, then the duck
   constexpr bool HASOBJ = OBJ || COMB;
   constexpr int EPW = kWave / G;                     // envs per wave
+  const int nblk = (D.npad + EPW - 1) / EPW;         // step blocks; blocks beyond are shadow workers
+  if ((int)blockIdx.x >= nblk) { shadow_worker<T, G, TKIND>(Pp, OCp, D, (int)blockIdx.x - nblk); return; }
   const int lane = threadIdx.x;
   const int sub = (G == 1) ? 0 : (lane & (G - 1));   // my lane within the env's group
   const int row = lane / G;                          // env slot within the wave
@@ -120,8 +215,11 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   rot_from_unit_quat<T>(S.q, R);
   ObjState<T> O;
   const ObjC<T>& OC = *OCp;
-  if (HASOBJ) obj_load<T>(D, envc, O);
+  if (HASOBJ) { obj_load<T>(D, envc, O); obj_update_near_mask<T, G>(P, OC, D, envc, O, S); }
   int32_t out_strike = 0;
+  // shadow bookkeeping (kernel-boundary hand-off, see shadow_* above)
+  unsigned long long sh_req = ~0ull, sh_done = 0ull;
+  if (GENERAL && D.shadow_on) { sh_req = D.sreq[envc]; sh_done = D.sdone[envc]; }
   int32_t step_count = D.i[IF_STEP * n + envc];
   int32_t tick = D.i[IF_TICK * n + envc];
   int32_t episode = D.i[IF_EPISODE * n + envc];
@@ -198,13 +296,38 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
           else if (COMB) comb_write_obs<T>(P, D, env, O, S, act_t, tgt_obs, [&](int k, T v) { trow[k] = v; });
           else write_obs<T>(P, D, env, S, act_t, tgt_obs, [&](int k, T v) { trow[k] = v; });
         }
-        warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase);
-        if (HASOBJ) {
-          obj_reset_state<T>(O);
-          if (OBJ) obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
-          else comb_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
-          if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (GENERAL && D.shadow_on && (int)(sh_done & 0xFF) == P.warmup_aviary_steps + 1 &&
+            (uint32_t)(sh_done >> 32) == (uint32_t)(episode + 1) && (uint32_t)((sh_done >> 8) & 0xFFFFFFu) != (D.epoch & 0xFFFFFFu)) {
+          // swap the pre-simulated episode in: a copy instead of 10 Aviary steps
+          const DevState<T> V = shadow_view<T>(D);
+          load_rigid<T>(V, env, S);
+          tick = D.is[env];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { wb[k] = V.r[(RF_WIND + k) * n + env]; wa[k] = V.r[(RF_WIND + 3 + k) * n + env]; }
+          wphase = V.r[(RF_WIND + 6) * n + env];
+          if (HASOBJ) obj_load<T>(V, env, O);
+          if (leader) {
+#pragma unroll 1
+            for (int k = 0; k < 7; ++k) D.r[(RF_WIND + k) * n + env] = V.r[(RF_WIND + k) * n + env];
+            if (!OBJ) {
+#pragma unroll 1
+              for (int k = 0; k < 3 * FW_MAX_TARGETS; ++k) D.r[(RF_TARGETS + k) * n + env] = V.r[(RF_TARGETS + k) * n + env];
+            }
+            if (HASOBJ) {
+#pragma unroll 1
+              for (int k = 0; k < 3 * FW_MAX_OBSTACLES; ++k) D.r[(RF_TASK + FW_ST_OBST + k) * n + env] = V.r[(RF_TASK + FW_ST_OBST + k) * n + env];
+            }
+          }
+          episode += 1; num_reached = 0; warm_left = 0;
+        } else {
+          warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase);
+          if (HASOBJ) {
+            obj_reset_state<T>(O);
+            if (OBJ) obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
+            else comb_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
+          }
         }
+        if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         step_count = 0; flags = 0; ep_return = (T)0; tgt_obs = 0;
         act_src = 2;
         rot_from_unit_quat<T>(S.q, R);
@@ -328,6 +451,8 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   // G = 8: waypoints sampled by sibling lanes during an in-launch reset are read back below
   if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 
+  if (GENERAL && D.shadow_on && active && leader && (uint32_t)(sh_req >> 32) != (uint32_t)(episode + 1))
+    D.sreq[env] = ((unsigned long long)(uint32_t)(episode + 1) << 32) | (unsigned long long)D.epoch;   // ask for the next episode
   if (active && leader) {
     reward[env] = out_rew;
     terminated[env] = (uint8_t)((out_flags & FL_TERM) ? 1 : 0);
@@ -425,6 +550,7 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
       if (OBJ) obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O); else comb_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
       if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
+    if (HASOBJ) obj_update_near_mask<T, G>(P, OC, D, envc, O, S);
     if (warm_left == 0) {
       if (OBJ) obj_compute_state<T>(O);
       else { new_dist = end_reset<T, G>(P, D, env, episode, S); if (COMB) comb_compute_state<T>(OC, O, P.num_targets == 0); }
@@ -636,6 +762,12 @@ struct fw_env {
   void* objc_dev = nullptr;     // ObjC<T>
   void* r_dev = nullptr;        // T[RF_COUNT][npad]
   int32_t* i_dev = nullptr;     // i32[IF_COUNT][npad]
+  void* rs_dev = nullptr;       // shadow T[RF_COUNT][npad]   (only when shadow_on)
+  int32_t* is_dev = nullptr;    // shadow ticks i32[npad]
+  unsigned long long* sreq_dev = nullptr;   // shadow requests / progress words, u64[npad] each
+  unsigned long long* sdone_dev = nullptr;
+  uint32_t epoch = 1;           // fw_step launch index
+  int32_t shadow_on = 0;        // background warm-up of the next episode (see shadow_* kernels)
   std::string err;
 };
 
@@ -659,7 +791,17 @@ struct DeviceGuard {
 };
 
 template <typename T> DevState<T> dev_state(fw_env* h) {
-  DevState<T> D; D.r = (T*)h->r_dev; D.i = h->i_dev; D.n = h->n; D.npad = h->npad; return D;
+  DevState<T> D; D.r = (T*)h->r_dev; D.i = h->i_dev; D.n = h->n; D.npad = h->npad;
+  D.rs = (T*)h->rs_dev; D.is = h->is_dev; D.sreq = h->sreq_dev; D.sdone = h->sdone_dev; D.epoch = h->epoch; D.shadow_on = h->shadow_on;
+  return D;
+}
+int invalidate_shadow(fw_env* h) {
+  if (!h->shadow_on) return FW_OK;
+  HIP_TRY(h, hipDeviceSynchronize());
+  HIP_TRY(h, hipMemset(h->sreq_dev, 0xFF, sizeof(unsigned long long) * h->npad));    // ~0 = nothing requested
+  HIP_TRY(h, hipMemset(h->sdone_dev, 0xFF, sizeof(unsigned long long) * h->npad));   // episode 0xFFFFFFFF never matches
+  HIP_TRY(h, hipMemset(h->is_dev, 0, sizeof(int32_t) * h->npad));
+  return FW_OK;
 }
 
 // LDS bytes of the padded [64/G][D+1] observation tile
@@ -690,6 +832,11 @@ void build_objc(const fw_config& c, ObjC<T>& O) {
   O.hold_steps = c.duck_lock_hold_steps; O.decay_steps = c.duck_lock_decay_steps; O.num_obstacles = c.num_obstacles;
   O.camera_ratio_ticks = (c.physics_hz / c.control_hz) * c.duck_camera_capture_interval_steps;
   O.switch_min_area = (T)c.duck_switch_min_area; O.switch_min_seen = c.duck_switch_min_consecutive_seen;
+  {
+    double rm = 0.0;
+    for (int i = 0; i < c.n_collision_pts; ++i) { const double* q = c.collision_pts[i]; rm = std::max(rm, std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2])); }
+    O.reach_margin = (T)(rm + 0.25);
+  }
 }
 
 template <typename T>
@@ -717,6 +864,19 @@ int create_T(fw_env* h) {
   HIP_TRY(h, hipMalloc((void**)&h->i_dev, sizeof(int32_t) * IF_COUNT * npad));
   int rc = upload_params<T>(h);
   if (rc != FW_OK) return rc;
+  // shadow warm-up whenever the reset warm-up cannot be cached (wind acting on the dynamics, camera tasks)
+  const bool cached = (h->cfg.task == FW_TASK_WAYPOINTS) &&
+                      (h->cfg.wind_mode == FW_WIND_OFF || h->cfg.wind_coupling == FW_WIND_COUPLE_NONE);
+  h->shadow_on = (!cached && h->cfg.auto_reset && !getenv("FWSIM_NO_SHADOW")) ? 1 : 0;
+  if (h->shadow_on) {
+    HIP_TRY(h, hipMalloc(&h->rs_dev, sizeof(T) * RF_COUNT * npad));
+    HIP_TRY(h, hipMemset(h->rs_dev, 0, sizeof(T) * RF_COUNT * npad));
+    HIP_TRY(h, hipMalloc((void**)&h->is_dev, sizeof(int32_t) * npad));
+    HIP_TRY(h, hipMalloc((void**)&h->sreq_dev, sizeof(unsigned long long) * npad));
+    HIP_TRY(h, hipMalloc((void**)&h->sdone_dev, sizeof(unsigned long long) * npad));
+    rc = invalidate_shadow(h);
+    if (rc != FW_OK) return rc;
+  }
   hipLaunchKernelGGL(fw_init_kernel<T>, dim3((h->npad + 255) / 256), dim3(256), 0, 0, dev_state<T>(h));
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipDeviceSynchronize());
@@ -724,7 +884,7 @@ int create_T(fw_env* h) {
 }
 
 #define FW_LAUNCH_STEP(KERNEL)                                                                                   \
-  hipLaunchKernelGGL((KERNEL), grid_of(h), dim3(kWave), tile_bytes<T>(h), st, (const Params<T>*)h->params_dev,   \
+  hipLaunchKernelGGL((KERNEL), step_grid, dim3(kWave), tile_bytes<T>(h), st, (const Params<T>*)h->params_dev,    \
                      (const ObjC<T>*)h->objc_dev, dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term,  \
                      trunc, (T*)tobs, info)
 
@@ -733,6 +893,8 @@ int step_T(fw_env* h, const void* actions, void* obs, void* reward, uint8_t* ter
            int32_t* info, hipStream_t st) {
   const bool general = h->cfg.wind_mode != FW_WIND_OFF;
   const bool g8 = h->lanes_per_env == 8;
+  dim3 step_grid = grid_of(h);
+  if (h->shadow_on) step_grid.x *= 2;          // second half of the grid = shadow workers
   if (h->cfg.task == FW_TASK_OBJLOCK) {
     if (g8) FW_LAUNCH_STEP((fw_step_kernel_obj_g8<T, FW_TASK_OBJLOCK>)); else FW_LAUNCH_STEP((fw_step_kernel_obj_g1<T, FW_TASK_OBJLOCK>));
   } else if (h->cfg.task == FW_TASK_WAYPOINT_OBJLOCK) {
@@ -743,6 +905,7 @@ int step_T(fw_env* h, const void* actions, void* obs, void* reward, uint8_t* ter
     if (g8) FW_LAUNCH_STEP((fw_step_kernel_g8<T, false>)); else FW_LAUNCH_STEP((fw_step_kernel_g1<T, false>));
   }
   HIP_TRY(h, hipGetLastError());
+  h->epoch += 1;
   return FW_OK;
 }
 
@@ -858,6 +1021,10 @@ int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64
     if (h->objc_dev) (void)hipFree(h->objc_dev);
     if (h->r_dev) (void)hipFree(h->r_dev);
     if (h->i_dev) (void)hipFree(h->i_dev);
+    if (h->rs_dev) (void)hipFree(h->rs_dev);
+    if (h->is_dev) (void)hipFree(h->is_dev);
+    if (h->sreq_dev) (void)hipFree(h->sreq_dev);
+    if (h->sdone_dev) (void)hipFree(h->sdone_dev);
     delete h;
     return rc;
   }
@@ -899,7 +1066,7 @@ int32_t fw_seed(fw_handle h, uint64_t seed) {
   if (rc != FW_OK) return rc;
   std::vector<int32_t> ep((size_t)h->npad, -1);
   HIP_TRY(h, hipMemcpy(h->i_dev + (size_t)IF_EPISODE * h->npad, ep.data(), sizeof(int32_t) * ep.size(), hipMemcpyHostToDevice));
-  return FW_OK;
+  return invalidate_shadow(h);                 // shadows were drawn with the old seed
 }
 
 int32_t fw_get_state(fw_handle h, double* state_out) {
@@ -969,6 +1136,10 @@ int32_t fw_destroy(fw_handle h) {
   if (h->objc_dev) (void)hipFree(h->objc_dev);
   if (h->r_dev) (void)hipFree(h->r_dev);
   if (h->i_dev) (void)hipFree(h->i_dev);
+  if (h->rs_dev) (void)hipFree(h->rs_dev);
+  if (h->is_dev) (void)hipFree(h->is_dev);
+  if (h->sreq_dev) (void)hipFree(h->sreq_dev);
+  if (h->sdone_dev) (void)hipFree(h->sdone_dev);
   delete h;
   return FW_OK;
 }

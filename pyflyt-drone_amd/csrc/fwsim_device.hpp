@@ -91,6 +91,13 @@ struct DevState {
   T* r;          // [RF_COUNT][npad]
   int32_t* i;    // [IF_COUNT][npad]
   int32_t n, npad;
+  // "shadow" = the pre-simulated start of each env's NEXT episode (see shadow_* in fwsim.hip)
+  T* rs;                     // [RF_COUNT][npad]  same layout as r; written ONLY by shadow workers
+  int32_t* is;               // [npad]            physics ticks of the shadow state
+  unsigned long long* sreq;  // [npad]  live -> worker:  (episode wanted << 32) | launch index of the request
+  unsigned long long* sdone; // [npad]  worker -> live:  (episode built << 32) | (launch index & 0xFFFFFF) << 8 | progress
+  uint32_t epoch;            // launch index of this fw_step (host counter)
+  int32_t shadow_on;
 };
 
 constexpr double kPi = 3.14159265358979323846;
@@ -215,6 +222,23 @@ template <int G, typename T> __device__ __forceinline__ T group_sum(T v) {
     v += dpp<0xB1>(v);    // quad_perm [1,0,3,2]  (lane ^ 1)
     v += dpp<0x4E>(v);    // quad_perm [2,3,0,1]  (lane ^ 2)
     v += dpp<0x141>(v);   // row_half_mirror      (the other quad of the 8)
+  }
+  return v;
+}
+// min / bitwise-or over the 8 lanes of a group (same DPP pattern; every lane gets the result)
+template <int G, typename T> __device__ __forceinline__ T group_min(T v) {
+  if (G == 8) {
+    T o = dpp<0xB1>(v); v = o < v ? o : v;
+    o = dpp<0x4E>(v); v = o < v ? o : v;
+    o = dpp<0x141>(v); v = o < v ? o : v;
+  }
+  return v;
+}
+template <int G> __device__ __forceinline__ uint32_t group_or(uint32_t v) {
+  if (G == 8) {
+    v |= (uint32_t)dpp_i32<0xB1>((int)v);
+    v |= (uint32_t)dpp_i32<0x4E>((int)v);
+    v |= (uint32_t)dpp_i32<0x141>((int)v);
   }
   return v;
 }

@@ -23,6 +23,7 @@ struct ObjC {          // wave-uniform task constants
   T k_dist, lock_radius, k_center, k_visible, k_area, lost_penalty, approach_clip, k_approach;
   T strike_dist, strike_reward, lock_step_reward;
   T switch_min_area;
+  T reach_margin;      // largest |collision point| + slack: how far from the COM a contact can happen
   int32_t hold_steps, decay_steps, num_obstacles, camera_ratio_ticks, switch_min_seen;
 };
 
@@ -33,6 +34,7 @@ struct ObjState {
   T frame[8];          // visible, cx, cy, area, depth_m, d_left, d_center, d_right
   float hist[kHist];   // float32 by construction (np.float32 feature vectors)
   float cur_z[3];      // combined task: obstacle-zone depths of the current feature vector (transient)
+  uint32_t near_mask;  // obstacles the aircraft can touch during this agent step (transient, conservative)
   int32_t nob;
   int32_t phase;       // combined task: bit0 duck_phase, bit1 post_waypoints
   T seen_consec;
@@ -159,14 +161,38 @@ __device__ __forceinline__ void comb_spawn(const Params<T>& P, const ObjC<T>& OC
   O.nob = nob;
 }
 
-// is world point pw inside the duck sphere or an obstacle cylinder?
+// Which cylinders can be touched during this agent step?  Conservative: horizontal distance of the COM to
+// the axis below radius + reach of the airframe + 1.25 x the distance flown in one agent step (+ slack).
+// The per-tick contact test then only visits these (usually none) instead of all 20.
+// G = 8: lane j screens obstacles j, j+8, j+16; the masks are OR-ed across the group.
+template <typename T, int G>
+__device__ __forceinline__ void obj_update_near_mask(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env,
+                                                     ObjState<T>& O, const Rigid<T>& S) {
+  const T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
+  const size_t n = D.npad;
+  const T speed = M<T>::sqrt_(S.v[0] * S.v[0] + S.v[1] * S.v[1] + S.v[2] * S.v[2]);
+  const T t_step = (T)(P.step_ratio * P.ticks_per_aviary) * P.dt;
+  const T reach = OC.obst_radius + OC.reach_margin + (speed + (T)5) * t_step * (T)1.25 + (T)0.5;
+  uint32_t m = 0u;
+  const int sub = (G == 1) ? 0 : (int)(threadIdx.x & (G - 1));
+  for (int o = sub; o < O.nob; o += G) {
+    T ox = S.p[0] - ob[(3 * o) * n], oy = S.p[1] - ob[(3 * o + 1) * n];
+    if (ox * ox + oy * oy <= reach * reach) m |= 1u << o;
+  }
+  O.near_mask = group_or<G>(m);
+}
+
+// is world point pw inside the duck sphere or a (near) obstacle cylinder?
 template <typename T>
 __device__ __forceinline__ bool obj_point_hit(const ObjC<T>& OC, const DevState<T>& D, int env, const ObjState<T>& O, const T pw[3]) {
   T dx = pw[0] - O.duck[0], dy = pw[1] - O.duck[1], dz = pw[2] - (O.duck[2] + OC.duck_radius);
   bool hit = dx * dx + dy * dy + dz * dz <= OC.duck_radius * OC.duck_radius;
   const T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
   const size_t n = D.npad;
-  for (int o = 0; o < O.nob; ++o) {
+  uint32_t m = O.near_mask;
+  while (m) {
+    const int o = __ffs((int)m) - 1;
+    m &= m - 1u;
     T ox = pw[0] - ob[(3 * o) * n], oy = pw[1] - ob[(3 * o + 1) * n];
     hit |= (ox * ox + oy * oy <= OC.obst_radius * OC.obst_radius) && (pw[2] <= ob[(3 * o + 2) * n]);
   }
@@ -193,49 +219,26 @@ __device__ __forceinline__ bool obj_contacts(const Params<T>& P, const TickC<T>&
   return hit;
 }
 
-// first hit of a camera ray with the ground / a cylinder, as depth along the view axis, clamped to [near, far]
+// One cylinder against a camera ray / the line of sight to the duck.
+// Returns the hit parameter t (depth along the view axis for rays built with unit forward component) or +inf.
 template <typename T>
-__device__ __forceinline__ T obj_ray_depth(const ObjC<T>& OC, const DevState<T>& D, int env, const ObjState<T>& O, const T cam[3], const T dw[3]) {
-  T best = OC.far_;
-  if (dw[2] < (T)0) { T t = M<T>::div_(-cam[2], dw[2]); if (t > (T)0 && t < best) best = t; }
-  const T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
-  const size_t n = D.npad;
-  for (int o = 0; o < O.nob; ++o) {
-    T ox = cam[0] - ob[(3 * o) * n], oy = cam[1] - ob[(3 * o + 1) * n], hh = ob[(3 * o + 2) * n];
-    T a = dw[0] * dw[0] + dw[1] * dw[1], b = (T)2 * (ox * dw[0] + oy * dw[1]), cc = ox * ox + oy * oy - OC.obst_radius * OC.obst_radius;
-    if (a <= (T)0) continue;
-    T disc = b * b - (T)4 * a * cc;
-    if (disc < (T)0) continue;
-    T t = M<T>::div_(-b - M<T>::sqrt_(disc), (T)2 * a);
-    if (t <= (T)0) continue;
-    T z = cam[2] + t * dw[2];
-    if (z < (T)0 || z > hh) continue;
-    if (t < best) best = t;
-  }
-  return best < OC.near_ ? OC.near_ : best;
-}
-template <typename T>
-__device__ __forceinline__ bool obj_occluded(const ObjC<T>& OC, const DevState<T>& D, int env, const ObjState<T>& O, const T cam[3], const T Pt[3]) {
-  T dw[3] = { Pt[0] - cam[0], Pt[1] - cam[1], Pt[2] - cam[2] };
-  const T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
-  const size_t n = D.npad;
-  bool occ = false;
-  for (int o = 0; o < O.nob; ++o) {
-    T ox = cam[0] - ob[(3 * o) * n], oy = cam[1] - ob[(3 * o + 1) * n], hh = ob[(3 * o + 2) * n];
-    T a = dw[0] * dw[0] + dw[1] * dw[1], b = (T)2 * (ox * dw[0] + oy * dw[1]), cc = ox * ox + oy * oy - OC.obst_radius * OC.obst_radius;
-    if (a <= (T)0) continue;
-    T disc = b * b - (T)4 * a * cc;
-    if (disc < (T)0) continue;
-    T t = M<T>::div_(-b - M<T>::sqrt_(disc), (T)2 * a);
-    if (t <= (T)0 || t >= (T)1) continue;
-    T z = cam[2] + t * dw[2];
-    occ |= (z >= (T)0 && z <= hh);
-  }
-  return occ;
+__device__ __forceinline__ T cyl_hit(const ObjC<T>& OC, T cx, T cy, T hh, const T cam[3], const T dw[3]) {
+  const T inf = (T)1e300;
+  T ox = cam[0] - cx, oy = cam[1] - cy;
+  T a = dw[0] * dw[0] + dw[1] * dw[1], b = (T)2 * (ox * dw[0] + oy * dw[1]), cc = ox * ox + oy * oy - OC.obst_radius * OC.obst_radius;
+  if (a <= (T)0) return inf;
+  T disc = b * b - (T)4 * a * cc;
+  if (disc < (T)0) return inf;
+  T t = M<T>::div_(-b - M<T>::sqrt_(disc), (T)2 * a);
+  if (t <= (T)0) return inf;
+  T z = cam[2] + t * dw[2];
+  return (z < (T)0 || z > hh) ? inf : t;
 }
 
-// Camera.capture_image() replaced by the analytic frame
-template <typename T>
+// Camera.capture_image() replaced by the analytic frame.  The three zone rays and the line of sight to the
+// duck are tested against every cylinder; G = 8: lane j takes cylinders j, j+8, j+16 and the four minima are
+// combined with DPP (every lane ends with the identical frame).
+template <typename T, int G>
 __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevState<T>& D, int env, ObjState<T>& O,
                                                    const Rigid<T>& S, const T R[9]) {
   T cam[3], offw[3];
@@ -246,6 +249,35 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
   T Cc[3] = { O.duck[0], O.duck[1], O.duck[2] + OC.duck_radius };
   T relw[3] = { Cc[0] - cam[0], Cc[1] - cam[1], Cc[2] - cam[2] }, relb[3];
   mtv(R, relw, relb);
+  // the three zone rays (centre column of each third of the middle row :698-729) in world coordinates
+  T dwz[3][3];
+#pragma unroll
+  for (int zid = 0; zid < 3; ++zid) {
+    T ucol = M<T>::div_((T)(2 * zid + 1) * W, (T)6) - (T)0.5;
+    T a = M<T>::div_(ucol - u0, F), b = M<T>::div_(OC.vmid - v0, F), db[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) db[k] = OC.cam_f[k] + a * OC.cam_r[k] + b * OC.cam_d[k];
+    mv(R, db, dwz[zid]);
+  }
+  // cylinders: per-lane partial minima
+  const T inf = (T)1e300;
+  T best[3] = { inf, inf, inf }, occ_t = inf;
+  {
+    const T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
+    const size_t n = D.npad;
+    const int sub = (G == 1) ? 0 : (int)(threadIdx.x & (G - 1));
+    for (int o = sub; o < O.nob; o += G) {
+      const T cx = ob[(3 * o) * n], cy = ob[(3 * o + 1) * n], hh = ob[(3 * o + 2) * n];
+#pragma unroll
+      for (int zid = 0; zid < 3; ++zid) { T t = cyl_hit<T>(OC, cx, cy, hh, cam, dwz[zid]); best[zid] = t < best[zid] ? t : best[zid]; }
+      T t = cyl_hit<T>(OC, cx, cy, hh, cam, relw);
+      occ_t = t < occ_t ? t : occ_t;
+    }
+#pragma unroll
+    for (int zid = 0; zid < 3; ++zid) best[zid] = group_min<G, T>(best[zid]);
+    occ_t = group_min<G, T>(occ_t);
+  }
+  // --- duck ---
   T zc = relb[0] * OC.cam_f[0] + relb[1] * OC.cam_f[1] + relb[2] * OC.cam_f[2];
   T xc = relb[0] * OC.cam_r[0] + relb[1] * OC.cam_r[1] + relb[2] * OC.cam_r[2];
   T yc = relb[0] * OC.cam_d[0] + relb[1] * OC.cam_d[1] + relb[2] * OC.cam_d[2];
@@ -256,7 +288,7 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
     T y0 = M<T>::fmax_(v - rho, (T)0), y1 = -M<T>::fmax_(-(v + rho), -(H - (T)1));
     if (x1 > x0 && y1 > y0) {
       T a = (T)(0.25 * kPi) * (x1 - x0) * (y1 - y0);
-      if (a >= (T)1 && !obj_occluded<T>(OC, D, env, O, cam, Cc)) {
+      if (a >= (T)1 && !(occ_t < (T)1)) {          // occluded <=> a cylinder cuts the segment camera -> duck (0 < t < 1)
         visible = (T)1;
         cx = M<T>::div_((T)0.5 * (x0 + x1), M<T>::fmax_((T)1, W - (T)1));
         cy = M<T>::div_((T)0.5 * (y0 + y1), M<T>::fmax_((T)1, H - (T)1));
@@ -267,14 +299,12 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
     }
   }
   O.frame[0] = visible; O.frame[1] = cx; O.frame[2] = cy; O.frame[3] = area; O.frame[4] = depth;
-#pragma unroll 1
-  for (int zid = 0; zid < 3; ++zid) {
-    T ucol = M<T>::div_((T)(2 * zid + 1) * W, (T)6) - (T)0.5;
-    T a = M<T>::div_(ucol - u0, F), b = M<T>::div_(OC.vmid - v0, F), db[3], dw[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) db[k] = OC.cam_f[k] + a * OC.cam_r[k] + b * OC.cam_d[k];
-    mv(R, db, dw);
-    O.frame[5 + zid] = obj_ray_depth<T>(OC, D, env, O, cam, dw);
+  for (int zid = 0; zid < 3; ++zid) {
+    T b = OC.far_;
+    if (dwz[zid][2] < (T)0) { T t = M<T>::div_(-cam[2], dwz[zid][2]); if (t > (T)0 && t < b) b = t; }     // ground plane
+    b = best[zid] < b ? best[zid] : b;
+    O.frame[5 + zid] = b < OC.near_ ? OC.near_ : b;
   }
   O.frame_has = (T)1;
 }
@@ -489,7 +519,7 @@ __device__ __forceinline__ bool aviary_step(const Params<T>& P, const TickC<T>& 
     if (OBJ) contact |= obj_contacts<T, G>(P, C, OC, D, env, O, S, R);
     tick += 1;
   }
-  if (OBJ && OC.camera_ratio_ticks > 0 && (tick % OC.camera_ratio_ticks) == 0) obj_camera_capture<T>(OC, D, env, O, S, R);
+  if (OBJ && OC.camera_ratio_ticks > 0 && (tick % OC.camera_ratio_ticks) == 0) obj_camera_capture<T, G>(OC, D, env, O, S, R);
   return contact;
 }
 

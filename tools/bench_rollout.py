@@ -9,7 +9,7 @@ configs[2] of BASELINE.json = objlock (train/train_objlock.py hyper-parameters: 
 (batch 128, 20 epochs).  n_steps is scaled so that one update sees the reference's sample count."""
 import json, sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import pyflyt_drone_amd as P
 from pyflyt_drone_amd import config as K, rollout as R
 
