@@ -55,6 +55,11 @@ __global__ void fw_warm_kernel(Params<T>* Pm) {
   for (int k = 0; k < 4; ++k) Pm->warm[3 + k] = S.q[k];
   for (int k = 0; k < FW_NUM_ACTUATORS; ++k) Pm->warm[13 + k] = S.act[k];
   Pm->warm_ticks = ticks;
+  // the observation every cached reset returns, up to its target deltas
+  const T a0[4] = {(T)0, (T)0, (T)0, (T)0};
+  T Rw[9];
+  (void)write_obs_attitude<T>(P, S, a0, Rw, [&](int k, T v) { Pm->warm_obs[k] = v; });
+  for (int k = 0; k < 9; ++k) Pm->warm_R[k] = Rw[k];
 }
 
 // action shown in the observation: src 0 = this step's input, 1 = stored (stale), 2 = zeros
@@ -120,7 +125,7 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
   const DevState<T> V = shadow_view<T>(D);
   if (begin) {
     Rigid<T> S0; int32_t tick0 = 0, episode = (int32_t)target - 1, nr = 0; T wb0[3], wa0[3], wph0;
-    (void)begin_reset<T, G>(P, V, env, S0, tick0, episode, nr, wb0, wa0, wph0);     // shadow_on implies !warm_valid
+    T tm0[3]; (void)begin_reset<T, G>(P, V, env, S0, tick0, episode, nr, wb0, wa0, wph0, tm0);     // shadow_on implies !warm_valid
     if (HASOBJ) {
       ObjState<T> O0;
       obj_reset_state<T>(O0);
@@ -160,6 +165,15 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
   }
 }
 
+// Dev-only per-wave cycle accounting (tools/wave_profile.py builds a second library with -DFW_PROFILE).
+#ifdef FW_PROFILE
+#define FWP_NOW() ((long long)__builtin_readcyclecounter())
+#define FWP(...) __VA_ARGS__
+constexpr int kProfSlots = 256, kProfWords = 12;
+#else
+#define FWP(...)
+#endif
+
 // Per-lane phase of the fused step state machine.
 enum Phase : int { PH_STEP = 0, PH_WARM = 1, PH_DONE = 2 };
 
@@ -190,8 +204,20 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   constexpr bool COMB = TKIND == FW_TASK_WAYPOINT_OBJLOCK;    // waypoints, then the duck
   constexpr bool HASOBJ = OBJ || COMB;
   constexpr int EPW = kWave / G;                     // envs per wave
+  // Wind-free waypoints (the headline config): the episode start is the cached warm state for every env, so an
+  // auto-reset is deferred to the epilogue -- the obs pass there writes the terminal observation, the new episode's
+  // observation is the cached attitude block + the deltas of the freshly sampled waypoints.  No second obs pass, no
+  // sampling inside the step loop, and the waves that contain a reset finish with the others.
+  constexpr bool DEFER = !GENERAL && TKIND == FW_TASK_WAYPOINTS;
   const int nblk = (D.npad + EPW - 1) / EPW;         // step blocks; blocks beyond are shadow workers
-  if ((int)blockIdx.x >= nblk) { shadow_worker<T, G, TKIND>(Pp, OCp, D, (int)blockIdx.x - nblk); return; }
+  FWP(const long long p_t0 = FWP_NOW(); long long p_reset = 0, p_avi = 0, p_task = 0, p_r1 = 0, p_r2 = 0, p_r3 = 0; int p_nreset = 0, p_nhit = 0;)
+  if ((int)blockIdx.x >= nblk) {
+    shadow_worker<T, G, TKIND>(Pp, OCp, D, (int)blockIdx.x - nblk);
+    FWP(if (D.prof && threadIdx.x == 0) {
+      long long* w = D.prof + ((size_t)(D.epoch % kProfSlots) * 2 * nblk + blockIdx.x) * kProfWords;
+      w[0] = FWP_NOW() - p_t0; })
+    return;
+  }
   const int lane = threadIdx.x;
   const int sub = (G == 1) ? 0 : (lane & (G - 1));   // my lane within the env's group
   const int row = lane / G;                          // env slot within the wave
@@ -277,17 +303,21 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   int32_t out_flags = 0, out_reached = 0, out_steps = 0, out_strike_latched = 0;
   int phase = active ? PH_STEP : PH_DONE;
   int it = 0, warm_left = 0;
+  bool resetting = false;                            // DEFER: auto-reset pending for the epilogue
   bool step_over = active && done_at_entry;          // nothing to simulate: finalise immediately
 
+  FWP(const long long p_t1 = FWP_NOW();)
 #pragma unroll 1
   for (;;) {
+    FWP(const long long p_a = FWP_NOW();)
     if (phase == PH_STEP && step_over) {
       // ---- end of env.step(): :346, outputs, SB3 worker auto-reset ----
       step_count += 1;
       ep_return += rew;
       out_rew = rew; out_flags = flags; out_reached = num_reached; out_steps = step_count; out_strike_latched = out_strike;
       phase = PH_DONE;
-      if ((flags & (FL_TERM | FL_TRUNC)) && P.auto_reset) {
+      if (DEFER) resetting = (flags & (FL_TERM | FL_TRUNC)) && P.auto_reset;
+      if (!DEFER && (flags & (FL_TERM | FL_TRUNC)) && P.auto_reset) {
         if (terminal_obs && leader) {
           T* trow = terminal_obs + (size_t)env * Dobs;
           T act_t[4];
@@ -296,6 +326,8 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
           else if (COMB) comb_write_obs<T>(P, D, env, O, S, act_t, tgt_obs, [&](int k, T v) { trow[k] = v; });
           else write_obs<T>(P, D, env, S, act_t, tgt_obs, [&](int k, T v) { trow[k] = v; });
         }
+        T t_mine[3] = {(T)0, (T)0, (T)0};            // first waypoint of the new episode
+        FWP(const long long p_ra = FWP_NOW(); p_r1 += p_ra - p_a;)
         if (GENERAL && D.shadow_on && (int)(sh_done & 0xFF) == P.warmup_aviary_steps + 1 &&
             (uint32_t)(sh_done >> 32) == (uint32_t)(episode + 1) && (uint32_t)((sh_done >> 8) & 0xFFFFFFu) != (D.epoch & 0xFFFFFFu)) {
           // swap the pre-simulated episode in: a copy instead of 10 Aviary steps
@@ -306,36 +338,44 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
           for (int k = 0; k < 3; ++k) { wb[k] = V.r[(RF_WIND + k) * n + env]; wa[k] = V.r[(RF_WIND + 3 + k) * n + env]; }
           wphase = V.r[(RF_WIND + 6) * n + env];
           if (HASOBJ) obj_load<T>(V, env, O);
-          if (leader) {
-#pragma unroll 1
-            for (int k = 0; k < 7; ++k) D.r[(RF_WIND + k) * n + env] = V.r[(RF_WIND + k) * n + env];
-            if (!OBJ) {
-#pragma unroll 1
-              for (int k = 0; k < 3 * FW_MAX_TARGETS; ++k) D.r[(RF_TARGETS + k) * n + env] = V.r[(RF_TARGETS + k) * n + env];
-            }
-            if (HASOBJ) {
-#pragma unroll 1
-              for (int k = 0; k < 3 * FW_MAX_OBSTACLES; ++k) D.r[(RF_TASK + FW_ST_OBST + k) * n + env] = V.r[(RF_TASK + FW_ST_OBST + k) * n + env];
-            }
+          if (!OBJ) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t_mine[k] = V.r[(size_t)(RF_TARGETS + k) * n + env];     // waypoint 0, for end_reset
           }
+          copy_words<T, G>(D.r, V.r, RF_WIND, 7, n, env);
+          if (!OBJ) copy_words<T, G>(D.r, V.r, RF_TARGETS, 3 * P.num_targets, n, env);
+          if (HASOBJ) copy_words<T, G>(D.r, V.r, RF_TASK + FW_ST_OBST, 3 * FW_MAX_OBSTACLES, n, env);
           episode += 1; num_reached = 0; warm_left = 0;
+          FWP(p_nhit += 1;)
         } else {
-          warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase);
+          warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase, t_mine);
+          if (G > 1) {                                          // the group's lane 0 sampled waypoint 0
+            const int src = lane & ~(G - 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t_mine[k] = __shfl(t_mine[k], src, kWave);
+          }
           if (HASOBJ) {
             obj_reset_state<T>(O);
             if (OBJ) obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
             else comb_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
           }
         }
-        if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (G > 1 && warm_left > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the warm-up's camera reads the obstacles
+        FWP(const long long p_rb = FWP_NOW(); p_r2 += p_rb - p_ra;)
         step_count = 0; flags = 0; ep_return = (T)0; tgt_obs = 0;
         act_src = 2;
+        FWP(p_nreset += 1;)
         rot_from_unit_quat<T>(S.q, R);
         if (GENERAL && warm_left > 0) phase = PH_WARM;
         else if (OBJ) obj_compute_state<T>(O);                 // end_reset(): first compute_state of the episode
-        else { new_dist = end_reset<T, G>(P, D, env, episode, S); if (COMB) comb_compute_state<T>(OC, O, P.num_targets == 0); }
+        else {
+          new_dist = end_reset<T, G>(P, D, env, episode, S, t_mine);
+          if (COMB) comb_compute_state<T>(OC, O, P.num_targets == 0);
+        }
+        FWP(p_r3 += FWP_NOW() - p_rb;)
       }
     }
+    FWP(const long long p_b = FWP_NOW(); p_reset += p_b - p_a;)
     if (__ballot(phase != PH_DONE) == 0ull) break;   // wave-uniform exit
     // noise of this iteration's Aviary step (all stepping envs of the wave are at sub-step `it`)
     T z0 = (T)0, z1 = (T)0;
@@ -357,6 +397,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       } else {
         contact = aviary_step<T, false, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd, tick, z0, z1, wb, wa, wphase, mine, wmask);    // :339
       }
+      FWP(const long long p_c = FWP_NOW(); p_avi += p_c - p_b;)
       if (stepping && OBJ) {
         obj_compute_state<T>(O);                                                                   // :342
         // compute_base_term_trunc_reward(): :296-312
@@ -445,11 +486,13 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
           phase = PH_DONE;
         }
       }
+      FWP(p_task += FWP_NOW() - p_c;)
     }
     it += 1;
   }
+  FWP(const long long p_t2 = FWP_NOW();)
   // G = 8: waypoints sampled by sibling lanes during an in-launch reset are read back below
-  if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  if (G > 1 && !DEFER) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 
   if (GENERAL && D.shadow_on && active && leader && (uint32_t)(sh_req >> 32) != (uint32_t)(episode + 1))
     D.sreq[env] = ((unsigned long long)(uint32_t)(episode + 1) << 32) | (unsigned long long)D.epoch;   // ask for the next episode
@@ -462,11 +505,74 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       ip[0] = make_int4(out_reached, (out_flags & FL_COLLISION) ? 1 : 0, (out_flags & FL_OOB) ? 1 : 0, (out_flags & FL_COMPLETE) ? 1 : 0);
       ip[1] = make_int4(out_strike_latched, OBJ ? out_strike_latched : 0, out_steps, 0);
     }
-    T act_obs[4];
+  }
+  T act_obs[4] = {(T)0, (T)0, (T)0, (T)0};
+  if (active && leader) {
     load_action<T>(D, actions, env, act_src, act_obs);
     if (OBJ) obj_write_obs<T>(P, O, S, act_obs, [&](int k, T v) { tile[row * ld + k] = v; });
     else if (COMB) comb_write_obs<T>(P, D, env, O, S, act_obs, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
     else write_obs<T>(P, D, env, S, act_obs, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
+  }
+  if (DEFER && resetting) {                          // group-uniform: all G lanes of the env take part
+    // the row just written is the terminal observation: move it out before the new episode's row replaces it
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (terminal_obs) {
+      T* trow = terminal_obs + (size_t)env * Dobs;
+      for (int k = sub; k < Dobs; k += G) trow[k] = tile[row * ld + k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    episode += 1;
+    Scenario<T> sc;
+    sample_scenario<T, G>(Pp, D.r, n, env, (uint32_t)episode, &sc);      // reads the old waypoints above, overwrites them here
+    const int nt = min(P.ctx, P.num_targets);
+    T t0[3] = {(T)0, (T)0, (T)0};
+#pragma unroll 1
+    for (int i = 0; i < P.ctx; ++i) {
+      T tw[3] = {(T)0, (T)0, (T)0};
+      if (G > 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tw[k] = __shfl(sc.t_mine[k], (lane & ~(G - 1)) | (i & (G - 1)), kWave);    // lane i of the group sampled waypoint i
+      } else if (i < nt) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tw[k] = D.r[(size_t)(RF_TARGETS + 3 * i + k) * n + env];                      // own stores, program order
+      }
+      T d[3] = {(T)0, (T)0, (T)0}, b[3] = {(T)0, (T)0, (T)0};
+      if (i < nt) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k] = tw[k] - P.warm[k];
+        mtv(P.warm_R, d, b);
+        if (i == 0) { t0[0] = tw[0]; t0[1] = tw[1]; t0[2] = tw[2]; }
+      }
+      if (leader) { tile[row * ld + P.att_dim + 3 * i] = b[0]; tile[row * ld + P.att_dim + 3 * i + 1] = b[1]; tile[row * ld + P.att_dim + 3 * i + 2] = b[2]; }
+    }
+    if (leader) {
+#pragma unroll 1
+      for (int k = 0; k < P.att_dim; ++k) tile[row * ld + k] = P.warm_obs[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { S.p[k] = P.warm[k]; S.v[k] = P.warm[7 + k]; S.w[k] = P.warm[10 + k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) S.q[k] = P.warm[3 + k];
+#pragma unroll
+    for (int k = 0; k < FW_NUM_ACTUATORS; ++k) S.act[k] = P.warm[13 + k];
+    tick = P.warm_ticks;
+    step_count = 0; flags = 0; ep_return = (T)0; tgt_obs = 0; num_reached = 0;
+    new_dist = (T)0;
+    if (P.num_targets > 0) {
+      if (G == 1 && nt == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t0[k] = D.r[(size_t)(RF_TARGETS + k) * n + env];
+      } else if (G > 1 && nt == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t0[k] = __shfl(sc.t_mine[k], lane & ~(G - 1), kWave);
+      }
+      T dx = t0[0] - S.p[0], dy = t0[1] - S.p[1], dz = t0[2] - S.p[2];
+      new_dist = M<T>::sqrt_(dx * dx + dy * dy + dz * dz);                 // end_reset -> compute_state
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) act_obs[k] = (T)0;
+  }
+  if (active && leader) {
     store_rigid<T>(D, env, S);
     if (HASOBJ) obj_store<T>(D, env, O);
 #pragma unroll
@@ -481,6 +587,18 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   }
   __syncthreads();
   flush_obs_tile<T>(tile, ld, obs, env0, EPW, D.n, Dobs);
+  FWP(if (D.prof) {
+    const int nr = __popcll(__ballot(leader && p_nreset > 0)), nh = __popcll(__ballot(leader && p_nhit > 0));
+    for (int o = 32; o > 0; o >>= 1) {               // the reset split is per lane (divergent region): wave max
+      p_r1 = max(p_r1, (long long)__shfl_xor((long long)p_r1, o, kWave));
+      p_r2 = max(p_r2, (long long)__shfl_xor((long long)p_r2, o, kWave));
+      p_r3 = max(p_r3, (long long)__shfl_xor((long long)p_r3, o, kWave));
+    }
+    if (lane == 0) {
+      long long* w = D.prof + ((size_t)(D.epoch % kProfSlots) * 2 * nblk + blockIdx.x) * kProfWords;
+      const long long t3 = FWP_NOW();
+      w[0] = t3 - p_t0; w[1] = p_t1 - p_t0; w[2] = p_reset; w[3] = p_avi; w[4] = p_task; w[5] = t3 - p_t2; w[6] = it | (nr << 8) | (nh << 16); w[7] = p_t0; w[8] = p_r1; w[9] = p_r2; w[10] = p_r3;
+    } })
 }
 
 #ifndef FW_G1_WAVES
@@ -544,7 +662,8 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
   T new_dist = (T)0, wb[3] = {(T)0, (T)0, (T)0}, wa[3] = {(T)0, (T)0, (T)0}, wphase = (T)0;
   int warm_left = 0;
   if (resetting) {
-    warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase);
+    T t_mine[3] = {(T)0, (T)0, (T)0};
+    warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase, t_mine);
     if (HASOBJ) {
       obj_reset_state<T>(O);
       if (OBJ) obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O); else comb_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
@@ -767,6 +886,7 @@ struct fw_env {
   unsigned long long* sreq_dev = nullptr;   // shadow requests / progress words, u64[npad] each
   unsigned long long* sdone_dev = nullptr;
   uint32_t epoch = 1;           // fw_step launch index
+  long long* prof_dev = nullptr; // FW_PROFILE builds only
   int32_t shadow_on = 0;        // background warm-up of the next episode (see shadow_* kernels)
   std::string err;
 };
@@ -793,6 +913,7 @@ struct DeviceGuard {
 template <typename T> DevState<T> dev_state(fw_env* h) {
   DevState<T> D; D.r = (T*)h->r_dev; D.i = h->i_dev; D.n = h->n; D.npad = h->npad;
   D.rs = (T*)h->rs_dev; D.is = h->is_dev; D.sreq = h->sreq_dev; D.sdone = h->sdone_dev; D.epoch = h->epoch; D.shadow_on = h->shadow_on;
+  FWP(D.prof = h->prof_dev;)
   return D;
 }
 int invalidate_shadow(fw_env* h) {
@@ -1140,8 +1261,24 @@ int32_t fw_destroy(fw_handle h) {
   if (h->is_dev) (void)hipFree(h->is_dev);
   if (h->sreq_dev) (void)hipFree(h->sreq_dev);
   if (h->sdone_dev) (void)hipFree(h->sdone_dev);
+  FWP(if (h->prof_dev) (void)hipFree(h->prof_dev);)
   delete h;
   return FW_OK;
 }
+
+#ifdef FW_PROFILE
+// Dev-only (not part of include/fwsim.h): per-wave cycle accounting ring of the last 256 launches.
+// Layout long long[256][2 * blocks][8]; returns the number of step blocks.
+int32_t fw_debug_profile(fw_handle h, long long* host_out, int32_t enable) {
+  if (!h) return FW_EINVAL;
+  DeviceGuard g(h->device);
+  const size_t nblk = grid_of(h).x, bytes = sizeof(long long) * kProfSlots * 2 * nblk * kProfWords;
+  (void)hipDeviceSynchronize();
+  if (enable && !h->prof_dev) { (void)hipMalloc((void**)&h->prof_dev, bytes); (void)hipMemset(h->prof_dev, 0, bytes); }
+  if (host_out && h->prof_dev) (void)hipMemcpy(host_out, h->prof_dev, bytes, hipMemcpyDeviceToHost);
+  return (int32_t)nblk;
+}
+int32_t fw_debug_epoch(fw_handle h) { return h ? (int32_t)h->epoch : 0; }
+#endif
 
 }  // extern "C"

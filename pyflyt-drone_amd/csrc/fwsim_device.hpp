@@ -75,6 +75,7 @@ struct Params {
   T wind_base[3], wind_amp[3], wind_phase, gust_omega, wind_force_coef;
   double wind_base_range[3][2], wind_amp_range[3][2];
   T warm[19];                             // cached post-warm-up rigid(13)+act(6) state
+  T warm_obs[24], warm_R[9];              // ... its observation's attitude block (zero action) and the rotation its target deltas use
   int32_t warm_valid, warm_ticks;
   int32_t n_coll, gyroscopic;
   int32_t task, angle_repr, att_dim, obs_dim, ctx;
@@ -98,6 +99,9 @@ struct DevState {
   unsigned long long* sdone; // [npad]  worker -> live:  (episode built << 32) | (launch index & 0xFFFFFF) << 8 | progress
   uint32_t epoch;            // launch index of this fw_step (host counter)
   int32_t shadow_on;
+#ifdef FW_PROFILE
+  long long* prof;           // dev-only per-wave cycle accounting (fwsim.hip)
+#endif
 };
 
 constexpr double kPi = 3.14159265358979323846;
@@ -660,9 +664,7 @@ __device__ __forceinline__ void quat_from_euler(const T e[3], T q[4]) {
 //   the identity on the rotation, so q itself is used and the round trip is
 //   taken only on the (rare) guarded branch or when the quaternion is observed.
 template <typename T, typename W>
-__device__ __forceinline__ void write_obs(const Params<T>& P, const DevState<T>& D, int env, const Rigid<T>& S,
-                                          const T action[4], int tgt_idx, W&& put) {
-  T R[9];
+__device__ __forceinline__ int write_obs_attitude(const Params<T>& P, const Rigid<T>& S, const T action[4], T R[9], W&& put) {
   rot_from_quat(S.q, R);
   T ang_vel[3], lin_vel[3], eul[3];
   mtv(R, S.w, ang_vel);
@@ -682,6 +684,13 @@ __device__ __forceinline__ void write_obs(const Params<T>& P, const DevState<T>&
   put(o++, action[0]); put(o++, action[1]); put(o++, action[2]); put(o++, action[3]);
 #pragma unroll
   for (int k = 0; k < FW_NUM_ACTUATORS; ++k) put(o++, S.act[k]);
+  return o;
+}
+template <typename T, typename W>
+__device__ __forceinline__ void write_obs(const Params<T>& P, const DevState<T>& D, int env, const Rigid<T>& S,
+                                          const T action[4], int tgt_idx, W&& put) {
+  T R[9];
+  int o = write_obs_attitude<T>(P, S, action, R, put);
   for (int i = 0; i < P.ctx; ++i) {
     int t = tgt_idx + i;
     T d[3] = {(T)0, (T)0, (T)0}, b[3] = {(T)0, (T)0, (T)0};
@@ -718,6 +727,22 @@ __device__ __forceinline__ void store_rigid(const DevState<T>& D, int env, const
   for (int k = 0; k < FW_NUM_ACTUATORS; ++k) b[(RF_ACT + k) * n] = S.act[k];
 }
 
+// Copy `count` consecutive SoA words of one env between two state arrays: the group's lanes
+// take every G-th word and keep their loads in flight together (one memory round trip, not `count`).
+template <typename T, int G>
+__device__ __forceinline__ void copy_words(T* __restrict__ dst, const T* __restrict__ src, int base, int count, size_t n, int env) {
+  const int sub = (G == 1) ? 0 : (int)(threadIdx.x & (G - 1));
+  constexpr int B = 8;
+#pragma unroll 1
+  for (int k0 = sub; k0 < count; k0 += B * G) {
+    T tmp[B];
+#pragma unroll
+    for (int m = 0; m < B; ++m) { const int k = k0 + m * G; if (k < count) tmp[m] = src[(size_t)(base + k) * n + env]; }
+#pragma unroll
+    for (int m = 0; m < B; ++m) { const int k = k0 + m * G; if (k < count) dst[(size_t)(base + k) * n + env] = tmp[m]; }
+  }
+}
+
 // ------------------------------------------------------------------------
 // reset of one env, split like the reference: begin_reset (+ scenario sampling)
 // and end_reset; the warm-up Aviary steps in between are run by the caller's
@@ -726,14 +751,16 @@ __device__ __forceinline__ void store_rigid(const DevState<T>& D, int env, const
 // Returns the number of warm-up Aviary steps still to run (0 when the cached
 // env-independent warm state could be copied).  G = 8: lane `sub` samples waypoint
 // `sub` (num_targets <= 8 = group size); only the group leader stores wind.
+// Scenario sampling of a reset (wind + waypoints).  Deliberately NOT inlined: the double-precision
+// sincos / Philox live ranges would otherwise be added to the register budget of the step loop
+// (+80 VGPRs in the headline kernel), and only the few waves that contain a reset ever run it.
+template <typename T> struct Scenario { T wb[3], wa[3], wph, t_mine[3]; };
 template <typename T, int G>
-__device__ __forceinline__ int begin_reset(const Params<T>& P, const DevState<T>& D, int env, Rigid<T>& S, int32_t& tick,
-                                           int32_t& episode, int32_t& num_reached, T wb[3], T wa[3], T& wphase) {
-  episode += 1;
-  const uint32_t ep = (uint32_t)episode;
+__device__ __noinline__ void sample_scenario(const Params<T>* Pp, T* r, size_t n, int env, uint32_t ep, Scenario<T>* out) {
+  const Params<T>& P = *Pp;
   const uint32_t genv = (uint32_t)(P.env_offset + env);
-  const size_t n = D.npad;
   const int sub = (G == 1) ? 0 : (int)(threadIdx.x & (G - 1));
+  T wb[3], wa[3], wphase;
   // wind: base(3), gust amp(3), phase -- fixedwing_base_env.py:139-165
 #pragma unroll
   for (int k = 0; k < 3; ++k) { wb[k] = P.wind_base[k]; wa[k] = P.wind_amp[k]; }
@@ -749,9 +776,10 @@ __device__ __forceinline__ int begin_reset(const Params<T>& P, const DevState<T>
   }
   if (P.wind_mode != FW_WIND_OFF && sub == 0) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { D.r[(RF_WIND + k) * n + env] = wb[k]; D.r[(RF_WIND + 3 + k) * n + env] = wa[k]; }
-    D.r[(RF_WIND + 6) * n + env] = wphase;
+    for (int k = 0; k < 3; ++k) { r[(RF_WIND + k) * n + env] = wb[k]; r[(RF_WIND + 3 + k) * n + env] = wa[k]; }
+    r[(RF_WIND + 6) * n + env] = wphase;
   }
+  T tm[3] = {(T)0, (T)0, (T)0};
   // WaypointHandler.reset: polar sampling (always in double, cast once)
   if (P.task != FW_TASK_OBJLOCK) {
     const int i0 = (G == 1) ? 0 : sub, i1 = (G == 1) ? P.num_targets : min(sub + 1, P.num_targets);
@@ -765,9 +793,27 @@ __device__ __forceinline__ int begin_reset(const Params<T>& P, const DevState<T>
       M<double>::sincos_(theta, &sth, &cth);
       double x = dist * sphi * cth, y = dist * sphi * sth, z = ::fabs(dist * cphi);
       z = z > (double)P.min_height ? z : (double)P.min_height;
-      T* tp = D.r + (size_t)(RF_TARGETS + 3 * i) * n + env;
+      T* tp = r + (size_t)(RF_TARGETS + 3 * i) * n + env;
       tp[0] = (T)x; tp[n] = (T)y; tp[2 * n] = (T)z;
+      if (G > 1 || i == 0) { tm[0] = (T)x; tm[1] = (T)y; tm[2] = (T)z; }
     }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { out->wb[k] = wb[k]; out->wa[k] = wa[k]; out->t_mine[k] = tm[k]; }
+  out->wph = wphase;
+}
+
+template <typename T, int G>
+__device__ __forceinline__ int begin_reset(const Params<T>& P, const DevState<T>& D, int env, Rigid<T>& S, int32_t& tick,
+                                           int32_t& episode, int32_t& num_reached, T wb[3], T wa[3], T& wphase,
+                                           T t_mine[3] /* out: the waypoint this lane sampled (G = 8) / waypoint 0 (G = 1) */) {
+  episode += 1;
+  {
+    Scenario<T> sc;
+    sample_scenario<T, G>(&P, D.r, (size_t)D.npad, env, (uint32_t)episode, &sc);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { wb[k] = sc.wb[k]; wa[k] = sc.wa[k]; t_mine[k] = sc.t_mine[k]; }
+    wphase = sc.wph;
   }
   num_reached = 0;
   // Aviary(): start pose + PyFlyt starting velocity, zero actuators
@@ -791,8 +837,8 @@ __device__ __forceinline__ int begin_reset(const Params<T>& P, const DevState<T>
   return P.warmup_aviary_steps;
 }
 
-// first waypoint of the episode that was just sampled (regenerated from the RNG so that
-// no lane has to read back what another lane has just stored)
+// first waypoint of an episode regenerated from the RNG (G = 8, after an in-kernel warm-up:
+// nothing is kept live across it and no lane reads back what another lane has just stored)
 template <typename T>
 __device__ __forceinline__ void first_target(const Params<T>& P, uint32_t genv, uint32_t ep, T t0[3]) {
   double theta = rng_uniform<T>(P, genv, ep, J_THETA, 0.0, 2.0 * kPi);
@@ -808,11 +854,14 @@ __device__ __forceinline__ void first_target(const Params<T>& P, uint32_t genv, 
 
 // end_reset -> compute_state: WaypointHandler distances (old = 0 -> new)
 template <typename T, int G>
-__device__ __forceinline__ T end_reset(const Params<T>& P, const DevState<T>& D, int env, int32_t episode, const Rigid<T>& S) {
+__device__ __forceinline__ T end_reset(const Params<T>& P, const DevState<T>& D, int env, int32_t episode, const Rigid<T>& S,
+                                       const T* t_first = nullptr /* waypoint 0 of the episode, if the caller still holds it */) {
   T new_dist = (T)0;
   if (P.task != FW_TASK_OBJLOCK && P.num_targets > 0) {
     T t0[3];
-    if (G == 1) {
+    if (t_first) {
+      t0[0] = t_first[0]; t0[1] = t_first[1]; t0[2] = t_first[2];
+    } else if (G == 1) {
       const size_t n = D.npad;
       const T* tp = D.r + (size_t)RF_TARGETS * n + env;
       t0[0] = tp[0]; t0[1] = tp[n]; t0[2] = tp[2 * n];

@@ -92,7 +92,7 @@ __device__ __forceinline__ void obj_reset_state(ObjState<T>& O) {
 // _spawn_duck :461-491, _spawn_obstacles :507-565.  Every lane computes the scenario; only the
 // leader writes the obstacle list to HBM.
 template <typename T>
-__device__ __forceinline__ void obj_spawn(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env, uint32_t ep,
+__device__ __forceinline__ void obj_spawn_impl(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env, uint32_t ep,
                                           bool leader, ObjState<T>& O) {
   const uint32_t genv = (uint32_t)(P.env_offset + env);
   const double r = (double)OC.half_dome;
@@ -134,7 +134,7 @@ __device__ __forceinline__ void nth_target(const Params<T>& P, uint32_t genv, ui
 // combined task: duck at the last waypoint's x,y (envs/fixedwing_waypoint_objlock_env.py:394-436), obstacles
 // with the origin rejection only (:452-503)
 template <typename T>
-__device__ __forceinline__ void comb_spawn(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env, uint32_t ep,
+__device__ __forceinline__ void comb_spawn_impl(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env, uint32_t ep,
                                            bool leader, ObjState<T>& O) {
   const uint32_t genv = (uint32_t)(P.env_offset + env);
   if (P.num_targets > 0) {
@@ -159,6 +159,28 @@ __device__ __forceinline__ void comb_spawn(const Params<T>& P, const ObjC<T>& OC
   if (leader)
     for (int i = nob; i < FW_MAX_OBSTACLES; ++i) { ob[(3 * i + 0) * n] = (T)0; ob[(3 * i + 1) * n] = (T)0; ob[(3 * i + 2) * n] = (T)0; }
   O.nob = nob;
+}
+
+// Out-of-line entry points of the spawners (cold path: keeps their live ranges out of the step loop's register budget).
+template <typename T> struct Spawned { T duck[3]; int32_t nob; };
+template <typename T, int TKIND>
+__device__ __noinline__ void spawn_task(const Params<T>* Pp, const ObjC<T>* OCp, T* r, int npad, int env, uint32_t ep, bool leader, Spawned<T>* out) {
+  DevState<T> D; D.r = r; D.npad = npad;
+  ObjState<T> O;
+  if (TKIND == FW_TASK_OBJLOCK) obj_spawn_impl<T>(*Pp, *OCp, D, env, ep, leader, O); else comb_spawn_impl<T>(*Pp, *OCp, D, env, ep, leader, O);
+  out->duck[0] = O.duck[0]; out->duck[1] = O.duck[1]; out->duck[2] = O.duck[2]; out->nob = O.nob;
+}
+template <typename T>
+__device__ __forceinline__ void obj_spawn(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env, uint32_t ep, bool leader, ObjState<T>& O) {
+  Spawned<T> sp;
+  spawn_task<T, FW_TASK_OBJLOCK>(&P, &OC, D.r, D.npad, env, ep, leader, &sp);
+  O.duck[0] = sp.duck[0]; O.duck[1] = sp.duck[1]; O.duck[2] = sp.duck[2]; O.nob = sp.nob;
+}
+template <typename T>
+__device__ __forceinline__ void comb_spawn(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env, uint32_t ep, bool leader, ObjState<T>& O) {
+  Spawned<T> sp;
+  spawn_task<T, FW_TASK_WAYPOINT_OBJLOCK>(&P, &OC, D.r, D.npad, env, ep, leader, &sp);
+  O.duck[0] = sp.duck[0]; O.duck[1] = sp.duck[1]; O.duck[2] = sp.duck[2]; O.nob = sp.nob;
 }
 
 // Which cylinders can be touched during this agent step?  Conservative: horizontal distance of the COM to
