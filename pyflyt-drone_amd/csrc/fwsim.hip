@@ -211,7 +211,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   constexpr bool DEFER = !GENERAL && TKIND == FW_TASK_WAYPOINTS;
   const int nblk = (D.npad + EPW - 1) / EPW;         // step blocks; blocks beyond are shadow workers
   FWP(const long long p_t0 = FWP_NOW(); long long p_reset = 0, p_avi = 0, p_task = 0, p_r1 = 0, p_r2 = 0, p_r3 = 0; int p_nreset = 0, p_nhit = 0;)
-  if ((int)blockIdx.x >= nblk) {
+  if (GENERAL && (int)blockIdx.x >= nblk) {          // (the wind-free kernels are never launched with workers)
     shadow_worker<T, G, TKIND>(Pp, OCp, D, (int)blockIdx.x - nblk);
     FWP(if (D.prof && threadIdx.x == 0) {
       long long* w = D.prof + ((size_t)(D.epoch % kProfSlots) * 2 * nblk + blockIdx.x) * kProfWords;
@@ -230,12 +230,33 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   const int Dobs = P.obs_dim;
   const int ld = Dobs + 1;
 
+  // Loads first, in the order their results are needed (vmcnt retires in order): the counters that feed
+  // the RNG and the target window, then the rigid state, then the launch-resident constants.
+  int32_t step_count = D.i[IF_STEP * n + envc];
+  int32_t tick = D.i[IF_TICK * n + envc];
+  int32_t episode = D.i[IF_EPISODE * n + envc];
+  int32_t flags = D.i[IF_FLAGS * n + envc];
+  int32_t num_reached = D.i[IF_NUM_REACHED * n + envc];
+  // G = 8, wind-free waypoints: lane j of the group keeps waypoint j (num_targets <= 8) and component j & 3 of the
+  // action; the current waypoint, the obs deltas and the obs action are fetched by shuffle -- no dependent loads.
+  constexpr bool LANE_T = DEFER && G == 8;
+  T tmine[3] = {(T)0, (T)0, (T)0};
+  T a_keep = (T)0;
+  if (LANE_T) {
+    if (sub < P.num_targets) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tmine[k] = D.r[(size_t)(RF_TARGETS + 3 * sub + k) * n + envc];
+    }
+    a_keep = actions[(size_t)envc * 4 + (sub & 3)];
+  }
+  Rigid<T> S;
+  load_rigid<T>(D, envc, S);
+  T new_dist = D.r[RF_NEW_DIST * n + envc];
+  T ep_return = D.r[RF_EP_RETURN * n + envc];
   // tick constants + this lane's lifting surface (G = 8: resident in VGPRs for the whole launch)
   TickC<T> C; SurfC<T> mine; T wmask;
   load_tick_constants<T, G>(Pp, C, mine, wmask);
 
-  Rigid<T> S;
-  load_rigid<T>(D, envc, S);
   normalize_quat<T>(S.q);
   T R[9];
   rot_from_unit_quat<T>(S.q, R);
@@ -246,13 +267,6 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   // shadow bookkeeping (kernel-boundary hand-off, see shadow_* above)
   unsigned long long sh_req = ~0ull, sh_done = 0ull;
   if (GENERAL && D.shadow_on) { sh_req = D.sreq[envc]; sh_done = D.sdone[envc]; }
-  int32_t step_count = D.i[IF_STEP * n + envc];
-  int32_t tick = D.i[IF_TICK * n + envc];
-  int32_t episode = D.i[IF_EPISODE * n + envc];
-  int32_t flags = D.i[IF_FLAGS * n + envc];
-  int32_t num_reached = D.i[IF_NUM_REACHED * n + envc];
-  T new_dist = D.r[RF_NEW_DIST * n + envc];
-  T ep_return = D.r[RF_EP_RETURN * n + envc];
   T wb[3] = {(T)0, (T)0, (T)0}, wa[3] = {(T)0, (T)0, (T)0}, wphase = (T)0;
   if (GENERAL) {
 #pragma unroll
@@ -272,7 +286,11 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
 
   // current and next waypoint stay in registers (no L2 round trip per sub-step)
   T tcur[3] = {(T)0, (T)0, (T)0}, tnext[3] = {(T)0, (T)0, (T)0};
-  if (!OBJ) {
+  const int gbase = lane & ~(G - 1);                  // first lane of my group
+  if (LANE_T) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tcur[k] = __shfl(tmine[k], gbase | (num_reached & (G - 1)), kWave);
+  } else if (!OBJ) {
     const int i0 = min(num_reached, FW_MAX_TARGETS - 1), i1 = min(num_reached + 1, FW_MAX_TARGETS - 1);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -472,9 +490,14 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
             rew = (T)100;
             num_reached += 1;
             if (num_reached == P.num_targets) flags |= FL_TRUNC | FL_COMPLETE;
-            const int i1 = min(num_reached + 1, FW_MAX_TARGETS - 1);       // advance_targets(): shift the register window
+            if (LANE_T) {                                                   // advance_targets(): the next waypoint's lane hands it over
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { tcur[k] = tnext[k]; tnext[k] = D.r[(size_t)(RF_TARGETS + 3 * i1 + k) * n + env]; }
+              for (int k = 0; k < 3; ++k) tcur[k] = __shfl(tmine[k], gbase | (num_reached & (G - 1)), kWave);
+            } else {
+              const int i1 = min(num_reached + 1, FW_MAX_TARGETS - 1);     // advance_targets(): shift the register window
+#pragma unroll
+              for (int k = 0; k < 3; ++k) { tcur[k] = tnext[k]; tnext[k] = D.r[(size_t)(RF_TARGETS + 3 * i1 + k) * n + env]; }
+            }
           }
         }
         step_over = (it + 1 >= P.step_ratio) || (flags & (FL_TERM | FL_TRUNC));     // :334-337
@@ -507,7 +530,31 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     }
   }
   T act_obs[4] = {(T)0, (T)0, (T)0, (T)0};
-  if (active && leader) {
+  if (LANE_T) {
+    // every lane runs the pass (same issue cost as one lane), the leader stores; action and waypoints come by shuffle
+#pragma unroll
+    for (int k = 0; k < 4; ++k) act_obs[k] = __shfl(a_keep, gbase | k, kWave);
+    if (act_src == 1) {                              // bare-Gymnasium stale view: the stored action
+#pragma unroll
+      for (int k = 0; k < 4; ++k) act_obs[k] = D.r[(size_t)(RF_ACTION + k) * n + envc];
+    }
+    T Ro[9];
+    int o = write_obs_attitude<T>(P, S, act_obs, Ro, [&](int k, T v) { if (leader) tile[row * ld + k] = v; });
+#pragma unroll 1
+    for (int i = 0; i < P.ctx; ++i) {
+      const int t = tgt_obs + i;
+      T tw[3], d[3], b[3] = {(T)0, (T)0, (T)0};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tw[k] = __shfl(tmine[k], gbase | (t & (G - 1)), kWave);
+      if (t < P.num_targets) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k] = tw[k] - S.p[k];
+        mtv(Ro, d, b);
+      }
+      if (leader) { tile[row * ld + o] = b[0]; tile[row * ld + o + 1] = b[1]; tile[row * ld + o + 2] = b[2]; }
+      o += 3;
+    }
+  } else if (active && leader) {
     load_action<T>(D, actions, env, act_src, act_obs);
     if (OBJ) obj_write_obs<T>(P, O, S, act_obs, [&](int k, T v) { tile[row * ld + k] = v; });
     else if (COMB) comb_write_obs<T>(P, D, env, O, S, act_obs, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
@@ -523,7 +570,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     episode += 1;
     Scenario<T> sc;
-    sample_scenario<T, G>(Pp, D.r, n, env, (uint32_t)episode, &sc);      // reads the old waypoints above, overwrites them here
+    sample_scenario_inl<T, G>(Pp, D.r, n, env, (uint32_t)episode, &sc);  // the obs pass above read the old waypoints; overwritten here
     const int nt = min(P.ctx, P.num_targets);
     T t0[3] = {(T)0, (T)0, (T)0};
 #pragma unroll 1

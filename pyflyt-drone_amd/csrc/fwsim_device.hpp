@@ -751,12 +751,12 @@ __device__ __forceinline__ void copy_words(T* __restrict__ dst, const T* __restr
 // Returns the number of warm-up Aviary steps still to run (0 when the cached
 // env-independent warm state could be copied).  G = 8: lane `sub` samples waypoint
 // `sub` (num_targets <= 8 = group size); only the group leader stores wind.
-// Scenario sampling of a reset (wind + waypoints).  Deliberately NOT inlined: the double-precision
-// sincos / Philox live ranges would otherwise be added to the register budget of the step loop
-// (+80 VGPRs in the headline kernel), and only the few waves that contain a reset ever run it.
+// Scenario sampling of a reset (wind + waypoints).  Inside the step loop it is called out of line
+// (sample_scenario below): the double-precision sincos / Philox live ranges would otherwise be added
+// to the register budget of the loop (+80 VGPRs), and only the few waves that contain a reset run it.
 template <typename T> struct Scenario { T wb[3], wa[3], wph, t_mine[3]; };
 template <typename T, int G>
-__device__ __noinline__ void sample_scenario(const Params<T>* Pp, T* r, size_t n, int env, uint32_t ep, Scenario<T>* out) {
+__device__ __forceinline__ void sample_scenario_inl(const Params<T>* Pp, T* r, size_t n, int env, uint32_t ep, Scenario<T>* out) {
   const Params<T>& P = *Pp;
   const uint32_t genv = (uint32_t)(P.env_offset + env);
   const int sub = (G == 1) ? 0 : (int)(threadIdx.x & (G - 1));
@@ -801,6 +801,13 @@ __device__ __noinline__ void sample_scenario(const Params<T>* Pp, T* r, size_t n
 #pragma unroll
   for (int k = 0; k < 3; ++k) { out->wb[k] = wb[k]; out->wa[k] = wa[k]; out->t_mine[k] = tm[k]; }
   out->wph = wphase;
+}
+
+// out-of-line entry for call sites inside the step loop (the deferred reset of the wind-free kernel inlines it
+// into the epilogue instead, where almost nothing is live)
+template <typename T, int G>
+__device__ __noinline__ void sample_scenario(const Params<T>* Pp, T* r, size_t n, int env, uint32_t ep, Scenario<T>* out) {
+  sample_scenario_inl<T, G>(Pp, r, n, env, ep, out);
 }
 
 template <typename T, int G>
