@@ -194,6 +194,15 @@ def main():
                   f"{WORDS_PER_ENV_STEP * word * m / us / 1e3:.1f} GB/s algorithmic", file=sys.stderr, flush=True)
             e2.close()
 
+    # HBM bytes per launch from the PMC counters are collected offline (rocprofv3 --pmc cannot run inside this
+    # process); the committed summary is quoted when it was taken on this very workload, else null.
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_pmc_traffic.json")
+    if n == 4096 and args.dtype == "float64" and os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch"]["total"]
+        traffic_src = "profiles/r01_d_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, calibrated with tools/calib_pmc.hip)"
+
     if rank == 0:
         out = {
             "metric": "env-steps/sec at N parallel envs (FixedwingWaypoints)",
@@ -213,7 +222,7 @@ def main():
                        "envs_per_gpu": n, "obs_dim": env.obs_dim, "ticks_per_env_step": 8,
                        "launch": "eager" if args.no_graph else "hipGraph(64 launches)", "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "fw_step_kernel", "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "element-wise fp64 physics at N=4096 is latency/VALU-bound, not HBM-bound (DESIGN.md section 6)"},

@@ -211,8 +211,14 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   constexpr bool DEFER = !GENERAL && TKIND == FW_TASK_WAYPOINTS;
   const int nblk = (D.npad + EPW - 1) / EPW;         // step blocks; blocks beyond are shadow workers
   FWP(const long long p_t0 = FWP_NOW(); long long p_reset = 0, p_avi = 0, p_task = 0, p_r1 = 0, p_r2 = 0, p_r3 = 0; int p_nreset = 0, p_nhit = 0;)
+  // XCD-aware block -> env-block map (G = 8): a wave touches 64 B of every SoA row, i.e. half a 128-B L2 line, and
+  // consecutive workgroups are dealt round-robin to the 8 XCDs, whose L2s are private -- with the identity map both
+  // halves of every line are fetched by two different L2s (PMC: 2x the algorithmic read traffic).  Give each XCD a
+  // contiguous range of env blocks instead.  (Speed only: nothing depends on where a block really lands.)
+  const int wg = (int)blockIdx.x % nblk;
+  const int blk = (G == 8 && (nblk & 7) == 0) ? (wg & 7) * (nblk >> 3) + (wg >> 3) : wg;
   if (GENERAL && (int)blockIdx.x >= nblk) {          // (the wind-free kernels are never launched with workers)
-    shadow_worker<T, G, TKIND>(Pp, OCp, D, (int)blockIdx.x - nblk);
+    shadow_worker<T, G, TKIND>(Pp, OCp, D, blk);
     FWP(if (D.prof && threadIdx.x == 0) {
       long long* w = D.prof + ((size_t)(D.epoch % kProfSlots) * 2 * nblk + blockIdx.x) * kProfWords;
       w[0] = FWP_NOW() - p_t0; })
@@ -222,7 +228,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   const int sub = (G == 1) ? 0 : (lane & (G - 1));   // my lane within the env's group
   const int row = lane / G;                          // env slot within the wave
   const bool leader = sub == 0;
-  const int env0 = blockIdx.x * EPW;
+  const int env0 = blk * EPW;
   const int env = env0 + row;
   const bool active = env < D.n;
   const int envc = active ? env : D.n - 1;           // inactive lanes shadow the last env and never store
