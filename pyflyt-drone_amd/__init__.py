@@ -11,6 +11,7 @@ from .spaces import Box
 from .vec_env import (FixedwingObjLockVecEnv, FixedwingVecEnv, FixedwingWaypointObjLockVecEnv,
                       FixedwingWaypointsVecEnv)
 from . import rollout
+from . import checkpoint, evaluate
 
 __all__ = ["config", "FwConfig", "Box", "FixedwingVecEnv", "FixedwingWaypointsVecEnv", "FixedwingObjLockVecEnv", "FixedwingWaypointObjLockVecEnv",
            "waypoints_config", "train_waypoints_v3_config"]

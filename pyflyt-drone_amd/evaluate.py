@@ -1,0 +1,181 @@
+"""Evaluation harness: the reference's acceptance metrics on the device envs.
+
+Mirrors, for the device-resident envs:
+
+* SB3 ``evaluate_policy(model, eval_env, n_eval_episodes, deterministic=True,
+  return_episode_rewards=True, callback=...)`` as the reference calls it
+  (train/train_Fixedwing_Waypoints_v3.py:161-170): episodes are counted per env with the
+  targets ``(n_eval_episodes + i) // n_envs`` so that short episodes of fast envs do not bias
+  the sample, rewards are the *un-normalised* env rewards, observations are normalised with
+  frozen statistics (``training=False, norm_reward=False`` eval wrapper, ``:264-270``);
+* ``sync_envs_normalization`` before every evaluation (``:146-150``);
+* the logged scalars of ``WaypointEvalCallback._on_step`` (``:196-214``): ``eval/mean_reward``,
+  ``eval/mean_ep_length``, ``eval/wp{i}_reach_rate`` = mean(num_targets_reached >= i),
+  ``eval/success_rate`` = mean(is_success); the ObjLock scripts add ``duck_strike_rate``
+  (train/train_objlock.py:163-167, eval/eval_objlock.py:260-325);
+* ``evaluations.npz`` (timesteps / results / ep_lengths / successes) and ``best_model`` on a
+  new best mean reward (``:172-190, 216-222``).
+
+Everything per step stays on the device; the host reads one small ``dones`` mask per
+vec-step (the episode bookkeeping is host-side like SB3's).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import config as K
+
+
+def sync_envs_normalization(train_env, eval_env) -> None:
+    """Copy the running statistics of the training wrapper into the eval wrapper
+    (SB3 ``sync_envs_normalization``)."""
+    eval_env.obs_rms.load_state_dict(train_env.obs_rms.state_dict())
+    eval_env.ret_rms.load_state_dict(train_env.ret_rms.state_dict())
+
+
+@dataclass
+class EvalResult:
+    episode_rewards: List[float]
+    episode_lengths: List[int]
+    num_targets_reached: List[int] = field(default_factory=list)
+    is_success: List[bool] = field(default_factory=list)
+    duck_strike: List[bool] = field(default_factory=list)
+
+    @property
+    def mean_reward(self) -> float: return float(np.mean(self.episode_rewards))
+    @property
+    def std_reward(self) -> float: return float(np.std(self.episode_rewards))
+    @property
+    def mean_ep_length(self) -> float: return float(np.mean(self.episode_lengths))
+    @property
+    def std_ep_length(self) -> float: return float(np.std(self.episode_lengths))
+
+    def scalars(self, num_targets_total: int = 0, has_duck: bool = False) -> Dict[str, float]:
+        """The ``eval/*`` scalars the reference's callbacks record."""
+        out = {"eval/mean_reward": self.mean_reward, "eval/mean_ep_length": self.mean_ep_length}
+        if self.num_targets_reached and num_targets_total > 0:
+            reached = np.asarray(self.num_targets_reached, dtype=np.float64)
+            for i in range(1, num_targets_total + 1):
+                out[f"eval/wp{i}_reach_rate"] = float(np.mean(reached >= i))
+        if self.is_success:
+            out["eval/success_rate"] = float(np.mean(self.is_success))
+        if has_duck and self.duck_strike:
+            out["eval/duck_strike_rate"] = float(np.mean(self.duck_strike))
+        return out
+
+
+@torch.no_grad()
+def evaluate_policy(policy, env, n_eval_episodes: int = 10, deterministic: bool = True,
+                    callback: Optional[Callable[[dict], None]] = None, max_vec_steps: Optional[int] = None,
+                    generator: Optional[torch.Generator] = None) -> EvalResult:
+    """Run ``policy`` on ``env`` (a :class:`~.rollout.VecNormalizeDevice` over a device env,
+    normally with ``training=False, norm_reward=False``) until ``n_eval_episodes`` episodes are
+    complete.  ``callback(info_dict)`` is called for every finished episode with the keys the
+    reference's callbacks read (``num_targets_reached``, ``is_success``, ``duck_strike``, ...)."""
+    venv = env.venv
+    n = env.num_envs
+    targets = np.array([(n_eval_episodes + i) // n for i in range(n)], dtype=np.int64)
+    counts = np.zeros(n, dtype=np.int64)
+    cur_rew = torch.zeros(n, dtype=torch.float64, device=env.device)
+    cur_len = torch.zeros(n, dtype=torch.int64, device=env.device)
+    res = EvalResult([], [])
+    has_info = hasattr(venv, "info")
+    is_objlock = getattr(getattr(venv, "cfg", None), "task", K.FW_TASK_WAYPOINTS) != K.FW_TASK_WAYPOINTS
+    obs = env.reset()
+    steps = 0
+    while (counts < targets).any():
+        actions, _, _ = policy(obs, deterministic=deterministic, generator=generator)
+        clipped = actions.clamp(-1.0, 1.0).to(venv.torch_dtype)
+        obs, _, dones, _, _ = env.step(clipped)
+        cur_rew += venv.rewards.to(torch.float64)        # un-normalised reward of the wrapped env
+        cur_len += 1
+        d = dones.cpu().numpy()
+        if d.any():
+            idx = np.nonzero(d)[0]
+            rew_h, len_h = cur_rew.cpu().numpy(), cur_len.cpu().numpy()
+            info_h = venv.info.cpu().numpy() if has_info else None
+            for i in idx:
+                if counts[i] < targets[i]:
+                    counts[i] += 1
+                    res.episode_rewards.append(float(rew_h[i])); res.episode_lengths.append(int(len_h[i]))
+                    info = {"episode": {"r": float(rew_h[i]), "l": int(len_h[i])}}
+                    if info_h is not None:
+                        info["num_targets_reached"] = int(info_h[i, K.INFO_NUM_TARGETS_REACHED])
+                        info["collision"] = bool(info_h[i, K.INFO_COLLISION])
+                        info["out_of_bounds"] = bool(info_h[i, K.INFO_OUT_OF_BOUNDS])
+                        info["env_complete"] = bool(info_h[i, K.INFO_ENV_COMPLETE])
+                        res.num_targets_reached.append(info["num_targets_reached"])
+                        if is_objlock:
+                            info["duck_strike"] = bool(info_h[i, K.INFO_DUCK_STRIKE])
+                            info["is_success"] = bool(info_h[i, K.INFO_IS_SUCCESS])
+                            res.duck_strike.append(info["duck_strike"])
+                        else:
+                            info["is_success"] = info["env_complete"]
+                        res.is_success.append(info["is_success"])
+                    if callback is not None:
+                        callback(info)
+            m = torch.as_tensor(d, device=env.device)
+            cur_rew.masked_fill_(m, 0.0); cur_len.masked_fill_(m, 0)
+        steps += 1
+        if max_vec_steps is not None and steps >= max_vec_steps:
+            break
+    return res
+
+
+class EvalCallback:
+    """``WaypointEvalCallback`` / SB3 ``EvalCallback`` for :meth:`rollout.PPO.learn`: every
+    ``eval_freq`` vec-steps of training (the reference passes ``10000 // num_envs``) sync the
+    normaliser, evaluate, append to ``evaluations.npz``, keep ``best_model``."""
+
+    def __init__(self, eval_env, n_eval_episodes: int = 5, eval_freq: int = 10000, log_path: Optional[str] = None,
+                 best_model_save_path: Optional[str] = None, deterministic: bool = True, num_targets_total: int = 0,
+                 verbose: int = 0):
+        self.eval_env, self.n_eval_episodes, self.eval_freq = eval_env, n_eval_episodes, max(int(eval_freq), 1)
+        self.log_path = os.path.join(log_path, "evaluations") if log_path else None
+        self.best_model_save_path, self.deterministic = best_model_save_path, deterministic
+        self.num_targets_total, self.verbose = num_targets_total, verbose
+        self.best_mean_reward, self.last_mean_reward = -np.inf, -np.inf
+        self.evaluations_timesteps: List[int] = []
+        self.evaluations_results: List[List[float]] = []
+        self.evaluations_length: List[List[int]] = []
+        self.evaluations_successes: List[List[bool]] = []
+        self.last_scalars: Dict[str, float] = {}
+        self._next_eval_calls = self.eval_freq
+        self.n_evals = 0
+
+    def on_rollout_end(self, ppo) -> bool:
+        n_calls = ppo.num_timesteps // max(ppo.env.num_envs * ppo.world_size, 1)      # vec-steps so far (SB3 n_calls)
+        if n_calls < self._next_eval_calls:
+            return True
+        while self._next_eval_calls <= n_calls:
+            self._next_eval_calls += self.eval_freq
+        from . import checkpoint
+        sync_envs_normalization(ppo.env, self.eval_env)
+        r = evaluate_policy(ppo.policy, self.eval_env, self.n_eval_episodes, deterministic=self.deterministic)
+        self.n_evals += 1
+        self.evaluations_timesteps.append(ppo.num_timesteps)
+        self.evaluations_results.append(r.episode_rewards); self.evaluations_length.append(r.episode_lengths)
+        if self.log_path is not None:
+            os.makedirs(os.path.dirname(self.log_path), exist_ok=True)
+            kw = {}
+            if r.is_success:
+                self.evaluations_successes.append(r.is_success); kw = dict(successes=np.array(self.evaluations_successes, dtype=object))
+            np.savez(self.log_path, timesteps=self.evaluations_timesteps, results=np.array(self.evaluations_results, dtype=object),
+                     ep_lengths=np.array(self.evaluations_length, dtype=object), **kw)
+        self.last_mean_reward = r.mean_reward
+        is_objlock = getattr(getattr(self.eval_env.venv, "cfg", None), "task", 0) != K.FW_TASK_WAYPOINTS
+        self.last_scalars = r.scalars(self.num_targets_total, has_duck=is_objlock)
+        self.last_scalars["time/total_timesteps"] = ppo.num_timesteps
+        if self.verbose:
+            print(f"Eval num_timesteps={ppo.num_timesteps}, episode_reward={r.mean_reward:.2f} +/- {r.std_reward:.2f}")
+            print(f"Episode length: {r.mean_ep_length:.2f} +/- {r.std_ep_length:.2f}")
+        if r.mean_reward > self.best_mean_reward:
+            self.best_mean_reward = r.mean_reward
+            if self.best_model_save_path is not None:
+                checkpoint.save(os.path.join(self.best_model_save_path, "best_model.pt"), ppo, include_env_state=False)
+        return True

@@ -72,8 +72,8 @@ class RunningMeanStd:
         tot = cnt + bn
         new_mean = self.mean + delta * bn / tot
         m2 = self.var * cnt + bv * bn + delta * delta * cnt * bn / tot
-        self.mean, self.var = new_mean, m2 / tot
-        self.count = tot.reshape(1)
+        # in place: a captured rollout graph holds these addresses and must see the accumulated statistics
+        self.mean.copy_(new_mean); self.var.copy_(m2 / tot); self.count.copy_(tot.reshape(1))
 
     def state_dict(self):
         return {"mean": self.mean.cpu(), "var": self.var.cpu(), "count": self.count.cpu()}
@@ -146,14 +146,14 @@ class VecNormalizeDevice:
         obs_n = self._process_obs(obs, update=self.training)
         rew64 = rew.to(torch.float64)
         if self.training and self.norm_reward:
-            self.returns = self.returns * self.gamma + rew64
+            self.returns.mul_(self.gamma).add_(rew64)               # in place (graph-captured address)
             self.ret_rms.update(self.returns)
         if self.norm_reward:
             rew_n = (rew64 / torch.sqrt(self.ret_rms.var + self.epsilon)).clamp(-self.clip_reward, self.clip_reward)
         else:
             rew_n = rew64
         tobs_n = self.normalize_obs(self.venv.terminal_obs, self.tobs_out)
-        self.returns = torch.where(dones, torch.zeros_like(self.returns), self.returns)
+        self.returns.masked_fill_(dones, 0.0)
         return obs_n, rew_n.to(torch.float32), dones, trunc.bool() & ~term.bool(), tobs_n
 
     def state_dict(self):
@@ -428,7 +428,7 @@ class PPO:
             self._adv_s.copy_(adv); self._ret_s.copy_(ret); self._gm.copy_(g_mean); self._gs.copy_(g_std)
             self._idx.copy_(torch.randperm(B, device=self.device)[:bs])
             sd_p = [p.detach().clone() for p in params]
-            sd_o = self.optimizer.state_dict()
+            sd_o = {p: {k: v.clone() for k, v in stt.items() if torch.is_tensor(v)} for p, stt in self.optimizer.state.items()}
             st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(st):
                 for _ in range(3):                               # warm-up on the side stream, then undone below
@@ -437,13 +437,16 @@ class PPO:
             self._g_update = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_update):
                 self._minibatch_step(obs, act, old_logp, self._adv_s, self._ret_s, self._idx, self._gm, self._gs, params)
-            with torch.no_grad():                                # restore weights; zero the Adam moments the warm-up touched
+            with torch.no_grad():                                # undo the warm-up: weights and Adam moments / step
                 for p, q in zip(params, sd_p):
                     p.copy_(q)
-                for stt in self.optimizer.state.values():
+                for p, stt in self.optimizer.state.items():
                     for k, v in stt.items():
                         if torch.is_tensor(v):
-                            v.zero_()
+                            if p in sd_o and k in sd_o[p]:
+                                v.copy_(sd_o[p][k])
+                            else:
+                                v.zero_()
             self._loss_acc.zero_()
         if use_graph:
             self._adv_s.copy_(adv); self._ret_s.copy_(ret); self._gm.copy_(g_mean); self._gs.copy_(g_std)
@@ -460,10 +463,30 @@ class PPO:
         self.logs = {"policy_loss": la[0], "value_loss": la[1], "entropy_loss": la[2],
                      "adv_mean": float(g_mean), "adv_std": float(g_std)}
 
-    def learn(self, total_timesteps: int):
-        while self.num_timesteps < total_timesteps:
+    @property
+    def world_size(self) -> int:
+        td = _dist()
+        return td.get_world_size() if td is not None else 1
+
+    @property
+    def rank(self) -> int:
+        td = _dist()
+        return td.get_rank() if td is not None else 0
+
+    def learn(self, total_timesteps: int, callbacks=(), reset_num_timesteps: bool = True):
+        """``model.learn(total_timesteps, reset_num_timesteps, callback=[eval, checkpoint])``
+        (train/train_Fixedwing_Waypoints_v3.py:329-334).  Callbacks get ``on_rollout_end(ppo)``
+        after every update; returning False stops training."""
+        if reset_num_timesteps:
+            self.num_timesteps = 0
+        else:
+            total_timesteps += self.num_timesteps          # SB3: continue for another total_timesteps
+        go = True
+        while go and self.num_timesteps < total_timesteps:
             self.collect_rollouts()
             self.train()
+            for cb in callbacks:
+                go = bool(cb.on_rollout_end(self)) and go
         return self
 
     # ---- checkpoint (model + normaliser), train/train_Fixedwing_Waypoints_v3.py:340-347 ----------
@@ -473,5 +496,6 @@ class PPO:
 
     def load_state_dict(self, sd, reset_num_timesteps: bool = True):
         self.policy.load_state_dict(sd["policy"]); self.optimizer.load_state_dict(sd["optimizer"])
+        self._g_update = None              # the optimiser's state tensors were replaced: re-capture the update graph
         self.env.load_state_dict(sd["vecnormalize"])
         self.num_timesteps = 0 if reset_num_timesteps else int(sd["num_timesteps"])

@@ -1,0 +1,102 @@
+"""Eval harness and checkpoint/resume on the real device envs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pyflyt_drone_amd as P
+from pyflyt_drone_amd import checkpoint, evaluate
+from pyflyt_drone_amd import config as K
+from pyflyt_drone_amd import rollout as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _wp_cfg():
+    # short episodes: low start, small dome -> crashes / OOB within a few dozen steps
+    return K.train_waypoints_v3_config(flight_dome_size=30.0, max_duration_seconds=4.0)
+
+
+def test_eval_harness_waypoints_metrics_are_consistent_with_the_env_info():
+    venv = P.FixedwingVecEnv(_wp_cfg(), 64, seed=5)
+    env = R.VecNormalizeDevice(venv, training=False, norm_reward=False)
+    pol = R.MlpPolicy(env.obs_dim).cuda()
+    infos = []
+    r = evaluate.evaluate_policy(pol, env, n_eval_episodes=100, deterministic=True, callback=infos.append)
+    assert len(r.episode_rewards) == 100 == len(infos)
+    assert float(env.obs_rms.count) == pytest.approx(1e-4)            # frozen statistics
+    for i in infos:                                                   # every episode ended for a reason the env reported
+        assert i["episode"]["l"] >= 1
+        assert i["collision"] or i["out_of_bounds"] or i["env_complete"] or i["episode"]["l"] >= K.max_steps(venv.cfg)
+        assert i["is_success"] == i["env_complete"]
+        # reference reward bounds: -0.1 per step, -100 on crash/OOB, +100 per waypoint (sparse)
+        assert i["episode"]["r"] <= 100.0 * i["num_targets_reached"] + 1e-9
+    sc = r.scalars(num_targets_total=8)
+    rates = [sc[f"eval/wp{k}_reach_rate"] for k in range(1, 9)]
+    assert all(a >= b for a, b in zip(rates, rates[1:]))              # reaching k+1 implies reaching k
+    assert sc["eval/success_rate"] == pytest.approx(rates[-1])
+    # a second evaluation of the same deterministic policy on a re-seeded env reproduces the first
+    venv.seed(5)
+    r2 = evaluate.evaluate_policy(pol, env, n_eval_episodes=100, deterministic=True)
+    assert sorted(r2.episode_lengths) == sorted(r.episode_lengths)
+
+
+def test_eval_harness_objlock_reports_duck_strike_rate():
+    venv = P.FixedwingVecEnv(K.train_objlock_config(max_duration_seconds=3.0), 32, seed=1)
+    env = R.VecNormalizeDevice(venv, training=False, norm_reward=False)
+    pol = R.MlpPolicy(env.obs_dim).cuda()
+    r = evaluate.evaluate_policy(pol, env, n_eval_episodes=32, deterministic=True)
+    sc = r.scalars(has_duck=True)
+    assert len(r.duck_strike) == 32 and 0.0 <= sc["eval/duck_strike_rate"] <= 1.0
+    assert sc["eval/success_rate"] == pytest.approx(np.mean(r.is_success))
+
+
+def _ppo(seed, graphs):
+    venv = P.FixedwingVecEnv(_wp_cfg(), 256, seed=seed)
+    env = R.VecNormalizeDevice(venv)
+    return R.PPO(env, R.PPOConfig(n_steps=8, batch_size=256, n_epochs=2, seed=seed, use_graphs=graphs))
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_checkpoint_resume_continues_the_interrupted_episodes(tmp_path, graphs):
+    a = _ppo(7, graphs)
+    a.learn(3 * 8 * 256)
+    path = checkpoint.save(str(tmp_path / "ck.pt"), a)
+    state_at_save = a.env.venv.get_state().copy()
+    a.learn(2 * 8 * 256, reset_num_timesteps=False)
+    ref_params = [p.detach().clone() for p in a.policy.parameters()]
+    ref_state = a.env.venv.get_state()
+
+    b = _ppo(7, graphs)
+    if graphs:
+        b.learn(2 * 8 * 256)                                          # graphs captured BEFORE the load: it must update them in place
+    sd = checkpoint.load(path, b, reset_num_timesteps=False, restore_env_state=True)
+    np.testing.assert_array_equal(b.env.venv.get_state(), state_at_save)
+    assert b.num_timesteps == sd["num_timesteps"] == 3 * 8 * 256
+    b.learn(2 * 8 * 256, reset_num_timesteps=False)
+    assert b.num_timesteps == 5 * 8 * 256
+    tol = dict(rtol=0, atol=0) if not graphs else dict(rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(b.env.venv.get_state(), ref_state, **(dict(rtol=0, atol=0) if not graphs else dict(rtol=1e-6, atol=1e-6)))
+    for p, q in zip(ref_params, b.policy.parameters()):
+        torch.testing.assert_close(q, p, **tol)
+
+
+def test_train_script_flow_eval_best_model_checkpoints_and_final_save(tmp_path):
+    """The callback wiring of train/train_Fixedwing_Waypoints_v3.py:271-347 end to end."""
+    a = _ppo(3, True)
+    eval_env = R.VecNormalizeDevice(P.FixedwingVecEnv(_wp_cfg(), 16, seed=3, global_env_offset=256), training=False, norm_reward=False)
+    ev = evaluate.EvalCallback(eval_env, n_eval_episodes=16, eval_freq=16, log_path=str(tmp_path / "logs"),
+                               best_model_save_path=str(tmp_path / "models"), num_targets_total=8)
+    ck = checkpoint.CheckpointCallback(save_freq=16, save_path=str(tmp_path / "models"), name_prefix="waypoints_ppo")
+    a.learn(4 * 8 * 256, callbacks=[ev, ck])
+    assert ev.n_evals == 2 and len(ck.saved) == 2
+    assert torch.equal(eval_env.obs_rms.mean, a.env.obs_rms.mean)                 # synced before evaluating
+    final = checkpoint.save(str(tmp_path / "models" / "final_model.pt"), a)
+    vn = checkpoint.save_vecnormalize(str(tmp_path / "models" / "vecnorm.pt"), a.env)
+    assert checkpoint.infer_vecnorm_path(final, None) == vn
+    b = _ppo(4, True)
+    checkpoint.set_parameters(os.path.join(str(tmp_path / "models"), "best_model.pt"), b)
+    checkpoint.load_vecnormalize(vn, b.env, training=True, norm_reward=True)
+    b.learn(8 * 256)                                                              # fresh counter, pretrained weights
+    assert b.num_timesteps == 8 * 256 and all(torch.isfinite(p).all() for p in b.policy.parameters())

@@ -94,3 +94,23 @@ def test_collect_rollouts_is_graph_capturable():
         g.replay()
     torch.cuda.synchronize()
     assert float(vn.obs_rms.count) == pytest.approx(c0 + 5 * 4096) and torch.isfinite(obs).all()
+    # the reward statistics accumulate across replays too (they are updated in place, not rebound)
+    assert float(vn.ret_rms.count) == pytest.approx(1e-4 + (3 + 5) * 4096)     # capture itself executes nothing
+
+
+def test_graph_replayed_rollouts_accumulate_the_same_statistics_as_eager_ones():
+    """4 rollouts through PPO.collect_rollouts with and without hipGraph replay: identical sample counts in both
+    normalisers, and the discounted-return tracker carries over from one replay to the next."""
+    out = {}
+    for graphs in (False, True):
+        env = P.FixedwingVecEnv(K.train_waypoints_v3_config(), 512, seed=2)
+        ppo = R.PPO(R.VecNormalizeDevice(env), R.PPOConfig(n_steps=8, batch_size=512, n_epochs=1, seed=2, use_graphs=graphs))
+        for _ in range(4):
+            ppo.collect_rollouts()
+        torch.cuda.synchronize()
+        out[graphs] = (float(ppo.env.obs_rms.count), float(ppo.env.ret_rms.count), ppo.env.returns.abs().max().item(),
+                       float(ppo.env.ret_rms.var))
+    assert out[True][0] == pytest.approx(1e-4 + (4 * 8 + 1) * 512) == pytest.approx(out[False][0])
+    assert out[True][1] == pytest.approx(1e-4 + 4 * 8 * 512) == pytest.approx(out[False][1])
+    assert out[True][2] > 1.0 and out[False][2] > 1.0              # ~32 steps of -0.1 discounted: the tracker was not restarted
+    assert out[True][3] == pytest.approx(out[False][3], rel=0.2)
