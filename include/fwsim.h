@@ -330,6 +330,34 @@ int32_t fw_gae(const float* rewards, const float* values, const float* episode_s
 int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t D, double* mean, double* var,
                          double* count, int32_t update, float clip, float eps, float* obs_out, void* hip_stream);
 
+/* PPO minibatch updates (SB3 PPO.train() inner loop; train/train_Fixedwing_Waypoints_v3.py:293-310) for the
+ * reference's MlpPolicy (separate 64-64 tanh nets for pi and V, 4-dim diagonal Gaussian, log_std parameter),
+ * fused into ONE kernel that walks `n_minibatches` consecutive minibatches: forward, clipped-surrogate +
+ * value + entropy loss, backward, global grad-norm clipping and Adam, weights resident in LDS.
+ * Flat layout of params (float32, fw_ppo_param_count(obs_dim) elements):
+ *   for net in (pi, vf): W1[Dp][64] b1[64] W2[64][64] b2[64] Wo[64][KO] bo[KO]   (KO = 4, 1; W = Linear.weight^T;
+ *   Dp = obs_dim rounded up to even, the pad row is zero), then log_std[4].
+ * Adam moments mom_m / mom_v (float32, fw_ppo_moment_count() elements each) are in the kernel's "slot" order, in
+ * which every lane's elements are contiguous: fw_ppo_moment_map(obs_dim, out) gives the flat parameter index of
+ * each slot (-1 for padding), which is all a caller needs to move them to and from its optimiser.
+ * obs[S,obs_dim], act[S,4], old_logp[S], adv[S], ret[S]: the rollout buffer (float32, device);
+ * perm[n_minibatches * batch_size]: sample indices of consecutive minibatches (int32, device).
+ * batch_size must be a multiple of 64, obs_dim <= 64.  loss_acc[3] (may be NULL) accumulates the per-minibatch
+ * mean policy loss, value loss and entropy loss.  The caller advances its Adam step count by n_minibatches. */
+typedef struct fw_ppo_hyper {
+  float lr, clip_range, ent_coef, vf_coef, max_grad_norm, beta1, beta2, eps;
+  float adv_mean, adv_std;      /* used when norm_adv == 2 */
+  int32_t norm_adv;             /* 0: off, 1: per minibatch (SB3 default), 2: with the given statistics */
+  int32_t step0;                /* Adam steps taken before this call */
+} fw_ppo_hyper;
+int32_t fw_ppo_param_count(int32_t obs_dim);
+int32_t fw_ppo_moment_count(void);
+int32_t fw_ppo_moment_map(int32_t obs_dim, int32_t* flat_index_of_slot /* host, [fw_ppo_moment_count()] */);
+int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* obs, const float* act,
+                      const float* old_logp, const float* adv, const float* ret, const int32_t* perm,
+                      int32_t n_minibatches, int32_t batch_size, int32_t obs_dim, const fw_ppo_hyper* hyper,
+                      float* loss_acc, void* hip_stream);
+
 int32_t fw_num_envs(fw_handle h);
 const char* fw_last_error(fw_handle h); /* h may be NULL: last create/validate error */
 int32_t fw_destroy(fw_handle h);

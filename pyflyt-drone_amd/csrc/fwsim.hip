@@ -13,6 +13,7 @@
 
 #include "fwsim_device.hpp"
 #include "fwsim_rollout.hpp"
+#include "fwsim_ppo.hpp"
 #include "fwsim_objlock.hpp"
 
 using namespace fwsim;
@@ -1294,6 +1295,34 @@ int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t 
   const int total = N * D;
   if (in_is_f64) hipLaunchKernelGGL(fw_obs_normalize_kernel<double>, dim3((total + 255) / 256), dim3(256), 0, st, (const double*)obs, total, D, mean, var, clip, eps, obs_out);
   else hipLaunchKernelGGL(fw_obs_normalize_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)obs, total, D, mean, var, clip, eps, obs_out);
+  HIP_TRY((fw_env*)nullptr, hipGetLastError());
+  return FW_OK;
+}
+
+int32_t fw_ppo_param_count(int32_t obs_dim) { return obs_dim > 0 ? ppo_total_params((obs_dim + 1) & ~1) : FW_EINVAL; }
+int32_t fw_ppo_moment_count(void) { return kPMomentSlots; }
+int32_t fw_ppo_moment_map(int32_t obs_dim, int32_t* flat_index_of_slot) {
+  if (obs_dim <= 0 || obs_dim > 64 || !flat_index_of_slot) { g_err = "fw_ppo_moment_map: bad arguments"; return FW_EINVAL; }
+  ppo_moment_map(obs_dim, flat_index_of_slot);
+  return FW_OK;
+}
+
+int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* obs, const float* act, const float* old_logp,
+                      const float* adv, const float* ret, const int32_t* perm, int32_t n_minibatches, int32_t batch_size,
+                      int32_t obs_dim, const fw_ppo_hyper* hyper, float* loss_acc, void* hip_stream) {
+  static_assert(sizeof(fw_ppo_hyper) == sizeof(PpoHyper), "fw_ppo_hyper layout");
+  if (!params || !mom_m || !mom_v || !obs || !act || !old_logp || !adv || !ret || !perm || !hyper || n_minibatches <= 0) {
+    g_err = "fw_ppo_update: bad arguments"; return FW_EINVAL;
+  }
+  if (batch_size <= 0 || batch_size % kPChunk != 0) { g_err = "fw_ppo_update: batch_size must be a multiple of 64"; return FW_EINVAL; }
+  if (obs_dim <= 0 || obs_dim > 64) { g_err = "fw_ppo_update: obs_dim must be in [1, 64]"; return FW_EINVAL; }
+  const size_t lds = ppo_lds_bytes(obs_dim);
+  if (lds > 160 * 1024) { g_err = "fw_ppo_update: networks do not fit the 160 KB of LDS"; return FW_EINVAL; }
+  HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  PpoHyper H;
+  std::memcpy(&H, hyper, sizeof H);
+  hipLaunchKernelGGL(fw_ppo_update_kernel, dim3(1), dim3(kPThreads), lds, (hipStream_t)hip_stream, params, mom_m, mom_v, obs, act,
+                     old_logp, adv, ret, perm, n_minibatches, batch_size, obs_dim, H, loss_acc);
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;
 }

@@ -1,0 +1,553 @@
+// Fused PPO minibatch updates (SB3 `PPO.train()` inner loop) for the reference's policy: separate
+// 64-64 tanh MLPs for pi and V, diagonal Gaussian with a state-independent log_std, Adam.
+//   reference: train/train_Fixedwing_Waypoints_v3.py:293-310 (PPO("MlpPolicy", ... batch_size=128,
+//   n_epochs=20, clip_range=0.2, ent_coef, vf_coef=0.5, max_grad_norm=0.5)), train/train_objlock.py:255-290.
+//
+// Why a kernel: with thousands of envs one update is ~10^4 *sequential* minibatch steps of a 12 k-parameter
+// network.  As framework ops that is ~30 launches per step and the update, not the simulator, bounds
+// end-to-end throughput (4.5 s per 65 536-sample update).  Here ONE workgroup walks the whole minibatch
+// sequence: weights stay in LDS for the entire call, activations of a 64-sample chunk live in LDS, every
+// GEMM (forward, dW = A^T G, dX = G W^T) is the same strided 32x32 tile routine on `v_mfma_f32_32x32x2_f32`
+// (exact fp32, so parity with the torch path is fp32 rounding), weight-gradient tiles accumulate in
+// registers across chunks, and each lane applies gradient clipping + Adam to exactly the elements it holds
+// (no gradient staging, no second kernel).  The path is sequential by definition of SGD; the only parallelism
+// is inside a minibatch, which is why it is one CU and not a grid.
+//
+// Flat parameter layout (floats), used for params / exp_avg / exp_avg_sq alike (rollout.py builds it):
+//   for net in (pi, vf):  W1[Dp][64]  b1[64]  W2[64][64]  b2[64]  Wo[64][KO]  bo[KO]     (KO = 4 / 1)
+//   then log_std[4].       W*[in][out] = torch Linear.weight^T;  Dp = D rounded up to even (zero row).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fwsim {
+
+struct PpoHyper {
+  float lr, clip_range, ent_coef, vf_coef, max_grad_norm, beta1, beta2, eps;
+  float adv_mean, adv_std;     // used when norm_adv == 2 (statistics over the whole, all-gathered rollout)
+  int32_t norm_adv;            // 0 off, 1 per minibatch (SB3), 2 given statistics
+  int32_t step0;               // Adam step count before this call
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kPH = 64;            // hidden width
+constexpr int kPChunk = 64;        // samples per pass through the networks
+constexpr int kPLdh = kPH + 1;     // row stride of the hidden activations / of W2 in LDS (odd: conflict-free column reads)
+constexpr int kPThreads = 256;
+
+__host__ __device__ inline int ppo_net_params(int Dp, int KO) { return Dp * kPH + kPH + kPH * kPH + kPH + kPH * KO + KO; }
+__host__ __device__ inline int ppo_total_params(int Dp) { return ppo_net_params(Dp, 4) + ppo_net_params(Dp, 1) + 4; }
+
+// LDS image of one network
+struct PpoNetLds { float *W1, *b1, *W2, *b2, *Wo, *bo; };
+__host__ __device__ inline int ppo_net_lds_floats(int Dp, int KO) { return Dp * kPH + kPH + kPH * kPLdh + kPH + kPH * KO + KO; }
+
+// C(32x32) += A(32xK) * B(Kx32); A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]; K even.
+// Operand layout of v_mfma_f32_32x32x2_f32: lane l supplies A(l % 32, l / 32) and B(l / 32, l % 32);
+// accumulator register v of lane l is C((v / 4) * 8 + (l / 32) * 4 + v % 4, l % 32).
+// The operands of STEPS consecutive MFMAs are fetched from LDS first and the MFMAs then issue back to back:
+// one exposed LDS latency per batch instead of one per MFMA (the compiler does not pipeline the rolled loop).
+template <int STEPS, typename FA, typename FB>
+__device__ __forceinline__ f32x16 ppo_mfma_batch(FA&& fa, FB&& fb, int step0, f32x16 acc) {
+  float av[STEPS], bv[STEPS];
+#pragma unroll
+  for (int i = 0; i < STEPS; ++i) { av[i] = fa(2 * (step0 + i)); bv[i] = fb(2 * (step0 + i)); }
+#pragma unroll
+  for (int i = 0; i < STEPS; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+  return acc;
+}
+// fa(k0) / fb(k0): this lane's A / B operand of the MFMA covering k0, k0 + 1
+template <typename FA, typename FB>
+__device__ __forceinline__ f32x16 ppo_mfma_k(FA&& fa, FB&& fb, int K, f32x16 acc) {
+  const int steps = K >> 1;
+  int s = 0;
+  for (; s + 16 <= steps; s += 16) acc = ppo_mfma_batch<16>(fa, fb, s, acc);
+  if (s + 8 <= steps) { acc = ppo_mfma_batch<8>(fa, fb, s, acc); s += 8; }
+  if (s + 4 <= steps) { acc = ppo_mfma_batch<4>(fa, fb, s, acc); s += 4; }
+  if (s + 2 <= steps) { acc = ppo_mfma_batch<2>(fa, fb, s, acc); s += 2; }
+  if (s < steps) acc = ppo_mfma_batch<1>(fa, fb, s, acc);
+  return acc;
+}
+__device__ __forceinline__ f32x16 ppo_mfma_tile(const float* A, int sam, int sak, const float* B, int sbk, int sbn, int K, f32x16 acc) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const float* a = A + r * sam + h * sak;
+  const float* b = B + h * sbk + r * sbn;
+  return ppo_mfma_k([&](int k0) { return a[k0 * sak]; }, [&](int k0) { return b[k0 * sbk]; }, K, acc);
+}
+__device__ __forceinline__ int ppo_acc_row(int v) { return (v >> 2) * 8 + ((threadIdx.x & 63) >> 5) * 4 + (v & 3); }
+
+__device__ __forceinline__ float ppo_block_sum(float x, float* red) {
+  // 256 threads -> all threads get the sum (red: 8 floats of LDS)
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// One lane's Adam update of one element (torch.optim.Adam, amsgrad off, weight decay 0):
+//   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+// (hardware sqrt / reciprocal, 1 ulp: ~10^2 of these per lane and minibatch sit on the sequential path)
+__device__ __forceinline__ float ppo_adam(float p, float g, float* mp, float* vp, const PpoHyper& H, float step_size, float inv_sqrt_bc2) {
+  const float m = H.beta1 * (*mp) + (1.0f - H.beta1) * g;
+  const float v = H.beta2 * (*vp) + (1.0f - H.beta2) * g * g;
+  *mp = m; *vp = v;
+  const float denom = __builtin_amdgcn_sqrtf(v) * inv_sqrt_bc2 + H.eps;
+  return p - step_size * m * __builtin_amdgcn_rcpf(denom);
+}
+// tanh to ~1e-7 absolute: odd series near 0 (no cancellation), 1 - 2 / (e^{2x} + 1) elsewhere (v_exp_f32 + v_rcp_f32)
+__device__ __forceinline__ float ppo_tanh(float x) {
+  const float ax = fabsf(x);
+  const float x2 = x * x;
+  const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
+  const float e = __builtin_amdgcn_exp2f(fminf(ax, 12.0f) * 2.8853900817779268f);      // e^{2|x|}
+  const float big = copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f), x);
+  return ax < 0.25f ? small : big;
+}
+__device__ __forceinline__ float ppo_wave_sum(float x) {
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+// Adam moments are kept in "slot" order: slot = ((net * 3 + kind) * 4 + wave) * 1024 + lane * 16 + v for the
+// accumulator tiles (kind 0 = W2, 1 = W1, 2 = Wo), then kPTileSlots + q * 256 + thread for the scalars
+// (q = 3 net + {0: b1, 1: b2, 2: bo}, q = 6: log_std).  Slots nobody owns are padding.
+constexpr int kPTileSlots = 2 * 3 * 4 * 64 * 16;
+constexpr int kPMomentSlots = kPTileSlots + 7 * kPThreads;
+__host__ __device__ inline int ppo_tile_slot(int net, int kind, int wave, int lane) { return (((net * 3 + kind) * 4 + wave) * 64 + lane) * 16; }
+
+// flat parameter index of every moment slot (-1 = padding); host side of the layout above
+inline void ppo_moment_map(int D, int32_t* flat_of_slot) {
+  const int Dp = (D + 1) & ~1;
+  const int tilesW1 = ((Dp + 31) / 32) * 2;
+  for (int i = 0; i < kPMomentSlots; ++i) flat_of_slot[i] = -1;
+  int off = 0, oLs = 0;
+  for (int n = 0; n < 2; ++n) {
+    const int KO = n == 0 ? 4 : 1;
+    const int oW1 = off, ob1 = oW1 + Dp * kPH, oW2 = ob1 + kPH, ob2 = oW2 + kPH * kPH, oWo = ob2 + kPH, obo = oWo + kPH * KO;
+    off = obo + KO;
+    for (int wave = 0; wave < 4; ++wave)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int v = 0; v < 16; ++v) {
+          const int r = lane & 31, hh = lane >> 5, mt = wave >> 1, nt = wave & 1;
+          const int row = (v >> 2) * 8 + hh * 4 + (v & 3);
+          const int i = mt * 32 + row, j = nt * 32 + r;
+          flat_of_slot[ppo_tile_slot(n, 0, wave, lane) + v] = oW2 + i * kPH + j;
+          if (wave < tilesW1 && i < D) flat_of_slot[ppo_tile_slot(n, 1, wave, lane) + v] = oW1 + i * kPH + j;
+          if (wave < 2 && r < KO) flat_of_slot[ppo_tile_slot(n, 2, wave, lane) + v] = oWo + (wave * 32 + row) * KO + r;
+        }
+    for (int t = 0; t < kPH; ++t) { flat_of_slot[kPTileSlots + (n * 3 + 0) * kPThreads + t] = ob1 + t; flat_of_slot[kPTileSlots + (n * 3 + 1) * kPThreads + t] = ob2 + t; }
+    for (int t = 0; t < KO; ++t) flat_of_slot[kPTileSlots + (n * 3 + 2) * kPThreads + t] = obo + t;
+    oLs = off;
+  }
+  for (int t = 0; t < 4; ++t) flat_of_slot[kPTileSlots + 6 * kPThreads + t] = oLs + t;
+}
+
+// Work split of the 256 threads (4 waves, one per SIMD, fixed for the whole call):
+//   * every 64 x 64 product (H1, H2, G2, G1, dW2) is 2 x 2 tiles of 32 x 32: wave w owns tile (w >> 1, w & 1);
+//   * dW1 is ceil(Dp / 32) x 2 tiles (waves 0-1 or all four); the head products (64 x KO, masked to KO columns)
+//     are 2 row tiles on waves 0-1;
+//   * bias gradients are column sums: thread (wave q, lane n) sums rows 16 q .. 16 q + 15 of column n;
+//   * the per-sample loss runs one sample per lane on wave 0.
+// Each lane applies clipping + Adam to the accumulator elements it holds (their moments stay in global memory / L2,
+// in slot order; held in registers for the whole call they push the kernel past the 512-register budget).
+__global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(
+    float* __restrict__ params, float* __restrict__ mom_m, float* __restrict__ mom_v,
+    const float* __restrict__ obs, const float* __restrict__ act, const float* __restrict__ old_logp,
+    const float* __restrict__ adv, const float* __restrict__ ret, const int32_t* __restrict__ perm,
+    int32_t n_mb, int32_t B, int32_t D, PpoHyper H, float* __restrict__ loss_acc /* [3] += policy, value, entropy loss */) {
+  extern __shared__ __align__(16) float lds[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, hh = lane >> 5;
+  const int Dp = (D + 1) & ~1;
+  const int ldx = Dp + 1;
+
+  // ---- LDS carve-up ----
+  float* p = lds;
+  PpoNetLds N[2];
+  for (int n = 0; n < 2; ++n) {
+    const int KO = n == 0 ? 4 : 1;
+    N[n].W1 = p; p += Dp * kPH; N[n].b1 = p; p += kPH; N[n].W2 = p; p += kPH * kPLdh; N[n].b2 = p; p += kPH;
+    N[n].Wo = p; p += kPH * KO; N[n].bo = p; p += KO;
+  }
+  float* log_std = p; p += 4;
+  float* X = p;  p += kPChunk * ldx + 64;         // (+64: the padded dW1 tile reads a few floats past the last row)
+  float* H1 = p; p += kPChunk * kPLdh;
+  float* H2 = p; p += kPChunk * kPLdh;
+  float* gout = p; p += kPChunk * 4;              // head output, then dL/d(head output) of the chunk
+  float* sA = p; p += kPChunk * 4;                // gathered actions
+  float* sS = p; p += kPChunk * 4;                // per-sample scalars: old_logp, adv (normalised), ret, -
+  float* bred = p; p += 4 * 4 * kPH;              // bias-gradient partials [array][wave][64]
+  float* red = p; p += 8;
+  int* sIdx = (int*)p; p += kPChunk;
+
+  // flat offsets of the two nets
+  int oW1[2], ob1[2], oW2[2], ob2[2], oWo[2], obo[2], oLs;
+  {
+    int off = 0;
+    for (int n = 0; n < 2; ++n) {
+      const int KO = n == 0 ? 4 : 1;
+      oW1[n] = off; ob1[n] = oW1[n] + Dp * kPH; oW2[n] = ob1[n] + kPH; ob2[n] = oW2[n] + kPH * kPH; oWo[n] = ob2[n] + kPH; obo[n] = oWo[n] + kPH * KO;
+      off = obo[n] + KO;
+    }
+    oLs = off;
+  }
+
+  // ---- load the weights once ----
+  for (int n = 0; n < 2; ++n) {
+    const int KO = n == 0 ? 4 : 1;
+    for (int i = t; i < Dp * kPH; i += kPThreads) N[n].W1[i] = params[oW1[n] + i];
+    for (int i = t; i < kPH; i += kPThreads) { N[n].b1[i] = params[ob1[n] + i]; N[n].b2[i] = params[ob2[n] + i]; }
+    for (int i = t; i < kPH * kPH; i += kPThreads) N[n].W2[(i >> 6) * kPLdh + (i & 63)] = params[oW2[n] + i];
+    for (int i = t; i < kPH * KO + KO; i += kPThreads) N[n].Wo[i] = params[oWo[n] + i];       // Wo and bo are contiguous in both images
+  }
+  if (t < 4) log_std[t] = params[oLs + t];
+  for (int i = t; i < kPChunk * ldx + 64; i += kPThreads) X[i] = 0.f;                           // incl. the pad the dW1 tiles read
+  __syncthreads();
+
+  const int mt = wave >> 1, nt = wave & 1;
+  const int tilesW1 = ((Dp + 31) / 32) * 2;       // 2 or 4 tiles of dW1
+  const bool hasW1 = wave < tilesW1, hasWo = wave < 2;
+
+  float bc1 = powf(H.beta1, (float)H.step0), bc2 = powf(H.beta2, (float)H.step0);     // beta^t
+  float acc_pl = 0.f, acc_vl = 0.f;               // loss sums (wave 0 lanes, reduced at the end)
+  const float invB = 1.0f / (float)B;
+
+#ifdef FW_PPO_PROF
+  long long pf_stats = 0, pf_gather = 0, pf_net = 0, pf_adam = 0;
+#define PPO_T() ((long long)__builtin_readcyclecounter())
+#endif
+#pragma unroll 1
+  for (int mb = 0; mb < n_mb; ++mb) {
+    const int32_t* idx = perm + (size_t)mb * B;
+#ifdef FW_PPO_PROF
+    const long long pf0 = PPO_T();
+#endif
+    // ---- advantage statistics of the minibatch (SB3: (a - mean) / (std + 1e-8), unbiased std) ----
+    float a_mean = 0.f, a_std = 1.f;
+    if (H.norm_adv == 1 && B > 1) {
+      float s1 = 0.f;
+      for (int i = t; i < B; i += kPThreads) s1 += adv[idx[i]];
+      a_mean = ppo_block_sum(s1, red) * invB;
+      float s2 = 0.f;
+      for (int i = t; i < B; i += kPThreads) { float d = adv[idx[i]] - a_mean; s2 += d * d; }
+      a_std = sqrtf(ppo_block_sum(s2, red) / (float)(B - 1));
+    } else if (H.norm_adv == 2) { a_mean = H.adv_mean; a_std = H.adv_std; }
+
+#ifdef FW_PPO_PROF
+    pf_stats += PPO_T() - pf0;
+#endif
+    // gradient accumulators of this minibatch (registers)
+    f32x16 gW2[2], gW1[2], gWo[2];
+    float gb1p[2] = {0.f, 0.f}, gb2p[2] = {0.f, 0.f};                 // column-sum partials of this thread's 16 rows
+    float gbo[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gls[4] = {0.f, 0.f, 0.f, 0.f};   // wave 0, replicated over its lanes
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) { gW2[n][v] = 0.f; gW1[n][v] = 0.f; gWo[n][v] = 0.f; }
+
+#pragma unroll 1
+    for (int c0 = 0; c0 < B; c0 += kPChunk) {
+      // ---- gather the chunk ----
+#ifdef FW_PPO_PROF
+      const long long pf1 = PPO_T();
+#endif
+      __syncthreads();                                                   // the previous chunk's readers of X / sA / sS are done
+      {
+        // 4 threads per sample: each copies a quarter of the observation row, one action component and one scalar
+        const int s = t >> 2, k = t & 3;
+        const int si = idx[c0 + s];
+        const int per = (Dp + 3) >> 2, d0 = k * per;
+        const float* orow = obs + (size_t)si * D;
+        for (int d = d0; d < d0 + per && d < Dp; ++d) X[s * ldx + d] = d < D ? orow[d] : 0.f;
+        sA[t] = act[(size_t)si * 4 + k];
+        float sv = 0.f;
+        if (k == 0) sv = old_logp[si];
+        else if (k == 1) { sv = adv[si]; if (H.norm_adv) sv = (sv - a_mean) / (a_std + 1e-8f); }
+        else if (k == 2) sv = ret[si];
+        sS[t] = sv;
+      }
+      __syncthreads();
+#ifdef FW_PPO_PROF
+      const long long pf2 = PPO_T(); pf_gather += pf2 - pf1;
+#endif
+
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int KO = n == 0 ? 4 : 1;
+        const PpoNetLds& W = N[n];
+        // ---- forward: H1 = tanh(X W1 + b1), H2 = tanh(H1 W2 + b2) ----
+        {
+          f32x16 c;
+          const float bias = W.b1[nt * 32 + r];
+#pragma unroll
+          for (int v = 0; v < 16; ++v) c[v] = bias;
+          c = ppo_mfma_tile(X + mt * 32 * ldx, ldx, 1, W.W1 + nt * 32, kPH, 1, Dp, c);
+#pragma unroll
+          for (int v = 0; v < 16; ++v) H1[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
+        }
+        __syncthreads();
+        {
+          f32x16 c;
+          const float bias = W.b2[nt * 32 + r];
+#pragma unroll
+          for (int v = 0; v < 16; ++v) c[v] = bias;
+          c = ppo_mfma_tile(H1 + mt * 32 * kPLdh, kPLdh, 1, W.W2 + nt * 32, kPLdh, 1, kPH, c);
+#pragma unroll
+          for (int v = 0; v < 16; ++v) H2[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
+        }
+        __syncthreads();
+        // ---- head: out = H2 Wo + bo (rows 32 w .. on waves 0-1, columns masked to KO) ----
+        if (hasWo) {
+          f32x16 c;
+          const float bias = r < KO ? W.bo[r < KO ? r : 0] : 0.f;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) c[v] = bias;
+          const float* a = H2 + (wave * 32 + r) * kPLdh + hh;
+          const float* wo = W.Wo + hh * KO + (r < KO ? r : 0);
+          c = ppo_mfma_k([&](int k0) { return a[k0]; }, [&](int k0) { return r < KO ? wo[k0 * KO] : 0.f; }, kPH, c);
+          if (r < KO) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) gout[(wave * 32 + ppo_acc_row(v)) * 4 + r] = c[v];
+          }
+        }
+        __syncthreads();
+        // ---- loss gradient wrt the head output: one sample per lane of wave 0 ----
+        if (wave == 0) {
+          const int s = lane;
+          float go[4] = {0.f, 0.f, 0.f, 0.f};
+          if (n == 0) {
+            // log pi(a|s), ratio, clipped surrogate (SB3 PPO.train)
+            float logp = 0.f, z[4], iv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float ls = log_std[k];
+              iv[k] = expf(-2.0f * ls);                         // 1 / sigma^2
+              z[k] = sA[s * 4 + k] - gout[s * 4 + k];
+              logp += -0.5f * z[k] * z[k] * iv[k] - ls - 0.9189385332046727f;
+            }
+            const float a = sS[s * 4 + 1];
+            const float ratio = expf(logp - sS[s * 4 + 0]);
+            const float rc = fminf(fmaxf(ratio, 1.0f - H.clip_range), 1.0f + H.clip_range);
+            const float l1 = a * ratio, l2 = a * rc;
+            acc_pl += -fminf(l1, l2);
+            // d(-min(l1, l2))/dlogp: through l1 when it is the smaller; on a tie (ratio inside the range: rc == ratio)
+            // torch.min halves the gradient between the two branches and the clamp passes its half
+            const bool inside = ratio >= 1.0f - H.clip_range && ratio <= 1.0f + H.clip_range;
+            const float coef = (l1 < l2 || (l1 == l2 && inside)) ? -a * ratio * invB : (l1 == l2 ? -0.5f * a * ratio * invB : 0.f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              go[k] = coef * z[k] * iv[k];                                  // dL/dmu_k = dL/dlogp * (a_k - mu_k) / sigma_k^2
+              gls[k] += ppo_wave_sum(coef * (z[k] * z[k] * iv[k] - 1.0f));  // dL/dlog_std_k
+            }
+          } else {
+            const float dv = gout[s * 4] - sS[s * 4 + 2];
+            acc_vl += dv * dv;
+            go[0] = H.vf_coef * 2.0f * dv * invB;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (k < KO) { gout[s * 4 + k] = go[k]; gbo[n][k] += ppo_wave_sum(go[k]); }
+          }
+        }
+        __syncthreads();
+        // ---- dWo += H2^T gout (before H2 is overwritten) ----
+        if (hasWo) {
+          const float* a = H2 + wave * 32 + r + hh * kPLdh;                 // A(m = hidden unit, k = sample)
+          const float* go = gout + hh * 4 + (r < KO ? r : 0);
+          gWo[n] = ppo_mfma_k([&](int k0) { return a[k0 * kPLdh]; }, [&](int k0) { return r < KO ? go[k0 * 4] : 0.f; }, kPChunk, gWo[n]);
+        }
+        __syncthreads();
+        // ---- G2 = (gout Wo^T) * (1 - H2^2), in place over H2 (K = KO <= 4) ----
+        {
+          f32x16 c;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) c[v] = 0.f;
+#pragma unroll
+          for (int k0 = 0; k0 < KO; k0 += 2) {
+            const int k = k0 + hh;
+            const float av = k < KO ? gout[(mt * 32 + r) * 4 + (k < KO ? k : 0)] : 0.f;
+            const float bv = k < KO ? W.Wo[(nt * 32 + r) * KO + (k < KO ? k : 0)] : 0.f;
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
+          }
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int a = (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r;
+            const float h = H2[a];
+            H2[a] = c[v] * (1.0f - h * h);
+          }
+        }
+        __syncthreads();
+        // ---- dW2 += H1^T G2 (rows = input unit), db2 partial ----
+        gW2[n] = ppo_mfma_tile(H1 + mt * 32, 1, kPLdh, H2 + nt * 32, kPLdh, 1, kPChunk, gW2[n]);
+        {
+          float sgb = 0.f;
+#pragma unroll
+          for (int s = 0; s < 16; ++s) sgb += H2[(wave * 16 + s) * kPLdh + lane];
+          gb2p[n] += sgb;
+        }
+        __syncthreads();
+        // ---- G1 = (G2 W2^T) * (1 - H1^2), in place over H1 ----
+        {
+          f32x16 c;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) c[v] = 0.f;
+          c = ppo_mfma_tile(H2 + mt * 32 * kPLdh, kPLdh, 1, W.W2 + nt * 32 * kPLdh, 1, kPLdh, kPH, c);
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int a = (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r;
+            const float h = H1[a];
+            H1[a] = c[v] * (1.0f - h * h);
+          }
+        }
+        __syncthreads();
+        // ---- dW1 += X^T G1 (rows = obs feature, padded to 32 / 64), db1 partial ----
+        if (hasW1) gW1[n] = ppo_mfma_tile(X + mt * 32, 1, ldx, H1 + nt * 32, kPLdh, 1, kPChunk, gW1[n]);
+        {
+          float sgb = 0.f;
+#pragma unroll
+          for (int s = 0; s < 16; ++s) sgb += H1[(wave * 16 + s) * kPLdh + lane];
+          gb1p[n] += sgb;
+        }
+        __syncthreads();
+      }
+#ifdef FW_PPO_PROF
+      pf_net += PPO_T() - pf2;
+#endif
+    }
+
+#ifdef FW_PPO_PROF
+    const long long pf3 = PPO_T();
+#endif
+    // ---- finish the bias gradients: sum the four row-block partials ----
+#pragma unroll
+    for (int n = 0; n < 2; ++n) { bred[((n * 2 + 0) * 4 + wave) * kPH + lane] = gb1p[n]; bred[((n * 2 + 1) * 4 + wave) * kPH + lane] = gb2p[n]; }
+    __syncthreads();
+    float gb1[2] = {0.f, 0.f}, gb2[2] = {0.f, 0.f};
+    if (t < kPH) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { gb1[n] += bred[((n * 2 + 0) * 4 + q) * kPH + t]; gb2[n] += bred[((n * 2 + 1) * 4 + q) * kPH + t]; }
+    }
+    // entropy bonus: entropy_loss = -mean(sum_k (c + log_std_k)) -> d/dlog_std_k = -ent_coef
+    const float my_gls = (t == 0 ? gls[0] : t == 1 ? gls[1] : t == 2 ? gls[2] : gls[3]) - H.ent_coef;
+
+    // ---- global gradient norm over everything this block holds (each element counted by its owner) ----
+    float ss = 0.f;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int KO = n == 0 ? 4 : 1;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        ss += gW2[n][v] * gW2[n][v];
+        if (hasW1 && mt * 32 + ppo_acc_row(v) < D) ss += gW1[n][v] * gW1[n][v];
+        if (hasWo && r < KO) ss += gWo[n][v] * gWo[n][v];
+      }
+      if (t < kPH) ss += gb1[n] * gb1[n] + gb2[n] * gb2[n];
+      if (t < KO) { const float g = t == 0 ? gbo[n][0] : t == 1 ? gbo[n][1] : t == 2 ? gbo[n][2] : gbo[n][3]; ss += g * g; }
+    }
+    if (t < 4) ss += my_gls * my_gls;
+    const float total_norm = sqrtf(ppo_block_sum(ss, red));
+    const float clipc = fminf(H.max_grad_norm / (total_norm + 1e-6f), 1.0f);
+
+    // ---- Adam on the elements each lane holds.  The moments live in global memory (L2) in "slot" order
+    // (ppo_moment_map): the 16 accumulator elements of a lane are 16 consecutive floats, so a tile's moments
+    // are four dwordx4 loads / stores from one address, with no per-element index arithmetic or branches.
+    bc1 *= H.beta1; bc2 *= H.beta2;
+    const float c1 = H.lr / (1.0f - bc1), sc2 = 1.0f / sqrtf(1.0f - bc2);      // step size, 1 / sqrt(bias correction 2)
+    auto adam_tile = [&](const f32x16& g, int slot0, auto&& lds_of /* v -> weight in LDS or nullptr */) {
+      float4* mp = reinterpret_cast<float4*>(mom_m + slot0);
+      float4* vp = reinterpret_cast<float4*>(mom_v + slot0);
+      float4 m4[4], v4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { m4[q] = mp[q]; v4[q] = vp[q]; }
+      float upd[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float* mm = reinterpret_cast<float*>(&m4[q]);
+        float* vv = reinterpret_cast<float*>(&v4[q]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gg = g[q * 4 + e] * clipc;
+          mm[e] = H.beta1 * mm[e] + (1.0f - H.beta1) * gg;
+          vv[e] = H.beta2 * vv[e] + (1.0f - H.beta2) * gg * gg;
+          upd[q * 4 + e] = c1 * mm[e] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv[e]) * sc2 + H.eps);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { mp[q] = m4[q]; vp[q] = v4[q]; }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) { float* w = lds_of(v); if (w) *w -= upd[v]; }
+    };
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int KO = n == 0 ? 4 : 1;
+      const PpoNetLds& W = N[n];
+      adam_tile(gW2[n], ppo_tile_slot(n, 0, wave, lane), [&](int v) { return W.W2 + (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r; });
+      if (hasW1) adam_tile(gW1[n], ppo_tile_slot(n, 1, wave, lane),
+                           [&](int v) { const int i = mt * 32 + ppo_acc_row(v); return i < D ? W.W1 + i * kPH + nt * 32 + r : (float*)nullptr; });
+      if (hasWo) adam_tile(gWo[n], ppo_tile_slot(n, 2, wave, lane),
+                           [&](int v) { return r < KO ? W.Wo + (wave * 32 + ppo_acc_row(v)) * KO + r : (float*)nullptr; });
+    }
+    {
+      // scalars: slot q * 256 + t for q = b1, b2, bo of both nets and log_std; the owner test only gates the LDS write
+      float gs[7], *ws[7], mm[7], vv[7];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int KO = n == 0 ? 4 : 1;
+        gs[n * 3 + 0] = gb1[n]; ws[n * 3 + 0] = t < kPH ? N[n].b1 + t : nullptr;
+        gs[n * 3 + 1] = gb2[n]; ws[n * 3 + 1] = t < kPH ? N[n].b2 + t : nullptr;
+        gs[n * 3 + 2] = t == 0 ? gbo[n][0] : t == 1 ? gbo[n][1] : t == 2 ? gbo[n][2] : gbo[n][3];
+        ws[n * 3 + 2] = t < KO ? N[n].bo + t : nullptr;
+      }
+      gs[6] = my_gls; ws[6] = t < 4 ? log_std + t : nullptr;
+      const int sbase = kPTileSlots + t;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) { mm[q] = mom_m[sbase + q * kPThreads]; vv[q] = mom_v[sbase + q * kPThreads]; }
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const float gg = gs[q] * clipc;
+        mm[q] = H.beta1 * mm[q] + (1.0f - H.beta1) * gg; vv[q] = H.beta2 * vv[q] + (1.0f - H.beta2) * gg * gg;
+      }
+#pragma unroll
+      for (int q = 0; q < 7; ++q) { mom_m[sbase + q * kPThreads] = mm[q]; mom_v[sbase + q * kPThreads] = vv[q]; }
+#pragma unroll
+      for (int q = 0; q < 7; ++q) if (ws[q]) *ws[q] -= c1 * mm[q] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv[q]) * sc2 + H.eps);
+    }
+    __syncthreads();
+#ifdef FW_PPO_PROF
+    pf_adam += PPO_T() - pf3;
+#endif
+  }
+
+  // ---- write the weights back, report the losses ----
+  for (int n = 0; n < 2; ++n) {
+    const int KO = n == 0 ? 4 : 1;
+    for (int i = t; i < Dp * kPH; i += kPThreads) params[oW1[n] + i] = N[n].W1[i];
+    for (int i = t; i < kPH; i += kPThreads) { params[ob1[n] + i] = N[n].b1[i]; params[ob2[n] + i] = N[n].b2[i]; }
+    for (int i = t; i < kPH * kPH; i += kPThreads) params[oW2[n] + i] = N[n].W2[(i >> 6) * kPLdh + (i & 63)];
+    for (int i = t; i < kPH * KO + KO; i += kPThreads) params[oWo[n] + i] = N[n].Wo[i];
+  }
+  if (t < 4) params[oLs + t] = log_std[t];
+  const float pl = ppo_block_sum(acc_pl, red), vl = ppo_block_sum(acc_vl, red);
+  if (t == 0 && loss_acc) {
+    float ent = 0.f;
+    for (int k = 0; k < 4; ++k) ent += 1.4189385332046727f + log_std[k];
+    loss_acc[0] += pl * invB;            // sums over minibatches of the per-minibatch means
+    loss_acc[1] += vl * invB;
+    loss_acc[2] += -ent * (float)n_mb;   // entropy loss at the final log_std (it is state-independent)
+#ifdef FW_PPO_PROF
+    loss_acc[3] = (float)pf_stats / n_mb; loss_acc[4] = (float)pf_gather / n_mb; loss_acc[5] = (float)pf_net / n_mb; loss_acc[6] = (float)pf_adam / n_mb;
+#endif
+  }
+}
+
+inline size_t ppo_lds_bytes(int D) {
+  const int Dp = (D + 1) & ~1, ldx = Dp + 1;
+  size_t f = (size_t)ppo_net_lds_floats(Dp, 4) + ppo_net_lds_floats(Dp, 1) + 4 + (size_t)kPChunk * ldx + 64 + 2 * (size_t)kPChunk * kPLdh +
+             3 * (size_t)kPChunk * 4 + 16 * kPH + 8 + kPChunk;
+  return f * sizeof(float);
+}
+
+}  // namespace fwsim

@@ -22,6 +22,7 @@ import math
 from dataclasses import dataclass
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -312,6 +313,115 @@ class PPOConfig:
     adv_norm_scope: str = "minibatch"      # "minibatch" (SB3) | "global" (all-gathered statistics)
     seed: int = 42
     use_graphs: bool = True                # replay the rollout / minibatch update as hipGraphs (single-GPU, device envs)
+    fused_update: bool = True              # run the whole minibatch sequence of train() in one HIP kernel (fw_ppo_update) when it applies
+
+
+class _PpoHyper(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("lr", "clip_range", "ent_coef", "vf_coef", "max_grad_norm", "beta1", "beta2", "eps",
+                                         "adv_mean", "adv_std")] + [("norm_adv", C.c_int32), ("step0", C.c_int32)]
+
+
+class FusedPpoUpdate:
+    """Host side of ``fw_ppo_update``: keeps the flat float32 images of the parameters and Adam moments the kernel
+    works on (layout in include/fwsim.h) and moves them to / from the ``nn.Module`` and ``torch.optim.Adam`` state, so
+    checkpoints, the torch path and the kernel stay interchangeable."""
+
+    def __init__(self, policy: "MlpPolicy", optimizer: torch.optim.Adam, obs_dim: int):
+        self.policy, self.opt, self.D = policy, optimizer, obs_dim
+        self.Dp = (obs_dim + 1) & ~1
+        dev = policy.log_std.device
+        n = _lib.lib().fw_ppo_param_count(obs_dim)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)          # flat order (staging)
+        ns = _lib.lib().fw_ppo_moment_count()
+        smap = np.empty(ns, dtype=np.int32)
+        _lib.check(_lib.lib().fw_ppo_moment_map(obs_dim, smap.ctypes.data_as(C.c_void_p)))
+        owned = np.nonzero(smap >= 0)[0]
+        self._slot = torch.as_tensor(owned, dtype=torch.long, device=dev)                  # owned slots ...
+        self._flat_of_slot = torch.as_tensor(smap[owned], dtype=torch.long, device=dev)    # ... and their flat indices
+        self.mom_m = torch.zeros(ns, dtype=torch.float32, device=dev)                      # slot order (what the kernel sees)
+        self.mom_v = torch.zeros_like(self.mom_m)
+        self.loss = torch.zeros(8, dtype=torch.float32, device=dev)
+
+    @staticmethod
+    def applies(policy, cfg, obs_dim: int, batch_size: int, device) -> bool:
+        lin = [m for m in list(policy.pi_net) + list(policy.vf_net) if isinstance(m, nn.Linear)]
+        return (cfg.fused_update and device.type == "cuda" and _dist() is None and batch_size % 64 == 0 and obs_dim <= 64
+                and len(lin) == 4 and all(m.out_features == 64 for m in lin) and policy.action_net.out_features == 4)
+
+    def _slots(self):
+        """(tensor, flat offset, view shape in the flat image, needs transpose) per parameter, in layout order."""
+        p, out, off = self.policy, [], 0
+        for net, head in ((p.pi_net, p.action_net), (p.vf_net, p.value_net)):
+            l1, l2 = net[0], net[2]
+            ko = head.out_features
+            out.append((l1.weight, off, (self.Dp, 64), True)); off += self.Dp * 64
+            out.append((l1.bias, off, (64,), False)); off += 64
+            out.append((l2.weight, off, (64, 64), True)); off += 64 * 64
+            out.append((l2.bias, off, (64,), False)); off += 64
+            out.append((head.weight, off, (64, ko), True)); off += 64 * ko
+            out.append((head.bias, off, (ko,), False)); off += ko
+        out.append((p.log_std, off, (4,), False)); off += 4
+        assert off == self.flat.numel()
+        return out
+
+    def _put(self, flat, src, off, shape, tr):
+        view = flat[off:off + int(np.prod(shape))].view(shape)
+        if tr:
+            view[:src.shape[1], :].copy_(src.t())         # W[in][out] = weight^T (rows past obs_dim stay zero)
+        else:
+            view.copy_(src)
+
+    def _get(self, flat, dst, off, shape, tr):
+        view = flat[off:off + int(np.prod(shape))].view(shape)
+        dst.copy_(view[:dst.shape[1], :].t() if tr else view)
+
+    @torch.no_grad()
+    def load_from_torch(self) -> int:
+        self.flat.zero_(); self.m.zero_(); self.v.zero_()
+        step = 0
+        for t, off, shape, tr in self._slots():
+            self._put(self.flat, t.data, off, shape, tr)
+            st = self.opt.state.get(t)
+            if st:
+                self._put(self.m, st["exp_avg"], off, shape, tr); self._put(self.v, st["exp_avg_sq"], off, shape, tr)
+                step = int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"])
+        self.mom_m.zero_(); self.mom_v.zero_()
+        self.mom_m[self._slot] = self.m[self._flat_of_slot]; self.mom_v[self._slot] = self.v[self._flat_of_slot]
+        return step
+
+    @torch.no_grad()
+    def store_to_torch(self, step: int) -> None:
+        capturable = bool(self.opt.param_groups[0].get("capturable", False))
+        self.m[self._flat_of_slot] = self.mom_m[self._slot]; self.v[self._flat_of_slot] = self.mom_v[self._slot]
+        for t, off, shape, tr in self._slots():
+            self._get(self.flat, t.data, off, shape, tr)
+            st = self.opt.state[t]
+            if not st:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=t.device if capturable else "cpu")
+                st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(t), torch.zeros_like(t)
+            self._get(self.m, st["exp_avg"], off, shape, tr); self._get(self.v, st["exp_avg_sq"], off, shape, tr)
+            if torch.is_tensor(st["step"]):
+                st["step"].fill_(float(step))
+            else:
+                st["step"] = step
+
+    def run(self, cfg, obs, act, old_logp, adv, ret, perm_i32, n_mb: int, g_mean: float, g_std: float):
+        step0 = self.load_from_torch()
+        pg = self.opt.param_groups[0]
+        H = _PpoHyper(lr=pg["lr"], clip_range=cfg.clip_range, ent_coef=cfg.ent_coef, vf_coef=cfg.vf_coef,
+                      max_grad_norm=cfg.max_grad_norm, beta1=pg["betas"][0], beta2=pg["betas"][1], eps=pg["eps"],
+                      adv_mean=g_mean, adv_std=g_std,
+                      norm_adv=(0 if not cfg.normalize_advantage else (2 if cfg.adv_norm_scope == "global" else 1)), step0=step0)
+        self.loss.zero_()
+        for x in (obs, act, old_logp, adv, ret):
+            assert x.dtype == torch.float32 and x.is_contiguous()
+        assert perm_i32.dtype == torch.int32 and perm_i32.numel() == n_mb * cfg.batch_size
+        rc = _lib.lib().fw_ppo_update(_p(self.flat), _p(self.mom_m), _p(self.mom_v), _p(obs), _p(act), _p(old_logp), _p(adv), _p(ret),
+                                      _p(perm_i32), n_mb, cfg.batch_size, self.D, C.byref(H), _p(self.loss), _stream(obs.device))
+        _lib.check(rc)
+        self.store_to_torch(step0 + n_mb)
+        return (self.loss[:3] / n_mb).tolist()
 
 
 class PPO:
@@ -329,6 +439,7 @@ class PPO:
         self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5,
                                           capturable=self._graphs)
         self._g_rollout = self._g_update = None
+        self._fused = None
         self._warm_rollouts = 0
         self._loss_acc = torch.zeros(3, device=self.device)
         self.gen = torch.Generator(device=self.device)
@@ -420,6 +531,18 @@ class PPO:
         self._loss_acc.zero_()          # persistent buffer: the captured update graph holds its address
         nb = 0
         bs = cfg.batch_size
+        if B % bs == 0 and FusedPpoUpdate.applies(self.policy, cfg, self.env.obs_dim, bs, self.device):
+            # the whole minibatch sequence in one kernel; the permutations are drawn exactly like the loop below
+            if self._fused is None:
+                self._fused = FusedPpoUpdate(self.policy, self.optimizer, self.env.obs_dim)
+            perm = torch.cat([torch.randperm(B, device=self.device, generator=self.gen) for _ in range(cfg.n_epochs)]).to(torch.int32)
+            nb = cfg.n_epochs * (B // bs)
+            la = self._fused.run(cfg, obs.contiguous(), act.contiguous(), old_logp.contiguous(), adv.contiguous(), ret.contiguous(),
+                                 perm, nb, float(g_mean), float(g_std))
+            self._g_update = None              # the torch-path graph (if any) holds stale Adam state
+            self.logs = {"policy_loss": la[0], "value_loss": la[1], "entropy_loss": la[2],
+                         "adv_mean": float(g_mean), "adv_std": float(g_std)}
+            return
         use_graph = self._graphs and B % bs == 0
         if use_graph and self._g_update is None:
             self._idx = torch.zeros(bs, dtype=torch.long, device=self.device)

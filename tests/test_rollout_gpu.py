@@ -114,3 +114,60 @@ def test_graph_replayed_rollouts_accumulate_the_same_statistics_as_eager_ones():
     assert out[True][1] == pytest.approx(1e-4 + 4 * 8 * 512) == pytest.approx(out[False][1])
     assert out[True][2] > 1.0 and out[False][2] > 1.0              # ~32 steps of -0.1 discounted: the tracker was not restarted
     assert out[True][3] == pytest.approx(out[False][3], rel=0.2)
+
+
+class _BufEnv:
+    """Just enough env for PPO.__init__ / train(): the update is tested on hand-filled rollout buffers."""
+    def __init__(self, n, d):
+        self.device, self.num_envs, self.obs_dim = torch.device("cuda"), n, d
+
+
+def _filled_ppo(fused, d, bs, n_epochs, T=4, n=256, seed=5, scope="minibatch", steps_before=0):
+    ppo = R.PPO(_BufEnv(n, d), R.PPOConfig(n_steps=T, batch_size=bs, n_epochs=n_epochs, seed=seed, use_graphs=False,
+                                           fused_update=fused, adv_norm_scope=scope, ent_coef=0.01))
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    ppo.buf_obs.copy_(torch.randn(ppo.buf_obs.shape, device="cuda", generator=g).clamp(-10, 10))
+    with torch.no_grad():
+        a, v, lp = ppo.policy(ppo.buf_obs.reshape(-1, d), generator=g)
+        ppo.buf_act.copy_((a + 0.3 * torch.randn(a.shape, device="cuda", generator=g)).reshape(ppo.buf_act.shape))   # off-policy enough to hit the clip
+        _, lp2, _ = ppo.policy.evaluate_actions(ppo.buf_obs.reshape(-1, d), ppo.buf_act.reshape(-1, 4))
+        ppo.buf_logp.copy_((lp2 + 0.2 * torch.randn(lp2.shape, device="cuda", generator=g)).reshape(T, n))
+    ppo.adv = torch.randn((T, n), device="cuda", generator=g) * 2.0 + 0.5
+    ppo.ret = torch.randn((T, n), device="cuda", generator=g) * 3.0
+    return ppo
+
+
+@pytest.mark.parametrize("d,bs,scope", [(28, 128, "minibatch"), (56, 64, "minibatch"), (28, 64, "global"), (27, 256, "minibatch")])
+def test_fused_ppo_update_matches_the_torch_path(d, bs, scope):
+    """fw_ppo_update (one kernel for the whole minibatch sequence) against the plain torch PPO.train() on the same
+    buffers, permutations, initial weights and Adam state: parameters, Adam moments and step count agree to fp32
+    rounding after 2 epochs (16-32 sequential minibatch steps), and again after a second call (warm Adam state)."""
+    a, b = _filled_ppo(True, d, bs, 2, scope=scope), _filled_ppo(False, d, bs, 2, scope=scope)
+    for p, q in zip(a.policy.parameters(), b.policy.parameters()):
+        assert torch.equal(p, q)
+    for rnd in range(2):
+        a.train(); b.train()
+        assert a._fused is not None and b._fused is None
+        for (na, p), (nb_, q) in zip(a.policy.named_parameters(), b.policy.named_parameters()):
+            torch.testing.assert_close(p, q, rtol=2e-3, atol=2e-5, msg=lambda m: f"{na} round {rnd}: {m}")
+            sa, sb = a.optimizer.state[p], b.optimizer.state[q]
+            assert float(sa["step"]) == float(sb["step"]) == (rnd + 1) * 2 * (4 * 256 // bs)
+            torch.testing.assert_close(sa["exp_avg"], sb["exp_avg"], rtol=5e-3, atol=1e-6)
+            torch.testing.assert_close(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=5e-3, atol=1e-9)
+        for k in ("policy_loss", "value_loss"):
+            assert a.logs[k] == pytest.approx(b.logs[k], rel=2e-3, abs=1e-5)
+    # the update moved the policy and did not blow up
+    assert all(torch.isfinite(p).all() for p in a.policy.parameters())
+
+
+def test_fused_ppo_update_rejects_what_it_cannot_run():
+    from pyflyt_drone_amd import _lib
+    L = _lib.lib()
+    assert L.fw_ppo_param_count(28) == 2 * (28 * 64 + 64 + 64 * 64 + 64) + 64 * 4 + 4 + 64 + 1 + 4
+    z = torch.zeros(64, device="cuda")
+    H = R._PpoHyper()
+    import ctypes as C
+    args = [R._p(z)] * 8 + [R._p(z.to(torch.int32))]
+    assert L.fw_ppo_update(*args, 1, 100, 28, C.byref(H), None, None) == K.FW_EINVAL      # batch not a multiple of 64
+    assert L.fw_ppo_update(*args, 1, 64, 65, C.byref(H), None, None) == K.FW_EINVAL       # obs_dim too large
+    assert L.fw_ppo_update(*args, 0, 64, 28, C.byref(H), None, None) == K.FW_EINVAL
