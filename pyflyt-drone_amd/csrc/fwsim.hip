@@ -1318,11 +1318,20 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   if (obs_dim <= 0 || obs_dim > 64) { g_err = "fw_ppo_update: obs_dim must be in [1, 64]"; return FW_EINVAL; }
   const size_t lds = ppo_lds_bytes(obs_dim);
   if (lds > 160 * 1024) { g_err = "fw_ppo_update: networks do not fit the 160 KB of LDS"; return FW_EINVAL; }
+  hipStream_t st = (hipStream_t)hip_stream;
+  // exchange words of the two blocks (per device, allocated on first use: call once outside hipGraph capture)
+  static unsigned long long* xch_dev[64] = {nullptr};
+  int dev = 0;
+  HIP_TRY((fw_env*)nullptr, hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) { g_err = "device index out of range"; return FW_EINVAL; }
+  if (!xch_dev[dev]) HIP_TRY((fw_env*)nullptr, hipMalloc((void**)&xch_dev[dev], 4 * sizeof(unsigned long long)));
+  HIP_TRY((fw_env*)nullptr, hipMemsetAsync(xch_dev[dev], 0, 4 * sizeof(unsigned long long), st));
   HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  PpoHyper H;
-  std::memcpy(&H, hyper, sizeof H);
-  hipLaunchKernelGGL(fw_ppo_update_kernel, dim3(1), dim3(kPThreads), lds, (hipStream_t)hip_stream, params, mom_m, mom_v, obs, act,
-                     old_logp, adv, ret, perm, n_minibatches, batch_size, obs_dim, H, loss_acc);
+  PpoArgs A;
+  A.params = params; A.mom_m = mom_m; A.mom_v = mom_v; A.obs = obs; A.act = act; A.old_logp = old_logp; A.adv = adv; A.ret = ret;
+  A.perm = perm; A.n_mb = n_minibatches; A.B = batch_size; A.D = obs_dim; A.loss_acc = loss_acc; A.xch = xch_dev[dev];
+  std::memcpy(&A.H, hyper, sizeof A.H);
+  hipLaunchKernelGGL(fw_ppo_update_kernel, dim3(2), dim3(kPThreads), lds, st, A);
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;
 }

@@ -144,7 +144,10 @@ inline void ppo_moment_map(int D, int32_t* flat_of_slot) {
   for (int t = 0; t < 4; ++t) flat_of_slot[kPTileSlots + 6 * kPThreads + t] = oLs + t;
 }
 
-// Work split of the 256 threads (4 waves, one per SIMD, fixed for the whole call):
+// Two workgroups, one per network (pi: block 0, V: block 1) -- the two networks share nothing but the scalar
+// gradient norm that SB3 clips jointly, which the blocks exchange once per minibatch through one 64-bit word
+// each (tag | partial sum of squares, device-scope atomics; both blocks are always co-resident: grid = 2).
+// Work split of the 256 threads of a block (4 waves, one per SIMD, fixed for the whole call):
 //   * every 64 x 64 product (H1, H2, G2, G1, dW2) is 2 x 2 tiles of 32 x 32: wave w owns tile (w >> 1, w & 1);
 //   * dW1 is ceil(Dp / 32) x 2 tiles (waves 0-1 or all four); the head products (64 x KO, masked to KO columns)
 //     are 2 row tiles on waves 0-1;
@@ -152,24 +155,32 @@ inline void ppo_moment_map(int D, int32_t* flat_of_slot) {
 //   * the per-sample loss runs one sample per lane on wave 0.
 // Each lane applies clipping + Adam to the accumulator elements it holds (their moments stay in global memory / L2,
 // in slot order; held in registers for the whole call they push the kernel past the 512-register budget).
-__global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(
-    float* __restrict__ params, float* __restrict__ mom_m, float* __restrict__ mom_v,
-    const float* __restrict__ obs, const float* __restrict__ act, const float* __restrict__ old_logp,
-    const float* __restrict__ adv, const float* __restrict__ ret, const int32_t* __restrict__ perm,
-    int32_t n_mb, int32_t B, int32_t D, PpoHyper H, float* __restrict__ loss_acc /* [3] += policy, value, entropy loss */) {
-  extern __shared__ __align__(16) float lds[];
+struct PpoArgs {
+  float *params, *mom_m, *mom_v;
+  const float *obs, *act, *old_logp, *adv, *ret;
+  const int32_t* perm;
+  int32_t n_mb, B, D;
+  PpoHyper H;
+  float* loss_acc;                   // [3] += policy, value, entropy loss
+  unsigned long long* xch;           // [2 parities][2 blocks], zeroed by the host before the launch
+};
+
+template <int NET>
+__device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
+  constexpr int n = NET, KO = NET == 0 ? 4 : 1;
+  float* __restrict__ params = A.params; float* __restrict__ mom_m = A.mom_m; float* __restrict__ mom_v = A.mom_v;
+  const float* __restrict__ obs = A.obs; const float* __restrict__ act = A.act; const float* __restrict__ old_logp = A.old_logp;
+  const float* __restrict__ adv = A.adv; const float* __restrict__ ret = A.ret; const int32_t* __restrict__ perm = A.perm;
+  const int n_mb = A.n_mb, B = A.B, D = A.D;
+  const PpoHyper H = A.H;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, hh = lane >> 5;
   const int Dp = (D + 1) & ~1;
   const int ldx = Dp + 1;
 
   // ---- LDS carve-up ----
   float* p = lds;
-  PpoNetLds N[2];
-  for (int n = 0; n < 2; ++n) {
-    const int KO = n == 0 ? 4 : 1;
-    N[n].W1 = p; p += Dp * kPH; N[n].b1 = p; p += kPH; N[n].W2 = p; p += kPH * kPLdh; N[n].b2 = p; p += kPH;
-    N[n].Wo = p; p += kPH * KO; N[n].bo = p; p += KO;
-  }
+  PpoNetLds W;
+  W.W1 = p; p += Dp * kPH; W.b1 = p; p += kPH; W.W2 = p; p += kPH * kPLdh; W.b2 = p; p += kPH; W.Wo = p; p += kPH * KO; W.bo = p; p += KO;
   float* log_std = p; p += 4;
   float* X = p;  p += kPChunk * ldx + 64;         // (+64: the padded dW1 tile reads a few floats past the last row)
   float* H1 = p; p += kPChunk * kPLdh;
@@ -177,30 +188,19 @@ __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(
   float* gout = p; p += kPChunk * 4;              // head output, then dL/d(head output) of the chunk
   float* sA = p; p += kPChunk * 4;                // gathered actions
   float* sS = p; p += kPChunk * 4;                // per-sample scalars: old_logp, adv (normalised), ret, -
-  float* bred = p; p += 4 * 4 * kPH;              // bias-gradient partials [array][wave][64]
+  float* bred = p; p += 2 * 4 * kPH;              // bias-gradient partials [b1 | b2][wave][64]
   float* red = p; p += 8;
-  int* sIdx = (int*)p; p += kPChunk;
 
-  // flat offsets of the two nets
-  int oW1[2], ob1[2], oW2[2], ob2[2], oWo[2], obo[2], oLs;
-  {
-    int off = 0;
-    for (int n = 0; n < 2; ++n) {
-      const int KO = n == 0 ? 4 : 1;
-      oW1[n] = off; ob1[n] = oW1[n] + Dp * kPH; oW2[n] = ob1[n] + kPH; ob2[n] = oW2[n] + kPH * kPH; oWo[n] = ob2[n] + kPH; obo[n] = oWo[n] + kPH * KO;
-      off = obo[n] + KO;
-    }
-    oLs = off;
-  }
+  // flat offsets of this net
+  const int nP0 = ppo_net_params(Dp, 4);
+  const int oW1 = n == 0 ? 0 : nP0, ob1 = oW1 + Dp * kPH, oW2 = ob1 + kPH, ob2 = oW2 + kPH * kPH, oWo = ob2 + kPH, obo = oWo + kPH * KO;
+  const int oLs = nP0 + ppo_net_params(Dp, 1);
 
   // ---- load the weights once ----
-  for (int n = 0; n < 2; ++n) {
-    const int KO = n == 0 ? 4 : 1;
-    for (int i = t; i < Dp * kPH; i += kPThreads) N[n].W1[i] = params[oW1[n] + i];
-    for (int i = t; i < kPH; i += kPThreads) { N[n].b1[i] = params[ob1[n] + i]; N[n].b2[i] = params[ob2[n] + i]; }
-    for (int i = t; i < kPH * kPH; i += kPThreads) N[n].W2[(i >> 6) * kPLdh + (i & 63)] = params[oW2[n] + i];
-    for (int i = t; i < kPH * KO + KO; i += kPThreads) N[n].Wo[i] = params[oWo[n] + i];       // Wo and bo are contiguous in both images
-  }
+  for (int i = t; i < Dp * kPH; i += kPThreads) W.W1[i] = params[oW1 + i];
+  for (int i = t; i < kPH; i += kPThreads) { W.b1[i] = params[ob1 + i]; W.b2[i] = params[ob2 + i]; }
+  for (int i = t; i < kPH * kPH; i += kPThreads) W.W2[(i >> 6) * kPLdh + (i & 63)] = params[oW2 + i];
+  for (int i = t; i < kPH * KO + KO; i += kPThreads) W.Wo[i] = params[oWo + i];              // Wo and bo are contiguous in both images
   if (t < 4) log_std[t] = params[oLs + t];
   for (int i = t; i < kPChunk * ldx + 64; i += kPThreads) X[i] = 0.f;                           // incl. the pad the dW1 tiles read
   __syncthreads();
@@ -210,41 +210,40 @@ __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(
   const bool hasW1 = wave < tilesW1, hasWo = wave < 2;
 
   float bc1 = powf(H.beta1, (float)H.step0), bc2 = powf(H.beta2, (float)H.step0);     // beta^t
-  float acc_pl = 0.f, acc_vl = 0.f;               // loss sums (wave 0 lanes, reduced at the end)
+  float acc_l = 0.f;                              // loss sum (wave 0 lanes, reduced at the end)
   const float invB = 1.0f / (float)B;
-
 #ifdef FW_PPO_PROF
   long long pf_stats = 0, pf_gather = 0, pf_net = 0, pf_adam = 0;
 #define PPO_T() ((long long)__builtin_readcyclecounter())
 #endif
+
 #pragma unroll 1
   for (int mb = 0; mb < n_mb; ++mb) {
     const int32_t* idx = perm + (size_t)mb * B;
 #ifdef FW_PPO_PROF
     const long long pf0 = PPO_T();
 #endif
-    // ---- advantage statistics of the minibatch (SB3: (a - mean) / (std + 1e-8), unbiased std) ----
+    // ---- advantage statistics of the minibatch (SB3: (a - mean) / (std + 1e-8), unbiased std); pi only ----
     float a_mean = 0.f, a_std = 1.f;
-    if (H.norm_adv == 1 && B > 1) {
-      float s1 = 0.f;
-      for (int i = t; i < B; i += kPThreads) s1 += adv[idx[i]];
-      a_mean = ppo_block_sum(s1, red) * invB;
-      float s2 = 0.f;
-      for (int i = t; i < B; i += kPThreads) { float d = adv[idx[i]] - a_mean; s2 += d * d; }
-      a_std = sqrtf(ppo_block_sum(s2, red) / (float)(B - 1));
-    } else if (H.norm_adv == 2) { a_mean = H.adv_mean; a_std = H.adv_std; }
-
+    if (NET == 0) {
+      if (H.norm_adv == 1 && B > 1) {
+        float s1 = 0.f;
+        for (int i = t; i < B; i += kPThreads) s1 += adv[idx[i]];
+        a_mean = ppo_block_sum(s1, red) * invB;
+        float s2 = 0.f;
+        for (int i = t; i < B; i += kPThreads) { float d = adv[idx[i]] - a_mean; s2 += d * d; }
+        a_std = sqrtf(ppo_block_sum(s2, red) / (float)(B - 1));
+      } else if (H.norm_adv == 2) { a_mean = H.adv_mean; a_std = H.adv_std; }
+    }
 #ifdef FW_PPO_PROF
     pf_stats += PPO_T() - pf0;
 #endif
     // gradient accumulators of this minibatch (registers)
-    f32x16 gW2[2], gW1[2], gWo[2];
-    float gb1p[2] = {0.f, 0.f}, gb2p[2] = {0.f, 0.f};                 // column-sum partials of this thread's 16 rows
-    float gbo[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gls[4] = {0.f, 0.f, 0.f, 0.f};   // wave 0, replicated over its lanes
+    f32x16 gW2, gW1, gWo;
+    float gb1p = 0.f, gb2p = 0.f;                                     // column-sum partials of this thread's 16 rows
+    float gbo[4] = {0.f, 0.f, 0.f, 0.f}, gls[4] = {0.f, 0.f, 0.f, 0.f};   // wave 0: per-lane (= per-sample) partials
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) { gW2[n][v] = 0.f; gW1[n][v] = 0.f; gWo[n][v] = 0.f; }
+    for (int v = 0; v < 16; ++v) { gW2[v] = 0.f; gW1[v] = 0.f; gWo[v] = 0.f; }
 
 #pragma unroll 1
     for (int c0 = 0; c0 < B; c0 += kPChunk) {
@@ -260,156 +259,148 @@ __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(
         const int per = (Dp + 3) >> 2, d0 = k * per;
         const float* orow = obs + (size_t)si * D;
         for (int d = d0; d < d0 + per && d < Dp; ++d) X[s * ldx + d] = d < D ? orow[d] : 0.f;
-        sA[t] = act[(size_t)si * 4 + k];
         float sv = 0.f;
-        if (k == 0) sv = old_logp[si];
-        else if (k == 1) { sv = adv[si]; if (H.norm_adv) sv = (sv - a_mean) / (a_std + 1e-8f); }
-        else if (k == 2) sv = ret[si];
+        if (NET == 0) {
+          sA[t] = act[(size_t)si * 4 + k];
+          if (k == 0) sv = old_logp[si];
+          else if (k == 1) { sv = adv[si]; if (H.norm_adv) sv = (sv - a_mean) / (a_std + 1e-8f); }
+        } else if (k == 2) sv = ret[si];
         sS[t] = sv;
       }
       __syncthreads();
 #ifdef FW_PPO_PROF
       const long long pf2 = PPO_T(); pf_gather += pf2 - pf1;
 #endif
-
+      // ---- forward: H1 = tanh(X W1 + b1), H2 = tanh(H1 W2 + b2) ----
+      {
+        f32x16 c;
+        const float bias = W.b1[nt * 32 + r];
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const int KO = n == 0 ? 4 : 1;
-        const PpoNetLds& W = N[n];
-        // ---- forward: H1 = tanh(X W1 + b1), H2 = tanh(H1 W2 + b2) ----
-        {
-          f32x16 c;
-          const float bias = W.b1[nt * 32 + r];
+        for (int v = 0; v < 16; ++v) c[v] = bias;
+        c = ppo_mfma_tile(X + mt * 32 * ldx, ldx, 1, W.W1 + nt * 32, kPH, 1, Dp, c);
 #pragma unroll
-          for (int v = 0; v < 16; ++v) c[v] = bias;
-          c = ppo_mfma_tile(X + mt * 32 * ldx, ldx, 1, W.W1 + nt * 32, kPH, 1, Dp, c);
+        for (int v = 0; v < 16; ++v) H1[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
+      }
+      __syncthreads();
+      {
+        f32x16 c;
+        const float bias = W.b2[nt * 32 + r];
 #pragma unroll
-          for (int v = 0; v < 16; ++v) H1[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
+        for (int v = 0; v < 16; ++v) c[v] = bias;
+        c = ppo_mfma_tile(H1 + mt * 32 * kPLdh, kPLdh, 1, W.W2 + nt * 32, kPLdh, 1, kPH, c);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) H2[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
+      }
+      __syncthreads();
+      // ---- head: out = H2 Wo + bo (rows 32 w .. on waves 0-1, columns masked to KO) ----
+      if (hasWo) {
+        f32x16 c;
+        const float bias = r < KO ? W.bo[r < KO ? r : 0] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) c[v] = bias;
+        const float* a = H2 + (wave * 32 + r) * kPLdh + hh;
+        const float* wo = W.Wo + hh * KO + (r < KO ? r : 0);
+        c = ppo_mfma_k([&](int k0) { return a[k0]; }, [&](int k0) { return r < KO ? wo[k0 * KO] : 0.f; }, kPH, c);
+        if (r < KO) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) gout[(wave * 32 + ppo_acc_row(v)) * 4 + r] = c[v];
         }
-        __syncthreads();
-        {
-          f32x16 c;
-          const float bias = W.b2[nt * 32 + r];
-#pragma unroll
-          for (int v = 0; v < 16; ++v) c[v] = bias;
-          c = ppo_mfma_tile(H1 + mt * 32 * kPLdh, kPLdh, 1, W.W2 + nt * 32, kPLdh, 1, kPH, c);
-#pragma unroll
-          for (int v = 0; v < 16; ++v) H2[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
-        }
-        __syncthreads();
-        // ---- head: out = H2 Wo + bo (rows 32 w .. on waves 0-1, columns masked to KO) ----
-        if (hasWo) {
-          f32x16 c;
-          const float bias = r < KO ? W.bo[r < KO ? r : 0] : 0.f;
-#pragma unroll
-          for (int v = 0; v < 16; ++v) c[v] = bias;
-          const float* a = H2 + (wave * 32 + r) * kPLdh + hh;
-          const float* wo = W.Wo + hh * KO + (r < KO ? r : 0);
-          c = ppo_mfma_k([&](int k0) { return a[k0]; }, [&](int k0) { return r < KO ? wo[k0 * KO] : 0.f; }, kPH, c);
-          if (r < KO) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) gout[(wave * 32 + ppo_acc_row(v)) * 4 + r] = c[v];
-          }
-        }
-        __syncthreads();
-        // ---- loss gradient wrt the head output: one sample per lane of wave 0 ----
-        if (wave == 0) {
-          const int s = lane;
-          float go[4] = {0.f, 0.f, 0.f, 0.f};
-          if (n == 0) {
-            // log pi(a|s), ratio, clipped surrogate (SB3 PPO.train)
-            float logp = 0.f, z[4], iv[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const float ls = log_std[k];
-              iv[k] = expf(-2.0f * ls);                         // 1 / sigma^2
-              z[k] = sA[s * 4 + k] - gout[s * 4 + k];
-              logp += -0.5f * z[k] * z[k] * iv[k] - ls - 0.9189385332046727f;
-            }
-            const float a = sS[s * 4 + 1];
-            const float ratio = expf(logp - sS[s * 4 + 0]);
-            const float rc = fminf(fmaxf(ratio, 1.0f - H.clip_range), 1.0f + H.clip_range);
-            const float l1 = a * ratio, l2 = a * rc;
-            acc_pl += -fminf(l1, l2);
-            // d(-min(l1, l2))/dlogp: through l1 when it is the smaller; on a tie (ratio inside the range: rc == ratio)
-            // torch.min halves the gradient between the two branches and the clamp passes its half
-            const bool inside = ratio >= 1.0f - H.clip_range && ratio <= 1.0f + H.clip_range;
-            const float coef = (l1 < l2 || (l1 == l2 && inside)) ? -a * ratio * invB : (l1 == l2 ? -0.5f * a * ratio * invB : 0.f);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              go[k] = coef * z[k] * iv[k];                                  // dL/dmu_k = dL/dlogp * (a_k - mu_k) / sigma_k^2
-              gls[k] += ppo_wave_sum(coef * (z[k] * z[k] * iv[k] - 1.0f));  // dL/dlog_std_k
-            }
-          } else {
-            const float dv = gout[s * 4] - sS[s * 4 + 2];
-            acc_vl += dv * dv;
-            go[0] = H.vf_coef * 2.0f * dv * invB;
-          }
+      }
+      __syncthreads();
+      // ---- loss gradient wrt the head output: one sample per lane of wave 0 ----
+      if (wave == 0) {
+        const int s = lane;
+        float go[4] = {0.f, 0.f, 0.f, 0.f};
+        if (NET == 0) {
+          // log pi(a|s), ratio, clipped surrogate (SB3 PPO.train)
+          float logp = 0.f, z[4], iv[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            if (k < KO) { gout[s * 4 + k] = go[k]; gbo[n][k] += ppo_wave_sum(go[k]); }
+            const float ls = log_std[k];
+            iv[k] = expf(-2.0f * ls);                         // 1 / sigma^2
+            z[k] = sA[s * 4 + k] - gout[s * 4 + k];
+            logp += -0.5f * z[k] * z[k] * iv[k] - ls - 0.9189385332046727f;
           }
-        }
-        __syncthreads();
-        // ---- dWo += H2^T gout (before H2 is overwritten) ----
-        if (hasWo) {
-          const float* a = H2 + wave * 32 + r + hh * kPLdh;                 // A(m = hidden unit, k = sample)
-          const float* go = gout + hh * 4 + (r < KO ? r : 0);
-          gWo[n] = ppo_mfma_k([&](int k0) { return a[k0 * kPLdh]; }, [&](int k0) { return r < KO ? go[k0 * 4] : 0.f; }, kPChunk, gWo[n]);
-        }
-        __syncthreads();
-        // ---- G2 = (gout Wo^T) * (1 - H2^2), in place over H2 (K = KO <= 4) ----
-        {
-          f32x16 c;
+          const float a = sS[s * 4 + 1];
+          const float ratio = expf(logp - sS[s * 4 + 0]);
+          const float rc = fminf(fmaxf(ratio, 1.0f - H.clip_range), 1.0f + H.clip_range);
+          const float l1 = a * ratio, l2 = a * rc;
+          acc_l += -fminf(l1, l2);
+          // d(-min(l1, l2))/dlogp: through l1 when it is the smaller; on a tie (ratio inside the range: rc == ratio)
+          // torch.min halves the gradient between the two branches and the clamp passes its half
+          const bool inside = ratio >= 1.0f - H.clip_range && ratio <= 1.0f + H.clip_range;
+          const float coef = (l1 < l2 || (l1 == l2 && inside)) ? -a * ratio * invB : (l1 == l2 ? -0.5f * a * ratio * invB : 0.f);
 #pragma unroll
-          for (int v = 0; v < 16; ++v) c[v] = 0.f;
-#pragma unroll
-          for (int k0 = 0; k0 < KO; k0 += 2) {
-            const int k = k0 + hh;
-            const float av = k < KO ? gout[(mt * 32 + r) * 4 + (k < KO ? k : 0)] : 0.f;
-            const float bv = k < KO ? W.Wo[(nt * 32 + r) * KO + (k < KO ? k : 0)] : 0.f;
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
+          for (int k = 0; k < 4; ++k) {
+            go[k] = coef * z[k] * iv[k];                                  // dL/dmu_k = dL/dlogp * (a_k - mu_k) / sigma_k^2
+            gls[k] += coef * (z[k] * z[k] * iv[k] - 1.0f);                // dL/dlog_std_k of this lane's samples
           }
-#pragma unroll
-          for (int v = 0; v < 16; ++v) {
-            const int a = (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r;
-            const float h = H2[a];
-            H2[a] = c[v] * (1.0f - h * h);
-          }
+        } else {
+          const float dv = gout[s * 4] - sS[s * 4 + 2];
+          acc_l += dv * dv;
+          go[0] = H.vf_coef * 2.0f * dv * invB;
         }
-        __syncthreads();
-        // ---- dW2 += H1^T G2 (rows = input unit), db2 partial ----
-        gW2[n] = ppo_mfma_tile(H1 + mt * 32, 1, kPLdh, H2 + nt * 32, kPLdh, 1, kPChunk, gW2[n]);
-        {
-          float sgb = 0.f;
 #pragma unroll
-          for (int s = 0; s < 16; ++s) sgb += H2[(wave * 16 + s) * kPLdh + lane];
-          gb2p[n] += sgb;
+        for (int k = 0; k < KO; ++k) { gout[s * 4 + k] = go[k]; gbo[k] += go[k]; }
+      }
+      __syncthreads();
+      // ---- dWo += H2^T gout (before H2 is overwritten) ----
+      if (hasWo) {
+        const float* a = H2 + wave * 32 + r + hh * kPLdh;                 // A(m = hidden unit, k = sample)
+        const float* go = gout + hh * 4 + (r < KO ? r : 0);
+        gWo = ppo_mfma_k([&](int k0) { return a[k0 * kPLdh]; }, [&](int k0) { return r < KO ? go[k0 * 4] : 0.f; }, kPChunk, gWo);
+      }
+      __syncthreads();
+      // ---- G2 = (gout Wo^T) * (1 - H2^2), in place over H2 (K = KO <= 4) ----
+      {
+        f32x16 c;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) c[v] = 0.f;
+#pragma unroll
+        for (int k0 = 0; k0 < KO; k0 += 2) {
+          const int k = k0 + hh;
+          const float av = k < KO ? gout[(mt * 32 + r) * 4 + (k < KO ? k : 0)] : 0.f;
+          const float bv = k < KO ? W.Wo[(nt * 32 + r) * KO + (k < KO ? k : 0)] : 0.f;
+          c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
         }
-        __syncthreads();
-        // ---- G1 = (G2 W2^T) * (1 - H1^2), in place over H1 ----
-        {
-          f32x16 c;
 #pragma unroll
-          for (int v = 0; v < 16; ++v) c[v] = 0.f;
-          c = ppo_mfma_tile(H2 + mt * 32 * kPLdh, kPLdh, 1, W.W2 + nt * 32 * kPLdh, 1, kPLdh, kPH, c);
-#pragma unroll
-          for (int v = 0; v < 16; ++v) {
-            const int a = (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r;
-            const float h = H1[a];
-            H1[a] = c[v] * (1.0f - h * h);
-          }
+        for (int v = 0; v < 16; ++v) {
+          const int a = (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r;
+          const float h = H2[a];
+          H2[a] = c[v] * (1.0f - h * h);
         }
-        __syncthreads();
-        // ---- dW1 += X^T G1 (rows = obs feature, padded to 32 / 64), db1 partial ----
-        if (hasW1) gW1[n] = ppo_mfma_tile(X + mt * 32, 1, ldx, H1 + nt * 32, kPLdh, 1, kPChunk, gW1[n]);
-        {
-          float sgb = 0.f;
+      }
+      __syncthreads();
+      // ---- dW2 += H1^T G2 (rows = input unit), db2 partial ----
+      gW2 = ppo_mfma_tile(H1 + mt * 32, 1, kPLdh, H2 + nt * 32, kPLdh, 1, kPChunk, gW2);
+      {
+        float sgb = 0.f;
 #pragma unroll
-          for (int s = 0; s < 16; ++s) sgb += H1[(wave * 16 + s) * kPLdh + lane];
-          gb1p[n] += sgb;
+        for (int s = 0; s < 16; ++s) sgb += H2[(wave * 16 + s) * kPLdh + lane];
+        gb2p += sgb;
+      }
+      __syncthreads();
+      // ---- G1 = (G2 W2^T) * (1 - H1^2), in place over H1 ----
+      {
+        f32x16 c;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) c[v] = 0.f;
+        c = ppo_mfma_tile(H2 + mt * 32 * kPLdh, kPLdh, 1, W.W2 + nt * 32 * kPLdh, 1, kPLdh, kPH, c);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int a = (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r;
+          const float h = H1[a];
+          H1[a] = c[v] * (1.0f - h * h);
         }
-        __syncthreads();
+      }
+      __syncthreads();
+      // ---- dW1 += X^T G1 (rows = obs feature, padded to 32 / 64), db1 partial ----
+      if (hasW1) gW1 = ppo_mfma_tile(X + mt * 32, 1, ldx, H1 + nt * 32, kPLdh, 1, kPChunk, gW1);
+      {
+        float sgb = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) sgb += H1[(wave * 16 + s) * kPLdh + lane];
+        gb1p += sgb;
       }
 #ifdef FW_PPO_PROF
       pf_net += PPO_T() - pf2;
@@ -419,36 +410,58 @@ __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(
 #ifdef FW_PPO_PROF
     const long long pf3 = PPO_T();
 #endif
-    // ---- finish the bias gradients: sum the four row-block partials ----
-#pragma unroll
-    for (int n = 0; n < 2; ++n) { bred[((n * 2 + 0) * 4 + wave) * kPH + lane] = gb1p[n]; bred[((n * 2 + 1) * 4 + wave) * kPH + lane] = gb2p[n]; }
+    // ---- finish the bias gradients: sum the four row-block partials; reduce the per-sample partials of wave 0 ----
     __syncthreads();
-    float gb1[2] = {0.f, 0.f}, gb2[2] = {0.f, 0.f};
+    bred[wave * kPH + lane] = gb1p; bred[(4 + wave) * kPH + lane] = gb2p;
+    __syncthreads();
+    float gb1 = 0.f, gb2 = 0.f;
     if (t < kPH) {
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { gb1[n] += bred[((n * 2 + 0) * 4 + q) * kPH + t]; gb2[n] += bred[((n * 2 + 1) * 4 + q) * kPH + t]; }
+      for (int q = 0; q < 4; ++q) { gb1 += bred[q * kPH + t]; gb2 += bred[(4 + q) * kPH + t]; }
     }
-    // entropy bonus: entropy_loss = -mean(sum_k (c + log_std_k)) -> d/dlog_std_k = -ent_coef
-    const float my_gls = (t == 0 ? gls[0] : t == 1 ? gls[1] : t == 2 ? gls[2] : gls[3]) - H.ent_coef;
+    float my_gbo = 0.f, my_gls = 0.f;
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < KO; ++k) { const float sfull = ppo_wave_sum(gbo[k]); if (lane == k) my_gbo = sfull; }
+      if (NET == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float sfull = ppo_wave_sum(gls[k]); if (lane == k) my_gls = sfull; }
+        my_gls -= H.ent_coef;        // entropy bonus: entropy_loss = -mean(sum_k (c + log_std_k)) -> d/dlog_std_k = -ent_coef
+      }
+    }
 
-    // ---- global gradient norm over everything this block holds (each element counted by its owner) ----
+    // ---- global gradient norm: own elements, then the other network's partial ----
     float ss = 0.f;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const int KO = n == 0 ? 4 : 1;
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        ss += gW2[n][v] * gW2[n][v];
-        if (hasW1 && mt * 32 + ppo_acc_row(v) < D) ss += gW1[n][v] * gW1[n][v];
-        if (hasWo && r < KO) ss += gWo[n][v] * gWo[n][v];
-      }
-      if (t < kPH) ss += gb1[n] * gb1[n] + gb2[n] * gb2[n];
-      if (t < KO) { const float g = t == 0 ? gbo[n][0] : t == 1 ? gbo[n][1] : t == 2 ? gbo[n][2] : gbo[n][3]; ss += g * g; }
+    for (int v = 0; v < 16; ++v) {
+      ss += gW2[v] * gW2[v];
+      if (hasW1 && mt * 32 + ppo_acc_row(v) < D) ss += gW1[v] * gW1[v];
+      if (hasWo && r < KO) ss += gWo[v] * gWo[v];
     }
-    if (t < 4) ss += my_gls * my_gls;
-    const float total_norm = sqrtf(ppo_block_sum(ss, red));
+    if (t < kPH) ss += gb1 * gb1 + gb2 * gb2;
+    if (t < KO) ss += my_gbo * my_gbo;
+    if (NET == 0 && t < 4) ss += my_gls * my_gls;
+    const float ss_mine = ppo_block_sum(ss, red);
+    float ss_other = 0.f;
+    {
+      // one 64-bit word per block and minibatch parity: (minibatch + 1) << 32 | float bits
+      unsigned long long* mine = A.xch + (mb & 1) * 2 + NET;
+      unsigned long long* other = A.xch + (mb & 1) * 2 + (1 - NET);
+      if (t == 0) {
+        __hip_atomic_store(mine, ((unsigned long long)(unsigned)(mb + 1) << 32) | (unsigned long long)__float_as_uint(ss_mine),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long w = 0;
+        long long spins = 0;
+        do {
+          w = __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (++spins > (1ll << 26)) __builtin_trap();      // the partner block is gone: fail loudly instead of hanging
+        } while ((unsigned)(w >> 32) != (unsigned)(mb + 1));
+        red[4] = __uint_as_float((unsigned)w);
+      }
+      __syncthreads();
+      ss_other = red[4];
+    }
+    const float total_norm = sqrtf(ss_mine + ss_other);
     const float clipc = fminf(H.max_grad_norm / (total_norm + 1e-6f), 1.0f);
 
     // ---- Adam on the elements each lane holds.  The moments live in global memory (L2) in "slot" order
@@ -480,40 +493,31 @@ __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(
 #pragma unroll
       for (int v = 0; v < 16; ++v) { float* w = lds_of(v); if (w) *w -= upd[v]; }
     };
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const int KO = n == 0 ? 4 : 1;
-      const PpoNetLds& W = N[n];
-      adam_tile(gW2[n], ppo_tile_slot(n, 0, wave, lane), [&](int v) { return W.W2 + (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r; });
-      if (hasW1) adam_tile(gW1[n], ppo_tile_slot(n, 1, wave, lane),
-                           [&](int v) { const int i = mt * 32 + ppo_acc_row(v); return i < D ? W.W1 + i * kPH + nt * 32 + r : (float*)nullptr; });
-      if (hasWo) adam_tile(gWo[n], ppo_tile_slot(n, 2, wave, lane),
-                           [&](int v) { return r < KO ? W.Wo + (wave * 32 + ppo_acc_row(v)) * KO + r : (float*)nullptr; });
-    }
+    adam_tile(gW2, ppo_tile_slot(n, 0, wave, lane), [&](int v) { return W.W2 + (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r; });
+    if (hasW1) adam_tile(gW1, ppo_tile_slot(n, 1, wave, lane),
+                         [&](int v) { const int i = mt * 32 + ppo_acc_row(v); return i < D ? W.W1 + i * kPH + nt * 32 + r : (float*)nullptr; });
+    if (hasWo) adam_tile(gWo, ppo_tile_slot(n, 2, wave, lane),
+                         [&](int v) { return r < KO ? W.Wo + (wave * 32 + ppo_acc_row(v)) * KO + r : (float*)nullptr; });
     {
-      // scalars: slot q * 256 + t for q = b1, b2, bo of both nets and log_std; the owner test only gates the LDS write
-      float gs[7], *ws[7], mm[7], vv[7];
+      // scalars: slot q * 256 + t for q = 3 net + {b1, b2, bo} and q = 6 (log_std, pi block); the owner test only gates the LDS write
+      constexpr int NQ = NET == 0 ? 4 : 3;
+      float gs[NQ], *ws[NQ], mm[NQ], vv[NQ];
+      int sl[NQ];
+      gs[0] = gb1; ws[0] = t < kPH ? W.b1 + t : nullptr; sl[0] = kPTileSlots + (n * 3 + 0) * kPThreads + t;
+      gs[1] = gb2; ws[1] = t < kPH ? W.b2 + t : nullptr; sl[1] = kPTileSlots + (n * 3 + 1) * kPThreads + t;
+      gs[2] = my_gbo; ws[2] = t < KO ? W.bo + t : nullptr; sl[2] = kPTileSlots + (n * 3 + 2) * kPThreads + t;
+      if (NET == 0) { gs[NQ - 1] = my_gls; ws[NQ - 1] = t < 4 ? log_std + t : nullptr; sl[NQ - 1] = kPTileSlots + 6 * kPThreads + t; }
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const int KO = n == 0 ? 4 : 1;
-        gs[n * 3 + 0] = gb1[n]; ws[n * 3 + 0] = t < kPH ? N[n].b1 + t : nullptr;
-        gs[n * 3 + 1] = gb2[n]; ws[n * 3 + 1] = t < kPH ? N[n].b2 + t : nullptr;
-        gs[n * 3 + 2] = t == 0 ? gbo[n][0] : t == 1 ? gbo[n][1] : t == 2 ? gbo[n][2] : gbo[n][3];
-        ws[n * 3 + 2] = t < KO ? N[n].bo + t : nullptr;
-      }
-      gs[6] = my_gls; ws[6] = t < 4 ? log_std + t : nullptr;
-      const int sbase = kPTileSlots + t;
+      for (int q = 0; q < NQ; ++q) { mm[q] = mom_m[sl[q]]; vv[q] = mom_v[sl[q]]; }
 #pragma unroll
-      for (int q = 0; q < 7; ++q) { mm[q] = mom_m[sbase + q * kPThreads]; vv[q] = mom_v[sbase + q * kPThreads]; }
-#pragma unroll
-      for (int q = 0; q < 7; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const float gg = gs[q] * clipc;
         mm[q] = H.beta1 * mm[q] + (1.0f - H.beta1) * gg; vv[q] = H.beta2 * vv[q] + (1.0f - H.beta2) * gg * gg;
       }
 #pragma unroll
-      for (int q = 0; q < 7; ++q) { mom_m[sbase + q * kPThreads] = mm[q]; mom_v[sbase + q * kPThreads] = vv[q]; }
+      for (int q = 0; q < NQ; ++q) { mom_m[sl[q]] = mm[q]; mom_v[sl[q]] = vv[q]; }
 #pragma unroll
-      for (int q = 0; q < 7; ++q) if (ws[q]) *ws[q] -= c1 * mm[q] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv[q]) * sc2 + H.eps);
+      for (int q = 0; q < NQ; ++q) if (ws[q]) *ws[q] -= c1 * mm[q] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv[q]) * sc2 + H.eps);
     }
     __syncthreads();
 #ifdef FW_PPO_PROF
@@ -522,31 +526,38 @@ __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(
   }
 
   // ---- write the weights back, report the losses ----
-  for (int n = 0; n < 2; ++n) {
-    const int KO = n == 0 ? 4 : 1;
-    for (int i = t; i < Dp * kPH; i += kPThreads) params[oW1[n] + i] = N[n].W1[i];
-    for (int i = t; i < kPH; i += kPThreads) { params[ob1[n] + i] = N[n].b1[i]; params[ob2[n] + i] = N[n].b2[i]; }
-    for (int i = t; i < kPH * kPH; i += kPThreads) params[oW2[n] + i] = N[n].W2[(i >> 6) * kPLdh + (i & 63)];
-    for (int i = t; i < kPH * KO + KO; i += kPThreads) params[oWo[n] + i] = N[n].Wo[i];
-  }
-  if (t < 4) params[oLs + t] = log_std[t];
-  const float pl = ppo_block_sum(acc_pl, red), vl = ppo_block_sum(acc_vl, red);
-  if (t == 0 && loss_acc) {
-    float ent = 0.f;
-    for (int k = 0; k < 4; ++k) ent += 1.4189385332046727f + log_std[k];
-    loss_acc[0] += pl * invB;            // sums over minibatches of the per-minibatch means
-    loss_acc[1] += vl * invB;
-    loss_acc[2] += -ent * (float)n_mb;   // entropy loss at the final log_std (it is state-independent)
+  for (int i = t; i < Dp * kPH; i += kPThreads) params[oW1 + i] = W.W1[i];
+  for (int i = t; i < kPH; i += kPThreads) { params[ob1 + i] = W.b1[i]; params[ob2 + i] = W.b2[i]; }
+  for (int i = t; i < kPH * kPH; i += kPThreads) params[oW2 + i] = W.W2[(i >> 6) * kPLdh + (i & 63)];
+  for (int i = t; i < kPH * KO + KO; i += kPThreads) params[oWo + i] = W.Wo[i];
+  if (NET == 0 && t < 4) params[oLs + t] = log_std[t];
+  const float lsum = ppo_block_sum(acc_l, red);
+  if (t == 0 && A.loss_acc) {
+    if (NET == 0) {
+      float ent = 0.f;
+      for (int k = 0; k < 4; ++k) ent += 1.4189385332046727f + log_std[k];
+      A.loss_acc[0] += lsum * invB;          // sums over minibatches of the per-minibatch means
+      A.loss_acc[2] += -ent * (float)n_mb;   // entropy loss at the final log_std (it is state-independent)
+    } else {
+      A.loss_acc[1] += lsum * invB;
+    }
 #ifdef FW_PPO_PROF
-    loss_acc[3] = (float)pf_stats / n_mb; loss_acc[4] = (float)pf_gather / n_mb; loss_acc[5] = (float)pf_net / n_mb; loss_acc[6] = (float)pf_adam / n_mb;
+    float* pr = A.loss_acc + 3 + NET * 4;
+    pr[0] = (float)pf_stats / n_mb; pr[1] = (float)pf_gather / n_mb; pr[2] = (float)pf_net / n_mb; pr[3] = (float)pf_adam / n_mb;
 #endif
   }
 }
 
+// grid = 2 blocks (block 0: policy network, block 1: value network) x 256 threads; dynamic LDS = ppo_lds_bytes().
+__global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(PpoArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  if (blockIdx.x == 0) ppo_net_body<0>(A, lds); else ppo_net_body<1>(A, lds);
+}
+
 inline size_t ppo_lds_bytes(int D) {
   const int Dp = (D + 1) & ~1, ldx = Dp + 1;
-  size_t f = (size_t)ppo_net_lds_floats(Dp, 4) + ppo_net_lds_floats(Dp, 1) + 4 + (size_t)kPChunk * ldx + 64 + 2 * (size_t)kPChunk * kPLdh +
-             3 * (size_t)kPChunk * 4 + 16 * kPH + 8 + kPChunk;
+  size_t f = (size_t)ppo_net_lds_floats(Dp, 4) + 4 + (size_t)kPChunk * ldx + 64 + 2 * (size_t)kPChunk * kPLdh +
+             3 * (size_t)kPChunk * 4 + 8 * kPH + 8;
   return f * sizeof(float);
 }
 

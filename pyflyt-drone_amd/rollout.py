@@ -341,7 +341,7 @@ class FusedPpoUpdate:
         self._flat_of_slot = torch.as_tensor(smap[owned], dtype=torch.long, device=dev)    # ... and their flat indices
         self.mom_m = torch.zeros(ns, dtype=torch.float32, device=dev)                      # slot order (what the kernel sees)
         self.mom_v = torch.zeros_like(self.mom_m)
-        self.loss = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(16, dtype=torch.float32, device=dev)
 
     @staticmethod
     def applies(policy, cfg, obs_dim: int, batch_size: int, device) -> bool:

@@ -15,7 +15,7 @@ for D, B in ((28, 128), (28, 64), (56, 64), (28, 256)):
     obs = torch.randn((S, D), device="cuda", generator=g); act = torch.randn((S, 4), device="cuda", generator=g)
     lp = torch.randn(S, device="cuda", generator=g) - 4; adv = torch.randn(S, device="cuda", generator=g); ret = torch.randn(S, device="cuda", generator=g)
     perm = torch.randint(0, S, (n_mb * B,), device="cuda", generator=g, dtype=torch.int32)
-    loss = torch.zeros(8, device="cuda")
+    loss = torch.zeros(16, device="cuda")
     H = R._PpoHyper(lr=3e-4, clip_range=0.2, ent_coef=0.001, vf_coef=0.5, max_grad_norm=0.5, beta1=0.9, beta2=0.999, eps=1e-5, norm_adv=1, step0=0)
     def run():
         rc = L.fw_ppo_update(R._p(flat), R._p(m), R._p(v), R._p(obs), R._p(act), R._p(lp), R._p(adv), R._p(ret), R._p(perm), n_mb, B, D,
@@ -24,4 +24,4 @@ for D, B in ((28, 128), (28, 64), (56, 64), (28, 256)):
     run(); torch.cuda.synchronize()
     t0 = time.perf_counter(); run(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     l = loss.tolist()
-    print(f"D={D} B={B}: {dt / n_mb * 1e6:.1f} us/minibatch; cycles/minibatch: stats {l[3]:.0f} gather {l[4]:.0f} nets {l[5]:.0f} norm+adam {l[6]:.0f}", flush=True)
+    print(f"D={D} B={B}: {dt / n_mb * 1e6:.1f} us/minibatch; cycles/minibatch pi: stats {l[3]:.0f} gather {l[4]:.0f} net {l[5]:.0f} norm+adam {l[6]:.0f} | V: gather {l[8]:.0f} net {l[9]:.0f} norm+adam {l[10]:.0f}", flush=True)
