@@ -358,6 +358,24 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
                       int32_t n_minibatches, int32_t batch_size, int32_t obs_dim, const fw_ppo_hyper* hyper,
                       float* loss_acc, void* hip_stream);
 
+/* Rollout collection between two env steps (SB3 OnPolicyAlgorithm.collect_rollouts + VecNormalize reward path,
+ * train/train_Fixedwing_Waypoints_v3.py:260,293-310), for the same MlpPolicy / flat parameter image as fw_ppo_update.
+ * fw_policy_act: obs[N,obs_dim] (normalised, float32) -> for `nets` bit 0 (policy): act_raw[N,4] = mean + sigma * z
+ *   (z ~ N(0,1) from Philox(rng[0] = seed; rng[1] = draw counter, global env id = env_offset + row); mean if
+ *   `deterministic`), logp[N], act_env[N,4] = clip(act_raw, +-1) in the env dtype (the fw_step input), and obs copied to
+ *   obs_copy (rollout buffer, may be NULL); for bit 1 (value): value[N].
+ * fw_rollout_post: VecNormalize.step_wait's reward path + the bootstrap of truncated episodes:
+ *   returns = returns * gamma + reward; running variance of `returns` (if training && norm_reward);
+ *   rew_out = clip(reward / sqrt(var + epsilon), +-clip_reward) (+ gamma * tvalue where truncated && !terminated);
+ *   start_out = terminated | truncated; returns = 0 where done; rng[1] += 1 (rng may be NULL). */
+int32_t fw_policy_act(const float* params, const float* obs, int32_t N, int32_t obs_dim, int32_t nets, int32_t deterministic,
+                      const uint64_t* rng, int64_t env_offset, float* obs_copy, float* act_raw, void* act_env,
+                      int32_t act_is_f64, float* logp, float* value, void* hip_stream);
+int32_t fw_rollout_post(const void* reward, int32_t rew_is_f64, const uint8_t* terminated, const uint8_t* truncated,
+                        const float* tvalue, double* returns, double* ret_mean, double* ret_var, double* ret_count,
+                        int32_t N, int32_t training, int32_t norm_reward, double gamma, float clip_reward, float epsilon,
+                        float* rew_out, float* start_out, uint64_t* rng, void* hip_stream);
+
 int32_t fw_num_envs(fw_handle h);
 const char* fw_last_error(fw_handle h); /* h may be NULL: last create/validate error */
 int32_t fw_destroy(fw_handle h);

@@ -64,6 +64,8 @@ def save(path: str, ppo, include_env_state: bool = True) -> str:
             sd["last_obs"] = ppo.last_obs.detach().cpu()
             sd["last_starts"] = ppo.last_starts.detach().cpu()
         sd["sampler_rng_state"] = ppo.gen.get_state().cpu()        # action-sampling generator: resume draws the same actions
+        if getattr(ppo, "_collect_fused", False):
+            sd["collect_rng"] = ppo._rng.detach().cpu()             # (seed, draw counter) of fw_policy_act
     tmp = path + ".tmp"
     torch.save(sd, tmp)
     os.replace(tmp, path)                     # never leave a half-written checkpoint behind
@@ -103,6 +105,8 @@ def load(path: str, ppo, reset_num_timesteps: bool = True, restore_env_state: bo
                 ppo.last_values = torch.zeros(ppo.env.num_envs, dtype=torch.float32, device=ppo.device)
         if "sampler_rng_state" in sd:
             ppo.gen.set_state(sd["sampler_rng_state"])
+        if "collect_rng" in sd and getattr(ppo, "_collect_fused", False):
+            ppo._rng.copy_(sd["collect_rng"].to(ppo.device))
     return sd
 
 
@@ -113,6 +117,7 @@ def set_parameters(path: str, ppo) -> None:
     ppo.policy.load_state_dict(sd["policy"])
     ppo.optimizer.load_state_dict(sd["optimizer"])
     ppo._g_update = None                     # new optimiser state tensors: the captured update graph is stale
+    ppo._flat_current = False
 
 
 def save_vecnormalize(path: str, env) -> str:

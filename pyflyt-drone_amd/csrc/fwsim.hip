@@ -14,6 +14,7 @@
 #include "fwsim_device.hpp"
 #include "fwsim_rollout.hpp"
 #include "fwsim_ppo.hpp"
+#include "fwsim_collect.hpp"
 #include "fwsim_objlock.hpp"
 
 using namespace fwsim;
@@ -1332,6 +1333,38 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   A.perm = perm; A.n_mb = n_minibatches; A.B = batch_size; A.D = obs_dim; A.loss_acc = loss_acc; A.xch = xch_dev[dev];
   std::memcpy(&A.H, hyper, sizeof A.H);
   hipLaunchKernelGGL(fw_ppo_update_kernel, dim3(2), dim3(kPThreads), lds, st, A);
+  HIP_TRY((fw_env*)nullptr, hipGetLastError());
+  return FW_OK;
+}
+
+int32_t fw_policy_act(const float* params, const float* obs, int32_t N, int32_t obs_dim, int32_t nets, int32_t deterministic,
+                      const uint64_t* rng, int64_t env_offset, float* obs_copy, float* act_raw, void* act_env, int32_t act_is_f64,
+                      float* logp, float* value, void* hip_stream) {
+  if (!params || !obs || N <= 0 || obs_dim <= 0 || obs_dim > 64 || (nets & ~3) || !nets) { g_err = "fw_policy_act: bad arguments"; return FW_EINVAL; }
+  if ((nets & 1) && (!act_raw || !act_env || !logp || (!deterministic && !rng))) { g_err = "fw_policy_act: policy outputs missing"; return FW_EINVAL; }
+  if ((nets & 2) && !value) { g_err = "fw_policy_act: value output missing"; return FW_EINVAL; }
+  const size_t lds = act_lds_bytes(obs_dim);
+  HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_policy_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  ActArgs A;
+  A.params = params; A.obs = obs; A.N = N; A.D = obs_dim; A.nets = nets; A.deterministic = deterministic; A.act_is_f64 = act_is_f64;
+  A.rng = rng; A.env_offset = env_offset; A.obs_copy = obs_copy; A.act_raw = act_raw; A.act_env = act_env; A.logp = logp; A.value = value;
+  hipLaunchKernelGGL(fw_policy_act_kernel, dim3((N + kPChunk - 1) / kPChunk, 2), dim3(kPThreads), lds, (hipStream_t)hip_stream, A);
+  HIP_TRY((fw_env*)nullptr, hipGetLastError());
+  return FW_OK;
+}
+
+int32_t fw_rollout_post(const void* reward, int32_t rew_is_f64, const uint8_t* terminated, const uint8_t* truncated, const float* tvalue,
+                        double* returns, double* ret_mean, double* ret_var, double* ret_count, int32_t N, int32_t training,
+                        int32_t norm_reward, double gamma, float clip_reward, float epsilon, float* rew_out, float* start_out,
+                        uint64_t* rng, void* hip_stream) {
+  if (!reward || !terminated || !truncated || !tvalue || !returns || !ret_mean || !ret_var || !ret_count || !rew_out || !start_out || N <= 0) {
+    g_err = "fw_rollout_post: bad arguments"; return FW_EINVAL;
+  }
+  PostArgs A;
+  A.reward = reward; A.rew_is_f64 = rew_is_f64; A.terminated = terminated; A.truncated = truncated; A.tvalue = tvalue; A.returns = returns;
+  A.ret_mean = ret_mean; A.ret_var = ret_var; A.ret_count = ret_count; A.N = N; A.training = training; A.norm_reward = norm_reward;
+  A.gamma = gamma; A.clip_reward = clip_reward; A.epsilon = epsilon; A.rew_out = rew_out; A.start_out = start_out; A.rng = rng;
+  hipLaunchKernelGGL(fw_rollout_post_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, A);
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;
 }

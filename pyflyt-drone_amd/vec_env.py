@@ -53,6 +53,7 @@ class FixedwingVecEnv:
         self.device = dev
         self.cfg = cfg.copy()
         self.num_envs = int(num_envs)
+        self.global_env_offset = int(global_env_offset)
         self.obs_dim = K.obs_dim(cfg)
         self.np_dtype = np.float64 if cfg.dtype == K.FW_F64 else np.float32
         self.torch_dtype = torch.float64 if cfg.dtype == K.FW_F64 else torch.float32

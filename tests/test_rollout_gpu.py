@@ -171,3 +171,117 @@ def test_fused_ppo_update_rejects_what_it_cannot_run():
     assert L.fw_ppo_update(*args, 1, 100, 28, C.byref(H), None, None) == K.FW_EINVAL      # batch not a multiple of 64
     assert L.fw_ppo_update(*args, 1, 64, 65, C.byref(H), None, None) == K.FW_EINVAL       # obs_dim too large
     assert L.fw_ppo_update(*args, 0, 64, 28, C.byref(H), None, None) == K.FW_EINVAL
+
+
+def _flat_params(pol, d):
+    f = R.FusedPpoUpdate(pol, torch.optim.Adam(pol.parameters()), d)
+    f.load_params_from_torch()
+    return f.flat
+
+
+@pytest.mark.parametrize("d,n,dtype", [(28, 4096, torch.float64), (56, 1000, torch.float32), (27, 65, torch.float64)])
+def test_fw_policy_act_matches_the_torch_policy(d, n, dtype):
+    """Deterministic mode is the torch forward to fp32 rounding; sampling mode draws unit normals, reports the matching
+    log-prob, clips the env copy of the action and fills the rollout-buffer slots."""
+    from pyflyt_drone_amd import _lib
+    import ctypes as C
+    L = _lib.lib()
+    torch.manual_seed(d)
+    pol = R.MlpPolicy(d).cuda()
+    with torch.no_grad():
+        pol.log_std.copy_(torch.tensor([-0.5, 0.0, 0.3, -1.0]))
+        for p in pol.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    flat = _flat_params(pol, d)
+    obs = (torch.randn((n, d), device="cuda") * 2).clamp(-10, 10)
+    rng = torch.tensor([1234, 7], dtype=torch.int64, device="cuda")
+    oc, ar = torch.zeros_like(obs), torch.zeros((n, 4), device="cuda")
+    ae, lp, val = torch.zeros((n, 4), device="cuda", dtype=dtype), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    def act(det, nets=3):
+        _lib.check(L.fw_policy_act(R._p(flat), R._p(obs), n, d, nets, det, R._p(rng), 0, R._p(oc), R._p(ar), R._p(ae), int(dtype == torch.float64),
+                                   R._p(lp), R._p(val), None))
+    act(1)
+    with torch.no_grad():
+        a0, v0, lp0 = pol(obs, deterministic=True)
+    torch.testing.assert_close(ar, a0, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(val, v0, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(lp, lp0, rtol=1e-5, atol=1e-5)
+    assert torch.equal(oc, obs)
+    torch.testing.assert_close(ae.float(), a0.clamp(-1, 1), rtol=1e-4, atol=2e-5)
+    act(0)
+    with torch.no_grad():
+        z = (ar - a0) / torch.exp(pol.log_std)
+        lp1 = pol._log_prob(ar, a0, pol.log_std)
+    torch.testing.assert_close(lp, lp1, rtol=1e-3, atol=2e-3)
+    if n >= 1000:
+        assert abs(float(z.mean())) < 0.05 and abs(float(z.std()) - 1.0) < 0.05
+        assert abs(float((z[:, 0] * z[:, 1]).mean())) < 0.06                      # components are independent
+    assert float(ae.abs().max()) <= 1.0
+    ar_first = ar.clone()
+    act(0)
+    assert torch.equal(ar, ar_first)                                              # counter-based: same (seed, draw) -> same noise
+    rng[1] += 1
+    act(0)
+    assert not torch.equal(ar, ar_first)
+    before = val.clone(); val.zero_(); ar.zero_()
+    act(0, nets=2)                                                                # value block only
+    assert torch.equal(val, before) and float(ar.abs().max()) == 0.0
+
+
+def test_fw_rollout_post_matches_vecnormalize_reward_path():
+    from pyflyt_drone_amd import _lib
+    L = _lib.lib()
+    n = 3000
+    g = torch.Generator().manual_seed(3)
+
+    class V:
+        device, num_envs, obs_dim = torch.device("cuda"), n, 5
+    ref = R.VecNormalizeDevice(V(), use_fused_kernel=False)
+    ret = torch.zeros(n, dtype=torch.float64, device="cuda")
+    mean, var, cnt = (x.clone() for x in (ref.ret_rms.mean, ref.ret_rms.var, ref.ret_rms.count))
+    rng = torch.tensor([5, 0], dtype=torch.int64, device="cuda")
+    for step in range(6):
+        rew = (torch.randn(n, generator=g, dtype=torch.float64) * 30).cuda()
+        term = (torch.rand(n, generator=g) < 0.1).to(torch.uint8).cuda()
+        trunc = (torch.rand(n, generator=g) < 0.1).to(torch.uint8).cuda()
+        tv = torch.randn(n, generator=g).cuda()
+        # reference: the torch statements of VecNormalizeDevice.step + PPO._rollout_body
+        ref.returns.mul_(ref.gamma).add_(rew); ref.ret_rms.update(ref.returns)
+        rn = (rew / torch.sqrt(ref.ret_rms.var + ref.epsilon)).clamp(-10, 10).float()
+        done = (term | trunc).bool()
+        rn = rn + 0.99 * tv * (trunc.bool() & ~term.bool()).float()
+        ref.returns.masked_fill_(done, 0.0)
+        out, start = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        _lib.check(L.fw_rollout_post(R._p(rew), 1, R._p(term), R._p(trunc), R._p(tv), R._p(ret), R._p(mean), R._p(var), R._p(cnt), n, 1, 1,
+                                     0.99, 10.0, 1e-8, R._p(out), R._p(start), R._p(rng), None))
+        torch.testing.assert_close(out, rn, rtol=1e-5, atol=1e-5)
+        assert torch.equal(start.bool(), done)
+        torch.testing.assert_close(ret, ref.returns, rtol=1e-12, atol=1e-12)
+        torch.testing.assert_close(var, ref.ret_rms.var, rtol=1e-10, atol=0)
+        torch.testing.assert_close(cnt, ref.ret_rms.count)
+    assert int(rng[1]) == 6
+
+
+def test_fused_collection_fills_the_buffers_like_the_torch_path():
+    """Whole rollouts through PPO.collect_rollouts with fw_policy_act / fw_rollout_post (graph-replayed) against the
+    module: stored log-probs and values are those of the stored (obs, action) pairs, episode starts follow the env's
+    done flags, both normalisers see every sample, and the reward statistics match a torch-path run of the same length."""
+    out = {}
+    for fused in (True, False):
+        env = P.FixedwingVecEnv(K.train_waypoints_v3_config(flight_dome_size=40.0), 1024, seed=9)
+        ppo = R.PPO(R.VecNormalizeDevice(env), R.PPOConfig(n_steps=8, batch_size=1024, n_epochs=1, seed=9, fused_collect=fused))
+        assert ppo._collect_fused == fused
+        for _ in range(4):
+            ppo.collect_rollouts()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            v, lp, _ = ppo.policy.evaluate_actions(ppo.buf_obs.reshape(-1, env.obs_dim), ppo.buf_act.reshape(-1, 4))
+        torch.testing.assert_close(lp.reshape(8, 1024), ppo.buf_logp, rtol=1e-3, atol=2e-3)
+        torch.testing.assert_close(v.reshape(8, 1024), ppo.buf_val, rtol=1e-4, atol=1e-4)
+        assert float(ppo.env.obs_rms.count) == pytest.approx(1e-4 + (4 * 8 + 1) * 1024)
+        assert float(ppo.env.ret_rms.count) == pytest.approx(1e-4 + 4 * 8 * 1024)
+        assert torch.isfinite(ppo.buf_rew).all() and torch.isfinite(ppo.adv).all()
+        assert set(ppo.buf_start.unique().tolist()) <= {0.0, 1.0}
+        out[fused] = (float(ppo.env.ret_rms.var), float(ppo.buf_start.mean()), float(ppo.buf_act.std()))
+    assert out[True][0] == pytest.approx(out[False][0], rel=0.35)         # same reward scale (different action noise streams)
+    assert out[True][2] == pytest.approx(out[False][2], rel=0.05)
