@@ -371,6 +371,13 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
 int32_t fw_policy_act(const float* params, const float* obs, int32_t N, int32_t obs_dim, int32_t nets, int32_t deterministic,
                       const uint64_t* rng, int64_t env_offset, float* obs_copy, float* act_raw, void* act_env,
                       int32_t act_is_f64, float* logp, float* value, void* hip_stream);
+/* V(normalised terminal_observation) for the envs whose episode was truncated but not terminated (the only ones SB3
+ * bootstraps): terminal_obs[N,obs_dim] is the env's raw buffer (fw_step's terminal_obs), normalised on load with
+ * (mean, var, clip, eps) exactly like fw_normalize_obs; value[i] is written for every row of a 64-row block that
+ * contains such an env and left untouched elsewhere. */
+int32_t fw_policy_terminal_value(const float* params, const void* terminal_obs, int32_t obs_is_f64, int32_t N, int32_t obs_dim,
+                                 const double* mean, const double* var, float clip, float eps, const uint8_t* terminated,
+                                 const uint8_t* truncated, float* value, void* hip_stream);
 int32_t fw_rollout_post(const void* reward, int32_t rew_is_f64, const uint8_t* terminated, const uint8_t* truncated,
                         const float* tvalue, double* returns, double* ret_mean, double* ret_var, double* ret_count,
                         int32_t N, int32_t training, int32_t norm_reward, double gamma, float clip_reward, float epsilon,

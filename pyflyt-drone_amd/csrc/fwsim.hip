@@ -1271,7 +1271,7 @@ int32_t fw_gae(const float* rewards, const float* values, const float* episode_s
 
 int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t D, double* mean, double* var,
                          double* count, int32_t update, float clip, float eps, float* obs_out, void* hip_stream) {
-  if (!obs || !mean || !var || !count || !obs_out || N <= 0 || D <= 0 || D > 4096) { g_err = "fw_normalize_obs: bad arguments"; return FW_EINVAL; }
+  if (!obs || !mean || !var || !count || !obs_out || N <= 0 || D <= 0 || D > 256) { g_err = "fw_normalize_obs: bad arguments"; return FW_EINVAL; }
   hipStream_t st = (hipStream_t)hip_stream;
   if (update) {
     // partial sums live in a small per-device scratch buffer (allocated once; never freed in a launch path)
@@ -1281,17 +1281,17 @@ int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t 
     int dev = 0;
     HIP_TRY((fw_env*)nullptr, hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) { g_err = "device index out of range"; return FW_EINVAL; }
-    const int nblocks = 64;
-    const size_t need = (size_t)nblocks * 2 * D;
+    const int nblocks = N >= 64 * 64 ? 64 : (N + 63) / 64;       // >= 64 rows per block
+    const size_t need = (size_t)64 * 2 * D;
     if (scratch_elems_dev[dev] < need) {
       if (scratch_dev[dev]) (void)hipFree(scratch_dev[dev]);
       HIP_TRY((fw_env*)nullptr, hipMalloc((void**)&scratch_dev[dev], sizeof(double) * need));
       scratch_elems_dev[dev] = need;
     }
     double* scratch = scratch_dev[dev];
-    if (in_is_f64) hipLaunchKernelGGL(fw_obs_moments_kernel<double>, dim3(nblocks), dim3(256), 8 * sizeof(double), st, (const double*)obs, N, D, scratch);
-    else hipLaunchKernelGGL(fw_obs_moments_kernel<float>, dim3(nblocks), dim3(256), 8 * sizeof(double), st, (const float*)obs, N, D, scratch);
-    hipLaunchKernelGGL(fw_obs_merge_kernel, dim3((D + 63) / 64), dim3(64), 0, st, scratch, nblocks, N, D, mean, var, count);
+    if (in_is_f64) hipLaunchKernelGGL(fw_obs_moments_kernel<double>, dim3(nblocks), dim3(256), 0, st, (const double*)obs, N, D, scratch);
+    else hipLaunchKernelGGL(fw_obs_moments_kernel<float>, dim3(nblocks), dim3(256), 0, st, (const float*)obs, N, D, scratch);
+    hipLaunchKernelGGL(fw_obs_merge_kernel, dim3(1), dim3(256), 0, st, scratch, nblocks, N, D, mean, var, count);
   }
   const int total = N * D;
   if (in_is_f64) hipLaunchKernelGGL(fw_obs_normalize_kernel<double>, dim3((total + 255) / 256), dim3(256), 0, st, (const double*)obs, total, D, mean, var, clip, eps, obs_out);
@@ -1348,6 +1348,25 @@ int32_t fw_policy_act(const float* params, const float* obs, int32_t N, int32_t 
   ActArgs A;
   A.params = params; A.obs = obs; A.N = N; A.D = obs_dim; A.nets = nets; A.deterministic = deterministic; A.act_is_f64 = act_is_f64;
   A.rng = rng; A.env_offset = env_offset; A.obs_copy = obs_copy; A.act_raw = act_raw; A.act_env = act_env; A.logp = logp; A.value = value;
+  A.raw = nullptr; A.raw_is_f64 = 0; A.mean = A.var = nullptr; A.clip = A.eps = 0.f; A.terminated = A.truncated = nullptr;
+  hipLaunchKernelGGL(fw_policy_act_kernel, dim3((N + kPChunk - 1) / kPChunk, 2), dim3(kPThreads), lds, (hipStream_t)hip_stream, A);
+  HIP_TRY((fw_env*)nullptr, hipGetLastError());
+  return FW_OK;
+}
+
+int32_t fw_policy_terminal_value(const float* params, const void* terminal_obs, int32_t obs_is_f64, int32_t N, int32_t obs_dim,
+                                 const double* mean, const double* var, float clip, float eps, const uint8_t* terminated,
+                                 const uint8_t* truncated, float* value, void* hip_stream) {
+  if (!params || !terminal_obs || !mean || !var || !terminated || !truncated || !value || N <= 0 || obs_dim <= 0 || obs_dim > 64) {
+    g_err = "fw_policy_terminal_value: bad arguments"; return FW_EINVAL;
+  }
+  const size_t lds = act_lds_bytes(obs_dim);
+  HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_policy_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  ActArgs A;
+  std::memset(&A, 0, sizeof A);
+  A.params = params; A.N = N; A.D = obs_dim; A.nets = 2; A.deterministic = 1; A.value = value;
+  A.raw = terminal_obs; A.raw_is_f64 = obs_is_f64; A.mean = mean; A.var = var; A.clip = clip; A.eps = eps;
+  A.terminated = terminated; A.truncated = truncated;
   hipLaunchKernelGGL(fw_policy_act_kernel, dim3((N + kPChunk - 1) / kPChunk, 2), dim3(kPThreads), lds, (hipStream_t)hip_stream, A);
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;

@@ -25,6 +25,12 @@ struct ActArgs {
   void* act_env;              // [N, 4] clipped to [-1, 1] in the env's dtype (fw_step input)
   float* logp;                // [N]
   float* value;               // [N]
+  // value-of-terminal-observation mode (obs == nullptr): rows are normalised on load from the env's raw buffer and
+  // a block whose 64 rows hold no truncated-but-not-terminated env returns at once (SB3 only bootstraps those)
+  const void* raw; int32_t raw_is_f64;
+  const double *mean, *var;
+  float clip, eps;
+  const uint8_t *terminated, *truncated;
 };
 
 // counter-based N(0,1) x 4 for (env, draw): Philox4x32-10 + Box-Muller (float32)
@@ -51,6 +57,11 @@ __global__ __launch_bounds__(kPThreads) void fw_policy_act_kernel(ActArgs A) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, hh = lane >> 5;
   const int D = A.D, Dp = (D + 1) & ~1, ldx = Dp + 1;
   const int row0 = blockIdx.x * kPChunk;
+  if (!A.obs && A.truncated) {
+    const int row = row0 + (t & 63);
+    const int need = (t < kPChunk && row < A.N && A.truncated[row] && !A.terminated[row]) ? 1 : 0;
+    if (!__syncthreads_or(need)) return;
+  }
 
   float* p = lds;
   PpoNetLds W;
@@ -76,7 +87,13 @@ __global__ __launch_bounds__(kPThreads) void fw_policy_act_kernel(ActArgs A) {
     const int row = row0 + s;
     float x = 0.f;
     if (d < D && row < A.N) {
-      x = A.obs[(size_t)row * D + d];
+      if (A.obs) {
+        x = A.obs[(size_t)row * D + d];
+      } else {
+        const double raw = A.raw_is_f64 ? reinterpret_cast<const double*>(A.raw)[(size_t)row * D + d]
+                                        : (double)reinterpret_cast<const float*>(A.raw)[(size_t)row * D + d];
+        x = fminf(fmaxf((float)((raw - A.mean[d]) / sqrt(A.var[d] + (double)A.eps)), -A.clip), A.clip);
+      }
       if (net == 0 && A.obs_copy) A.obs_copy[(size_t)row * D + d] = x;
     }
     X[e] = x;

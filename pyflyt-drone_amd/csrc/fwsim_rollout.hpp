@@ -37,51 +37,65 @@ __global__ __launch_bounds__(256) void fw_gae_kernel(const float* __restrict__ r
 template <typename TIN>
 __global__ __launch_bounds__(256) void fw_obs_moments_kernel(const TIN* __restrict__ obs, int N, int D,
                                                              double* __restrict__ part /*[gridDim.x][2][D]*/) {
-  // each block reduces rows [r0, r1) for all D columns; thread = (row lane, column)
-  extern __shared__ double sm[];       // [256] scratch per pass
+  // Block b reduces rows [r0, r1).  Thread t handles column t % D of rows r0 + t / D + k * (256 / D): consecutive
+  // threads read consecutive addresses; one LDS reduction over the 256 / D row slots at the end.  (D <= 256)
+  __shared__ double sm1[256], sm2[256];
+  const int t = threadIdx.x;
   const int rows_per_block = (N + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
-  for (int d = 0; d < D; ++d) {
+  const int rpi = 256 / D;
+  const bool on = t < rpi * D;
+  const int col = on ? t % D : 0, rr = on ? t / D : 0;
+  double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;          // two chains: the loads are independent, the adds are not
+  if (on) {
+    int r = r0 + rr;
+    for (; r + rpi < r1; r += 2 * rpi) {
+      const double x0 = (double)obs[(size_t)r * D + col], x1 = (double)obs[(size_t)(r + rpi) * D + col];
+      a0 += x0; b0 += x0 * x0; a1 += x1; b1 += x1 * x1;
+    }
+    if (r < r1) { const double x0 = (double)obs[(size_t)r * D + col]; a0 += x0; b0 += x0 * x0; }
+  }
+  sm1[t] = a0 + a1; sm2[t] = b0 + b1;
+  __syncthreads();
+  if (t < D) {
     double s = 0.0, s2 = 0.0;
-    for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-      double x = (double)obs[(size_t)r * D + d];
-      s += x; s2 += x * x;
-    }
-    // block reduce (wave shuffles then LDS)
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o, 64); s2 += __shfl_down(s2, o, 64); }
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (l == 0) { sm[w] = s; sm[4 + w] = s2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double a = 0, b = 0;
-      for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { a += sm[k]; b += sm[4 + k]; }
-      part[((size_t)blockIdx.x * 2 + 0) * D + d] = a;
-      part[((size_t)blockIdx.x * 2 + 1) * D + d] = b;
-    }
-    __syncthreads();
+    for (int k = 0; k < rpi; ++k) { s += sm1[k * D + t]; s2 += sm2[k * D + t]; }
+    part[((size_t)blockIdx.x * 2 + 0) * D + t] = s;
+    part[((size_t)blockIdx.x * 2 + 1) * D + t] = s2;
   }
 }
 
-// RunningMeanStd.update_from_moments (SB3 common/running_mean_std.py)
-__global__ void fw_obs_merge_kernel(const double* __restrict__ part, int nblocks, int N, int D, double* __restrict__ mean,
-                                    double* __restrict__ var, double* __restrict__ count) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+// RunningMeanStd.update_from_moments (SB3 common/running_mean_std.py); one block of 256 threads:
+// thread (q, d) sums a quarter of the per-block partials of column d (fixed order => reproducible), D <= 64 per pass
+__global__ __launch_bounds__(256) void fw_obs_merge_kernel(const double* __restrict__ part, int nblocks, int N, int D,
+                                                           double* __restrict__ mean, double* __restrict__ var,
+                                                           double* __restrict__ count) {
+  __shared__ double sm1[256], sm2[256];
+  const int t = threadIdx.x, q = t >> 6, dl = t & 63;
   const double cnt = count[0];
-  if (d < D) {
+  for (int d0 = 0; d0 < D; d0 += 64) {
+    const int d = d0 + dl;
     double s = 0, s2 = 0;
-    for (int b = 0; b < nblocks; ++b) { s += part[((size_t)b * 2 + 0) * D + d]; s2 += part[((size_t)b * 2 + 1) * D + d]; }
-    const double bm = s / N;
-    double bv = s2 / N - bm * bm;                // population variance, as np.var
-    bv = bv < 0 ? 0 : bv;
-    const double delta = bm - mean[d];
-    const double tot = cnt + N;
-    const double new_mean = mean[d] + delta * N / tot;
-    const double m2 = var[d] * cnt + bv * N + delta * delta * cnt * N / tot;
-    mean[d] = new_mean;
-    var[d] = m2 / tot;
+    if (d < D)
+      for (int b = q; b < nblocks; b += 4) { s += part[((size_t)b * 2 + 0) * D + d]; s2 += part[((size_t)b * 2 + 1) * D + d]; }
+    sm1[t] = s; sm2[t] = s2;
+    __syncthreads();
+    if (q == 0 && d < D) {
+      s = sm1[dl] + sm1[64 + dl] + sm1[128 + dl] + sm1[192 + dl];
+      s2 = sm2[dl] + sm2[64 + dl] + sm2[128 + dl] + sm2[192 + dl];
+      const double bm = s / N;
+      double bv = s2 / N - bm * bm;                // population variance, as np.var
+      bv = bv < 0 ? 0 : bv;
+      const double delta = bm - mean[d];
+      const double tot = cnt + N;
+      const double new_mean = mean[d] + delta * N / tot;
+      const double m2 = var[d] * cnt + bv * N + delta * delta * cnt * N / tot;
+      mean[d] = new_mean;
+      var[d] = m2 / tot;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) count[0] = cnt + N;
+  if (t == 0) count[0] = cnt + N;
 }
 
 template <typename TIN>

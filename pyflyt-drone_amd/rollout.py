@@ -506,7 +506,7 @@ class PPO:
 
     def _rollout_body_fused(self):
         """collect_rollouts with the between-steps work in two kernels (fw_policy_act, fw_rollout_post) around fw_step and
-        fw_normalize_obs: 8 launches per vec-step instead of ~70 framework ops.  Same data flow as _rollout_body."""
+        fw_normalize_obs: 5 launches per vec-step instead of ~70 framework ops.  Same data flow as _rollout_body."""
         cfg, env, L = self.cfg, self.env, _lib.lib()
         venv, T = env.venv, cfg.n_steps
         st = _stream(self.device)
@@ -516,10 +516,9 @@ class PPO:
             self._act(obs, 3, t=t)                                                   # buffers of step t, clipped action for the env
             raw_obs, rew, term, trunc = venv.step_tensor(self._act_env)
             obs = env._process_obs(raw_obs, update=env.training)                     # fw_normalize_obs -> env.obs_out
-            _lib.check(L.fw_normalize_obs(_p(venv.terminal_obs), int(venv.terminal_obs.dtype == torch.float64), env.num_envs,
-                                          env.obs_dim, _p(env.obs_rms.mean), _p(env.obs_rms.var), _p(env.obs_rms.count), 0,
-                                          float(env.clip_obs), float(env.epsilon), _p(env.tobs_out), st))
-            self._act(env.tobs_out, 2, value_out=self._tval)                         # V(terminal_observation)
+            _lib.check(L.fw_policy_terminal_value(_p(self._fused.flat), _p(venv.terminal_obs), int(venv.terminal_obs.dtype == torch.float64),
+                                                  env.num_envs, env.obs_dim, _p(env.obs_rms.mean), _p(env.obs_rms.var),
+                                                  float(env.clip_obs), float(env.epsilon), _p(term), _p(trunc), _p(self._tval), st))
             nxt = self.buf_start[t + 1] if t + 1 < T else self.last_starts
             _lib.check(L.fw_rollout_post(_p(rew), int(rew.dtype == torch.float64), _p(term), _p(trunc), _p(self._tval),
                                          _p(env.returns), _p(env.ret_rms.mean), _p(env.ret_rms.var), _p(env.ret_rms.count),

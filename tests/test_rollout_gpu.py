@@ -285,3 +285,30 @@ def test_fused_collection_fills_the_buffers_like_the_torch_path():
         out[fused] = (float(ppo.env.ret_rms.var), float(ppo.buf_start.mean()), float(ppo.buf_act.std()))
     assert out[True][0] == pytest.approx(out[False][0], rel=0.35)         # same reward scale (different action noise streams)
     assert out[True][2] == pytest.approx(out[False][2], rel=0.05)
+
+
+def test_fw_policy_terminal_value_bootstraps_only_truncated_rows():
+    from pyflyt_drone_amd import _lib
+    L = _lib.lib()
+    d, n = 28, 1000
+    torch.manual_seed(4)
+    pol = R.MlpPolicy(d).cuda()
+    flat = _flat_params(pol, d)
+    tobs = torch.randn((n, d), device="cuda", dtype=torch.float64) * 5 + 1
+    mean, var = torch.randn(d, device="cuda", dtype=torch.float64), torch.rand(d, device="cuda", dtype=torch.float64) * 4 + 0.1
+    term = torch.zeros(n, dtype=torch.uint8, device="cuda"); trunc = torch.zeros_like(term)
+    trunc[[3, 70, 999]] = 1; term[70] = 1; trunc[500] = 1                       # row 70 is terminated as well: not a timeout
+    val = torch.full((n,), -7.0, device="cuda")
+    _lib.check(L.fw_policy_terminal_value(R._p(flat), R._p(tobs), 1, n, d, R._p(mean), R._p(var), 10.0, 1e-8, R._p(term), R._p(trunc), R._p(val), None))
+    with torch.no_grad():
+        x = ((tobs - mean) / torch.sqrt(var + 1e-8)).float().clamp(-10, 10)
+        ref = pol.predict_values(x)
+    for row in (3, 500, 999):
+        assert float(val[row]) == pytest.approx(float(ref[row]), rel=1e-4, abs=2e-5)
+    blocks_with_timeout = {3 // 64, 500 // 64, 999 // 64}
+    for b in range((n + 63) // 64):
+        rows = slice(b * 64, min(n, b * 64 + 64))
+        if b in blocks_with_timeout:
+            torch.testing.assert_close(val[rows], ref[rows], rtol=1e-4, atol=2e-5)
+        else:
+            assert bool((val[rows] == -7.0).all())                               # skipped blocks leave the buffer alone
