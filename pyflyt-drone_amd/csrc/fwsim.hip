@@ -1327,11 +1327,24 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   if (dev < 0 || dev >= 64) { g_err = "device index out of range"; return FW_EINVAL; }
   if (!xch_dev[dev]) HIP_TRY((fw_env*)nullptr, hipMalloc((void**)&xch_dev[dev], 4 * sizeof(unsigned long long)));
   HIP_TRY((fw_env*)nullptr, hipMemsetAsync(xch_dev[dev], 0, 4 * sizeof(unsigned long long), st));
+  // per-minibatch advantage statistics, computed in parallel up front (scratch grows on demand, outside graph capture)
+  static float* stats_dev[64] = {nullptr};
+  static size_t stats_cap[64] = {0};
+  if (hyper->norm_adv == 1 && batch_size > 1) {
+    if (stats_cap[dev] < (size_t)n_minibatches) {
+      if (stats_dev[dev]) (void)hipFree(stats_dev[dev]);
+      HIP_TRY((fw_env*)nullptr, hipMalloc((void**)&stats_dev[dev], sizeof(float) * 2 * (size_t)n_minibatches));
+      stats_cap[dev] = (size_t)n_minibatches;
+    }
+    hipLaunchKernelGGL(fw_ppo_adv_stats_kernel, dim3(n_minibatches), dim3(64), 0, st, adv, perm, batch_size, stats_dev[dev]);
+  }
   HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   PpoArgs A;
   A.params = params; A.mom_m = mom_m; A.mom_v = mom_v; A.obs = obs; A.act = act; A.old_logp = old_logp; A.adv = adv; A.ret = ret;
   A.perm = perm; A.n_mb = n_minibatches; A.B = batch_size; A.D = obs_dim; A.loss_acc = loss_acc; A.xch = xch_dev[dev];
+  A.adv_stats = stats_dev[dev];
   std::memcpy(&A.H, hyper, sizeof A.H);
+  if (batch_size <= 1 && A.H.norm_adv == 1) A.H.norm_adv = 0;      // SB3 skips the normalisation of single-sample minibatches
   hipLaunchKernelGGL(fw_ppo_update_kernel, dim3(2), dim3(kPThreads), lds, st, A);
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;

@@ -144,6 +144,20 @@ inline void ppo_moment_map(int D, int32_t* flat_of_slot) {
   for (int t = 0; t < 4; ++t) flat_of_slot[kPTileSlots + 6 * kPThreads + t] = oLs + t;
 }
 
+// Advantage statistics of every minibatch, off the sequential path: one 64-lane block per minibatch.
+// (SB3: advantages = (a - a.mean()) / (a.std() + 1e-8) with the unbiased std.)
+__global__ __launch_bounds__(64) void fw_ppo_adv_stats_kernel(const float* __restrict__ adv, const int32_t* __restrict__ perm, int32_t B,
+                                                             float* __restrict__ out) {
+  const int32_t* idx = perm + (size_t)blockIdx.x * B;
+  float s1 = 0.f;
+  for (int i = threadIdx.x; i < B; i += 64) s1 += adv[idx[i]];
+  const float mean = ppo_wave_sum(s1) / (float)B;
+  float s2 = 0.f;
+  for (int i = threadIdx.x; i < B; i += 64) { const float d = adv[idx[i]] - mean; s2 += d * d; }
+  const float var = ppo_wave_sum(s2) / (float)(B > 1 ? B - 1 : 1);
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = mean; out[2 * blockIdx.x + 1] = sqrtf(var); }
+}
+
 // Two workgroups, one per network (pi: block 0, V: block 1) -- the two networks share nothing but the scalar
 // gradient norm that SB3 clips jointly, which the blocks exchange once per minibatch through one 64-bit word
 // each (tag | partial sum of squares, device-scope atomics; both blocks are always co-resident: grid = 2).
@@ -163,6 +177,7 @@ struct PpoArgs {
   PpoHyper H;
   float* loss_acc;                   // [3] += policy, value, entropy loss
   unsigned long long* xch;           // [2 parities][2 blocks], zeroed by the host before the launch
+  const float* adv_stats;            // [n_mb][2] mean, std of each minibatch's advantages (fw_ppo_adv_stats_kernel)
 };
 
 template <int NET>
@@ -217,24 +232,42 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
 #define PPO_T() ((long long)__builtin_readcyclecounter())
 #endif
 
+  // Gather of a 64-sample chunk, software-pipelined: 4 threads per sample, each holding a quarter of the observation
+  // row, one action component and one scalar in registers until the chunk's turn comes.
+  const int gs = t >> 2, gk = t & 3;
+  const int per = (Dp + 3) >> 2, gd0 = gk * per;                          // per <= 16
+  const int cpm = B / kPChunk, total_chunks = n_mb * cpm;
+  float pre_x[16], pre_a = 0.f, pre_s = 0.f;
+  auto prefetch = [&](int g) {
+    const int si = perm[(size_t)g * kPChunk + gs];
+    const float* orow = obs + (size_t)si * D;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const int d = gd0 + j; pre_x[j] = (j < per && d < D) ? orow[d] : 0.f; }
+    pre_s = 0.f;
+    if (NET == 0) {
+      pre_a = act[(size_t)si * 4 + gk];
+      if (gk == 0) pre_s = old_logp[si];
+      else if (gk == 1) {
+        pre_s = adv[si];
+        if (H.norm_adv == 1) { const int m = g / cpm; pre_s = (pre_s - A.adv_stats[2 * m]) / (A.adv_stats[2 * m + 1] + 1e-8f); }
+        else if (H.norm_adv == 2) pre_s = (pre_s - H.adv_mean) / (H.adv_std + 1e-8f);
+      }
+    } else if (gk == 2) pre_s = ret[si];
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const int d = gd0 + j; if (j < per && d < Dp) X[gs * ldx + d] = pre_x[j]; }
+    if (NET == 0) sA[t] = pre_a;
+    sS[t] = pre_s;
+  };
+  int gchunk = 0;
+  prefetch(0);
+
 #pragma unroll 1
   for (int mb = 0; mb < n_mb; ++mb) {
-    const int32_t* idx = perm + (size_t)mb * B;
 #ifdef FW_PPO_PROF
     const long long pf0 = PPO_T();
 #endif
-    // ---- advantage statistics of the minibatch (SB3: (a - mean) / (std + 1e-8), unbiased std); pi only ----
-    float a_mean = 0.f, a_std = 1.f;
-    if (NET == 0) {
-      if (H.norm_adv == 1 && B > 1) {
-        float s1 = 0.f;
-        for (int i = t; i < B; i += kPThreads) s1 += adv[idx[i]];
-        a_mean = ppo_block_sum(s1, red) * invB;
-        float s2 = 0.f;
-        for (int i = t; i < B; i += kPThreads) { float d = adv[idx[i]] - a_mean; s2 += d * d; }
-        a_std = sqrtf(ppo_block_sum(s2, red) / (float)(B - 1));
-      } else if (H.norm_adv == 2) { a_mean = H.adv_mean; a_std = H.adv_std; }
-    }
 #ifdef FW_PPO_PROF
     pf_stats += PPO_T() - pf0;
 #endif
@@ -252,21 +285,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
       const long long pf1 = PPO_T();
 #endif
       __syncthreads();                                                   // the previous chunk's readers of X / sA / sS are done
-      {
-        // 4 threads per sample: each copies a quarter of the observation row, one action component and one scalar
-        const int s = t >> 2, k = t & 3;
-        const int si = idx[c0 + s];
-        const int per = (Dp + 3) >> 2, d0 = k * per;
-        const float* orow = obs + (size_t)si * D;
-        for (int d = d0; d < d0 + per && d < Dp; ++d) X[s * ldx + d] = d < D ? orow[d] : 0.f;
-        float sv = 0.f;
-        if (NET == 0) {
-          sA[t] = act[(size_t)si * 4 + k];
-          if (k == 0) sv = old_logp[si];
-          else if (k == 1) { sv = adv[si]; if (H.norm_adv) sv = (sv - a_mean) / (a_std + 1e-8f); }
-        } else if (k == 2) sv = ret[si];
-        sS[t] = sv;
-      }
+      commit();
+      if (gchunk + 1 < total_chunks) prefetch(gchunk + 1);               // the next chunk's loads fly during this chunk's GEMMs
+      gchunk += 1;
       __syncthreads();
 #ifdef FW_PPO_PROF
       const long long pf2 = PPO_T(); pf_gather += pf2 - pf1;
