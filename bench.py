@@ -138,11 +138,19 @@ def main():
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no HIP device: pyflyt_drone_amd has no CPU fallback"}))
         sys.exit(2)
+    # Rehearsal knobs for a one-GPU box (never set by the driver): FW_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and
+    # FW_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device) for the barrier / max-reduce.
+    if os.environ.get("FW_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("FW_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            td.init_process_group(backend)
     n = args.envs_per_gpu
     cfg = K.train_waypoints_v3_config(dtype=args.dtype)
     env = P.FixedwingVecEnv(cfg, n, device=local_rank, seed=42, global_env_offset=rank * n)
@@ -166,7 +174,7 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if dist:
-        t = torch.tensor([wall], dtype=torch.float64, device=env.device)
+        t = torch.tensor([wall], dtype=torch.float64, device=env.device if backend == "nccl" else "cpu")
         td.all_reduce(t, op=td.ReduceOp.MAX)
         wall = float(t.item())
 
@@ -227,7 +235,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "element-wise fp64 physics at N=4096 is latency/VALU-bound, not HBM-bound (DESIGN.md section 6)"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, n)
         print(json.dumps(out), flush=True)
     if dist:
