@@ -25,14 +25,14 @@ using namespace fwsim;
 
 // K0: mark every env as an un-reset shell (step() before reset() is inert).
 template <typename T>
-__global__ void fw_init_kernel(DevState<T> D) {
+__global__ void fw_init_kernel(DevState<T> D, int tile) {
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= D.npad) return;
-  for (int f = 0; f < RF_COUNT; ++f) D.r[(size_t)f * D.npad + env] = (T)0;
-  D.r[(size_t)(RF_QUAT + 3) * D.npad + env] = (T)1;
-  for (int f = 0; f < IF_COUNT; ++f) D.i[(size_t)f * D.npad + env] = 0;
-  D.i[(size_t)IF_FLAGS * D.npad + env] = FL_TERM;
-  D.i[(size_t)IF_EPISODE * D.npad + env] = -1;
+  for (int f = 0; f < RF_COUNT; ++f) D.r[tile_index(tile, RF_COUNT, f, env)] = (T)0;
+  D.r[tile_index(tile, RF_COUNT, RF_QUAT + 3, env)] = (T)1;
+  for (int f = 0; f < IF_COUNT; ++f) D.i[tile_index(tile, IF_COUNT, f, env)] = 0;
+  D.i[tile_index(tile, IF_COUNT, IF_FLAGS, env)] = FL_TERM;
+  D.i[tile_index(tile, IF_COUNT, IF_EPISODE, env)] = -1;
 }
 
 // Kw: one lane integrates the wind-free warm-up once; resets then copy it.
@@ -195,7 +195,7 @@ enum Phase : int { PH_STEP = 0, PH_WARM = 1, PH_DONE = 2 };
 // OBJ = the ObjLock task (duck / analytic camera / vision shaping, fwsim_objlock.hpp); its state rides in registers.
 template <typename T, bool GENERAL, int G, int TKIND>
 __device__ __forceinline__
-void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> D,
+void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> Dg,
                const T* __restrict__ actions, T* __restrict__ obs, T* __restrict__ reward,
                uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated, T* __restrict__ terminal_obs,
                int32_t* __restrict__ info) {
@@ -211,7 +211,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   // observation is the cached attitude block + the deltas of the freshly sampled waypoints.  No second obs pass, no
   // sampling inside the step loop, and the waves that contain a reset finish with the others.
   constexpr bool DEFER = !GENERAL && TKIND == FW_TASK_WAYPOINTS;
-  const int nblk = (D.npad + EPW - 1) / EPW;         // step blocks; blocks beyond are shadow workers
+  const int nblk = (Dg.npad + EPW - 1) / EPW;        // step blocks; blocks beyond are shadow workers
   FWP(const long long p_t0 = FWP_NOW(); long long p_reset = 0, p_avi = 0, p_task = 0, p_r1 = 0, p_r2 = 0, p_r3 = 0; int p_nreset = 0, p_nhit = 0;)
   // XCD-aware block -> env-block map (G = 8): a wave touches 64 B of every SoA row, i.e. half a 128-B L2 line, and
   // consecutive workgroups are dealt round-robin to the 8 XCDs, whose L2s are private -- with the identity map both
@@ -219,6 +219,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   // contiguous range of env blocks instead.  (Speed only: nothing depends on where a block really lands.)
   const int wg = (int)blockIdx.x % nblk;
   const int blk = (G == 8 && (nblk & 7) == 0) ? (wg & 7) * (nblk >> 3) + (wg >> 3) : wg;
+  const DevState<T> D = tile_view<T, EPW>(Dg, blk);  // this wave's tile: row stride EPW (a compile-time constant), global env ids
   if (GENERAL && (int)blockIdx.x >= nblk) {          // (the wind-free kernels are never launched with workers)
     shadow_worker<T, G, TKIND>(Pp, OCp, D, blk);
     FWP(if (D.prof && threadIdx.x == 0) {
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g1(FW_STEP_ARGS) { s
 // K2: reset (masked) + observation.  Same single-tick-site structure (warm-up only).
 template <typename T, int G, int TKIND>
 __global__ __launch_bounds__(kWave)
-void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> D,
+void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> Dg,
                      const uint8_t* __restrict__ mask, T* __restrict__ obs, int do_reset) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
@@ -692,6 +693,7 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
   const int sub = (G == 1) ? 0 : (lane & (G - 1));
   const int row = lane / G;
   const bool leader = sub == 0;
+  const DevState<T> D = tile_view<T, EPW>(Dg, (int)blockIdx.x);
   const int env0 = blockIdx.x * EPW;
   const int env = env0 + row;
   const bool active = env < D.n;
@@ -1053,7 +1055,7 @@ int create_T(fw_env* h) {
     rc = invalidate_shadow(h);
     if (rc != FW_OK) return rc;
   }
-  hipLaunchKernelGGL(fw_init_kernel<T>, dim3((h->npad + 255) / 256), dim3(256), 0, 0, dev_state<T>(h));
+  hipLaunchKernelGGL(fw_init_kernel<T>, dim3((h->npad + 255) / 256), dim3(256), 0, 0, dev_state<T>(h), kWave / h->lanes_per_env);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipDeviceSynchronize());
   return FW_OK;
@@ -1119,6 +1121,7 @@ const FieldMap kIntMap[] = {
 template <typename T>
 int get_state_T(fw_env* h, double* out) {
   const size_t npad = (size_t)h->npad;
+  const int tile = kWave / h->lanes_per_env;
   std::vector<T> r(RF_COUNT * npad);
   std::vector<int32_t> iv(IF_COUNT * npad);
   HIP_TRY(h, hipDeviceSynchronize());
@@ -1127,8 +1130,8 @@ int get_state_T(fw_env* h, double* out) {
   for (int e = 0; e < h->n; ++e) {
     double* rec = out + (size_t)e * FW_STATE_DIM;
     std::memset(rec, 0, sizeof(double) * FW_STATE_DIM);
-    for (const FieldMap& f : kRealMap) for (int k = 0; k < f.count; ++k) rec[f.rec + k] = (double)r[(size_t)(f.rf + k) * npad + e];
-    for (const FieldMap& f : kIntMap) rec[f.rec] = (double)iv[(size_t)f.rf * npad + e];
+    for (const FieldMap& f : kRealMap) for (int k = 0; k < f.count; ++k) rec[f.rec + k] = (double)r[tile_index(tile, RF_COUNT, f.rf + k, e)];
+    for (const FieldMap& f : kIntMap) rec[f.rec] = (double)iv[tile_index(tile, IF_COUNT, f.rf, e)];
   }
   return FW_OK;
 }
@@ -1136,6 +1139,7 @@ int get_state_T(fw_env* h, double* out) {
 template <typename T>
 int set_state_T(fw_env* h, const double* in) {
   const size_t npad = (size_t)h->npad;
+  const int tile = kWave / h->lanes_per_env;
   std::vector<T> r(RF_COUNT * npad, (T)0);
   std::vector<int32_t> iv(IF_COUNT * npad, 0);
   HIP_TRY(h, hipDeviceSynchronize());
@@ -1143,8 +1147,8 @@ int set_state_T(fw_env* h, const double* in) {
   HIP_TRY(h, hipMemcpy(iv.data(), h->i_dev, sizeof(int32_t) * iv.size(), hipMemcpyDeviceToHost));
   for (int e = 0; e < h->n; ++e) {
     const double* rec = in + (size_t)e * FW_STATE_DIM;
-    for (const FieldMap& f : kRealMap) for (int k = 0; k < f.count; ++k) r[(size_t)(f.rf + k) * npad + e] = (T)rec[f.rec + k];
-    for (const FieldMap& f : kIntMap) iv[(size_t)f.rf * npad + e] = (int32_t)rec[f.rec];
+    for (const FieldMap& f : kRealMap) for (int k = 0; k < f.count; ++k) r[tile_index(tile, RF_COUNT, f.rf + k, e)] = (T)rec[f.rec + k];
+    for (const FieldMap& f : kIntMap) iv[tile_index(tile, IF_COUNT, f.rf, e)] = (int32_t)rec[f.rec];
   }
   HIP_TRY(h, hipMemcpy(h->r_dev, r.data(), sizeof(T) * r.size(), hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->i_dev, iv.data(), sizeof(int32_t) * iv.size(), hipMemcpyHostToDevice));
@@ -1240,8 +1244,14 @@ int32_t fw_seed(fw_handle h, uint64_t seed) {
   HIP_TRY(h, hipDeviceSynchronize());
   int rc = (h->cfg.dtype == FW_F64) ? upload_params<double>(h) : upload_params<float>(h);
   if (rc != FW_OK) return rc;
-  std::vector<int32_t> ep((size_t)h->npad, -1);
-  HIP_TRY(h, hipMemcpy(h->i_dev + (size_t)IF_EPISODE * h->npad, ep.data(), sizeof(int32_t) * ep.size(), hipMemcpyHostToDevice));
+  {
+    // episode counters back to -1 (the next reset starts episode 0 of the new seed); rows are tiled, so go through a host copy
+    const int tile = kWave / h->lanes_per_env;
+    std::vector<int32_t> iv((size_t)IF_COUNT * h->npad);
+    HIP_TRY(h, hipMemcpy(iv.data(), h->i_dev, sizeof(int32_t) * iv.size(), hipMemcpyDeviceToHost));
+    for (int e = 0; e < h->npad; ++e) iv[tile_index(tile, IF_COUNT, IF_EPISODE, e)] = -1;
+    HIP_TRY(h, hipMemcpy(h->i_dev, iv.data(), sizeof(int32_t) * iv.size(), hipMemcpyHostToDevice));
+  }
   return invalidate_shadow(h);                 // shadows were drawn with the old seed
 }
 

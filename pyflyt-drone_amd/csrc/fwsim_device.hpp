@@ -104,6 +104,25 @@ struct DevState {
 #endif
 };
 
+// State layout: tiles of TILE = envs-per-wave consecutive envs; inside a tile field f of env e sits at f * TILE + e % TILE
+// (AoSoA).  One wave works on exactly one tile, so inside a kernel every field is `base + f * TILE * sizeof(T)` from ONE
+// per-lane address with compile-time offsets -- the plain SoA form (stride = the runtime env count) needed a separate
+// 64-bit address per field, ~100 of them live at once, and hipcc spilled them to scratch (each reload a memory round trip).
+__host__ __device__ inline size_t tile_index(int tile, int fields, int f, int env) {
+  return (size_t)(env / tile) * fields * tile + (size_t)f * tile + (size_t)(env % tile);
+}
+// View of tile `blk` in which the usual `field * npad + env` indexing (npad := TILE, env = GLOBAL env id) lands in the tile.
+template <typename T, int TILE>
+__device__ __forceinline__ DevState<T> tile_view(const DevState<T>& G, int blk) {
+  DevState<T> D = G;
+  const size_t t = (size_t)blk * TILE;
+  D.r = G.r + t * (RF_COUNT - 1);
+  D.i = G.i + t * (IF_COUNT - 1);
+  if (G.rs) D.rs = G.rs + t * (RF_COUNT - 1);
+  D.npad = TILE;
+  return D;
+}
+
 constexpr double kPi = 3.14159265358979323846;
 
 // ------------------------------------------------------------------------
