@@ -227,3 +227,47 @@ def test_update_time_collectives_world_size_2():
         p.join(timeout=60); assert p.exitcode == 0
     for rank, *oks in sorted(res):
         assert all(oks), (rank, oks)
+
+
+# ---------------------------------------------------------------- configs[0]: CPU plumbing
+class OracleVenv:
+    """Test-only adapter: the CPU oracle behind the device-env surface the learner consumes.  (The product has no CPU
+    env; this is BASELINE.json configs[0] -- "single env on CPU via the train script, plumbing" -- with the oracle in the
+    place of PyBullet, which cannot be installed here.)"""
+
+    def __init__(self, oracle, cfg, n, seed):
+        from pyflyt_drone_amd import config as K
+        self.env = oracle.OracleEnv(cfg, n, seed=seed)
+        self.device, self.num_envs, self.obs_dim = torch.device("cpu"), n, K.obs_dim(cfg)
+        self.torch_dtype = torch.float64
+        self.terminal_obs = torch.zeros((n, self.obs_dim), dtype=torch.float64)
+        self.rewards = torch.zeros(n, dtype=torch.float64)
+
+    def reset_tensor(self):
+        return torch.from_numpy(np.asarray(self.env.reset(), dtype=np.float64).copy())
+
+    def step_tensor(self, actions):
+        o, r, te, tr, to, info = self.env.step(actions.numpy())
+        self.terminal_obs = torch.from_numpy(np.asarray(to, dtype=np.float64).copy())
+        self.rewards = torch.from_numpy(np.asarray(r, dtype=np.float64).copy())
+        return (torch.from_numpy(np.asarray(o, dtype=np.float64).copy()), self.rewards,
+                torch.from_numpy(np.asarray(te, dtype=np.uint8).copy()), torch.from_numpy(np.asarray(tr, dtype=np.uint8).copy()))
+
+
+def test_config0_plumbing_oracle_env_driven_by_the_ppo_for_two_updates(oracle, K):
+    """train/train_Fixedwing_Waypoints_v3.py hyper-parameters (:27-55: batch 128, 20 -> 2 epochs here, lr 3e-4, ent 0.001,
+    num_targets 8, sparse, euler, 30 Hz) on a single CPU env: two updates, finite, counters right, fps reported."""
+    import time
+    cfg = K.train_waypoints_v3_config()
+    venv = OracleVenv(oracle, cfg, 1, seed=42)
+    env = R.VecNormalizeDevice(venv, use_fused_kernel=False)
+    ppo = R.PPO(env, R.PPOConfig(n_steps=256, batch_size=128, n_epochs=2, learning_rate=3e-4, ent_coef=0.001, seed=42,
+                                 use_graphs=False, fused_update=False, fused_collect=False), gae_fn=R.gae_reference)
+    t0 = time.perf_counter()
+    ppo.learn(2 * 256)
+    fps = ppo.num_timesteps / (time.perf_counter() - t0)
+    assert ppo.num_timesteps == 512 and fps > 0
+    assert all(torch.isfinite(p).all() for p in ppo.policy.parameters())
+    assert all(math.isfinite(v) for v in ppo.logs.values())
+    assert float(env.obs_rms.count) == pytest.approx(1e-4 + 513) and torch.isfinite(env.obs_rms.var).all()
+    print(f"configs[0] plumbing: {fps:.0f} env-steps/s (1 CPU env, oracle physics, torch PPO)")
