@@ -343,7 +343,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       ep_return += rew;
       out_rew = rew; out_flags = flags; out_reached = num_reached; out_steps = step_count; out_strike_latched = out_strike;
       phase = PH_DONE;
-      if (DEFER) resetting = (flags & (FL_TERM | FL_TRUNC)) && P.auto_reset;
+      if (DEFER) { resetting = (flags & (FL_TERM | FL_TRUNC)) && P.auto_reset; FWP(if (resetting) p_nreset += 1;) }
       if (!DEFER && (flags & (FL_TERM | FL_TRUNC)) && P.auto_reset) {
         if (terminal_obs && leader) {
           T* trow = terminal_obs + (size_t)env * Dobs;

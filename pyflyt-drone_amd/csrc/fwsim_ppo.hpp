@@ -86,16 +86,6 @@ __device__ __forceinline__ float ppo_block_sum(float x, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// One lane's Adam update of one element (torch.optim.Adam, amsgrad off, weight decay 0):
-//   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
-// (hardware sqrt / reciprocal, 1 ulp: ~10^2 of these per lane and minibatch sit on the sequential path)
-__device__ __forceinline__ float ppo_adam(float p, float g, float* mp, float* vp, const PpoHyper& H, float step_size, float inv_sqrt_bc2) {
-  const float m = H.beta1 * (*mp) + (1.0f - H.beta1) * g;
-  const float v = H.beta2 * (*vp) + (1.0f - H.beta2) * g * g;
-  *mp = m; *vp = v;
-  const float denom = __builtin_amdgcn_sqrtf(v) * inv_sqrt_bc2 + H.eps;
-  return p - step_size * m * __builtin_amdgcn_rcpf(denom);
-}
 // tanh to ~1e-7 absolute: odd series near 0 (no cancellation), 1 - 2 / (e^{2x} + 1) elsewhere (v_exp_f32 + v_rcp_f32)
 __device__ __forceinline__ float ppo_tanh(float x) {
   const float ax = fabsf(x);
