@@ -409,3 +409,22 @@ def test_f32_throughput_mode_single_step_error(oracle):
     assert err.max() < 2e-3, err.max()
     q = hip.get_state()[:, K.S_QUAT:K.S_QUAT + 4]
     np.testing.assert_allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("n", [1, 9, 65, 130])
+@pytest.mark.parametrize("task", ["waypoints_wind", "objlock"])
+def test_ragged_env_counts_match_the_oracle(oracle, lanes, n, task):
+    """Env counts that do not fill a tile / a wave / the 64-padding (partly and wholly inactive tiles, single env):
+    lockstep with the oracle incl. auto-resets, the background warm-up hand-off and get/set_state through the tiled layout."""
+    import pyflyt_drone_amd as P
+    from pyflyt_drone_amd import config as K
+    if task == "objlock":
+        cfg = K.train_objlock_config(max_duration_seconds=2.0)
+    else:
+        cfg = K.train_waypoints_v3_config(wind_config=K.TRAIN_OBJLOCK_WIND, flight_dome_size=25.0, max_duration_seconds=3.0)
+    hip, ora = P.FixedwingVecEnv(cfg, n, seed=11), oracle.OracleEnv(cfg, n, seed=11)
+    w = run_lockstep(hip, ora, 80, np.random.default_rng(n), atol=1e-7, state_atol=2e-5 if task == "objlock" else 1e-7)
+    assert w["dones"] >= 1
+    st = hip.get_state()
+    hip.set_state(st)
+    np.testing.assert_array_equal(hip.get_state(), st)
