@@ -218,7 +218,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
   float acc_l = 0.f;                              // loss sum (wave 0 lanes, reduced at the end)
   const float invB = 1.0f / (float)B;
 #ifdef FW_PPO_PROF
-  long long pf_stats = 0, pf_gather = 0, pf_net = 0, pf_adam = 0;
+  long long pf_stats = 0, pf_gather = 0, pf_net = 0, pf_adam = 0, pf_xch = 0;
 #define PPO_T() ((long long)__builtin_readcyclecounter())
 #endif
 
@@ -421,6 +421,18 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
 #ifdef FW_PPO_PROF
     const long long pf3 = PPO_T();
 #endif
+    // Adam moments of the tiles this wave owns: requested now, consumed after the norm exchange (their L2 latency
+    // hides behind the reductions and the partner's answer)
+    float4 pm[3][4], pv[3][4];
+    {
+      const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane), s2 = ppo_tile_slot(n, 2, wave, lane);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        pm[0][q] = reinterpret_cast<const float4*>(mom_m + s0)[q]; pv[0][q] = reinterpret_cast<const float4*>(mom_v + s0)[q];
+        if (hasW1) { pm[1][q] = reinterpret_cast<const float4*>(mom_m + s1)[q]; pv[1][q] = reinterpret_cast<const float4*>(mom_v + s1)[q]; }
+        if (hasWo) { pm[2][q] = reinterpret_cast<const float4*>(mom_m + s2)[q]; pv[2][q] = reinterpret_cast<const float4*>(mom_v + s2)[q]; }
+      }
+    }
     // ---- finish the bias gradients: sum the four row-block partials; reduce the per-sample partials of wave 0 ----
     __syncthreads();
     bred[wave * kPH + lane] = gb1p; bred[(4 + wave) * kPH + lane] = gb2p;
@@ -454,6 +466,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
     if (NET == 0 && t < 4) ss += my_gls * my_gls;
     const float ss_mine = ppo_block_sum(ss, red);
     float ss_other = 0.f;
+#ifdef FW_PPO_PROF
+    const long long pfx = PPO_T();
+#endif
     {
       // one 64-bit word per block and minibatch parity: (minibatch + 1) << 32 | float bits
       unsigned long long* mine = A.xch + (mb & 1) * 2 + NET;
@@ -472,6 +487,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
       __syncthreads();
       ss_other = red[4];
     }
+#ifdef FW_PPO_PROF
+    pf_xch += PPO_T() - pfx;
+#endif
     const float total_norm = sqrtf(ss_mine + ss_other);
     const float clipc = fminf(H.max_grad_norm / (total_norm + 1e-6f), 1.0f);
 
@@ -480,12 +498,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
     // are four dwordx4 loads / stores from one address, with no per-element index arithmetic or branches.
     bc1 *= H.beta1; bc2 *= H.beta2;
     const float c1 = H.lr / (1.0f - bc1), sc2 = 1.0f / sqrtf(1.0f - bc2);      // step size, 1 / sqrt(bias correction 2)
-    auto adam_tile = [&](const f32x16& g, int slot0, auto&& lds_of /* v -> weight in LDS or nullptr */) {
+    auto adam_tile = [&](const f32x16& g, int slot0, float4 (&m4)[4], float4 (&v4)[4], auto&& lds_of /* v -> weight in LDS or nullptr */) {
       float4* mp = reinterpret_cast<float4*>(mom_m + slot0);
       float4* vp = reinterpret_cast<float4*>(mom_v + slot0);
-      float4 m4[4], v4[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { m4[q] = mp[q]; v4[q] = vp[q]; }
       float upd[16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -504,10 +519,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) { float* w = lds_of(v); if (w) *w -= upd[v]; }
     };
-    adam_tile(gW2, ppo_tile_slot(n, 0, wave, lane), [&](int v) { return W.W2 + (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r; });
-    if (hasW1) adam_tile(gW1, ppo_tile_slot(n, 1, wave, lane),
+    adam_tile(gW2, ppo_tile_slot(n, 0, wave, lane), pm[0], pv[0], [&](int v) { return W.W2 + (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r; });
+    if (hasW1) adam_tile(gW1, ppo_tile_slot(n, 1, wave, lane), pm[1], pv[1],
                          [&](int v) { const int i = mt * 32 + ppo_acc_row(v); return i < D ? W.W1 + i * kPH + nt * 32 + r : (float*)nullptr; });
-    if (hasWo) adam_tile(gWo, ppo_tile_slot(n, 2, wave, lane),
+    if (hasWo) adam_tile(gWo, ppo_tile_slot(n, 2, wave, lane), pm[2], pv[2],
                          [&](int v) { return r < KO ? W.Wo + (wave * 32 + ppo_acc_row(v)) * KO + r : (float*)nullptr; });
     {
       // scalars: slot q * 256 + t for q = 3 net + {b1, b2, bo} and q = 6 (log_std, pi block); the owner test only gates the LDS write
@@ -554,7 +569,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
     }
 #ifdef FW_PPO_PROF
     float* pr = A.loss_acc + 3 + NET * 4;
-    pr[0] = (float)pf_stats / n_mb; pr[1] = (float)pf_gather / n_mb; pr[2] = (float)pf_net / n_mb; pr[3] = (float)pf_adam / n_mb;
+    pr[0] = (float)pf_xch / n_mb; pr[1] = (float)pf_gather / n_mb; pr[2] = (float)pf_net / n_mb; pr[3] = (float)pf_adam / n_mb;
 #endif
   }
 }
