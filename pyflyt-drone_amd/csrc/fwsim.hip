@@ -148,6 +148,8 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
 #pragma unroll
   for (int k = 0; k < 3; ++k) { wb[k] = V.r[(RF_WIND + k) * n + envc]; wa[k] = V.r[(RF_WIND + 3 + k) * n + envc]; }
   wph = V.r[(RF_WIND + 6) * n + envc];
+  T gust[2];
+  gust_init<T>(P, wph, tick, gust);
   ObjState<T> O;
   if (HASOBJ) { obj_load<T>(V, envc, O); O.near_mask = 0u; }
   const T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
@@ -155,7 +157,7 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
 #pragma unroll 1
   while (__ballot(left > 0) != 0ull) {
     if (left > 0) {
-      (void)aviary_step<T, true, G, HASOBJ>(P, C, OC, V, envc, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, wph, mine, wmask);
+      (void)aviary_step<T, true, G, HASOBJ>(P, C, OC, V, envc, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, gust, mine, wmask);
       left -= 1;
     }
   }
@@ -282,6 +284,8 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     for (int k = 0; k < 3; ++k) { wb[k] = D.r[(RF_WIND + k) * n + envc]; wa[k] = D.r[(RF_WIND + 3 + k) * n + envc]; }
     wphase = D.r[(RF_WIND + 6) * n + envc];
   }
+  T gust[2] = {(T)0, (T)1};                          // sin / cos of the gust phase at `tick`
+  if (GENERAL) gust_init<T>(P, wphase, tick, gust);
   // fixedwing_base_env.py:325-331
   T rew = (T)-0.1;
   T cmd[FW_NUM_ACTUATORS];
@@ -388,6 +392,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
           }
         }
         if (G > 1 && warm_left > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the warm-up's camera reads the obstacles
+        if (GENERAL) gust_init<T>(P, wphase, tick, gust);                                  // new clock, new phase
         FWP(const long long p_rb = FWP_NOW(); p_r2 += p_rb - p_ra;)
         step_count = 0; flags = 0; ep_return = (T)0; tgt_obs = 0;
         act_src = 2;
@@ -420,9 +425,9 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
 #pragma unroll
         for (int c = 0; c < FW_NUM_ACTUATORS; ++c) c_eff[c] = stepping ? cmd[c] : (T)0;
         z0 = stepping ? z0 : (T)0; z1 = stepping ? z1 : (T)0;
-        contact = aviary_step<T, true, G, HASOBJ>(P, C, OC, D, env, O, S, R, c_eff, tick, z0, z1, wb, wa, wphase, mine, wmask);   // :339
+        contact = aviary_step<T, true, G, HASOBJ>(P, C, OC, D, env, O, S, R, c_eff, tick, z0, z1, wb, wa, gust, mine, wmask);   // :339
       } else {
-        contact = aviary_step<T, false, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd, tick, z0, z1, wb, wa, wphase, mine, wmask);    // :339
+        contact = aviary_step<T, false, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd, tick, z0, z1, wb, wa, gust, mine, wmask);    // :339
       }
       FWP(const long long p_c = FWP_NOW(); p_avi += p_c - p_b;)
       if (stepping && OBJ) {
@@ -736,10 +741,12 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
   T R[9];
   normalize_quat<T>(S.q);
   rot_from_unit_quat<T>(S.q, R);
+  T gust[2];
+  gust_init<T>(P, wphase, tick, gust);
 #pragma unroll 1
   while (__ballot(warm_left > 0) != 0ull) {
     if (warm_left > 0) {
-      (void)aviary_step<T, true, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, wphase, mine, wmask);
+      (void)aviary_step<T, true, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, gust, mine, wmask);
       warm_left -= 1;
       if (warm_left == 0) {
         if (OBJ) obj_compute_state<T>(O);
@@ -906,6 +913,7 @@ bool build_params(const fw_config& c, uint64_t seed, int64_t env_offset, Params<
     for (int j = 0; j < 2; ++j) { P.wind_base_range[k][j] = c.wind_enu_mps_range[k][j]; P.wind_amp_range[k][j] = c.gust_amp_enu_mps_range[k][j]; }
   }
   P.wind_phase = (T)c.gust_phase_rad; P.gust_omega = (T)(2.0 * kPi * c.gust_freq_hz); P.wind_force_coef = (T)c.wind_force_coef;
+  P.gust_sd = (T)std::sin((double)P.gust_omega * (double)P.inv_physics_hz); P.gust_cd = (T)std::cos((double)P.gust_omega * (double)P.inv_physics_hz);
   P.wind_mode = c.wind_mode; P.wind_randomize = c.wind_randomize_on_reset; P.wind_randomize_phase = c.wind_randomize_phase;
   P.wind_coupling = (c.wind_mode == FW_WIND_OFF) ? FW_WIND_COUPLE_NONE : c.wind_coupling;
   P.task = c.task; P.angle_repr = c.angle_representation;
