@@ -14,7 +14,7 @@ import pyflyt_drone_amd as P
 from pyflyt_drone_amd import config as K, rollout as R
 
 task = sys.argv[1] if len(sys.argv) > 1 else "waypoints"
-n = 4096
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096          # envs on this GPU (configs[4] of BASELINE.json: 2048 per GPU)
 if task == "objlock":
     cfg, ppo_cfg = K.train_objlock_config(), R.PPOConfig(n_steps=8, batch_size=64, n_epochs=10)        # 16 x 2048 = 32768 samples
 elif task == "combined":
