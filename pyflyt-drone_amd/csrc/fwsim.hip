@@ -1319,10 +1319,11 @@ int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t 
 }
 
 int32_t fw_ppo_param_count(int32_t obs_dim) { return obs_dim > 0 ? ppo_total_params((obs_dim + 1) & ~1) : FW_EINVAL; }
-int32_t fw_ppo_moment_count(void) { return kPMomentSlots; }
+int32_t fw_ppo_moment_count(void) { return 2 * kPMomentSlots; }   // second half: working copy of the second chunk-half blocks
 int32_t fw_ppo_moment_map(int32_t obs_dim, int32_t* flat_index_of_slot) {
   if (obs_dim <= 0 || obs_dim > 64 || !flat_index_of_slot) { g_err = "fw_ppo_moment_map: bad arguments"; return FW_EINVAL; }
   ppo_moment_map(obs_dim, flat_index_of_slot);
+  for (int i = kPMomentSlots; i < 2 * kPMomentSlots; ++i) flat_index_of_slot[i] = -1;
   return FW_OK;
 }
 
@@ -1343,8 +1344,12 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   int dev = 0;
   HIP_TRY((fw_env*)nullptr, hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) { g_err = "device index out of range"; return FW_EINVAL; }
-  if (!xch_dev[dev]) HIP_TRY((fw_env*)nullptr, hipMalloc((void**)&xch_dev[dev], 4 * sizeof(unsigned long long)));
-  HIP_TRY((fw_env*)nullptr, hipMemsetAsync(xch_dev[dev], 0, 4 * sizeof(unsigned long long), st));
+  static float* gx_dev[64] = {nullptr};
+  if (!xch_dev[dev]) {
+    HIP_TRY((fw_env*)nullptr, hipMalloc((void**)&xch_dev[dev], 16 * sizeof(unsigned long long)));
+    HIP_TRY((fw_env*)nullptr, hipMalloc((void**)&gx_dev[dev], sizeof(float) * 8 * (size_t)kPMomentSlots));
+  }
+  HIP_TRY((fw_env*)nullptr, hipMemsetAsync(xch_dev[dev], 0, 16 * sizeof(unsigned long long), st));
   // per-minibatch advantage statistics, computed in parallel up front (scratch grows on demand, outside graph capture)
   static float* stats_dev[64] = {nullptr};
   static size_t stats_cap[64] = {0};
@@ -1359,11 +1364,12 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   PpoArgs A;
   A.params = params; A.mom_m = mom_m; A.mom_v = mom_v; A.obs = obs; A.act = act; A.old_logp = old_logp; A.adv = adv; A.ret = ret;
-  A.perm = perm; A.n_mb = n_minibatches; A.B = batch_size; A.D = obs_dim; A.loss_acc = loss_acc; A.xch = xch_dev[dev];
+  A.perm = perm; A.n_mb = n_minibatches; A.B = batch_size; A.D = obs_dim; A.loss_acc = loss_acc; A.xch = xch_dev[dev]; A.gx = gx_dev[dev];
   A.adv_stats = stats_dev[dev];
   std::memcpy(&A.H, hyper, sizeof A.H);
   if (batch_size <= 1 && A.H.norm_adv == 1) A.H.norm_adv = 0;      // SB3 skips the normalisation of single-sample minibatches
-  hipLaunchKernelGGL(fw_ppo_update_kernel, dim3(2), dim3(kPThreads), lds, st, A);
+  const int nhalf = batch_size >= 2 * kPChunk ? 2 : 1;            // two chunk-half blocks per network from 128 samples on
+  hipLaunchKernelGGL(fw_ppo_update_kernel, dim3(2 * nhalf), dim3(kPThreads), lds, st, A);
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;
 }

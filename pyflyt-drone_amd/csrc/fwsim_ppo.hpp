@@ -148,9 +148,13 @@ __global__ __launch_bounds__(64) void fw_ppo_adv_stats_kernel(const float* __res
   if (threadIdx.x == 0) { out[2 * blockIdx.x] = mean; out[2 * blockIdx.x + 1] = sqrtf(var); }
 }
 
-// Two workgroups, one per network (pi: block 0, V: block 1) -- the two networks share nothing but the scalar
-// gradient norm that SB3 clips jointly, which the blocks exchange once per minibatch through one 64-bit word
-// each (tag | partial sum of squares, device-scope atomics; both blocks are always co-resident: grid = 2).
+// One workgroup per network (pi / V) -- the two networks share nothing but the scalar gradient norm that SB3 clips
+// jointly, exchanged once per minibatch through one 64-bit word each (tag | partial sum of squares, device-scope
+// atomics).  Minibatches of >= 128 samples are additionally split over two workgroups per network, each running
+// every other 64-sample chunk; the pair swaps its gradient partials through global memory (release / acquire at
+// device scope, double-buffered by minibatch parity), after which both hold the same sum and apply the same Adam
+// step to their own LDS copy of the weights (the second one on a private copy of the moments).  grid = 2 or 4;
+// all blocks are always co-resident, every spin is bounded.
 // Work split of the 256 threads of a block (4 waves, one per SIMD, fixed for the whole call):
 //   * every 64 x 64 product (H1, H2, G2, G1, dW2) is 2 x 2 tiles of 32 x 32: wave w owns tile (w >> 1, w & 1);
 //   * dW1 is ceil(Dp / 32) x 2 tiles (waves 0-1 or all four); the head products (64 x KO, masked to KO columns)
@@ -166,14 +170,16 @@ struct PpoArgs {
   int32_t n_mb, B, D;
   PpoHyper H;
   float* loss_acc;                   // [3] += policy, value, entropy loss
-  unsigned long long* xch;           // [2 parities][2 blocks], zeroed by the host before the launch
+  unsigned long long* xch;           // [16] exchange words (norm partials [parity][net][half], gradient flags + 8), zeroed by the host
+  float* gx;                         // [2 parities][2 nets][2 halves][kPMomentSlots] gradient partials of the chunk halves
   const float* adv_stats;            // [n_mb][2] mean, std of each minibatch's advantages (fw_ppo_adv_stats_kernel)
 };
 
 template <int NET>
-__device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
+__device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const int half, const int nhalf) {
   constexpr int n = NET, KO = NET == 0 ? 4 : 1;
-  float* __restrict__ params = A.params; float* __restrict__ mom_m = A.mom_m; float* __restrict__ mom_v = A.mom_v;
+  float* __restrict__ params = A.params;
+  float* __restrict__ mom_m = A.mom_m + (size_t)half * kPMomentSlots; float* __restrict__ mom_v = A.mom_v + (size_t)half * kPMomentSlots;
   const float* __restrict__ obs = A.obs; const float* __restrict__ act = A.act; const float* __restrict__ old_logp = A.old_logp;
   const float* __restrict__ adv = A.adv; const float* __restrict__ ret = A.ret; const int32_t* __restrict__ perm = A.perm;
   const int n_mb = A.n_mb, B = A.B, D = A.D;
@@ -226,7 +232,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
   // row, one action component and one scalar in registers until the chunk's turn comes.
   const int gs = t >> 2, gk = t & 3;
   const int per = (Dp + 3) >> 2, gd0 = gk * per;                          // per <= 16
-  const int cpm = B / kPChunk, total_chunks = n_mb * cpm;
+  const int cpm = B / kPChunk;
   float pre_x[16], pre_a = 0.f, pre_s = 0.f;
   auto prefetch = [&](int g) {
     const int si = perm[(size_t)g * kPChunk + gs];
@@ -250,8 +256,22 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
     if (NET == 0) sA[t] = pre_a;
     sS[t] = pre_s;
   };
-  int gchunk = 0;
-  prefetch(0);
+  int pmb = 0, pci = half;                          // next chunk to prefetch: minibatch, chunk index inside it
+  if (half == 1) {
+    // private working copy of the Adam moments for the second chunk-half block (same lanes own the same slots)
+#pragma unroll
+    for (int kind = 0; kind < 3; ++kind) {
+      const int s0 = ppo_tile_slot(n, kind, wave, lane);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        reinterpret_cast<float4*>(mom_m + s0)[q] = reinterpret_cast<const float4*>(A.mom_m + s0)[q];
+        reinterpret_cast<float4*>(mom_v + s0)[q] = reinterpret_cast<const float4*>(A.mom_v + s0)[q];
+      }
+    }
+    for (int q = 0; q < 7; ++q) { mom_m[kPTileSlots + q * kPThreads + t] = A.mom_m[kPTileSlots + q * kPThreads + t]; mom_v[kPTileSlots + q * kPThreads + t] = A.mom_v[kPTileSlots + q * kPThreads + t]; }
+  }
+  prefetch(pmb * cpm + pci);
+  pci += nhalf; if (pci >= cpm) { pmb += 1; pci = half; }
 
 #pragma unroll 1
   for (int mb = 0; mb < n_mb; ++mb) {
@@ -269,15 +289,17 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
     for (int v = 0; v < 16; ++v) { gW2[v] = 0.f; gW1[v] = 0.f; gWo[v] = 0.f; }
 
 #pragma unroll 1
-    for (int c0 = 0; c0 < B; c0 += kPChunk) {
+    for (int c0 = half * kPChunk; c0 < B; c0 += nhalf * kPChunk) {
       // ---- gather the chunk ----
 #ifdef FW_PPO_PROF
       const long long pf1 = PPO_T();
 #endif
       __syncthreads();                                                   // the previous chunk's readers of X / sA / sS are done
       commit();
-      if (gchunk + 1 < total_chunks) prefetch(gchunk + 1);               // the next chunk's loads fly during this chunk's GEMMs
-      gchunk += 1;
+      if (pmb < n_mb) {                                                  // the next chunk's loads fly during this chunk's GEMMs
+        prefetch(pmb * cpm + pci);
+        pci += nhalf; if (pci >= cpm) { pmb += 1; pci = half; }
+      }
       __syncthreads();
 #ifdef FW_PPO_PROF
       const long long pf2 = PPO_T(); pf_gather += pf2 - pf1;
@@ -449,8 +471,45 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
       if (NET == 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const float sfull = ppo_wave_sum(gls[k]); if (lane == k) my_gls = sfull; }
-        my_gls -= H.ent_coef;        // entropy bonus: entropy_loss = -mean(sum_k (c + log_std_k)) -> d/dlog_std_k = -ent_coef
+        if (half == 0) my_gls -= H.ent_coef;   // entropy bonus: entropy_loss = -mean(sum_k (c + log_std_k)) -> d/dlog_std_k = -ent_coef (once)
       }
+    }
+
+    // ---- chunk halves: swap gradient partials with the partner block of this network, keep the sum ----
+    if (nhalf == 2) {
+      float* mine = A.gx + (size_t)((mb & 1) * 4 + NET * 2 + half) * kPMomentSlots;
+      const float* theirs = A.gx + (size_t)((mb & 1) * 4 + NET * 2 + (1 - half)) * kPMomentSlots;
+      unsigned long long* fmine = A.xch + 8 + (mb & 1) * 4 + NET * 2 + half;
+      unsigned long long* ftheirs = A.xch + 8 + (mb & 1) * 4 + NET * 2 + (1 - half);
+      const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane), s2 = ppo_tile_slot(n, 2, wave, lane);
+      // Plain vector stores / loads bracketed by a device-scope release (every storing wave, before the barrier and the
+      // flag) and acquire (after the flag).  (Tried: per-word sc1 atomics instead of the fences -- 27.4 vs 23.9 us.)
+      const int sq = kPTileSlots + t;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        reinterpret_cast<float4*>(mine + s0)[q] = make_float4(gW2[4 * q], gW2[4 * q + 1], gW2[4 * q + 2], gW2[4 * q + 3]);
+        if (hasW1) reinterpret_cast<float4*>(mine + s1)[q] = make_float4(gW1[4 * q], gW1[4 * q + 1], gW1[4 * q + 2], gW1[4 * q + 3]);
+        if (hasWo) reinterpret_cast<float4*>(mine + s2)[q] = make_float4(gWo[4 * q], gWo[4 * q + 1], gWo[4 * q + 2], gWo[4 * q + 3]);
+      }
+      mine[sq] = gb1; mine[sq + kPThreads] = gb2; mine[sq + 2 * kPThreads] = my_gbo; mine[sq + 3 * kPThreads] = my_gls;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");              // every storing wave: write back to where the partner can see it
+      __syncthreads();
+      if (t == 0) {
+        __hip_atomic_store(fmine, (unsigned long long)(unsigned)(mb + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        long long spins = 0;
+        while ((unsigned)__hip_atomic_load(ftheirs, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(mb + 1))
+          if (++spins > (1ll << 26)) __builtin_trap();                // the partner block is gone: fail loudly instead of hanging
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 a = reinterpret_cast<const float4*>(theirs + s0)[q];
+        gW2[4 * q] += a.x; gW2[4 * q + 1] += a.y; gW2[4 * q + 2] += a.z; gW2[4 * q + 3] += a.w;
+        if (hasW1) { const float4 b = reinterpret_cast<const float4*>(theirs + s1)[q]; gW1[4 * q] += b.x; gW1[4 * q + 1] += b.y; gW1[4 * q + 2] += b.z; gW1[4 * q + 3] += b.w; }
+        if (hasWo) { const float4 c = reinterpret_cast<const float4*>(theirs + s2)[q]; gWo[4 * q] += c.x; gWo[4 * q + 1] += c.y; gWo[4 * q + 2] += c.z; gWo[4 * q + 3] += c.w; }
+      }
+      gb1 += theirs[sq]; gb2 += theirs[sq + kPThreads]; my_gbo += theirs[sq + 2 * kPThreads]; my_gls += theirs[sq + 3 * kPThreads];
     }
 
     // ---- global gradient norm: own elements, then the other network's partial ----
@@ -471,8 +530,8 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
 #endif
     {
       // one 64-bit word per block and minibatch parity: (minibatch + 1) << 32 | float bits
-      unsigned long long* mine = A.xch + (mb & 1) * 2 + NET;
-      unsigned long long* other = A.xch + (mb & 1) * 2 + (1 - NET);
+      unsigned long long* mine = A.xch + (mb & 1) * 4 + NET * 2 + half;
+      unsigned long long* other = A.xch + (mb & 1) * 4 + (1 - NET) * 2 + half;
       if (t == 0) {
         __hip_atomic_store(mine, ((unsigned long long)(unsigned)(mb + 1) << 32) | (unsigned long long)__float_as_uint(ss_mine),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -552,20 +611,22 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
   }
 
   // ---- write the weights back, report the losses ----
-  for (int i = t; i < Dp * kPH; i += kPThreads) params[oW1 + i] = W.W1[i];
-  for (int i = t; i < kPH; i += kPThreads) { params[ob1 + i] = W.b1[i]; params[ob2 + i] = W.b2[i]; }
-  for (int i = t; i < kPH * kPH; i += kPThreads) params[oW2 + i] = W.W2[(i >> 6) * kPLdh + (i & 63)];
-  for (int i = t; i < kPH * KO + KO; i += kPThreads) params[oWo + i] = W.Wo[i];
-  if (NET == 0 && t < 4) params[oLs + t] = log_std[t];
+  if (half == 0) {
+    for (int i = t; i < Dp * kPH; i += kPThreads) params[oW1 + i] = W.W1[i];
+    for (int i = t; i < kPH; i += kPThreads) { params[ob1 + i] = W.b1[i]; params[ob2 + i] = W.b2[i]; }
+    for (int i = t; i < kPH * kPH; i += kPThreads) params[oW2 + i] = W.W2[(i >> 6) * kPLdh + (i & 63)];
+    for (int i = t; i < kPH * KO + KO; i += kPThreads) params[oWo + i] = W.Wo[i];
+    if (NET == 0 && t < 4) params[oLs + t] = log_std[t];
+  }
   const float lsum = ppo_block_sum(acc_l, red);
   if (t == 0 && A.loss_acc) {
     if (NET == 0) {
       float ent = 0.f;
       for (int k = 0; k < 4; ++k) ent += 1.4189385332046727f + log_std[k];
-      A.loss_acc[0] += lsum * invB;          // sums over minibatches of the per-minibatch means
-      A.loss_acc[2] += -ent * (float)n_mb;   // entropy loss at the final log_std (it is state-independent)
+      atomicAdd(&A.loss_acc[0], lsum * invB);                       // sums over minibatches of the per-minibatch means
+      if (half == 0) atomicAdd(&A.loss_acc[2], -ent * (float)n_mb); // entropy loss at the final log_std (it is state-independent)
     } else {
-      A.loss_acc[1] += lsum * invB;
+      atomicAdd(&A.loss_acc[1], lsum * invB);
     }
 #ifdef FW_PPO_PROF
     float* pr = A.loss_acc + 3 + NET * 4;
@@ -574,10 +635,11 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds) {
   }
 }
 
-// grid = 2 blocks (block 0: policy network, block 1: value network) x 256 threads; dynamic LDS = ppo_lds_bytes().
+// grid = 2 or 4 blocks x 256 threads: block b runs network b & 1 (0: policy, 1: value) on chunk half b >> 1; dynamic LDS = ppo_lds_bytes().
 __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(PpoArgs A) {
   extern __shared__ __align__(16) float lds[];
-  if (blockIdx.x == 0) ppo_net_body<0>(A, lds); else ppo_net_body<1>(A, lds);
+  const int half = blockIdx.x >> 1, nhalf = gridDim.x >> 1;
+  if ((blockIdx.x & 1) == 0) ppo_net_body<0>(A, lds, half, nhalf); else ppo_net_body<1>(A, lds, half, nhalf);
 }
 
 inline size_t ppo_lds_bytes(int D) {
