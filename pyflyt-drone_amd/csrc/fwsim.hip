@@ -169,6 +169,28 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
   }
 }
 
+// Wind-free waypoints: the reset itself is cached (warm state, its observation), what remains per env is sampling the next
+// episode's waypoints (3 Philox blocks + 2 sincos per waypoint).  The same hand-off as above lets a worker block do that
+// ahead of time into the shadow's waypoint rows; the reset then only copies 3 words per lane (requested at launch start).
+template <typename T, int G>
+__device__ __forceinline__ void scenario_worker(const Params<T>* __restrict__ Pp, DevState<T> D, int blk) {
+  constexpr int EPW = kWave / G;
+  const int lane = threadIdx.x, sub = (G == 1) ? 0 : (lane & (G - 1)), row = lane / G;
+  const int env = blk * EPW + row;
+  const bool active = env < D.n;
+  const int envc = active ? env : D.n - 1;
+  const unsigned long long req = D.sreq[envc], dn = D.sdone[envc];
+  const uint32_t target = (uint32_t)(req >> 32);
+  const bool fresh = active && (uint32_t)req != D.epoch && req != ~0ull;          // a request of an earlier launch
+  const bool begin = fresh && (uint32_t)(dn >> 32) != target;
+  if (__ballot(begin) == 0ull) return;
+  if (begin) {
+    Scenario<T> sc;
+    sample_scenario_inl<T, G>(Pp, D.rs, (size_t)D.npad, env, target, &sc);
+    if (sub == 0) D.sdone[env] = pack_done(target, D.epoch, 1);
+  }
+}
+
 // Dev-only per-wave cycle accounting (tools/wave_profile.py builds a second library with -DFW_PROFILE).
 #ifdef FW_PROFILE
 #define FWP_NOW() ((long long)__builtin_readcyclecounter())
@@ -222,8 +244,8 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   const int wg = (int)blockIdx.x % nblk;
   const int blk = (G == 8 && (nblk & 7) == 0) ? (wg & 7) * (nblk >> 3) + (wg >> 3) : wg;
   const DevState<T> D = tile_view<T, EPW>(Dg, blk);  // this wave's tile: row stride EPW (a compile-time constant), global env ids
-  if (GENERAL && (int)blockIdx.x >= nblk) {          // (the wind-free kernels are never launched with workers)
-    shadow_worker<T, G, TKIND>(Pp, OCp, D, blk);
+  if ((GENERAL || DEFER) && (int)blockIdx.x >= nblk) {
+    if (GENERAL) shadow_worker<T, G, TKIND>(Pp, OCp, D, blk); else scenario_worker<T, G>(Pp, D, blk);
     FWP(if (D.prof && threadIdx.x == 0) {
       long long* w = D.prof + ((size_t)(D.epoch % kProfSlots) * 2 * nblk + blockIdx.x) * kProfWords;
       w[0] = FWP_NOW() - p_t0; })
@@ -253,6 +275,11 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   constexpr bool LANE_T = DEFER && G == 8;
   T tmine[3] = {(T)0, (T)0, (T)0};
   T a_keep = (T)0;
+  T tpre[3] = {(T)0, (T)0, (T)0};                    // DEFER: the waypoint a worker block sampled for my next episode (if any)
+  if (DEFER && D.shadow_on && sub < P.num_targets) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tpre[k] = D.rs[(size_t)(RF_TARGETS + 3 * sub + k) * n + envc];
+  }
   if (LANE_T) {
     if (sub < P.num_targets) {
 #pragma unroll
@@ -277,7 +304,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   int32_t out_strike = 0;
   // shadow bookkeeping (kernel-boundary hand-off, see shadow_* above)
   unsigned long long sh_req = ~0ull, sh_done = 0ull;
-  if (GENERAL && D.shadow_on) { sh_req = D.sreq[envc]; sh_done = D.sdone[envc]; }
+  if ((GENERAL || DEFER) && D.shadow_on) { sh_req = D.sreq[envc]; sh_done = D.sdone[envc]; }
   T wb[3] = {(T)0, (T)0, (T)0}, wa[3] = {(T)0, (T)0, (T)0}, wphase = (T)0;
   if (GENERAL) {
 #pragma unroll
@@ -531,7 +558,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   // G = 8: waypoints sampled by sibling lanes during an in-launch reset are read back below
   if (G > 1 && !DEFER) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 
-  if (GENERAL && D.shadow_on && active && leader && (uint32_t)(sh_req >> 32) != (uint32_t)(episode + 1))
+  if ((GENERAL || DEFER) && D.shadow_on && active && leader && (uint32_t)(sh_req >> 32) != (uint32_t)(episode + 1))
     D.sreq[env] = ((unsigned long long)(uint32_t)(episode + 1) << 32) | (unsigned long long)D.epoch;   // ask for the next episode
   if (active && leader) {
     reward[env] = out_rew;
@@ -584,7 +611,19 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     episode += 1;
     Scenario<T> sc;
-    sample_scenario_inl<T, G>(Pp, D.r, n, env, (uint32_t)episode, &sc);  // the obs pass above read the old waypoints; overwritten here
+    // (the obs pass above read the old waypoints; they are overwritten here)
+    const bool pre = D.shadow_on && (int)(sh_done & 0xFF) == 1 && (uint32_t)(sh_done >> 32) == (uint32_t)episode &&
+                     (uint32_t)((sh_done >> 8) & 0xFFFFFFu) != (D.epoch & 0xFFFFFFu);
+    if (pre) {                                         // sampled ahead of time by a worker block of an earlier launch
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sc.t_mine[k] = tpre[k];
+      if (sub < P.num_targets) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) D.r[(size_t)(RF_TARGETS + 3 * sub + k) * n + env] = tpre[k];
+      }
+    } else {
+      sample_scenario_inl<T, G>(Pp, D.r, n, env, (uint32_t)episode, &sc);
+    }
     const int nt = min(P.ctx, P.num_targets);
     T t0[3] = {(T)0, (T)0, (T)0};
 #pragma unroll 1
@@ -606,10 +645,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       }
       if (leader) { tile[row * ld + P.att_dim + 3 * i] = b[0]; tile[row * ld + P.att_dim + 3 * i + 1] = b[1]; tile[row * ld + P.att_dim + 3 * i + 2] = b[2]; }
     }
-    if (leader) {
-#pragma unroll 1
-      for (int k = 0; k < P.att_dim; ++k) tile[row * ld + k] = P.warm_obs[k];
-    }
+    for (int k = sub; k < P.att_dim; k += G) tile[row * ld + k] = Pp->warm_obs[k];      // the env's lanes share the cached attitude block
 #pragma unroll
     for (int k = 0; k < 3; ++k) { S.p[k] = P.warm[k]; S.v[k] = P.warm[7 + k]; S.w[k] = P.warm[10 + k]; }
 #pragma unroll
@@ -1054,6 +1090,10 @@ int create_T(fw_env* h) {
   const bool cached = (h->cfg.task == FW_TASK_WAYPOINTS) &&
                       (h->cfg.wind_mode == FW_WIND_OFF || h->cfg.wind_coupling == FW_WIND_COUPLE_NONE);
   h->shadow_on = (!cached && h->cfg.auto_reset && !getenv("FWSIM_NO_SHADOW")) ? 1 : 0;
+  // wind-free waypoints on the latency mapping: workers only pre-sample the next episode's waypoints (scenario_worker)
+  if (h->cfg.task == FW_TASK_WAYPOINTS && h->cfg.wind_mode == FW_WIND_OFF && h->cfg.auto_reset && h->lanes_per_env == 8 &&
+      !getenv("FWSIM_NO_SHADOW"))
+    h->shadow_on = 2;
   if (h->shadow_on) {
     HIP_TRY(h, hipMalloc(&h->rs_dev, sizeof(T) * RF_COUNT * npad));
     HIP_TRY(h, hipMemset(h->rs_dev, 0, sizeof(T) * RF_COUNT * npad));
