@@ -60,7 +60,7 @@ __global__ void fw_warm_kernel(Params<T>* Pm) {
   // the observation every cached reset returns, up to its target deltas
   const T a0[4] = {(T)0, (T)0, (T)0, (T)0};
   T Rw[9];
-  (void)write_obs_attitude<T>(P, S, a0, Rw, [&](int k, T v) { Pm->warm_obs[k] = v; });
+  (void)write_obs_attitude<T, false>(P, S, a0, Rw, [&](int k, T v) { Pm->warm_obs[k] = v; });
   for (int k = 0; k < 9; ++k) Pm->warm_R[k] = Rw[k];
 }
 
@@ -580,7 +580,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       for (int k = 0; k < 4; ++k) act_obs[k] = D.r[(size_t)(RF_ACTION + k) * n + envc];
     }
     T Ro[9];
-    int o = write_obs_attitude<T>(P, S, act_obs, Ro, [&](int k, T v) { if (leader) tile[row * ld + k] = v; });
+    int o = write_obs_attitude<T, true>(P, S, act_obs, Ro, [&](int k, T v) { if (leader) tile[row * ld + k] = v; });
 #pragma unroll 1
     for (int i = 0; i < P.ctx; ++i) {
       const int t = tgt_obs + i;

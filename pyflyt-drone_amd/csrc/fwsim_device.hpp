@@ -685,6 +685,27 @@ __device__ __forceinline__ bool euler_from_quat(const T q[4], T e[3]) {
   }
   return lock;
 }
+// The same, for a pass that all 8 lanes of an env's group run: lanes 0-2 evaluate one angle each (one atan2 in the
+// instruction stream instead of three), the results are handed round by shuffle.  Same function, same arguments per
+// angle => bit-identical to euler_from_quat.
+template <typename T>
+__device__ __forceinline__ bool euler_from_quat_lanes8(const T q[4], T e[3]) {
+  const int lane = threadIdx.x, sub = lane & 7, gbase = lane & ~7;
+  T x = q[0], y = q[1], z = q[2], w = q[3];
+  T sarg = (T)-2 * (x * z - w * y);
+  const bool lock = (sarg <= (T)-0.99999) || (sarg >= (T)0.99999);
+  const bool neg = sarg <= (T)-0.99999;
+  T sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
+  T ya = (T)2 * (y * z + w * x), xa = squ - sqx - sqy + sqz;                         // roll
+  if (sub == 1) { ya = sarg; xa = M<T>::sqrt_(((T)1 - sarg) * ((T)1 + sarg)); }     // pitch = asin(sarg)
+  if (sub == 2) { ya = (T)2 * (x * y + w * z); xa = squ + sqx - sqy - sqz; }        // yaw
+  if (lock && sub == 2) { ya = neg ? x : -x; xa = neg ? -y : y; }
+  const T res = M<T>::atan2_(ya, xa);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) e[k] = __shfl(res, gbase | k, kWave);
+  if (lock) { e[0] = (T)0; e[1] = neg ? (T)(-0.5 * kPi) : (T)(0.5 * kPi); e[2] = (T)2 * e[2]; }
+  return lock;
+}
 template <typename T>
 __device__ __forceinline__ void quat_from_euler(const T e[3], T q[4]) {
   T sr, cr, sp, cp, sy, cy;
@@ -703,13 +724,13 @@ __device__ __forceinline__ void quat_from_euler(const T e[3], T q[4]) {
 //   (fixedwing_base_env.py:288); away from the gimbal guard that round trip is
 //   the identity on the rotation, so q itself is used and the round trip is
 //   taken only on the (rare) guarded branch or when the quaternion is observed.
-template <typename T, typename W>
+template <typename T, bool LANES8 = false, typename W>
 __device__ __forceinline__ int write_obs_attitude(const Params<T>& P, const Rigid<T>& S, const T action[4], T R[9], W&& put) {
   rot_from_quat(S.q, R);
   T ang_vel[3], lin_vel[3], eul[3];
   mtv(R, S.w, ang_vel);
   mtv(R, S.v, lin_vel);
-  bool lock = euler_from_quat(S.q, eul);
+  bool lock = LANES8 ? euler_from_quat_lanes8(S.q, eul) : euler_from_quat(S.q, eul);
   T qrt[4] = { S.q[0], S.q[1], S.q[2], S.q[3] };
   if (lock || P.angle_repr == 1) {
     quat_from_euler(eul, qrt);
@@ -730,7 +751,7 @@ template <typename T, typename W>
 __device__ __forceinline__ void write_obs(const Params<T>& P, const DevState<T>& D, int env, const Rigid<T>& S,
                                           const T action[4], int tgt_idx, W&& put) {
   T R[9];
-  int o = write_obs_attitude<T>(P, S, action, R, put);
+  int o = write_obs_attitude<T, false>(P, S, action, R, put);
   for (int i = 0; i < P.ctx; ++i) {
     int t = tgt_idx + i;
     T d[3] = {(T)0, (T)0, (T)0}, b[3] = {(T)0, (T)0, (T)0};
