@@ -52,7 +52,8 @@ __global__ void fw_warm_kernel(Params<T>* Pm) {
   T R[9];
   normalize_quat<T>(S.q);
   rot_from_unit_quat<T>(S.q, R);
-  for (int t = 0; t < ticks; ++t) (void)physics_tick<T, false, 1>(P, C, S, R, cmd0, (T)0, wind0, mine, wmask);
+  LaneAct<T> LA; LA.a = (T)0; LA.cmd = (T)0;      // (unused by the one-lane-per-env tick)
+  for (int t = 0; t < ticks; ++t) (void)physics_tick<T, false, 1>(P, C, S, R, cmd0, (T)0, wind0, mine, wmask, LA);
   for (int k = 0; k < 3; ++k) { Pm->warm[k] = S.p[k]; Pm->warm[7 + k] = S.v[k]; Pm->warm[10 + k] = S.w[k]; }
   for (int k = 0; k < 4; ++k) Pm->warm[3 + k] = S.q[k];
   for (int k = 0; k < FW_NUM_ACTUATORS; ++k) Pm->warm[13 + k] = S.act[k];
@@ -153,14 +154,17 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
   ObjState<T> O;
   if (HASOBJ) { obj_load<T>(V, envc, O); O.near_mask = 0u; }
   const T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
+  LaneAct<T> LA; LA.cmd = (T)0; LA.a = (T)0;
+  if (G == 8) lane_act_scatter<T>(S, LA);
   const int chunk = left;
 #pragma unroll 1
   while (__ballot(left > 0) != 0ull) {
     if (left > 0) {
-      (void)aviary_step<T, true, G, HASOBJ>(P, C, OC, V, envc, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, gust, mine, wmask);
+      (void)aviary_step<T, true, G, HASOBJ>(P, C, OC, V, envc, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, gust, mine, wmask, LA);
       left -= 1;
     }
   }
+  if (G == 8) lane_act_gather<T>(S, LA);
   if (chunk > 0 && leader) {
     store_rigid<T>(V, env, S);
     D.is[env] = tick;
@@ -323,6 +327,10 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     for (int c = 0; c < FW_NUM_ACTUATORS; ++c)
       cmd[c] = P.mixer[c][0] * sp[0] + P.mixer[c][1] * sp[1] + P.mixer[c][2] * sp[2] + P.mixer[c][3] * sp[3];
   }
+  // G = 8: my surface's actuator state and command stay lane-local during the ticks (see LaneAct)
+  LaneAct<T> LA; LA.a = (T)0; LA.cmd = (T)0;
+  T cmd_mine = (T)0;
+  if (G == 8) { lane_act_scatter<T>(S, LA); cmd_mine = lane_pick5<T>(cmd[0], cmd[1], cmd[2], cmd[3], cmd[4]); LA.cmd = cmd_mine; }
 
   // current and next waypoint stay in registers (no L2 round trip per sub-step)
   T tcur[3] = {(T)0, (T)0, (T)0}, tnext[3] = {(T)0, (T)0, (T)0};
@@ -376,6 +384,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       phase = PH_DONE;
       if (DEFER) { resetting = (flags & (FL_TERM | FL_TRUNC)) && P.auto_reset; FWP(if (resetting) p_nreset += 1;) }
       if (!DEFER && (flags & (FL_TERM | FL_TRUNC)) && P.auto_reset) {
+        if (G == 8) lane_act_gather<T>(S, LA);          // the terminal observation shows all six actuators
         if (terminal_obs && leader) {
           T* trow = terminal_obs + (size_t)env * Dobs;
           T act_t[4];
@@ -420,6 +429,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
         }
         if (G > 1 && warm_left > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the warm-up's camera reads the obstacles
         if (GENERAL) gust_init<T>(P, wphase, tick, gust);                                  // new clock, new phase
+        if (G == 8) lane_act_scatter<T>(S, LA);                                             // new episode's actuator state
         FWP(const long long p_rb = FWP_NOW(); p_r2 += p_rb - p_ra;)
         step_count = 0; flags = 0; ep_return = (T)0; tgt_obs = 0;
         act_src = 2;
@@ -452,9 +462,10 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
 #pragma unroll
         for (int c = 0; c < FW_NUM_ACTUATORS; ++c) c_eff[c] = stepping ? cmd[c] : (T)0;
         z0 = stepping ? z0 : (T)0; z1 = stepping ? z1 : (T)0;
-        contact = aviary_step<T, true, G, HASOBJ>(P, C, OC, D, env, O, S, R, c_eff, tick, z0, z1, wb, wa, gust, mine, wmask);   // :339
+        LA.cmd = stepping ? cmd_mine : (T)0;
+        contact = aviary_step<T, true, G, HASOBJ>(P, C, OC, D, env, O, S, R, c_eff, tick, z0, z1, wb, wa, gust, mine, wmask, LA);   // :339
       } else {
-        contact = aviary_step<T, false, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd, tick, z0, z1, wb, wa, gust, mine, wmask);    // :339
+        contact = aviary_step<T, false, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd, tick, z0, z1, wb, wa, gust, mine, wmask, LA);    // :339
       }
       FWP(const long long p_c = FWP_NOW(); p_avi += p_c - p_b;)
       if (stepping && OBJ) {
@@ -557,6 +568,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   FWP(const long long p_t2 = FWP_NOW();)
   // G = 8: waypoints sampled by sibling lanes during an in-launch reset are read back below
   if (G > 1 && !DEFER) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  if (G == 8) lane_act_gather<T>(S, LA);             // S.act[0..4] current again for the observation and the state store
 
   if ((GENERAL || DEFER) && D.shadow_on && active && leader && (uint32_t)(sh_req >> 32) != (uint32_t)(episode + 1))
     D.sreq[env] = ((unsigned long long)(uint32_t)(episode + 1) << 32) | (unsigned long long)D.epoch;   // ask for the next episode
@@ -779,10 +791,12 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
   rot_from_unit_quat<T>(S.q, R);
   T gust[2];
   gust_init<T>(P, wphase, tick, gust);
+  LaneAct<T> LA; LA.cmd = (T)0; LA.a = (T)0;
+  if (G == 8) lane_act_scatter<T>(S, LA);
 #pragma unroll 1
   while (__ballot(warm_left > 0) != 0ull) {
     if (warm_left > 0) {
-      (void)aviary_step<T, true, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, gust, mine, wmask);
+      (void)aviary_step<T, true, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, gust, mine, wmask, LA);
       warm_left -= 1;
       if (warm_left == 0) {
         if (OBJ) obj_compute_state<T>(O);
@@ -791,6 +805,7 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
     }
   }
   if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  if (G == 8) lane_act_gather<T>(S, LA);
   if (resetting) {
     action[0] = action[1] = action[2] = action[3] = (T)0;
     tgt_obs = 0;

@@ -537,6 +537,28 @@ __device__ __forceinline__ void normalize_quat(T q[4]) {
   }
 }
 
+// G = 8: the control-surface actuator lags are lane-local during the ticks -- lane j carries the state of surface
+// min(j, 4) and its command (`LaneAct`), instead of every lane updating all five and selecting its own afterwards.
+// S.act[0..4] is only current at the sync points (lane_act_gather); the motor (S.act[5]) stays replicated.
+template <typename T> struct LaneAct { T a, cmd; };
+// (operands by value: selecting between loads of one array makes the compiler index the array dynamically -- in scratch)
+template <typename T>
+__device__ __forceinline__ T lane_pick5(T v0, T v1, T v2, T v3, T v4) {
+  const int sub = threadIdx.x & 7;
+  T a = v0;
+  a = (sub == 1) ? v1 : a; a = (sub == 2) ? v2 : a; a = (sub == 3) ? v3 : a; a = (sub >= 4) ? v4 : a;
+  return a;
+}
+template <typename T> __device__ __forceinline__ void lane_act_scatter(const Rigid<T>& S, LaneAct<T>& LA) {
+  LA.a = lane_pick5<T>(S.act[0], S.act[1], S.act[2], S.act[3], S.act[4]);
+}
+template <typename T>
+__device__ __forceinline__ void lane_act_gather(Rigid<T>& S, const LaneAct<T>& LA) {
+  const int gbase = threadIdx.x & ~7;
+#pragma unroll
+  for (int k = 0; k < FW_NUM_SURFACES; ++k) S.act[k] = __shfl(LA.a, gbase | k, kWave);
+}
+
 // ---- one 1/240 s physics tick, in three stages ----
 // (1) actuator lags
 template <typename T>
@@ -595,18 +617,23 @@ __device__ __forceinline__ void quat_integrate(const TickC<T>& C, Rigid<T>& S) {
 template <typename T, bool WIND, int G>
 __device__ __forceinline__ bool physics_tick(const Params<T>& P, const TickC<T>& C, Rigid<T>& S, T R[9],
                                              const T cmd[FW_NUM_ACTUATORS], T noise_z, const T wind[3],
-                                             const SurfC<T>& mine, T wmask) {
-  tick_actuators<T>(C, S, cmd, noise_z);
+                                             const SurfC<T>& mine, T wmask, LaneAct<T>& LA) {
+  if (G == 8) {
+    LA.a += mine.dt_tau * (LA.cmd - LA.a);                          // my surface
+    T thr = S.act[FW_NUM_SURFACES];                                 // the motor, replicated
+    thr += C.motor_dt_tau * (cmd[FW_NUM_SURFACES] - thr);
+    thr += noise_z * thr * C.noise_ratio;
+    S.act[FW_NUM_SURFACES] = thr;
+  } else {
+    tick_actuators<T>(C, S, cmd, noise_z);
+  }
   T v_b[3], w_b[3], wind_b[3] = {(T)0, (T)0, (T)0};
   mtv(R, S.v, v_b);
   mtv(R, S.w, w_b);
   if (WIND && P.wind_coupling == FW_WIND_COUPLE_AIRSPEED) mtv(R, wind, wind_b);
   T F[3] = {(T)0, (T)0, (T)0}, Tq[3] = {(T)0, (T)0, (T)0};
   if (G == 8) {
-    const int sub = threadIdx.x & 7;
-    T a_s = S.act[0];
-    a_s = (sub == 1) ? S.act[1] : a_s; a_s = (sub == 2) ? S.act[2] : a_s;
-    a_s = (sub == 3) ? S.act[3] : a_s; a_s = (sub >= 4) ? S.act[4] : a_s;
+    const T a_s = LA.a;
     T f[3], tq[3];
     surface_wrench<T>(mine, a_s, v_b, w_b, wind_b, f, tq);
 #pragma unroll

@@ -531,13 +531,13 @@ template <typename T, bool WIND, int G, bool OBJ>
 __device__ __forceinline__ bool aviary_step(const Params<T>& P, const TickC<T>& C, const ObjC<T>& OC, const DevState<T>& D,
                                             int env, ObjState<T>& O, Rigid<T>& S, T R[9], const T cmd[FW_NUM_ACTUATORS],
                                             int32_t& tick, T z0, T z1, const T wb[3], const T wa[3], T gust[2],
-                                            const SurfC<T>& mine, T wmask) {
+                                            const SurfC<T>& mine, T wmask, LaneAct<T>& LA) {
   bool contact = false;
 #pragma unroll 1
   for (int t = 0; t < P.ticks_per_aviary; ++t) {
     T wind[3] = {(T)0, (T)0, (T)0};
     if (WIND) wind_from_phase<T>(P, wb, wa, gust, wind);
-    contact |= physics_tick<T, WIND, G>(P, C, S, R, cmd, (t & 1) ? z1 : z0, wind, mine, wmask);
+    contact |= physics_tick<T, WIND, G>(P, C, S, R, cmd, (t & 1) ? z1 : z0, wind, mine, wmask, LA);
     if (OBJ) contact |= obj_contacts<T, G>(P, C, OC, D, env, O, S, R);
     tick += 1;
     if (WIND) gust_advance<T>(P, gust);
