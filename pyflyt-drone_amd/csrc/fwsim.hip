@@ -279,11 +279,6 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   constexpr bool LANE_T = DEFER && G == 8;
   T tmine[3] = {(T)0, (T)0, (T)0};
   T a_keep = (T)0;
-  T tpre[3] = {(T)0, (T)0, (T)0};                    // DEFER: the waypoint a worker block sampled for my next episode (if any)
-  if (DEFER && D.shadow_on && sub < P.num_targets) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) tpre[k] = D.rs[(size_t)(RF_TARGETS + 3 * sub + k) * n + envc];
-  }
   if (LANE_T) {
     if (sub < P.num_targets) {
 #pragma unroll
@@ -569,6 +564,15 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   // G = 8: waypoints sampled by sibling lanes during an in-launch reset are read back below
   if (G > 1 && !DEFER) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   if (G == 8) lane_act_gather<T>(S, LA);             // S.act[0..4] current again for the observation and the state store
+  // DEFER: the waypoint a worker block sampled ahead of time for my next episode, requested only by resetting envs and only
+  // now -- its latency hides behind the observation pass below
+  T tpre[3] = {(T)0, (T)0, (T)0};
+  const bool pre = DEFER && resetting && D.shadow_on && (int)(sh_done & 0xFF) == 1 && (uint32_t)(sh_done >> 32) == (uint32_t)(episode + 1) &&
+                   (uint32_t)((sh_done >> 8) & 0xFFFFFFu) != (D.epoch & 0xFFFFFFu);
+  if (pre && sub < P.num_targets) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tpre[k] = D.rs[(size_t)(RF_TARGETS + 3 * sub + k) * n + env];
+  }
 
   if ((GENERAL || DEFER) && D.shadow_on && active && leader && (uint32_t)(sh_req >> 32) != (uint32_t)(episode + 1))
     D.sreq[env] = ((unsigned long long)(uint32_t)(episode + 1) << 32) | (unsigned long long)D.epoch;   // ask for the next episode
@@ -624,8 +628,6 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     episode += 1;
     Scenario<T> sc;
     // (the obs pass above read the old waypoints; they are overwritten here)
-    const bool pre = D.shadow_on && (int)(sh_done & 0xFF) == 1 && (uint32_t)(sh_done >> 32) == (uint32_t)episode &&
-                     (uint32_t)((sh_done >> 8) & 0xFFFFFFu) != (D.epoch & 0xFFFFFFu);
     if (pre) {                                         // sampled ahead of time by a worker block of an earlier launch
 #pragma unroll
       for (int k = 0; k < 3; ++k) sc.t_mine[k] = tpre[k];
