@@ -312,3 +312,23 @@ def test_fw_policy_terminal_value_bootstraps_only_truncated_rows():
             torch.testing.assert_close(val[rows], ref[rows], rtol=1e-4, atol=2e-5)
         else:
             assert bool((val[rows] == -7.0).all())                               # skipped blocks leave the buffer alone
+
+
+def test_objlock_training_learns_to_strike():
+    """The whole learner on the reference's ObjLock config and PPO hyper-parameters (train/train_objlock.py:27-86; batch 64,
+    10 epochs, 32 768 samples per update): ~1.3 M steps -- a few seconds -- take the deterministic policy from never
+    striking the duck to striking it in most evaluation episodes.  Everything in the loop is one of this package's kernels."""
+    from pyflyt_drone_amd import evaluate
+    cfg = K.train_objlock_config()
+    env = R.VecNormalizeDevice(P.FixedwingVecEnv(cfg, 4096, seed=42))
+    eval_env = R.VecNormalizeDevice(P.FixedwingVecEnv(cfg, 32, seed=42, global_env_offset=4096), training=False, norm_reward=False)
+    ppo = R.PPO(env, R.PPOConfig(n_steps=8, batch_size=64, n_epochs=10, learning_rate=3e-4, ent_coef=0.001, seed=42))
+    assert ppo._collect_fused and R.FusedPpoUpdate.applies(ppo.policy, ppo.cfg, env.obs_dim, 64, ppo.device)
+    evaluate.sync_envs_normalization(env, eval_env)
+    before = evaluate.evaluate_policy(ppo.policy, eval_env, 32, deterministic=True)
+    ppo.learn(1_300_000)
+    evaluate.sync_envs_normalization(env, eval_env)
+    after = evaluate.evaluate_policy(ppo.policy, eval_env, 32, deterministic=True)
+    s0, s1 = float(np.mean(before.duck_strike)), float(np.mean(after.duck_strike))
+    assert s0 <= 0.2 and s1 >= 0.5, (s0, s1)
+    assert after.mean_reward > before.mean_reward + 500.0
