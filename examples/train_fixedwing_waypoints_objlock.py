@@ -1,0 +1,83 @@
+"""Device-resident counterpart of the reference's train/train_Fixedwing_Waypoints_ObjLock.py (:35-92 config, :119-165 env).
+
+The combined task: 8 waypoints (dense reward, reach 8 m) through a field of 20 cylinders, then lock onto and strike the duck;
+gust wind; observation = the waypoint observation (28 x float64; `duck_vision` is not in the policy input, as in the
+reference's FlattenWaypointEnv).  Same PPO hyper-parameters (batch 128, 20 epochs, lr 3e-4, ent 0.001); 32 envs x 1024 steps
+become num_envs x (32 768 / num_envs).  The eval callback reports wp{i}_reach_rate, success_rate and duck_strike_rate.
+
+    python examples/train_fixedwing_waypoints_objlock.py --total_timesteps 5000000 --num_envs 4096 --out runs/combined
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pyflyt_drone_amd as P  # noqa: E402
+from pyflyt_drone_amd import checkpoint, evaluate, rollout as R  # noqa: E402
+
+TRAIN_CONFIG = dict(total_timesteps=20_000_000, n_eval_episodes=10, learning_rate=3e-4, samples_per_update=32 * 1024, batch_size=128,
+                    n_epochs=20, gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.001, vf_coef=0.5, max_grad_norm=0.5, seed=42)
+WIND = {"enabled": True, "mode": "gust_sine", "wind_enu_mps": [0.0, 0.0, 0.0],
+        "wind_enu_mps_range": [[-5.0, 5.0], [-5.0, 5.0], [-0.5, 0.5]], "gust_amp_enu_mps": [0.0, 0.0, 0.0],
+        "gust_amp_enu_mps_range": [[0.0, 3.0], [0.0, 3.0], [0.0, 0.3]], "gust_freq_hz": 0.2, "gust_phase_rad": 0.0,
+        "randomize_on_reset": True, "randomize_gust_phase": True}
+ENV_KW = dict(sparse_reward=False, num_targets=8, goal_reach_distance=8, flight_dome_size=100.0, max_duration_seconds=120.0,
+              angle_representation="euler", agent_hz=30, context_length=2, render_mode="rgb_array",
+              num_obstacles=20, obstacle_radius=2.0, obstacle_height_range=(10.0, 30.0), obstacle_safe_distance_m=5.0,
+              obstacle_avoid_reward_scale=1.0, obstacle_avoid_max_penalty=2.0, duck_camera_capture_interval_steps=6,
+              duck_lock_hold_steps=10, duck_strike_distance_m=8, duck_strike_reward=200.0, duck_lock_step_reward=0.1,
+              duck_approach_reward_scale=0.05, duck_switch_min_consecutive_seen=2, duck_switch_min_area=0.0005,
+              duck_global_scaling=30.0, wind_config=WIND)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pretrained_model", type=str, default=None)
+    ap.add_argument("--vecnorm_path", type=str, default=None)
+    ap.add_argument("--total_timesteps", type=int, default=None)
+    ap.add_argument("--num_envs", type=int, default=4096)
+    ap.add_argument("--out", type=str, default="runs/obj_strick_ppo")
+    a = ap.parse_args()
+    cfg = TRAIN_CONFIG
+    model_dir, log_dir = os.path.join(a.out, "models"), os.path.join(a.out, "logs")
+    os.makedirs(model_dir, exist_ok=True); os.makedirs(log_dir, exist_ok=True)
+
+    env = R.VecNormalizeDevice(P.FixedwingWaypointObjLockVecEnv(num_envs=a.num_envs, seed=cfg["seed"], **ENV_KW))
+    eval_env = R.VecNormalizeDevice(P.FixedwingWaypointObjLockVecEnv(num_envs=16, seed=cfg["seed"], global_env_offset=a.num_envs, **ENV_KW),
+                                    training=False, norm_reward=False)
+    vecnorm = checkpoint.infer_vecnorm_path(a.pretrained_model, a.vecnorm_path, model_dir)
+    if vecnorm:
+        checkpoint.load_vecnormalize(vecnorm, env, training=True, norm_reward=True)
+    n_steps = max(cfg["samples_per_update"] // a.num_envs, 1)
+    model = R.PPO(env, R.PPOConfig(n_steps=n_steps, batch_size=cfg["batch_size"], n_epochs=cfg["n_epochs"], learning_rate=cfg["learning_rate"],
+                                   gamma=cfg["gamma"], gae_lambda=cfg["gae_lambda"], clip_range=cfg["clip_range"], ent_coef=cfg["ent_coef"],
+                                   vf_coef=cfg["vf_coef"], max_grad_norm=cfg["max_grad_norm"], seed=cfg["seed"]))
+    if a.pretrained_model:
+        checkpoint.set_parameters(a.pretrained_model, model)
+    ev = evaluate.EvalCallback(eval_env, n_eval_episodes=max(cfg["n_eval_episodes"], 16), eval_freq=max(10000 // a.num_envs, 1) * 50,
+                               log_path=log_dir, best_model_save_path=model_dir, num_targets_total=ENV_KW["num_targets"], verbose=1)
+    ck = checkpoint.CheckpointCallback(save_freq=max(50000 // a.num_envs, 1) * 50, save_path=model_dir, name_prefix="obj_strick_ppo")
+
+    class Progress:
+        t0, last = time.perf_counter(), 0
+        def on_rollout_end(self, ppo):
+            if ppo.num_timesteps - self.last >= 20 * n_steps * a.num_envs:
+                dt = time.perf_counter() - self.t0
+                print(json.dumps({"timesteps": ppo.num_timesteps, "fps": round(ppo.num_timesteps / dt), **{k: round(v, 5) for k, v in ppo.logs.items()},
+                                  **{k: round(float(v), 4) for k, v in ev.last_scalars.items()}}), flush=True)
+                self.last = ppo.num_timesteps
+            return True
+
+    total = a.total_timesteps if a.total_timesteps is not None else cfg["total_timesteps"]
+    try:
+        model.learn(total, callbacks=[ev, ck, Progress()], reset_num_timesteps=True)
+    finally:
+        checkpoint.save(os.path.join(model_dir, "final_model.pt"), model)
+        checkpoint.save_vecnormalize(os.path.join(model_dir, "vecnorm.pt"), env)
+        env.venv.close(); eval_env.venv.close()
+
+
+if __name__ == "__main__":
+    main()
