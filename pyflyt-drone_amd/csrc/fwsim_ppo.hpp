@@ -483,7 +483,8 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       unsigned long long* ftheirs = A.xch + 8 + (mb & 1) * 4 + NET * 2 + (1 - half);
       const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane), s2 = ppo_tile_slot(n, 2, wave, lane);
       // Plain vector stores / loads bracketed by a device-scope release (every storing wave, before the barrier and the
-      // flag) and acquire (after the flag).  (Tried: per-word sc1 atomics instead of the fences -- 27.4 vs 23.9 us.)
+      // flag) and acquire (after the flag).  (Tried instead of the fences: per-word sc1 atomics -- 27.4 vs 23.9 us; sc1 dwordx4
+      // stores / loads by inline asm -- hand-off 12 k -> 9 k cycles but the chunk passes slow down by as much: no gain.)
       const int sq = kPTileSlots + t;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
