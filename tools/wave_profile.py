@@ -37,8 +37,5 @@ print(f"  slowest wave reset split: terminal obs {S[:, 8].mean():.0f}  swap-in /
 print(f"  loop iterations: mean {it.mean():.2f}  slowest-wave mean {(S[:, 6] & 0xFF).mean():.2f}  max {it.max()}")
 print(f"  env resets/launch {nr.sum(axis=1).mean():.1f}  of which swapped-in shadows {nh.sum(axis=1).mean():.1f}")
 print(f"  waves with a reset: {100.0 * (nr > 0).mean():.1f}%   with an in-kernel (fallback) reset: {100.0 * ((nr - nh) > 0).mean():.1f}%")
-# launch span = last wave end - first wave start
-t0 = st[:, :, 7]; span = (t0 + tot).max(axis=1) - t0.min(axis=1)
-print(f"  launch span (first wave start -> last step-wave end): mean {span.mean():.0f}  p50 {np.median(span):.0f}  max {span.max()}")
 if wk.any():
     print(f"  shadow worker waves: busy {100.0 * (wk > 2000).mean():.1f}%  mean busy cycles {wk[wk > 2000].mean() if (wk > 2000).any() else 0:.0f}  max {wk.max()}")
