@@ -65,13 +65,16 @@ def action_pool(n, dtype, device):
 
 
 class Stepper:
-    """Replays the pool of 64 fw_step launches as one hipGraph (captured from the
-    torch stream the C ABI launches on) or issues them eagerly."""
+    """Issues fw_step launches over the action pool, either eagerly or as replays of ONE captured hipGraph of
+    `graph_len` launches (captured from the torch stream the C ABI launches on); a remainder that does not fill a
+    replay is issued eagerly.  `counts` says what a run() really did, so the bench line can print it."""
 
-    def __init__(self, env, pool, use_graph):
+    def __init__(self, env, pool, use_graph, graph_len=POOL):
         self.env, self.pool, self.graph = env, pool, None
         self.i = 0
-        if use_graph:
+        self.graph_len = int(graph_len) if use_graph else 0
+        self.counts = {"replays": 0, "eager": 0}
+        if self.graph_len > 0:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
@@ -81,21 +84,36 @@ class Stepper:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                for a in pool:
-                    env.step_tensor(a)
+                for j in range(self.graph_len):
+                    env.step_tensor(pool[j % len(pool)])
             self.graph = g
+
+    def actions_of(self, k):
+        """The action tensors run(k) will use, in order (for checkers that step an oracle alongside)."""
+        if self.graph is None:
+            return [self.pool[(self.i + j) % len(self.pool)] for j in range(k)]
+        full, rest = divmod(k, self.graph_len)
+        one = [self.pool[j % len(self.pool)] for j in range(self.graph_len)]
+        return one * full + one[:rest]
 
     def run(self, k):
         """Run exactly k steps."""
         if self.graph is None:
             for _ in range(k):
-                self.env.step_tensor(self.pool[self.i % POOL]); self.i += 1
+                self.env.step_tensor(self.pool[self.i % len(self.pool)]); self.i += 1
+            self.counts["eager"] += k
             return
-        full, rest = divmod(k, POOL)
+        full, rest = divmod(k, self.graph_len)
         for _ in range(full):
             self.graph.replay()
         for j in range(rest):
-            self.env.step_tensor(self.pool[j])
+            self.env.step_tensor(self.pool[j % len(self.pool)])
+        self.counts["replays"] += full; self.counts["eager"] += rest
+
+    def describe(self, counts):
+        if self.graph is None:
+            return f"eager x{counts['eager']}"
+        return f"hipGraph({self.graph_len} launches) x{counts['replays']} replays + {counts['eager']} eager"
 
 
 def cpu_baseline(cfg, n, seconds_target=12.0):
@@ -156,7 +174,8 @@ def main():
     env = P.FixedwingVecEnv(cfg, n, device=local_rank, seed=42, global_env_offset=rank * n)
     env.reset_tensor()
     pool = action_pool(n, env.torch_dtype, env.device)
-    stepper = Stepper(env, pool, use_graph=not args.no_graph)
+    # the graph holds min(64, steps) launches, so that the timed region is made of replays whatever --steps is
+    stepper = Stepper(env, pool, use_graph=not args.no_graph, graph_len=max(1, min(POOL, args.steps)))
 
     def barrier():
         if dist:
@@ -168,7 +187,9 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
+    before = dict(stepper.counts)
     stepper.run(args.steps)
+    timed = {k: stepper.counts[k] - before[k] for k in before}
     ev1.record()
     barrier()
     wall = time.perf_counter() - t0
@@ -228,7 +249,7 @@ def main():
             "config": {"workload": f"FixedwingWaypoints-v3 TRAIN_CONFIG (8 targets, sparse, euler, 30 Hz), "
                                    f"{n} envs/GPU x {world} GPU, physics-only step(), motor noise + auto-reset on",
                        "envs_per_gpu": n, "obs_dim": env.obs_dim, "ticks_per_env_step": 8,
-                       "launch": "eager" if args.no_graph else "hipGraph(64 launches)", "parallelism": f"env-shard x{world}"},
+                       "launch": stepper.describe(timed), "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "fw_step_kernel", "launch_us": launch_s * 1e6,

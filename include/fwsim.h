@@ -22,6 +22,7 @@
  *   fw_seed     <- VecEnv.seed(seed) / env.reset(seed=seed+rank)
  *                  train/train_Fixedwing_Waypoints_v3.py:119
  *   fw_get_state/fw_set_state <- (no reference twin) parity tests + checkpoints
+ *   fw_get_counters <- (no reference twin) diagnostics of the auto-reset hand-off
  *   fw_destroy  <- Env.close()  envs/fixedwing_envs/fixedwing_base_env.py:187-191
  *
  * Conventions
@@ -45,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 4
+#define FW_ABI_VERSION 5
 
 #define FW_NUM_SURFACES 5         /* left aileron, right aileron, h-tail, v-tail, main wing */
 #define FW_NUM_ACTUATORS 6        /* 5 surfaces + throttle (aux_state order) */
@@ -260,6 +261,17 @@ enum {
   FW_INFO_DIM = 8
 };
 
+/* fw_get_counters columns: how the auto-resets of fw_step were served so far (diagnostics; they let a test assert that
+ * the background hand-off -- and not only its in-kernel fallback -- was exercised, e.g. under hipGraph replay). */
+enum {
+  FW_CTR_LAUNCHES = 0,       /* fw_step launches so far (the device-side launch index the hand-off protocol uses) */
+  FW_CTR_RESETS = 1,         /* auto-resets performed inside fw_step */
+  FW_CTR_SHADOW_HITS = 2,    /* ... served by a pre-simulated ("shadow") episode start: wind / camera tasks */
+  FW_CTR_SCENARIO_HITS = 3,  /* ... served by pre-sampled waypoints: wind-free waypoints task */
+  FW_CTR_FALLBACKS = 4,      /* ... served by the in-kernel sampler / warm-up */
+  FW_CTR_DIM = 8
+};
+
 typedef struct fw_env* fw_handle;
 
 /* Size of fw_config as compiled into the library (binding self-check). */
@@ -304,6 +316,9 @@ int32_t fw_seed(fw_handle h, uint64_t seed);
 /* Canonical state records, HOST memory, double[N, FW_STATE_DIM]. Synchronous. */
 int32_t fw_get_state(fw_handle h, double* state_out);
 int32_t fw_set_state(fw_handle h, const double* state_in);
+
+/* Diagnostic counters, HOST uint64[FW_CTR_DIM] (see FW_CTR_*).  Synchronous. */
+int32_t fw_get_counters(fw_handle h, uint64_t* out);
 
 /* Recompute the observation from the current state (no dynamics), device T[N,D]. */
 int32_t fw_observe(fw_handle h, void* obs_out, void* hip_stream);

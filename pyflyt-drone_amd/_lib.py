@@ -19,7 +19,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 EXPORTS = (
     "fw_sizeof_config", "fw_abi_version", "fw_state_dim", "fw_obs_dim", "fw_validate_config", "fw_create", "fw_reset",
-    "fw_step", "fw_seed", "fw_get_state", "fw_set_state", "fw_observe", "fw_num_envs", "fw_last_error",
+    "fw_step", "fw_seed", "fw_get_state", "fw_set_state", "fw_get_counters", "fw_observe", "fw_num_envs", "fw_last_error",
     "fw_destroy", "fw_gae", "fw_normalize_obs", "fw_ppo_param_count", "fw_ppo_moment_count", "fw_ppo_moment_map", "fw_ppo_update", "fw_policy_act", "fw_policy_terminal_value", "fw_rollout_post",
 )
 
@@ -63,6 +63,7 @@ def lib() -> C.CDLL:
         L.fw_seed.restype = i32; L.fw_seed.argtypes = [vp, u64]
         L.fw_get_state.restype = i32; L.fw_get_state.argtypes = [vp, vp]
         L.fw_set_state.restype = i32; L.fw_set_state.argtypes = [vp, vp]
+        L.fw_get_counters.restype = i32; L.fw_get_counters.argtypes = [vp, vp]
         L.fw_num_envs.restype = i32; L.fw_num_envs.argtypes = [vp]
         L.fw_last_error.restype = C.c_char_p; L.fw_last_error.argtypes = [vp]
         L.fw_destroy.restype = i32; L.fw_destroy.argtypes = [vp]

@@ -408,8 +408,10 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
           if (!OBJ) copy_words<T, G>(D.r, V.r, RF_TARGETS, 3 * P.num_targets, n, env);
           if (HASOBJ) copy_words<T, G>(D.r, V.r, RF_TASK + FW_ST_OBST, 3 * FW_MAX_OBSTACLES, n, env);
           episode += 1; num_reached = 0; warm_left = 0;
+          if (leader) stat_add(D.stats, FW_CTR_SHADOW_HITS);
           FWP(p_nhit += 1;)
         } else {
+          if (leader) stat_add(D.stats, FW_CTR_FALLBACKS);
           warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase, t_mine);
           if (G > 1) {                                          // the group's lane 0 sampled waypoint 0
             const int src = lane & ~(G - 1);
@@ -428,6 +430,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
         FWP(const long long p_rb = FWP_NOW(); p_r2 += p_rb - p_ra;)
         step_count = 0; flags = 0; ep_return = (T)0; tgt_obs = 0;
         act_src = 2;
+        if (leader) stat_add(D.stats, FW_CTR_RESETS);
         FWP(p_nreset += 1;)
         rot_from_unit_quat<T>(S.q, R);
         if (GENERAL && warm_left > 0) phase = PH_WARM;
@@ -626,6 +629,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     episode += 1;
+    if (leader) { stat_add(D.stats, FW_CTR_RESETS); stat_add(D.stats, pre ? FW_CTR_SCENARIO_HITS : FW_CTR_FALLBACKS); }
     Scenario<T> sc;
     // (the obs pass above read the old waypoints; they are overwritten here)
     if (pre) {                                         // sampled ahead of time by a worker block of an earlier launch
@@ -719,18 +723,20 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     const T* __restrict__ actions, T* __restrict__ obs, T* __restrict__ reward, uint8_t* __restrict__ terminated,        \
     uint8_t* __restrict__ truncated, T* __restrict__ terminal_obs, int32_t* __restrict__ info
 #define FW_STEP_PASS Pp, OCp, D, actions, obs, reward, terminated, truncated, terminal_obs, info
+// every step kernel: launch index from the workgroup's own device-side counter, advanced when the workgroup is finished
+#define FW_STEP_RUN(...) do { D.epoch = launch_index(D.lctr); step_body<__VA_ARGS__>(FW_STEP_PASS); launch_done(D.lctr, D.epoch); } while (0)
 // latency mapping (8 lanes per env): one wave per SIMD by construction, let the allocator use the whole file
 template <typename T, bool GENERAL>
-__global__ __launch_bounds__(kWave) void fw_step_kernel_g8(FW_STEP_ARGS) { step_body<T, GENERAL, 8, FW_TASK_WAYPOINTS>(FW_STEP_PASS); }
+__global__ __launch_bounds__(kWave) void fw_step_kernel_g8(FW_STEP_ARGS) { FW_STEP_RUN(T, GENERAL, 8, FW_TASK_WAYPOINTS); }
 // throughput mapping (one lane per env)
 template <typename T, bool GENERAL>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(FW_G1_WAVES, FW_G1_WAVES)))
-void fw_step_kernel_g1(FW_STEP_ARGS) { step_body<T, GENERAL, 1, FW_TASK_WAYPOINTS>(FW_STEP_PASS); }
+void fw_step_kernel_g1(FW_STEP_ARGS) { FW_STEP_RUN(T, GENERAL, 1, FW_TASK_WAYPOINTS); }
 // ObjLock task (always the GENERAL path: its training config has wind)
 template <typename T, int TKIND>
-__global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g8(FW_STEP_ARGS) { step_body<T, true, 8, TKIND>(FW_STEP_PASS); }
+__global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g8(FW_STEP_ARGS) { FW_STEP_RUN(T, true, 8, TKIND); }
 template <typename T, int TKIND>
-__global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g1(FW_STEP_ARGS) { step_body<T, true, 1, TKIND>(FW_STEP_PASS); }
+__global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g1(FW_STEP_ARGS) { FW_STEP_RUN(T, true, 1, TKIND); }
 
 // K2: reset (masked) + observation.  Same single-tick-site structure (warm-up only).
 template <typename T, int G, int TKIND>
@@ -1003,7 +1009,8 @@ struct fw_env {
   int32_t* is_dev = nullptr;    // shadow ticks i32[npad]
   unsigned long long* sreq_dev = nullptr;   // shadow requests / progress words, u64[npad] each
   unsigned long long* sdone_dev = nullptr;
-  uint32_t epoch = 1;           // fw_step launch index
+  uint32_t* lctr_dev = nullptr;             // device-side launch index, one word per workgroup (fwsim_device.hpp: launch_index)
+  unsigned long long* stats_dev = nullptr;  // hand-off counters (fw_get_counters)
   long long* prof_dev = nullptr; // FW_PROFILE builds only
   int32_t shadow_on = 0;        // background warm-up of the next episode (see shadow_* kernels)
   std::string err;
@@ -1030,7 +1037,8 @@ struct DeviceGuard {
 
 template <typename T> DevState<T> dev_state(fw_env* h) {
   DevState<T> D; D.r = (T*)h->r_dev; D.i = h->i_dev; D.n = h->n; D.npad = h->npad;
-  D.rs = (T*)h->rs_dev; D.is = h->is_dev; D.sreq = h->sreq_dev; D.sdone = h->sdone_dev; D.epoch = h->epoch; D.shadow_on = h->shadow_on;
+  D.rs = (T*)h->rs_dev; D.is = h->is_dev; D.sreq = h->sreq_dev; D.sdone = h->sdone_dev; D.epoch = 0; D.shadow_on = h->shadow_on;
+  D.lctr = h->lctr_dev; D.stats = h->stats_dev;
   FWP(D.prof = h->prof_dev;)
   return D;
 }
@@ -1103,6 +1111,11 @@ int create_T(fw_env* h) {
   HIP_TRY(h, hipMalloc((void**)&h->i_dev, sizeof(int32_t) * IF_COUNT * npad));
   int rc = upload_params<T>(h);
   if (rc != FW_OK) return rc;
+  const size_t nctr = 2 * (size_t)grid_of(h).x;              // step workgroups + (possibly) as many workers
+  HIP_TRY(h, hipMalloc((void**)&h->lctr_dev, sizeof(uint32_t) * nctr));
+  HIP_TRY(h, hipMemset(h->lctr_dev, 0, sizeof(uint32_t) * nctr));
+  HIP_TRY(h, hipMalloc((void**)&h->stats_dev, sizeof(unsigned long long) * FW_CTR_DIM));
+  HIP_TRY(h, hipMemset(h->stats_dev, 0, sizeof(unsigned long long) * FW_CTR_DIM));
   // shadow warm-up whenever the reset warm-up cannot be cached (wind acting on the dynamics, camera tasks)
   const bool cached = (h->cfg.task == FW_TASK_WAYPOINTS) &&
                       (h->cfg.wind_mode == FW_WIND_OFF || h->cfg.wind_coupling == FW_WIND_COUPLE_NONE);
@@ -1148,7 +1161,6 @@ int step_T(fw_env* h, const void* actions, void* obs, void* reward, uint8_t* ter
     if (g8) FW_LAUNCH_STEP((fw_step_kernel_g8<T, false>)); else FW_LAUNCH_STEP((fw_step_kernel_g1<T, false>));
   }
   HIP_TRY(h, hipGetLastError());
-  h->epoch += 1;
   return FW_OK;
 }
 
@@ -1270,6 +1282,8 @@ int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64
     if (h->is_dev) (void)hipFree(h->is_dev);
     if (h->sreq_dev) (void)hipFree(h->sreq_dev);
     if (h->sdone_dev) (void)hipFree(h->sdone_dev);
+    if (h->lctr_dev) (void)hipFree(h->lctr_dev);
+    if (h->stats_dev) (void)hipFree(h->stats_dev);
     delete h;
     return rc;
   }
@@ -1330,6 +1344,19 @@ int32_t fw_set_state(fw_handle h, const double* state_in) {
   if (!h || !state_in) return FW_EINVAL;
   DeviceGuard g(h->device);
   return (h->cfg.dtype == FW_F64) ? set_state_T<double>(h, state_in) : set_state_T<float>(h, state_in);
+}
+
+int32_t fw_get_counters(fw_handle h, uint64_t* out) {
+  if (!h || !out) return FW_EINVAL;
+  DeviceGuard g(h->device);
+  unsigned long long w[FW_CTR_DIM];
+  uint32_t launches = 0;
+  HIP_TRY(h, hipDeviceSynchronize());
+  HIP_TRY(h, hipMemcpy(w, h->stats_dev, sizeof w, hipMemcpyDeviceToHost));
+  HIP_TRY(h, hipMemcpy(&launches, h->lctr_dev, sizeof launches, hipMemcpyDeviceToHost));
+  for (int i = 0; i < FW_CTR_DIM; ++i) out[i] = w[i];
+  out[FW_CTR_LAUNCHES] = launches;
+  return FW_OK;
 }
 
 int32_t fw_gae(const float* rewards, const float* values, const float* episode_starts, const float* last_values,
@@ -1498,6 +1525,8 @@ int32_t fw_destroy(fw_handle h) {
   if (h->is_dev) (void)hipFree(h->is_dev);
   if (h->sreq_dev) (void)hipFree(h->sreq_dev);
   if (h->sdone_dev) (void)hipFree(h->sdone_dev);
+  if (h->lctr_dev) (void)hipFree(h->lctr_dev);
+  if (h->stats_dev) (void)hipFree(h->stats_dev);
   FWP(if (h->prof_dev) (void)hipFree(h->prof_dev);)
   delete h;
   return FW_OK;
@@ -1515,7 +1544,7 @@ int32_t fw_debug_profile(fw_handle h, long long* host_out, int32_t enable) {
   if (host_out && h->prof_dev) (void)hipMemcpy(host_out, h->prof_dev, bytes, hipMemcpyDeviceToHost);
   return (int32_t)nblk;
 }
-int32_t fw_debug_epoch(fw_handle h) { return h ? (int32_t)h->epoch : 0; }
+int32_t fw_debug_epoch(fw_handle h) { uint64_t c[FW_CTR_DIM]; return (h && fw_get_counters(h, c) == FW_OK) ? (int32_t)c[FW_CTR_LAUNCHES] + 1 : 0; }
 #endif
 
 }  // extern "C"

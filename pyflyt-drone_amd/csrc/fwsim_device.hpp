@@ -98,8 +98,10 @@ struct DevState {
   int32_t* is;               // [npad]            physics ticks of the shadow state
   unsigned long long* sreq;  // [npad]  live -> worker:  (episode wanted << 32) | launch index of the request
   unsigned long long* sdone; // [npad]  worker -> live:  (episode built << 32) | (launch index & 0xFFFFFF) << 8 | progress
-  uint32_t epoch;            // launch index of this fw_step (host counter)
+  uint32_t epoch;            // launch index of this fw_step: set IN the kernel from `lctr` (launch_index below)
   int32_t shadow_on;
+  uint32_t* lctr;            // [fw_step grid]  per-workgroup launch counters (launch_index below)
+  unsigned long long* stats;  // [FW_CTR_DIM]  hand-off counters (fw_get_counters), bumped on resets only
 #ifdef FW_PROFILE
   long long* prof;           // dev-only per-wave cycle accounting (fwsim.hip)
 #endif
@@ -125,6 +127,21 @@ __device__ __forceinline__ DevState<T> tile_view(const DevState<T>& G, int blk) 
 }
 
 constexpr double kPi = 3.14159265358979323846;
+
+// ------------------------------------------------------------------------
+// Launch index kept in DEVICE memory.  The shadow / scenario hand-off compares launch indices; a host counter passed
+// by value is frozen into a captured hipGraph node and repeats on every replay.  Instead every workgroup of the
+// fw_step grid owns one private word `lctr[blockIdx.x]`: it reads it when it starts and stores it + 1 when it is
+// finished.  The grid of a handle never changes and every launch runs every workgroup exactly once, so all the words
+// advance in lockstep -- the step workgroup of a tile and the worker workgroup of the same tile (the only two parties
+// that ever compare tags) always agree on the index, without atomics or any cross-workgroup traffic, eager launches
+// and graph replays number their launches identically, and which resets take the hand-off is reproducible.
+// ------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t launch_index(const uint32_t* lctr) { return 1u + lctr[blockIdx.x]; }       // uniform address: scalar load
+__device__ __forceinline__ void launch_done(uint32_t* lctr, uint32_t epoch) { if (threadIdx.x == 0) lctr[blockIdx.x] = epoch; }
+__device__ __forceinline__ void stat_add(unsigned long long* stats, int which) {
+  (void)__hip_atomic_fetch_add(stats + which, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ------------------------------------------------------------------------
 // math building blocks

@@ -208,6 +208,14 @@ class FixedwingVecEnv:
         _lib.check(_lib.lib().fw_get_state(self._h, s.ctypes.data_as(C.c_void_p)), self._h)
         return s
 
+    def get_counters(self) -> dict:
+        """How the auto-resets of ``fw_step`` were served so far (``fw_get_counters``): launches, resets and whether
+        they took the background hand-off (shadow / pre-sampled scenario) or the in-kernel fallback."""
+        c = np.zeros(K.FW_CTR_DIM, dtype=np.uint64)
+        _lib.check(_lib.lib().fw_get_counters(self._h, c.ctypes.data_as(C.c_void_p)), self._h)
+        return {"launches": int(c[K.CTR_LAUNCHES]), "resets": int(c[K.CTR_RESETS]), "shadow_hits": int(c[K.CTR_SHADOW_HITS]),
+                "scenario_hits": int(c[K.CTR_SCENARIO_HITS]), "fallbacks": int(c[K.CTR_FALLBACKS])}
+
     def set_state(self, state: np.ndarray) -> None:
         s = np.ascontiguousarray(state, dtype=np.float64).reshape(self.num_envs, K.FW_STATE_DIM)
         _lib.check(_lib.lib().fw_set_state(self._h, s.ctypes.data_as(C.c_void_p)), self._h)
