@@ -72,8 +72,9 @@ def main():
     try:
         model.learn(total, callbacks=[ev, ck, Progress()], reset_num_timesteps=True)
     finally:
-        checkpoint.save(os.path.join(model_dir, "final_model.pt"), model)
-        checkpoint.save_vecnormalize(os.path.join(model_dir, "vecnorm.pt"), env)
+        if model.rank == 0:                 # one writer per file in a multi-process job
+            checkpoint.save(os.path.join(model_dir, "final_model.pt"), model)
+            checkpoint.save_vecnormalize(os.path.join(model_dir, "vecnorm.pt"), env)
         env.venv.close(); eval_env.venv.close()
 
 

@@ -341,9 +341,17 @@ int32_t fw_gae(const float* rewards, const float* values, const float* episode_s
  *   (a) if `update` != 0 merges the batch moments into (mean[D], var[D], count[1]) (double),
  *   (b) writes clip((obs - mean) / sqrt(var + eps), +-clip) as float32 to obs_out[N,D]
  *       using the UPDATED statistics, as SB3 does.
- * mean/var/count are device double buffers owned by the caller (checkpointable). */
+ * mean/var/count are device double buffers owned by the caller (checkpointable).
+ * workspace: device buffer of fw_normalize_obs_workspace_bytes(D) bytes owned by the caller (needed when update != 0):
+ * the per-block partial sums live there, so concurrent callers / streams share nothing and nothing is ever allocated
+ * on the launch path (safe under hipGraph capture).
+ * batch_acc (may be NULL): device double[2 D + 1]; when update != 0 the batch's column sums, sums of squares and row count
+ * are ADDED to it.  A job sharded over GPUs all-reduces these accumulators once per rollout (RCCL) and re-derives the
+ * statistics of all envs from them (collective 2) -- no collective sits between two env steps. */
+int64_t fw_normalize_obs_workspace_bytes(int32_t D);
 int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t D, double* mean, double* var,
-                         double* count, int32_t update, float clip, float eps, float* obs_out, void* hip_stream);
+                         double* count, int32_t update, float clip, float eps, float* obs_out, void* workspace,
+                         double* batch_acc, void* hip_stream);
 
 /* PPO minibatch updates (SB3 PPO.train() inner loop; train/train_Fixedwing_Waypoints_v3.py:293-310) for the
  * reference's MlpPolicy (separate 64-64 tanh nets for pi and V, 4-dim diagonal Gaussian, log_std parameter),
@@ -359,7 +367,10 @@ int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t 
  * obs[S,obs_dim], act[S,4], old_logp[S], adv[S], ret[S]: the rollout buffer (float32, device);
  * perm[n_minibatches * batch_size]: sample indices of consecutive minibatches (int32, device).
  * batch_size must be a multiple of 64, obs_dim <= 64.  loss_acc[3] (may be NULL) accumulates the per-minibatch
- * mean policy loss, value loss and entropy loss.  The caller advances its Adam step count by n_minibatches. */
+ * mean policy loss, value loss and entropy loss.  The caller advances its Adam step count by n_minibatches.
+ * workspace: caller-owned device buffer of >= fw_ppo_update_workspace_bytes(n_minibatches) bytes (exchange words,
+ * gradient hand-off buffer and per-minibatch advantage statistics of THIS call; two learners never share it).
+ * The learner-side entry points run on the device their buffers live on, whatever the thread's current device. */
 typedef struct fw_ppo_hyper {
   float lr, clip_range, ent_coef, vf_coef, max_grad_norm, beta1, beta2, eps;
   float adv_mean, adv_std;      /* used when norm_adv == 2 */
@@ -369,10 +380,11 @@ typedef struct fw_ppo_hyper {
 int32_t fw_ppo_param_count(int32_t obs_dim);
 int32_t fw_ppo_moment_count(void);
 int32_t fw_ppo_moment_map(int32_t obs_dim, int32_t* flat_index_of_slot /* host, [fw_ppo_moment_count()] */);
+int64_t fw_ppo_update_workspace_bytes(int32_t n_minibatches);
 int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* obs, const float* act,
                       const float* old_logp, const float* adv, const float* ret, const int32_t* perm,
                       int32_t n_minibatches, int32_t batch_size, int32_t obs_dim, const fw_ppo_hyper* hyper,
-                      float* loss_acc, void* hip_stream);
+                      float* loss_acc, void* workspace, int64_t workspace_bytes, void* hip_stream);
 
 /* Rollout collection between two env steps (SB3 OnPolicyAlgorithm.collect_rollouts + VecNormalize reward path,
  * train/train_Fixedwing_Waypoints_v3.py:260,293-310), for the same MlpPolicy / flat parameter image as fw_ppo_update.
@@ -383,7 +395,9 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
  * fw_rollout_post: VecNormalize.step_wait's reward path + the bootstrap of truncated episodes:
  *   returns = returns * gamma + reward; running variance of `returns` (if training && norm_reward);
  *   rew_out = clip(reward / sqrt(var + epsilon), +-clip_reward) (+ gamma * tvalue where truncated && !terminated);
- *   start_out = terminated | truncated; returns = 0 where done; rng[1] += 1 (rng may be NULL). */
+ *   start_out = terminated | truncated; returns = 0 where done; rng[1] += 1 (rng may be NULL);
+ *   ret_acc (may be NULL): device double[3], the tracker batch's (sum, sum of squares, count) are added to it (the
+ *   reward-side twin of fw_normalize_obs's batch_acc). */
 int32_t fw_policy_act(const float* params, const float* obs, int32_t N, int32_t obs_dim, int32_t nets, int32_t deterministic,
                       const uint64_t* rng, int64_t env_offset, float* obs_copy, float* act_raw, void* act_env,
                       int32_t act_is_f64, float* logp, float* value, void* hip_stream);
@@ -397,7 +411,7 @@ int32_t fw_policy_terminal_value(const float* params, const void* terminal_obs, 
 int32_t fw_rollout_post(const void* reward, int32_t rew_is_f64, const uint8_t* terminated, const uint8_t* truncated,
                         const float* tvalue, double* returns, double* ret_mean, double* ret_var, double* ret_count,
                         int32_t N, int32_t training, int32_t norm_reward, double gamma, float clip_reward, float epsilon,
-                        float* rew_out, float* start_out, uint64_t* rng, void* hip_stream);
+                        float* rew_out, float* start_out, uint64_t* rng, double* ret_acc, void* hip_stream);
 
 int32_t fw_num_envs(fw_handle h);
 const char* fw_last_error(fw_handle h); /* h may be NULL: last create/validate error */

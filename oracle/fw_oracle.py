@@ -29,7 +29,41 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def build_fast() -> str:
+    """-O3 -march=native build of the SAME C for bench.py's cpu_baseline leg.  -march=native binds the binary to the
+    CPU it was compiled on, so it is rebuilt whenever the host CPU model differs from the one recorded beside it."""
+    path = os.path.join(_HERE, "libfw_oracle_fast.so")
+    tag = path + ".cpu"
+    src = os.path.join(_HERE, "fw_oracle.c")
+    model = _cpu_model()
+    ok = os.path.exists(path) and os.path.exists(tag) and open(tag).read() == model and os.path.getmtime(path) >= os.path.getmtime(src)
+    if not ok:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libfw_oracle_fast.so"], stdout=subprocess.DEVNULL)
+        with open(tag, "w") as f:
+            f.write(model)
+    return path
+
+
 _lib = None
+_fast = None
+
+
+def fast_lib() -> C.CDLL:
+    global _fast
+    if _fast is None:
+        _fast = _bind(C.CDLL(build_fast()))
+    return _fast
 
 
 def lib() -> C.CDLL:
@@ -37,39 +71,42 @@ def lib() -> C.CDLL:
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
-        vp, i32, u64, i64 = C.c_void_p, C.c_int32, C.c_uint64, C.c_int64
-        L.fwo_sizeof_config.restype = i32
-        L.fwo_abi_version.restype = i32
-        L.fwo_state_dim.restype = i32
-        L.fwo_obs_dim.restype = i32; L.fwo_obs_dim.argtypes = [vp]
-        L.fwo_validate_config.restype = i32; L.fwo_validate_config.argtypes = [vp, C.c_char_p, i32]
-        L.fwo_create.restype = i32; L.fwo_create.argtypes = [vp, i32, i32, u64, i64, C.POINTER(vp)]
-        L.fwo_reset.restype = i32; L.fwo_reset.argtypes = [vp, vp, vp, vp]
-        L.fwo_step.restype = i32; L.fwo_step.argtypes = [vp] * 9
-        L.fwo_observe.restype = i32; L.fwo_observe.argtypes = [vp, vp, vp]
-        L.fwo_seed.restype = i32; L.fwo_seed.argtypes = [vp, u64]
-        L.fwo_get_state.restype = i32; L.fwo_get_state.argtypes = [vp, vp]
-        L.fwo_set_state.restype = i32; L.fwo_set_state.argtypes = [vp, vp]
-        L.fwo_set_threads.restype = i32; L.fwo_set_threads.argtypes = [i32]
-        L.fwo_num_envs.restype = i32; L.fwo_num_envs.argtypes = [vp]
-        L.fwo_last_error.restype = C.c_char_p; L.fwo_last_error.argtypes = [vp]
-        L.fwo_destroy.restype = i32; L.fwo_destroy.argtypes = [vp]
-        L.fwo_aero_coeffs.restype = None; L.fwo_aero_coeffs.argtypes = [vp, C.c_double, C.c_double, vp]
-        L.fwo_surface_constants.restype = None; L.fwo_surface_constants.argtypes = [vp, vp]
-        L.fwo_surface_force.restype = None; L.fwo_surface_force.argtypes = [vp, i32, C.c_double, vp, vp, vp]
-        L.fwo_euler_from_quat.restype = None; L.fwo_euler_from_quat.argtypes = [vp, vp]
-        L.fwo_quat_from_euler.restype = None; L.fwo_quat_from_euler.argtypes = [vp, vp]
-        L.fwo_mat_from_quat.restype = None; L.fwo_mat_from_quat.argtypes = [vp, vp]
-        L.fwo_philox.restype = None; L.fwo_philox.argtypes = [vp, vp, vp]
-        L.fwo_rng_uniform01.restype = C.c_double; L.fwo_rng_uniform01.argtypes = [u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
-        L.fwo_rng_normal2.restype = None; L.fwo_rng_normal2.argtypes = [u64, C.c_uint32, C.c_uint32, C.c_uint32, vp]
-        L.fwo_wind_at.restype = None; L.fwo_wind_at.argtypes = [vp, vp, vp, C.c_double, C.c_double, vp]
-        L.fwo_depth_buffer_to_meters.restype = C.c_double; L.fwo_depth_buffer_to_meters.argtypes = [C.c_double]
-        if L.fwo_state_dim() != FW_STATE_DIM:
-            raise RuntimeError("oracle FW_STATE_DIM does not match the Python wrapper")
-        _lib = L
+        _lib = _bind(C.CDLL(_LIB_PATH))
     return _lib
+
+
+def _bind(L: C.CDLL) -> C.CDLL:
+    vp, i32, u64, i64 = C.c_void_p, C.c_int32, C.c_uint64, C.c_int64
+    L.fwo_sizeof_config.restype = i32
+    L.fwo_abi_version.restype = i32
+    L.fwo_state_dim.restype = i32
+    L.fwo_obs_dim.restype = i32; L.fwo_obs_dim.argtypes = [vp]
+    L.fwo_validate_config.restype = i32; L.fwo_validate_config.argtypes = [vp, C.c_char_p, i32]
+    L.fwo_create.restype = i32; L.fwo_create.argtypes = [vp, i32, i32, u64, i64, C.POINTER(vp)]
+    L.fwo_reset.restype = i32; L.fwo_reset.argtypes = [vp, vp, vp, vp]
+    L.fwo_step.restype = i32; L.fwo_step.argtypes = [vp] * 9
+    L.fwo_observe.restype = i32; L.fwo_observe.argtypes = [vp, vp, vp]
+    L.fwo_seed.restype = i32; L.fwo_seed.argtypes = [vp, u64]
+    L.fwo_get_state.restype = i32; L.fwo_get_state.argtypes = [vp, vp]
+    L.fwo_set_state.restype = i32; L.fwo_set_state.argtypes = [vp, vp]
+    L.fwo_set_threads.restype = i32; L.fwo_set_threads.argtypes = [i32]
+    L.fwo_num_envs.restype = i32; L.fwo_num_envs.argtypes = [vp]
+    L.fwo_last_error.restype = C.c_char_p; L.fwo_last_error.argtypes = [vp]
+    L.fwo_destroy.restype = i32; L.fwo_destroy.argtypes = [vp]
+    L.fwo_aero_coeffs.restype = None; L.fwo_aero_coeffs.argtypes = [vp, C.c_double, C.c_double, vp]
+    L.fwo_surface_constants.restype = None; L.fwo_surface_constants.argtypes = [vp, vp]
+    L.fwo_surface_force.restype = None; L.fwo_surface_force.argtypes = [vp, i32, C.c_double, vp, vp, vp]
+    L.fwo_euler_from_quat.restype = None; L.fwo_euler_from_quat.argtypes = [vp, vp]
+    L.fwo_quat_from_euler.restype = None; L.fwo_quat_from_euler.argtypes = [vp, vp]
+    L.fwo_mat_from_quat.restype = None; L.fwo_mat_from_quat.argtypes = [vp, vp]
+    L.fwo_philox.restype = None; L.fwo_philox.argtypes = [vp, vp, vp]
+    L.fwo_rng_uniform01.restype = C.c_double; L.fwo_rng_uniform01.argtypes = [u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.fwo_rng_normal2.restype = None; L.fwo_rng_normal2.argtypes = [u64, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.fwo_wind_at.restype = None; L.fwo_wind_at.argtypes = [vp, vp, vp, C.c_double, C.c_double, vp]
+    L.fwo_depth_buffer_to_meters.restype = C.c_double; L.fwo_depth_buffer_to_meters.argtypes = [C.c_double]
+    if L.fwo_state_dim() != FW_STATE_DIM:
+        raise RuntimeError("oracle FW_STATE_DIM does not match the Python wrapper")
+    return L
 
 
 def _ptr(a):
@@ -79,9 +116,9 @@ def _ptr(a):
 class OracleEnv:
     """N scalar CPU envs behind the same call shapes as the HIP library."""
 
-    def __init__(self, cfg, num_envs: int, seed: int = 0, global_env_offset: int = 0):
+    def __init__(self, cfg, num_envs: int, seed: int = 0, global_env_offset: int = 0, fast: bool = False):
         self._cfg = cfg
-        L = lib()
+        L = self._L = fast_lib() if fast else lib()
         if L.fwo_sizeof_config() != C.sizeof(cfg):
             raise RuntimeError("fw_config layout mismatch between Python mirror and oracle")
         h = C.c_void_p()
@@ -96,7 +133,7 @@ class OracleEnv:
 
     def close(self):
         if self._h:
-            lib().fwo_destroy(self._h)
+            self._L.fwo_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -108,7 +145,7 @@ class OracleEnv:
     def reset(self, mask=None) -> np.ndarray:
         obs = np.empty((self.num_envs, self.obs_dim), dtype=self.dtype)
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
-        rc = lib().fwo_reset(self._h, _ptr(m), _ptr(obs), None)
+        rc = self._L.fwo_reset(self._h, _ptr(m), _ptr(obs), None)
         assert rc == 0
         return obs
 
@@ -121,35 +158,35 @@ class OracleEnv:
         trunc = np.empty((n,), dtype=np.uint8)
         tobs = np.zeros((n, d), dtype=self.dtype)
         info = np.empty((n, FW_INFO_DIM), dtype=np.int32)
-        rc = lib().fwo_step(self._h, _ptr(a), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc), _ptr(tobs), _ptr(info), None)
+        rc = self._L.fwo_step(self._h, _ptr(a), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc), _ptr(tobs), _ptr(info), None)
         assert rc == 0
         return obs, rew, term, trunc, tobs, info
 
     def step_timed_only(self, actions, obs, rew, term, trunc, info):
         """Step into caller-provided buffers (bench leg; no allocation)."""
-        return lib().fwo_step(self._h, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc), None, _ptr(info), None)
+        return self._L.fwo_step(self._h, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(term), _ptr(trunc), None, _ptr(info), None)
 
     def observe(self) -> np.ndarray:
         obs = np.empty((self.num_envs, self.obs_dim), dtype=self.dtype)
-        assert lib().fwo_observe(self._h, _ptr(obs), None) == 0
+        assert self._L.fwo_observe(self._h, _ptr(obs), None) == 0
         return obs
 
     def seed(self, seed: int):
-        assert lib().fwo_seed(self._h, int(seed)) == 0
+        assert self._L.fwo_seed(self._h, int(seed)) == 0
 
     def get_state(self) -> np.ndarray:
         s = np.empty((self.num_envs, FW_STATE_DIM), dtype=np.float64)
-        assert lib().fwo_get_state(self._h, _ptr(s)) == 0
+        assert self._L.fwo_get_state(self._h, _ptr(s)) == 0
         return s
 
     def set_state(self, state):
         s = np.ascontiguousarray(state, dtype=np.float64).reshape(self.num_envs, FW_STATE_DIM)
-        assert lib().fwo_set_state(self._h, _ptr(s)) == 0
+        assert self._L.fwo_set_state(self._h, _ptr(s)) == 0
 
 
-def set_threads(n: int) -> int:
+def set_threads(n: int, fast: bool = False) -> int:
     """Set (n>0) / query (n<=0) the OpenMP thread count used by fwo_step."""
-    return int(lib().fwo_set_threads(int(n)))
+    return int((fast_lib() if fast else lib()).fwo_set_threads(int(n)))
 
 
 # ---- unit-level helpers for known-answer tests ----

@@ -22,7 +22,10 @@ episodes it was in.
 """
 from __future__ import annotations
 
+import ctypes as C
+import hashlib
 import os
+import tempfile
 from typing import Optional
 
 import numpy as np
@@ -43,8 +46,28 @@ def _to_cpu(obj):
     return obj
 
 
+def config_fingerprint(cfg) -> str:
+    """sha256 of the fw_config bytes: the saved simulator state only means the same thing under the same config."""
+    return hashlib.sha256(C.string_at(C.addressof(cfg), C.sizeof(cfg))).hexdigest()
+
+
+def _atomic_torch_save(obj, path: str) -> None:
+    """Write through a uniquely named temp file in the target directory, then rename: concurrent writers (several
+    ranks, several jobs) can never interleave into one file or remove each other's temp file."""
+    d = os.path.dirname(os.path.abspath(path)) or "."
+    os.makedirs(d, exist_ok=True)
+    fd, tmp = tempfile.mkstemp(prefix=os.path.basename(path) + ".", suffix=".tmp", dir=d)
+    try:
+        with os.fdopen(fd, "wb") as f:
+            torch.save(obj, f)
+        os.replace(tmp, path)                 # never leave a half-written checkpoint behind
+    except BaseException:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+        raise
+
+
 def save(path: str, ppo, include_env_state: bool = True) -> str:
-    os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
     venv = ppo.env.venv
     sd = {
         "format_version": FORMAT_VERSION,
@@ -59,6 +82,11 @@ def save(path: str, ppo, include_env_state: bool = True) -> str:
     }
     if include_env_state and hasattr(venv, "get_state"):
         sd["env_state"] = torch.from_numpy(np.ascontiguousarray(venv.get_state()))
+        # the episodes that follow are a function of (seed, global env id, episode): record what the state was drawn under
+        sd["env_seed"] = int(getattr(venv, "seed_value", 0))
+        sd["global_env_offset"] = int(getattr(venv, "global_env_offset", 0))
+        if hasattr(venv, "cfg"):
+            sd["config_sha256"] = config_fingerprint(venv.cfg)
         sd["env_returns"] = ppo.env.returns.detach().cpu()
         if getattr(ppo, "last_obs", None) is not None:
             sd["last_obs"] = ppo.last_obs.detach().cpu()
@@ -66,9 +94,7 @@ def save(path: str, ppo, include_env_state: bool = True) -> str:
         sd["sampler_rng_state"] = ppo.gen.get_state().cpu()        # action-sampling generator: resume draws the same actions
         if getattr(ppo, "_collect_fused", False):
             sd["collect_rng"] = ppo._rng.detach().cpu()             # (seed, draw counter) of fw_policy_act
-    tmp = path + ".tmp"
-    torch.save(sd, tmp)
-    os.replace(tmp, path)                     # never leave a half-written checkpoint behind
+    _atomic_torch_save(sd, path)
     return path
 
 
@@ -93,6 +119,12 @@ def load(path: str, ppo, reset_num_timesteps: bool = True, restore_env_state: bo
             raise ValueError(f"{path} holds no env state")
         if sd["num_envs"] != ppo.env.num_envs or sd["state_dim"] != K.FW_STATE_DIM or sd["abi_version"] != K.FW_ABI_VERSION:
             raise ValueError("env state in the checkpoint does not fit this env (num_envs / FW_STATE_DIM / ABI version)")
+        venv = ppo.env.venv
+        for key, have in (("env_seed", int(getattr(venv, "seed_value", 0))), ("global_env_offset", int(getattr(venv, "global_env_offset", 0))),
+                          ("config_sha256", config_fingerprint(venv.cfg) if hasattr(venv, "cfg") else None)):
+            if key in sd and have is not None and sd[key] != have:
+                raise ValueError(f"env state in the checkpoint was saved under a different {key} ({sd[key]!r} != {have!r}): "
+                                 "the episodes that follow would not be those of the interrupted run")
         ppo.env.venv.set_state(sd["env_state"].numpy())
         ppo.env.returns.copy_(sd["env_returns"].to(ppo.env.returns.device))
         if "last_obs" in sd:
@@ -118,11 +150,11 @@ def set_parameters(path: str, ppo) -> None:
     ppo.optimizer.load_state_dict(sd["optimizer"])
     ppo._g_update = None                     # new optimiser state tensors: the captured update graph is stale
     ppo._flat_current = False
+    ppo.invalidate_graphs()
 
 
 def save_vecnormalize(path: str, env) -> str:
-    os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
-    torch.save({"format_version": FORMAT_VERSION, "vecnormalize": _to_cpu(env.state_dict())}, path)
+    _atomic_torch_save({"format_version": FORMAT_VERSION, "vecnormalize": _to_cpu(env.state_dict())}, path)
     return path
 
 
@@ -135,6 +167,7 @@ def load_vecnormalize(path: str, env, training: Optional[bool] = None, norm_rewa
         env.training = training
     if norm_reward is not None:
         env.norm_reward = norm_reward
+    env.version += 1          # scalars frozen into a captured rollout graph (clip, gamma, flags) may have changed
     return env
 
 

@@ -478,6 +478,70 @@ def train_waypoint_objlock_config(**overrides) -> FwConfig:
     return waypoint_objlock_config(**kw)
 
 
+# ---------------------------------------------------------------------------------------------
+# the reference constructors' full keyword sets (so that the reference's make_env() call sites work unchanged)
+# ---------------------------------------------------------------------------------------------
+def _camera_resolution_of(render_mode, render_resolution, camera_resolution) -> int:
+    """envs/fixedwing_objlock_env.py:213-218: explicit camera_resolution, else render_resolution when a render mode is
+    set, else (128, 128).  The analytic camera is square."""
+    res = camera_resolution if camera_resolution is not None else (render_resolution if render_mode is not None else (128, 128))
+    if isinstance(res, (int, float)):
+        res = (int(res), int(res))
+    w, h = int(res[0]), int(res[1])
+    if w != h or w <= 0:
+        raise ValueError(f"camera resolution must be square and positive on the device env, got {(w, h)}")
+    return w
+
+
+def _check_common_reference_kwargs(render_mode, flight_mode) -> None:
+    if render_mode not in (None, "rgb_array"):
+        raise ValueError(f"Invalid render mode {render_mode}, only [None, 'rgb_array'] have a device counterpart.")
+    if int(flight_mode) != 0:
+        raise ValueError(f"flight_mode {flight_mode} is not available on the device env (mode 0: [roll, pitch, yaw, thrust])")
+
+
+def objlock_config_from_reference_kwargs(*, dtype: str = "float64", motor_noise: bool = True, auto_reset: bool = True,
+                                         flight_mode: int = 0, render_mode=None, render_resolution=(480, 480),
+                                         duck_urdf_path=None, use_egl: bool = False, camera_profile: str = "cockpit_fpv",
+                                         camera_position_offset=None, camera_angle_degrees=None, camera_FOV_degrees=None,
+                                         camera_resolution=None, duck_vision_history_len: int = 3,
+                                         duck_vision_use_deltas: bool = True, **env_kwargs) -> FwConfig:
+    """Every keyword of ``FixedwingObjLockEnv.__init__`` (envs/fixedwing_objlock_env.py:37-81), as passed by
+    train/train_objlock.py:113-153.  Render-only arguments (``use_egl``, ``duck_urdf_path``) are accepted and ignored;
+    what the device env cannot honour raises ``ValueError`` instead of being silently dropped."""
+    _check_common_reference_kwargs(render_mode, flight_mode)
+    del duck_urdf_path, use_egl                                   # renderer plumbing: no device counterpart needed
+    if int(max(1, duck_vision_history_len)) != FW_VISION_HIST:
+        raise ValueError(f"duck_vision_history_len must be {FW_VISION_HIST} on the device env (the observation layout is compiled in)")
+    if not bool(duck_vision_use_deltas):
+        raise ValueError("duck_vision_use_deltas=False is not available on the device env (the 4 deltas are part of the 56-wide observation)")
+    if camera_profile != "cockpit_fpv":
+        raise ValueError(f"camera_profile {camera_profile!r} is not available on the device env (body-fixed 'cockpit_fpv' only; "
+                         "'chase' is a tracking camera)")
+    res = _camera_resolution_of(render_mode, render_resolution, camera_resolution)
+    c = objlock_config(dtype=dtype, motor_noise=motor_noise, auto_reset=auto_reset, camera_resolution=res, **env_kwargs)
+    if camera_position_offset is not None:                        # :194-201
+        _set_vec(c.camera_offset, [float(v) for v in camera_position_offset])
+    if camera_angle_degrees is not None:                          # :203-209 (the reference truncates to int)
+        c.camera_angle_deg = float(int(camera_angle_degrees))
+    if camera_FOV_degrees is not None:                            # :211-212
+        c.camera_fov_deg = float(int(camera_FOV_degrees))
+    return c
+
+
+def waypoint_objlock_config_from_reference_kwargs(*, dtype: str = "float64", motor_noise: bool = True, auto_reset: bool = True,
+                                                  context_length: int = 2, flight_mode: int = 0, render_mode=None,
+                                                  render_resolution=(480, 480), duck_urdf_path=None, use_egl: bool = False,
+                                                  **env_kwargs) -> FwConfig:
+    """Every keyword of ``FixedwingWaypointObjLockEnv.__init__`` (envs/fixedwing_waypoint_objlock_env.py:42-76) plus the
+    wrapper's ``context_length``, as passed by train/train_Fixedwing_Waypoints_ObjLock.py:119-165."""
+    _check_common_reference_kwargs(render_mode, flight_mode)
+    del duck_urdf_path, use_egl
+    res = _camera_resolution_of(render_mode, render_resolution, env_kwargs.pop("camera_resolution", None))
+    return waypoint_objlock_config(dtype=dtype, motor_noise=motor_noise, auto_reset=auto_reset, context_length=context_length,
+                                   camera_resolution=res, **env_kwargs)
+
+
 def obs_dim(c: FwConfig) -> int:
     att = (12 if c.angle_representation == 0 else 13) + 4 + 6
     if c.task == FW_TASK_OBJLOCK:

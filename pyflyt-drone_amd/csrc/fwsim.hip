@@ -1035,6 +1035,20 @@ struct DeviceGuard {
   ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 
+// The learner-side entry points have no handle: the device is the one their buffers live on (never the thread's current
+// device), and everything they launch runs under a DeviceGuard for it.
+int device_of(const void* p) {
+  hipPointerAttribute_t a;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (p && hipPointerGetAttributes(&a, p) == hipSuccess && a.device >= 0) return a.device;
+  (void)hipGetLastError();                     // clear the sticky error of a failed query
+  return cur;
+}
+// Opt an LDS-resident learner kernel into `bytes` of dynamic LDS: done when a device first sees a size larger than any
+// before (i.e. on the first call per observation width), never again on the launch path.
+int ensure_learner_lds(int dev, int which /*0: fw_ppo_update, 1: fw_policy_act*/, size_t bytes);
+
 template <typename T> DevState<T> dev_state(fw_env* h) {
   DevState<T> D; D.r = (T*)h->r_dev; D.i = h->i_dev; D.n = h->n; D.npad = h->npad;
   D.rs = (T*)h->rs_dev; D.is = h->is_dev; D.sreq = h->sreq_dev; D.sdone = h->sdone_dev; D.epoch = 0; D.shadow_on = h->shadow_on;
@@ -1233,6 +1247,18 @@ int set_state_T(fw_env* h, const double* in) {
 }
 }  // namespace
 
+namespace {
+int ensure_learner_lds(int dev, int which, size_t bytes) {
+  static size_t have[64][2] = {};
+  if (dev < 0 || dev >= 64) { g_err = "device index out of range"; return FW_EINVAL; }
+  if (bytes <= have[dev][which]) return FW_OK;
+  const void* fn = which == 0 ? (const void*)fw_ppo_update_kernel : (const void*)fw_policy_act_kernel;
+  HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  have[dev][which] = bytes;
+  return FW_OK;
+}
+}  // namespace
+
 // ======================================================================
 // C ABI
 // ======================================================================
@@ -1365,35 +1391,29 @@ int32_t fw_gae(const float* rewards, const float* values, const float* episode_s
   if (!rewards || !values || !episode_starts || !last_values || !last_dones || !advantages || !returns || T <= 0 || N <= 0) {
     g_err = "fw_gae: bad arguments"; return FW_EINVAL;
   }
+  DeviceGuard g(device_of(rewards));
   hipLaunchKernelGGL(fw_gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, rewards, values,
                      episode_starts, last_values, last_dones, advantages, returns, T, N, gamma, gae_lambda);
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;
 }
 
+int64_t fw_normalize_obs_workspace_bytes(int32_t D) { return D > 0 ? (int64_t)sizeof(double) * 64 * 2 * D : FW_EINVAL; }
+
 int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t D, double* mean, double* var,
-                         double* count, int32_t update, float clip, float eps, float* obs_out, void* hip_stream) {
+                         double* count, int32_t update, float clip, float eps, float* obs_out, void* workspace,
+                         double* batch_acc, void* hip_stream) {
   if (!obs || !mean || !var || !count || !obs_out || N <= 0 || D <= 0 || D > 256) { g_err = "fw_normalize_obs: bad arguments"; return FW_EINVAL; }
+  if (update && !workspace) { g_err = "fw_normalize_obs: update needs a workspace of fw_normalize_obs_workspace_bytes(D) bytes"; return FW_EINVAL; }
   hipStream_t st = (hipStream_t)hip_stream;
+  DeviceGuard g(device_of(obs));
   if (update) {
-    // partial sums live in a small per-device scratch buffer (allocated once; never freed in a launch path)
-    // (first use per device allocates: call once outside hipGraph capture)
-    static double* scratch_dev[64] = {nullptr};
-    static size_t scratch_elems_dev[64] = {0};
-    int dev = 0;
-    HIP_TRY((fw_env*)nullptr, hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) { g_err = "device index out of range"; return FW_EINVAL; }
+    // per-block column sums land in the CALLER's workspace: nothing here is shared between callers or streams
+    double* scratch = (double*)workspace;
     const int nblocks = N >= 64 * 64 ? 64 : (N + 63) / 64;       // >= 64 rows per block
-    const size_t need = (size_t)64 * 2 * D;
-    if (scratch_elems_dev[dev] < need) {
-      if (scratch_dev[dev]) (void)hipFree(scratch_dev[dev]);
-      HIP_TRY((fw_env*)nullptr, hipMalloc((void**)&scratch_dev[dev], sizeof(double) * need));
-      scratch_elems_dev[dev] = need;
-    }
-    double* scratch = scratch_dev[dev];
     if (in_is_f64) hipLaunchKernelGGL(fw_obs_moments_kernel<double>, dim3(nblocks), dim3(256), 0, st, (const double*)obs, N, D, scratch);
     else hipLaunchKernelGGL(fw_obs_moments_kernel<float>, dim3(nblocks), dim3(256), 0, st, (const float*)obs, N, D, scratch);
-    hipLaunchKernelGGL(fw_obs_merge_kernel, dim3(1), dim3(256), 0, st, scratch, nblocks, N, D, mean, var, count);
+    hipLaunchKernelGGL(fw_obs_merge_kernel, dim3(1), dim3(256), 0, st, scratch, nblocks, N, D, mean, var, count, batch_acc);
   }
   const int total = N * D;
   if (in_is_f64) hipLaunchKernelGGL(fw_obs_normalize_kernel<double>, dim3((total + 255) / 256), dim3(256), 0, st, (const double*)obs, total, D, mean, var, clip, eps, obs_out);
@@ -1411,45 +1431,44 @@ int32_t fw_ppo_moment_map(int32_t obs_dim, int32_t* flat_index_of_slot) {
   return FW_OK;
 }
 
+// workspace layout of fw_ppo_update: [0,128) exchange words | gradient hand-off buffer | per-minibatch advantage statistics
+static constexpr size_t kPpoWsXch = 16 * sizeof(unsigned long long);
+static constexpr size_t kPpoWsGx = sizeof(float) * 8 * (size_t)kPMomentSlots;
+int64_t fw_ppo_update_workspace_bytes(int32_t n_minibatches) {
+  return n_minibatches > 0 ? (int64_t)(kPpoWsXch + kPpoWsGx + sizeof(float) * 2 * (size_t)n_minibatches) : FW_EINVAL;
+}
+
 int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* obs, const float* act, const float* old_logp,
                       const float* adv, const float* ret, const int32_t* perm, int32_t n_minibatches, int32_t batch_size,
-                      int32_t obs_dim, const fw_ppo_hyper* hyper, float* loss_acc, void* hip_stream) {
+                      int32_t obs_dim, const fw_ppo_hyper* hyper, float* loss_acc, void* workspace, int64_t workspace_bytes,
+                      void* hip_stream) {
   static_assert(sizeof(fw_ppo_hyper) == sizeof(PpoHyper), "fw_ppo_hyper layout");
   if (!params || !mom_m || !mom_v || !obs || !act || !old_logp || !adv || !ret || !perm || !hyper || n_minibatches <= 0) {
     g_err = "fw_ppo_update: bad arguments"; return FW_EINVAL;
   }
   if (batch_size <= 0 || batch_size % kPChunk != 0) { g_err = "fw_ppo_update: batch_size must be a multiple of 64"; return FW_EINVAL; }
   if (obs_dim <= 0 || obs_dim > 64) { g_err = "fw_ppo_update: obs_dim must be in [1, 64]"; return FW_EINVAL; }
+  if (!workspace || workspace_bytes < fw_ppo_update_workspace_bytes(n_minibatches)) {
+    g_err = "fw_ppo_update: workspace smaller than fw_ppo_update_workspace_bytes(n_minibatches)"; return FW_EINVAL;
+  }
   const size_t lds = ppo_lds_bytes(obs_dim);
   if (lds > 160 * 1024) { g_err = "fw_ppo_update: networks do not fit the 160 KB of LDS"; return FW_EINVAL; }
   hipStream_t st = (hipStream_t)hip_stream;
-  // exchange words of the two blocks (per device, allocated on first use: call once outside hipGraph capture)
-  static unsigned long long* xch_dev[64] = {nullptr};
-  int dev = 0;
-  HIP_TRY((fw_env*)nullptr, hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64) { g_err = "device index out of range"; return FW_EINVAL; }
-  static float* gx_dev[64] = {nullptr};
-  if (!xch_dev[dev]) {
-    HIP_TRY((fw_env*)nullptr, hipMalloc((void**)&xch_dev[dev], 16 * sizeof(unsigned long long)));
-    HIP_TRY((fw_env*)nullptr, hipMalloc((void**)&gx_dev[dev], sizeof(float) * 8 * (size_t)kPMomentSlots));
-  }
-  HIP_TRY((fw_env*)nullptr, hipMemsetAsync(xch_dev[dev], 0, 16 * sizeof(unsigned long long), st));
-  // per-minibatch advantage statistics, computed in parallel up front (scratch grows on demand, outside graph capture)
-  static float* stats_dev[64] = {nullptr};
-  static size_t stats_cap[64] = {0};
-  if (hyper->norm_adv == 1 && batch_size > 1) {
-    if (stats_cap[dev] < (size_t)n_minibatches) {
-      if (stats_dev[dev]) (void)hipFree(stats_dev[dev]);
-      HIP_TRY((fw_env*)nullptr, hipMalloc((void**)&stats_dev[dev], sizeof(float) * 2 * (size_t)n_minibatches));
-      stats_cap[dev] = (size_t)n_minibatches;
-    }
-    hipLaunchKernelGGL(fw_ppo_adv_stats_kernel, dim3(n_minibatches), dim3(64), 0, st, adv, perm, batch_size, stats_dev[dev]);
-  }
-  HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int dev = device_of(params);
+  DeviceGuard g(dev);
+  int rc = ensure_learner_lds(dev, 0, lds);
+  if (rc != FW_OK) return rc;
+  // everything the blocks exchange lives in the caller's workspace: two learners (or two streams) never share a word
+  unsigned long long* xch = (unsigned long long*)workspace;
+  float* gx = (float*)((char*)workspace + kPpoWsXch);
+  float* stats = (float*)((char*)workspace + kPpoWsXch + kPpoWsGx);
+  HIP_TRY((fw_env*)nullptr, hipMemsetAsync(xch, 0, kPpoWsXch, st));
+  if (hyper->norm_adv == 1 && batch_size > 1)     // per-minibatch advantage statistics, computed in parallel up front
+    hipLaunchKernelGGL(fw_ppo_adv_stats_kernel, dim3(n_minibatches), dim3(64), 0, st, adv, perm, batch_size, stats);
   PpoArgs A;
   A.params = params; A.mom_m = mom_m; A.mom_v = mom_v; A.obs = obs; A.act = act; A.old_logp = old_logp; A.adv = adv; A.ret = ret;
-  A.perm = perm; A.n_mb = n_minibatches; A.B = batch_size; A.D = obs_dim; A.loss_acc = loss_acc; A.xch = xch_dev[dev]; A.gx = gx_dev[dev];
-  A.adv_stats = stats_dev[dev];
+  A.perm = perm; A.n_mb = n_minibatches; A.B = batch_size; A.D = obs_dim; A.loss_acc = loss_acc; A.xch = xch; A.gx = gx;
+  A.adv_stats = stats;
   std::memcpy(&A.H, hyper, sizeof A.H);
   if (batch_size <= 1 && A.H.norm_adv == 1) A.H.norm_adv = 0;      // SB3 skips the normalisation of single-sample minibatches
   const int nhalf = batch_size >= 2 * kPChunk ? 2 : 1;            // two chunk-half blocks per network from 128 samples on
@@ -1465,7 +1484,9 @@ int32_t fw_policy_act(const float* params, const float* obs, int32_t N, int32_t 
   if ((nets & 1) && (!act_raw || !act_env || !logp || (!deterministic && !rng))) { g_err = "fw_policy_act: policy outputs missing"; return FW_EINVAL; }
   if ((nets & 2) && !value) { g_err = "fw_policy_act: value output missing"; return FW_EINVAL; }
   const size_t lds = act_lds_bytes(obs_dim);
-  HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_policy_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int dev = device_of(params);
+  DeviceGuard g(dev);
+  if (int rc = ensure_learner_lds(dev, 1, lds)) return rc;
   ActArgs A;
   A.params = params; A.obs = obs; A.N = N; A.D = obs_dim; A.nets = nets; A.deterministic = deterministic; A.act_is_f64 = act_is_f64;
   A.rng = rng; A.env_offset = env_offset; A.obs_copy = obs_copy; A.act_raw = act_raw; A.act_env = act_env; A.logp = logp; A.value = value;
@@ -1482,7 +1503,9 @@ int32_t fw_policy_terminal_value(const float* params, const void* terminal_obs, 
     g_err = "fw_policy_terminal_value: bad arguments"; return FW_EINVAL;
   }
   const size_t lds = act_lds_bytes(obs_dim);
-  HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_policy_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int dev = device_of(params);
+  DeviceGuard g(dev);
+  if (int rc = ensure_learner_lds(dev, 1, lds)) return rc;
   ActArgs A;
   std::memset(&A, 0, sizeof A);
   A.params = params; A.N = N; A.D = obs_dim; A.nets = 2; A.deterministic = 1; A.value = value;
@@ -1496,14 +1519,15 @@ int32_t fw_policy_terminal_value(const float* params, const void* terminal_obs, 
 int32_t fw_rollout_post(const void* reward, int32_t rew_is_f64, const uint8_t* terminated, const uint8_t* truncated, const float* tvalue,
                         double* returns, double* ret_mean, double* ret_var, double* ret_count, int32_t N, int32_t training,
                         int32_t norm_reward, double gamma, float clip_reward, float epsilon, float* rew_out, float* start_out,
-                        uint64_t* rng, void* hip_stream) {
+                        uint64_t* rng, double* ret_acc, void* hip_stream) {
   if (!reward || !terminated || !truncated || !tvalue || !returns || !ret_mean || !ret_var || !ret_count || !rew_out || !start_out || N <= 0) {
     g_err = "fw_rollout_post: bad arguments"; return FW_EINVAL;
   }
+  DeviceGuard g(device_of(returns));
   PostArgs A;
   A.reward = reward; A.rew_is_f64 = rew_is_f64; A.terminated = terminated; A.truncated = truncated; A.tvalue = tvalue; A.returns = returns;
   A.ret_mean = ret_mean; A.ret_var = ret_var; A.ret_count = ret_count; A.N = N; A.training = training; A.norm_reward = norm_reward;
-  A.gamma = gamma; A.clip_reward = clip_reward; A.epsilon = epsilon; A.rew_out = rew_out; A.start_out = start_out; A.rng = rng;
+  A.gamma = gamma; A.clip_reward = clip_reward; A.epsilon = epsilon; A.rew_out = rew_out; A.start_out = start_out; A.rng = rng; A.ret_acc = ret_acc;
   hipLaunchKernelGGL(fw_rollout_post_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, A);
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;

@@ -177,6 +177,7 @@ struct PostArgs {
   const float* tvalue;         // [N] V(normalised terminal observation)
   double* returns;             // [N] discounted-return tracker (in/out)
   double *ret_mean, *ret_var, *ret_count;   // running statistics of the tracker (in/out)
+  double* ret_acc;             // null, or [3] accumulators (sum, sum of squares, count) of the tracker batches: all-reduced once per rollout by a sharded job
   int32_t N, training, norm_reward;
   double gamma;                // (double: the tracker is float64 in SB3)
   float clip_reward, epsilon;
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(1024) void fw_rollout_post_kernel(PostArgs A) {
       const double delta = bm - mean, tot = cnt + n;
       const double m2 = var * cnt + bv * n + delta * delta * cnt * n / tot;
       A.ret_mean[0] = mean + delta * n / tot; A.ret_var[0] = m2 / tot; A.ret_count[0] = tot;
+      if (A.ret_acc) { A.ret_acc[0] += a; A.ret_acc[1] += b; A.ret_acc[2] += n; }
       s_var = m2 / tot;
     }
     __syncthreads();

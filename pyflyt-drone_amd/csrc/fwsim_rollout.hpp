@@ -67,9 +67,11 @@ __global__ __launch_bounds__(256) void fw_obs_moments_kernel(const TIN* __restri
 
 // RunningMeanStd.update_from_moments (SB3 common/running_mean_std.py); one block of 256 threads:
 // thread (q, d) sums a quarter of the per-block partials of column d (fixed order => reproducible), D <= 64 per pass
+// `acc` (may be null): double[2 D + 1] accumulators of the batch sums (sum, sum of squares per column, rows) -- what a
+// sharded job all-reduces once per rollout to bring every rank's statistics to the statistics of ALL envs.
 __global__ __launch_bounds__(256) void fw_obs_merge_kernel(const double* __restrict__ part, int nblocks, int N, int D,
                                                            double* __restrict__ mean, double* __restrict__ var,
-                                                           double* __restrict__ count) {
+                                                           double* __restrict__ count, double* __restrict__ acc) {
   __shared__ double sm1[256], sm2[256];
   const int t = threadIdx.x, q = t >> 6, dl = t & 63;
   const double cnt = count[0];
@@ -92,10 +94,11 @@ __global__ __launch_bounds__(256) void fw_obs_merge_kernel(const double* __restr
       const double m2 = var[d] * cnt + bv * N + delta * delta * cnt * N / tot;
       mean[d] = new_mean;
       var[d] = m2 / tot;
+      if (acc) { acc[d] += s; acc[D + d] += s2; }
     }
     __syncthreads();
   }
-  if (t == 0) count[0] = cnt + N;
+  if (t == 0) { count[0] = cnt + N; if (acc) acc[2 * D] += (double)N; }
 }
 
 template <typename TIN>

@@ -160,22 +160,29 @@ class EvalCallback:
         self.n_evals += 1
         self.evaluations_timesteps.append(ppo.num_timesteps)
         self.evaluations_results.append(r.episode_rewards); self.evaluations_length.append(r.episode_lengths)
-        if self.log_path is not None:
+        writer = ppo.rank == 0               # multi-process job: every rank evaluates (identical weights), ONE rank writes files
+        if ppo.world_size > 1:               # ... and every rank keeps rank 0's figure, so best_mean_reward agrees everywhere
+            import torch.distributed as td
+            t = torch.tensor([r.mean_reward], dtype=torch.float64, device=ppo.device if td.get_backend() == "nccl" else "cpu")
+            td.broadcast(t, src=0)
+            r.mean_reward_override = float(t.item())
+        if self.log_path is not None and writer:
             os.makedirs(os.path.dirname(self.log_path), exist_ok=True)
             kw = {}
             if r.is_success:
                 self.evaluations_successes.append(r.is_success); kw = dict(successes=np.array(self.evaluations_successes, dtype=object))
             np.savez(self.log_path, timesteps=self.evaluations_timesteps, results=np.array(self.evaluations_results, dtype=object),
                      ep_lengths=np.array(self.evaluations_length, dtype=object), **kw)
-        self.last_mean_reward = r.mean_reward
+        mean_reward = getattr(r, "mean_reward_override", r.mean_reward)
+        self.last_mean_reward = mean_reward
         is_objlock = getattr(getattr(self.eval_env.venv, "cfg", None), "task", 0) != K.FW_TASK_WAYPOINTS
         self.last_scalars = r.scalars(self.num_targets_total, has_duck=is_objlock)
         self.last_scalars["time/total_timesteps"] = ppo.num_timesteps
-        if self.verbose:
+        if self.verbose and writer:
             print(f"Eval num_timesteps={ppo.num_timesteps}, episode_reward={r.mean_reward:.2f} +/- {r.std_reward:.2f}")
             print(f"Episode length: {r.mean_ep_length:.2f} +/- {r.std_ep_length:.2f}")
-        if r.mean_reward > self.best_mean_reward:
-            self.best_mean_reward = r.mean_reward
-            if self.best_model_save_path is not None:
+        if mean_reward > self.best_mean_reward:
+            self.best_mean_reward = mean_reward
+            if self.best_model_save_path is not None and writer:
                 checkpoint.save(os.path.join(self.best_model_save_path, "best_model.pt"), ppo, include_env_state=False)
         return True

@@ -9,16 +9,22 @@ Everything lives on the GPU: the env step (fw_step), the normaliser (fw_normaliz
 the policy MLP (torch-ROCm), the rollout buffer and the GAE scan (fw_gae); nothing makes
 a host round trip inside the rollout loop.
 
-Multi-GPU (one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI):
-envs are sharded by rank; collectives happen only at update time --
-  * all-gather of the advantages (north_star) for the global normalisation statistics,
-  * all-reduce of one flattened gradient bucket per minibatch,
-  * all-reduce of the normaliser's batch sums.
+Multi-GPU (one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI): envs are sharded by rank
+(``global_env_offset = rank * N``: scenario, noise and action-sampling streams are keyed on the global env id), the
+fused kernels run on every rank exactly as on one GPU, and collectives happen only BETWEEN rollouts --
+  * one all-gather of the rank's rollout shard (obs, actions, log-probs, advantages, returns: ~9 MB per 65 536 samples)
+    at update time; every rank then runs the SAME minibatch sequence (same permutation seed) on the gathered buffer --
+    identical weights by construction, no collective per minibatch (north_star's "all-gather of advantages at update time");
+  * one all-reduce per rollout of the normaliser's accumulated batch sums (observations and discounted returns), from
+    which every rank re-derives the statistics of ALL envs (``stats_sync="rollout"``); the torch restatement can also
+    all-reduce them at every vec-step (``"step"``: the statistics of one big VecNormalize, used by the checkers).
+The old data-parallel form (gradient all-reduce per minibatch) is kept as ``PPOConfig.dist_update = "allreduce"``.
 """
 from __future__ import annotations
 
 import ctypes as C
 import math
+import time
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -42,6 +48,45 @@ def _dist():
     return td if (td.is_available() and td.is_initialized() and td.get_world_size() > 1) else None
 
 
+def _staged(td, t: torch.Tensor) -> bool:
+    """RCCL ("nccl") moves device tensors itself; any other backend (gloo rehearsals) gets a host copy."""
+    return t.is_cuda and td.get_backend() != "nccl"
+
+
+def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
+    """In-place sum over ranks (no-op in a single-process job)."""
+    td = _dist()
+    if td is None:
+        return t
+    if _staged(td, t):
+        h = t.detach().cpu()
+        td.all_reduce(h)
+        t.copy_(h)
+    else:
+        td.all_reduce(t)
+    return t
+
+
+def all_gather_cat(t: torch.Tensor, dim: int = 0) -> torch.Tensor:
+    """Concatenation over ranks (rank order) of ``t`` along ``dim``; one collective.  Single-process: ``t`` itself."""
+    td = _dist()
+    if td is None:
+        return t
+    w = td.get_world_size()
+    src = t.detach().contiguous()
+    if td.get_backend() == "nccl" and src.is_cuda:
+        # one direct all-gather on device tensors (RCCL: 7 peers on 7 xGMI links), not a ring of sends
+        out = torch.empty((w * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        td.all_gather_into_tensor(out, src)
+        out = out.reshape((w,) + tuple(src.shape))
+    else:
+        h = src.cpu() if src.is_cuda else src                       # gloo rehearsal: host copies
+        parts = [torch.empty_like(h) for _ in range(w)]
+        td.all_gather(parts, h)
+        out = torch.stack(parts).to(t.device)
+    return torch.cat(list(out.unbind(0)), dim=dim)
+
+
 # ---------------------------------------------------------------------------------------------
 # running statistics (SB3 common/running_mean_std.py): mean 0, var 1, count = epsilon = 1e-4
 # ---------------------------------------------------------------------------------------------
@@ -57,12 +102,15 @@ class RunningMeanStd:
         x = x.to(torch.float64).reshape(x.shape[0], -1)
         s, s2 = x.sum(0), (x * x).sum(0)
         n = torch.full((1,), float(x.shape[0]), dtype=torch.float64, device=x.device)   # fill kernel: graph-capturable
-        td = _dist()
-        if td is not None:
-            buf = torch.cat([s, s2, n])
-            td.all_reduce(buf)
+        if _dist() is not None:
+            buf = all_reduce_sum_(torch.cat([s, s2, n]))
             d = s.numel()
             s, s2, n = buf[:d], buf[d:2 * d], buf[2 * d:]
+        self.update_from_sums(s, s2, n)
+
+    def update_from_sums(self, s, s2, n) -> None:
+        """Merge a batch given as (column sums, sums of squares, rows) -- the form the kernels accumulate and ranks exchange."""
+        s, s2 = s.reshape(-1), s2.reshape(-1)
         bm = s / n
         bv = (s2 / n - bm * bm).clamp_min(0.0)
         self.update_from_moments(bm.reshape(self.mean.shape), bv.reshape(self.var.shape), n)
@@ -93,7 +141,7 @@ class VecNormalizeDevice:
 
     def __init__(self, venv, training: bool = True, norm_obs: bool = True, norm_reward: bool = True,
                  clip_obs: float = 10.0, clip_reward: float = 10.0, gamma: float = 0.99, epsilon: float = 1e-8,
-                 use_fused_kernel: Optional[bool] = None):
+                 use_fused_kernel: Optional[bool] = None, stats_sync: Optional[str] = None):
         self.venv = venv
         self.device = venv.device
         self.num_envs, self.obs_dim = venv.num_envs, venv.obs_dim
@@ -104,8 +152,22 @@ class VecNormalizeDevice:
         self.returns = torch.zeros(self.num_envs, dtype=torch.float64, device=self.device)
         self.obs_out = torch.zeros((self.num_envs, self.obs_dim), dtype=torch.float32, device=self.device)
         self.tobs_out = torch.zeros_like(self.obs_out)
-        # single-GPU: one fused HIP pass (moments + merge + normalise); multi-GPU: torch ops + all-reduce
-        self.use_fused = (_dist() is None) if use_fused_kernel is None else use_fused_kernel
+        # fused HIP passes (moments + merge + normalise) whenever the env lives on a GPU -- also in a sharded job, where
+        # the kernels additionally accumulate the batch sums that sync_statistics() all-reduces once per rollout
+        self.use_fused = (self.device.type == "cuda") if use_fused_kernel is None else use_fused_kernel
+        self.stats_sync = ("rollout" if self.use_fused else "step") if stats_sync is None else stats_sync
+        if self.stats_sync not in ("step", "rollout") or (self.use_fused and self.stats_sync == "step" and _dist() is not None):
+            raise ValueError("stats_sync must be 'rollout' (fused kernels) or 'step' / 'rollout' (torch restatement)")
+        self._ws = None
+        self._obs_acc = self._ret_acc = None
+        if self.use_fused:
+            nbytes = int(_lib.lib().fw_normalize_obs_workspace_bytes(self.obs_dim))
+            self._ws = torch.zeros(nbytes // 8, dtype=torch.float64, device=self.device)       # caller-owned scratch of fw_normalize_obs
+        if _dist() is not None and self.stats_sync == "rollout":
+            self._obs_acc = torch.zeros(2 * self.obs_dim + 1, dtype=torch.float64, device=self.device)
+            self._ret_acc = torch.zeros(3, dtype=torch.float64, device=self.device)
+            self._snap = self._snapshot()                   # the statistics every rank agreed on last (here: the initial ones)
+        self.version = 0          # bumped whenever a scalar a captured rollout graph froze may have changed (load_state_dict, flag overrides)
 
     # -- observation ---------------------------------------------------------------------------
     def _norm_obs_torch(self, obs, out):
@@ -121,12 +183,45 @@ class VecNormalizeDevice:
             rc = _lib.lib().fw_normalize_obs(_p(obs), int(obs.dtype == torch.float64), self.num_envs, self.obs_dim,
                                              _p(self.obs_rms.mean), _p(self.obs_rms.var), _p(self.obs_rms.count),
                                              int(update), float(self.clip_obs), float(self.epsilon), _p(self.obs_out),
-                                             _stream(self.device))
+                                             _p(self._ws), _p(self._obs_acc) if update else None, _stream(self.device))
             _lib.check(rc)
             return self.obs_out
         if update:
-            self.obs_rms.update(obs)
+            self._update_rms(self.obs_rms, obs, self._obs_acc)
         return self._norm_obs_torch(obs, self.obs_out)
+
+    # -- statistics of a sharded job ------------------------------------------------------------------
+    def _update_rms(self, rms, x, acc):
+        """Torch-path update: every vec-step over all ranks ("step"), or locally + accumulated for the per-rollout
+        exchange ("rollout": same arithmetic as the fused kernels)."""
+        if acc is None:
+            rms.update(x)                                     # all-reduces the batch sums itself in a multi-process job
+            return
+        x = x.to(torch.float64).reshape(x.shape[0], -1)
+        sx, sx2 = x.sum(0), (x * x).sum(0)
+        n = torch.full((1,), float(x.shape[0]), dtype=torch.float64, device=x.device)
+        rms.update_from_sums(sx, sx2, n)
+        acc.add_(torch.cat([sx, sx2, n]))
+
+    def _snapshot(self):
+        return [t.clone() for t in (self.obs_rms.mean, self.obs_rms.var, self.obs_rms.count,
+                                    self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count)]
+
+    def sync_statistics(self) -> None:
+        """Once per rollout in a sharded job (``stats_sync="rollout"``): all-reduce the accumulated batch sums (one small
+        collective: 2 D + 4 doubles) and re-derive the running statistics as  statistics at the last sync  (+)  the batches
+        of ALL ranks since -- afterwards every rank holds identical statistics, those of one VecNormalize over all envs."""
+        if self._obs_acc is None:
+            return
+        d = self.obs_dim
+        buf = all_reduce_sum_(torch.cat([self._obs_acc, self._ret_acc]))
+        for rms, snap, (sx, sx2, n) in ((self.obs_rms, self._snap[0:3], (buf[:d], buf[d:2 * d], buf[2 * d:2 * d + 1])),
+                                        (self.ret_rms, self._snap[3:6], (buf[2 * d + 1:2 * d + 2], buf[2 * d + 2:2 * d + 3], buf[2 * d + 3:]))):
+            rms.mean.copy_(snap[0]); rms.var.copy_(snap[1]); rms.count.copy_(snap[2])
+            if float(n.item()) > 0:
+                rms.update_from_sums(sx, sx2, n)
+        self._obs_acc.zero_(); self._ret_acc.zero_()
+        self._snap = self._snapshot()
 
     def normalize_obs(self, obs, out=None):
         """Normalise with the current statistics without updating them."""
@@ -148,7 +243,7 @@ class VecNormalizeDevice:
         rew64 = rew.to(torch.float64)
         if self.training and self.norm_reward:
             self.returns.mul_(self.gamma).add_(rew64)               # in place (graph-captured address)
-            self.ret_rms.update(self.returns)
+            self._update_rms(self.ret_rms, self.returns, self._ret_acc)
         if self.norm_reward:
             rew_n = (rew64 / torch.sqrt(self.ret_rms.var + self.epsilon)).clamp(-self.clip_reward, self.clip_reward)
         else:
@@ -164,8 +259,11 @@ class VecNormalizeDevice:
 
     def load_state_dict(self, sd):
         self.obs_rms.load_state_dict(sd["obs_rms"]); self.ret_rms.load_state_dict(sd["ret_rms"])
+        if self._obs_acc is not None:                        # loaded statistics are the new synchronised base
+            self._obs_acc.zero_(); self._ret_acc.zero_(); self._snap = self._snapshot()
         for k in ("clip_obs", "clip_reward", "gamma", "epsilon", "norm_obs", "norm_reward"):
             setattr(self, k, sd[k])
+        self.version += 1
 
 
 # ---------------------------------------------------------------------------------------------
@@ -315,6 +413,8 @@ class PPOConfig:
     use_graphs: bool = True                # replay the rollout / minibatch update as hipGraphs (single-GPU, device envs)
     fused_update: bool = True              # run the whole minibatch sequence of train() in one HIP kernel (fw_ppo_update) when it applies
     fused_collect: bool = True             # policy forward / sampling / buffer writes and the reward path as fw_policy_act + fw_rollout_post
+    dist_update: str = "replicated"        # multi-process job: "replicated" = all-gather the rollout shards, every rank runs the same
+                                           # minibatch sequence (no per-minibatch collective); "allreduce" = local minibatches + gradient all-reduce
 
 
 class _PpoHyper(C.Structure):
@@ -343,12 +443,20 @@ class FusedPpoUpdate:
         self.mom_m = torch.zeros(ns, dtype=torch.float32, device=dev)                      # slot order (what the kernel sees)
         self.mom_v = torch.zeros_like(self.mom_m)
         self.loss = torch.zeros(16, dtype=torch.float32, device=dev)
+        self._ws = None                    # caller-owned scratch of fw_ppo_update (grown here, never inside the call)
+
+    def _workspace(self, n_mb: int) -> torch.Tensor:
+        need = int(_lib.lib().fw_ppo_update_workspace_bytes(n_mb))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.zeros(need, dtype=torch.uint8, device=self.flat.device)
+        return self._ws
 
     @staticmethod
     def fits(policy, obs_dim: int, device) -> bool:
-        """The kernels are written for the reference's MlpPolicy: two 64-64 tanh nets, 4 actions, obs_dim <= 64, one GPU."""
+        """The kernels are written for the reference's MlpPolicy: two 64-64 tanh nets, 4 actions, obs_dim <= 64 (any number
+        of ranks: a sharded job runs them unchanged on every GPU)."""
         lin = [m for m in list(policy.pi_net) + list(policy.vf_net) if isinstance(m, nn.Linear)]
-        return (device.type == "cuda" and _dist() is None and obs_dim <= 64 and len(lin) == 4
+        return (device.type == "cuda" and obs_dim <= 64 and len(lin) == 4
                 and all(m.out_features == 64 for m in lin) and policy.action_net.out_features == 4)
 
     @staticmethod
@@ -428,8 +536,10 @@ class FusedPpoUpdate:
         for x in (obs, act, old_logp, adv, ret):
             assert x.dtype == torch.float32 and x.is_contiguous()
         assert perm_i32.dtype == torch.int32 and perm_i32.numel() == n_mb * cfg.batch_size
+        ws = self._workspace(n_mb)
         rc = _lib.lib().fw_ppo_update(_p(self.flat), _p(self.mom_m), _p(self.mom_v), _p(obs), _p(act), _p(old_logp), _p(adv), _p(ret),
-                                      _p(perm_i32), n_mb, cfg.batch_size, self.D, C.byref(H), _p(self.loss), _stream(obs.device))
+                                      _p(perm_i32), n_mb, cfg.batch_size, self.D, C.byref(H), _p(self.loss), _p(ws), ws.numel(),
+                                      _stream(obs.device))
         _lib.check(rc)
         self.store_to_torch(step0 + n_mb)
         return (self.loss[:3] / n_mb).tolist()
@@ -446,24 +556,39 @@ class PPO:
         if td is not None:                 # identical initial weights on every rank
             for p in self.policy.parameters():
                 td.broadcast(p.data, src=0)
-        self._graphs = bool(cfg.use_graphs) and self.device.type == "cuda" and td is None
+        if cfg.dist_update not in ("replicated", "allreduce"):
+            raise ValueError("dist_update must be 'replicated' or 'allreduce'")
+        self._replicated = td is not None and cfg.dist_update == "replicated"
+        self._fused_collect_ok = (bool(cfg.fused_collect) and FusedPpoUpdate.fits(self.policy, env.obs_dim, self.device)
+                                  and getattr(env, "use_fused", False) and env.norm_obs and hasattr(env.venv, "step_tensor")
+                                  and hasattr(env.venv, "terminal_obs") and hasattr(env.venv, "torch_dtype"))
+        # hipGraph replay needs a collective-free body: always on one GPU; in a sharded job when the collector is fused
+        # (its statistics are exchanged BETWEEN rollouts) and the update is replicated (no gradient all-reduce)
+        self._graphs = (bool(cfg.use_graphs) and self.device.type == "cuda"
+                        and (td is None or (self._fused_collect_ok and self._replicated)))
         self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5,
                                           capturable=self._graphs)
         self._g_rollout = self._g_update = None
+        self._g_rollout_key = None
         self._fused = None
         self._flat_current = False         # does self._fused.flat hold the current policy parameters?
-        self._collect_fused = (bool(cfg.fused_collect) and FusedPpoUpdate.fits(self.policy, env.obs_dim, self.device)
-                               and getattr(env, "use_fused", False) and env.norm_obs and hasattr(env.venv, "step_tensor")
-                               and hasattr(env.venv, "terminal_obs") and hasattr(env.venv, "torch_dtype"))
+        self._collect_fused = self._fused_collect_ok
         if self._collect_fused:
             self._fused = FusedPpoUpdate(self.policy, self.optimizer, env.obs_dim)
             self._rng = torch.tensor([cfg.seed * 7919 + 17, 0], dtype=torch.int64, device=self.device)      # seed, draw counter
             self._act_env = torch.zeros((env.num_envs, 4), dtype=env.venv.torch_dtype, device=self.device)
             self._tval = torch.zeros(env.num_envs, dtype=torch.float32, device=self.device)
         self._warm_rollouts = 0
+        self._gathered = None
+        self.allgather_ms = self.allgather_bytes = 0.0
         self._loss_acc = torch.zeros(3, device=self.device)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(cfg.seed + (td.get_rank() if td is not None else 0))
+        # minibatch permutations: the SAME stream on every rank, so that a replicated update walks identical minibatches
+        self.perm_gen = self.gen
+        if self._replicated:
+            self.perm_gen = torch.Generator(device=self.device)
+            self.perm_gen.manual_seed(cfg.seed * 1_000_003 + 12345)
         T, N, D = cfg.n_steps, env.num_envs, env.obs_dim
         f32 = dict(dtype=torch.float32, device=self.device)
         self.buf_obs = torch.zeros((T, N, D), **f32)
@@ -523,7 +648,8 @@ class PPO:
             _lib.check(L.fw_rollout_post(_p(rew), int(rew.dtype == torch.float64), _p(term), _p(trunc), _p(self._tval),
                                          _p(env.returns), _p(env.ret_rms.mean), _p(env.ret_rms.var), _p(env.ret_rms.count),
                                          env.num_envs, int(env.training), int(env.norm_reward), float(env.gamma),
-                                         float(env.clip_reward), float(env.epsilon), _p(self.buf_rew[t]), _p(nxt), _p(self._rng), st))
+                                         float(env.clip_reward), float(env.epsilon), _p(self.buf_rew[t]), _p(nxt), _p(self._rng),
+                                         _p(env._ret_acc), st))
         self.last_obs.copy_(obs)
         self._act(self.last_obs, 2, value_out=self.last_values)
 
@@ -539,6 +665,10 @@ class PPO:
             if not self._flat_current:
                 self._fused.load_params_from_torch(); self._flat_current = True
             body = self._rollout_body_fused
+        key = (getattr(env, "version", 0), bool(env.training), bool(env.norm_reward), bool(env.norm_obs))
+        if self._g_rollout is not None and key != self._g_rollout_key:
+            self._g_rollout = None             # the graph froze clip / gamma / training flags as kernel arguments: re-capture
+        self._g_rollout_key = key
         if self._graphs and self._warm_rollouts >= 1:
             # the n_steps x (policy forward, fw_step, fw_normalize_obs, buffer writes) chain is one
             # hipGraph: ~40 tiny launches per vec-step are otherwise host-bound (0.75 ms vs 27 us of physics).
@@ -554,6 +684,8 @@ class PPO:
         else:
             body()
         self._warm_rollouts += 1
+        if hasattr(env, "sync_statistics"):
+            env.sync_statistics()              # sharded job: one small all-reduce per rollout (no-op on one GPU)
         self.adv, self.ret = self._gae(self.buf_rew, self.buf_val, self.buf_start, self.last_values, self.last_starts,
                                        cfg.gamma, cfg.gae_lambda)
         td = _dist()
@@ -573,18 +705,58 @@ class PPO:
         loss = policy_loss + cfg.ent_coef * entropy_loss + cfg.vf_coef * value_loss
         self.optimizer.zero_grad(set_to_none=False)
         loss.backward()
-        allreduce_grads_(params)
+        if not self._replicated:
+            allreduce_grads_(params)           # "allreduce" mode only: a replicated update needs no collective here
         torch.nn.utils.clip_grad_norm_(params, cfg.max_grad_norm)
         self.optimizer.step()
         self._loss_acc += torch.stack([policy_loss.detach(), value_loss.detach(), entropy_loss.detach()])
 
+    def _update_buffers(self):
+        """``(obs, act, old_logp, adv, ret)`` flattened to [B, ...] as the update walks them: the rank's own rollout, or --
+        replicated update of a sharded job -- the rollouts of ALL ranks, all-gathered once (obs / actions / log-probs /
+        advantages / returns packed into one [T, N, D + 7] float32 tensor: one collective of ~9 MB per 65 536 samples) and
+        laid out exactly like the buffer of one big job over the concatenated envs ([T, W * N], rank-major env order)."""
+        T, N, D = self.cfg.n_steps, self.env.num_envs, self.env.obs_dim
+        if not self._replicated:
+            B = T * N
+            return (self.buf_obs.reshape(B, -1), self.buf_act.reshape(B, -1), self.buf_logp.reshape(B),
+                    self.adv.reshape(B), self.ret.reshape(B))
+        pack = torch.cat([self.buf_obs, self.buf_act, self.buf_logp.unsqueeze(-1), self.adv.unsqueeze(-1), self.ret.unsqueeze(-1)], dim=-1)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        g = all_gather_cat(pack, dim=1)                          # [T, W * N, D + 7]
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self.allgather_ms = (time.perf_counter() - t0) * 1e3
+        self.allgather_bytes = pack.numel() * 4
+        B = g.shape[0] * g.shape[1]
+        g = g.reshape(B, D + 7)
+        if self._gathered is None:                               # persistent: a captured update graph holds these addresses
+            f32 = dict(dtype=torch.float32, device=self.device)
+            self._gathered = (torch.empty((B, D), **f32), torch.empty((B, 4), **f32), torch.empty(B, **f32),
+                              torch.empty(B, **f32), torch.empty(B, **f32))
+        o, a, lp, ad, rt = self._gathered
+        o.copy_(g[:, :D]); a.copy_(g[:, D:D + 4]); lp.copy_(g[:, D + 4]); ad.copy_(g[:, D + 5]); rt.copy_(g[:, D + 6])
+        return self._gathered
+
+    def replica_checksum(self) -> float:
+        """Sum over ranks of |own parameters - rank 0's parameters|: exactly 0.0 while the replicas are bit-identical."""
+        flat = torch.cat([p.detach().reshape(-1) for p in self.policy.parameters()]).to(torch.float64)
+        td = _dist()
+        if td is None:
+            return 0.0
+        ref = all_gather_cat(flat.unsqueeze(0), dim=0)[0]
+        return float(all_reduce_sum_((flat - ref).abs().sum().reshape(1)).item())
+
     def train(self):
         cfg = self.cfg
-        T, N = cfg.n_steps, self.env.num_envs
-        B = T * N
-        obs = self.buf_obs.reshape(B, -1); act = self.buf_act.reshape(B, -1)
-        old_logp = self.buf_logp.reshape(B); adv = self.adv.reshape(B); ret = self.ret.reshape(B)
-        g_mean, g_std, _ = global_advantage_stats(adv)           # RCCL all-gather at update time
+        obs, act, old_logp, adv, ret = self._update_buffers()
+        B = obs.shape[0]
+        if self._replicated:                                     # the gathered advantages ARE the global ones
+            g_mean, g_std = adv.mean(), adv.std()
+        else:
+            g_mean, g_std, _ = global_advantage_stats(adv)       # "allreduce" mode: all-gather of the advantages only
         params = list(self.policy.parameters())
         self._loss_acc.zero_()          # persistent buffer: the captured update graph holds its address
         nb = 0
@@ -593,7 +765,7 @@ class PPO:
             # the whole minibatch sequence in one kernel; the permutations are drawn exactly like the loop below
             if self._fused is None:
                 self._fused = FusedPpoUpdate(self.policy, self.optimizer, self.env.obs_dim)
-            perm = torch.cat([torch.randperm(B, device=self.device, generator=self.gen) for _ in range(cfg.n_epochs)]).to(torch.int32)
+            perm = torch.cat([torch.randperm(B, device=self.device, generator=self.perm_gen) for _ in range(cfg.n_epochs)]).to(torch.int32)
             nb = cfg.n_epochs * (B // bs)
             la = self._fused.run(cfg, obs.contiguous(), act.contiguous(), old_logp.contiguous(), adv.contiguous(), ret.contiguous(),
                                  perm, nb, float(g_mean), float(g_std))
@@ -609,7 +781,7 @@ class PPO:
             self._gm = torch.zeros((), device=self.device); self._gs = torch.ones((), device=self.device)
             self._adv_s, self._ret_s = torch.zeros(B, device=self.device), torch.zeros(B, device=self.device)
             self._adv_s.copy_(adv); self._ret_s.copy_(ret); self._gm.copy_(g_mean); self._gs.copy_(g_std)
-            self._idx.copy_(torch.randperm(B, device=self.device)[:bs])
+            self._idx.copy_(torch.arange(bs, device=self.device))
             sd_p = [p.detach().clone() for p in params]
             sd_o = {p: {k: v.clone() for k, v in stt.items() if torch.is_tensor(v)} for p, stt in self.optimizer.state.items()}
             st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
@@ -634,7 +806,7 @@ class PPO:
         if use_graph:
             self._adv_s.copy_(adv); self._ret_s.copy_(ret); self._gm.copy_(g_mean); self._gs.copy_(g_std)
         for _ in range(cfg.n_epochs):
-            perm = torch.randperm(B, device=self.device, generator=self.gen)
+            perm = torch.randperm(B, device=self.device, generator=self.perm_gen)
             for s in range(0, B, bs):
                 if use_graph:
                     self._idx.copy_(perm[s:s + bs])
@@ -677,9 +849,15 @@ class PPO:
         return {"policy": self.policy.state_dict(), "optimizer": self.optimizer.state_dict(),
                 "vecnormalize": self.env.state_dict(), "num_timesteps": self.num_timesteps}
 
+    def invalidate_graphs(self) -> None:
+        """Drop the captured rollout / update graphs (their kernel arguments froze scalars and state addresses that a
+        checkpoint load may have replaced); the next rollout runs eagerly once and re-captures."""
+        self._g_rollout = self._g_update = None
+        self._warm_rollouts = 0
+
     def load_state_dict(self, sd, reset_num_timesteps: bool = True):
         self.policy.load_state_dict(sd["policy"]); self.optimizer.load_state_dict(sd["optimizer"])
-        self._g_update = None              # the optimiser's state tensors were replaced: re-capture the update graph
+        self.invalidate_graphs()           # the optimiser's state tensors were replaced, normaliser scalars may differ
         self._flat_current = False
         self.env.load_state_dict(sd["vecnormalize"])
         self.num_timesteps = 0 if reset_num_timesteps else int(sd["num_timesteps"])

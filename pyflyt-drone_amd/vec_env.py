@@ -54,6 +54,7 @@ class FixedwingVecEnv:
         self.cfg = cfg.copy()
         self.num_envs = int(num_envs)
         self.global_env_offset = int(global_env_offset)
+        self.seed_value = int(seed)
         self.obs_dim = K.obs_dim(cfg)
         self.np_dtype = np.float64 if cfg.dtype == K.FW_F64 else np.float32
         self.torch_dtype = torch.float64 if cfg.dtype == K.FW_F64 else torch.float32
@@ -160,6 +161,7 @@ class FixedwingVecEnv:
     def seed(self, seed: Optional[int] = None) -> Sequence[Optional[int]]:
         s = 0 if seed is None else int(seed)
         _lib.check(_lib.lib().fw_seed(self._h, s & (2**64 - 1)), self._h)
+        self.seed_value = s
         return [s + i for i in range(self.num_envs)]
 
     def close(self) -> None:
@@ -248,17 +250,15 @@ class FixedwingWaypointsVecEnv(FixedwingVecEnv):
 
 class FixedwingObjLockVecEnv(FixedwingVecEnv):
     """``FlattenObjLockEnv(FixedwingObjLockEnv(...))`` vectorised (envs/fixedwing_objlock_env.py:37-81,
-    envs/flatten_objlock_env.py; constructed at train/train_objlock.py:113-153).  Observations are
-    the reference's 56 float32 values (22 attitude + 3 target vector + 31 duck vision); with
-    ``dtype="float64"`` they are stored in float64 tensors but already rounded to float32."""
+    envs/flatten_objlock_env.py; constructed at train/train_objlock.py:113-153).  Accepts the reference
+    constructor's full keyword set (``config.objlock_config_from_reference_kwargs``: render-only arguments are ignored,
+    options the device env cannot honour raise ``ValueError``).  Observations are the reference's 56 float32 values
+    (22 attitude + 3 target vector + 31 duck vision); with ``dtype="float64"`` they are stored in float64 tensors
+    but already rounded to float32."""
 
-    def __init__(self, num_envs: int, *, render_mode: Optional[str] = None, dtype: str = "float64",
-                 motor_noise: bool = True, device=None, seed: int = 0, global_env_offset: int = 0, **env_kwargs):
-        if render_mode not in (None, "rgb_array"):
-            raise ValueError(f"Invalid render mode {render_mode}, only [None, 'rgb_array'] have a device counterpart.")
-        if render_mode == "rgb_array":          # camera_resolution = render_resolution (:213-218)
-            env_kwargs.setdefault("camera_resolution", int(env_kwargs.pop("render_resolution", (480, 480))[0]))
-        cfg = K.objlock_config(dtype=dtype, motor_noise=motor_noise, **env_kwargs)
+    def __init__(self, num_envs: int, *, dtype: str = "float64", motor_noise: bool = True, device=None, seed: int = 0,
+                 global_env_offset: int = 0, **env_kwargs):
+        cfg = K.objlock_config_from_reference_kwargs(dtype=dtype, motor_noise=motor_noise, **env_kwargs)
         super().__init__(cfg, num_envs, device=device, seed=seed, global_env_offset=global_env_offset)
         self.observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float32)
 
@@ -266,15 +266,12 @@ class FixedwingObjLockVecEnv(FixedwingVecEnv):
 class FixedwingWaypointObjLockVecEnv(FixedwingVecEnv):
     """``FlattenWaypointEnv(FixedwingWaypointObjLockEnv(...), context_length)`` vectorised
     (envs/fixedwing_waypoint_objlock_env.py:42-76; constructed at
-    train/train_Fixedwing_Waypoints_ObjLock.py:119-165).  Observation = attitude ++ the first
+    train/train_Fixedwing_Waypoints_ObjLock.py:119-165; full reference keyword set, see
+    ``config.waypoint_objlock_config_from_reference_kwargs``).  Observation = attitude ++ the first
     ``context_length`` rows of [remaining waypoints ..., duck] in the body frame (float64)."""
 
-    def __init__(self, num_envs: int, *, render_mode: Optional[str] = None, context_length: int = 2,
-                 dtype: str = "float64", motor_noise: bool = True, device=None, seed: int = 0,
-                 global_env_offset: int = 0, **env_kwargs):
-        if render_mode not in (None, "rgb_array"):
-            raise ValueError(f"Invalid render mode {render_mode}, only [None, 'rgb_array'] have a device counterpart.")
-        if render_mode == "rgb_array":
-            env_kwargs.setdefault("camera_resolution", int(env_kwargs.pop("render_resolution", (480, 480))[0]))
-        cfg = K.waypoint_objlock_config(dtype=dtype, motor_noise=motor_noise, context_length=context_length, **env_kwargs)
+    def __init__(self, num_envs: int, *, context_length: int = 2, dtype: str = "float64", motor_noise: bool = True,
+                 device=None, seed: int = 0, global_env_offset: int = 0, **env_kwargs):
+        cfg = K.waypoint_objlock_config_from_reference_kwargs(dtype=dtype, motor_noise=motor_noise,
+                                                              context_length=context_length, **env_kwargs)
         super().__init__(cfg, num_envs, device=device, seed=seed, global_env_offset=global_env_offset)

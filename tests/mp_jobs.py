@@ -1,0 +1,58 @@
+"""Jobs run by the two helper processes that tests/conftest.py starts BEFORE the pytest process touches the GPU (a
+process that has initialised the GPU must not start other programs on the GPU boxes; these helpers are started early
+and idle until a test hands them a job).  Each job is one rank of a world_size-2 ``gloo`` job whose ranks share cuda:0
+(RCCL refuses two ranks on one device; the product code stages collectives through the host for non-RCCL backends)."""
+import os
+import traceback
+
+
+def serve(rank, world, job_q, res_q):
+    while True:
+        job = job_q.get()
+        if job is None:
+            return
+        name, port, kwargs = job
+        try:
+            import torch.distributed as td
+            os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+            td.init_process_group("gloo", rank=rank, world_size=world)
+            try:
+                out = globals()[name](rank, world, **kwargs)
+            finally:
+                td.destroy_process_group()
+            res_q.put((rank, "ok", out))
+        except BaseException:                                   # report, keep serving
+            res_q.put((rank, "error", traceback.format_exc()))
+
+
+def sharded_training(rank, world, task, n_envs, n_steps, batch_size, n_epochs, iterations):
+    """One rank of a sharded training job: env shard at global_env_offset = rank * n_envs, fused collector (hipGraph),
+    rollout all-gather, fused replicated update."""
+    import numpy as np
+    import torch
+    import pyflyt_drone_amd as P
+    from pyflyt_drone_amd import config as K
+    from pyflyt_drone_amd import rollout as R
+    torch.cuda.set_device(0)
+    cfg = {"waypoints": K.train_waypoints_v3_config, "combined": K.train_waypoint_objlock_config}[task]()
+    venv = P.FixedwingVecEnv(cfg, n_envs, device=0, seed=42, global_env_offset=rank * n_envs)
+    env = R.VecNormalizeDevice(venv)
+    ppo = R.PPO(env, R.PPOConfig(n_steps=n_steps, batch_size=batch_size, n_epochs=n_epochs, seed=42))
+    facts = dict(fused_collect=bool(ppo._collect_fused), graphs=bool(ppo._graphs), replicated=bool(ppo._replicated),
+                 stats_sync=env.stats_sync, use_fused_norm=bool(env.use_fused))
+    first_obs = None
+    checks = []
+    for it in range(iterations):
+        ppo.collect_rollouts()
+        if first_obs is None:
+            first_obs = ppo.buf_obs[0].clone().cpu().numpy()
+        ppo.train()
+        checks.append(ppo.replica_checksum())
+    facts["fused_update"] = ppo._fused is not None and ppo._flat_current
+    facts["graph_captured"] = ppo._g_rollout is not None
+    flat = torch.cat([p.detach().reshape(-1) for p in ppo.policy.parameters()]).cpu().numpy()
+    stats = torch.cat([env.obs_rms.mean, env.obs_rms.var, env.obs_rms.count, env.ret_rms.var.reshape(1), env.ret_rms.count]).cpu().numpy()
+    ctr = venv.get_counters()
+    return dict(facts=facts, checks=checks, weights=flat, stats=stats, counters=ctr, num_timesteps=ppo.num_timesteps,
+                allgather_bytes=ppo.allgather_bytes, allgather_ms=ppo.allgather_ms, first_obs=first_obs,
+                logs=dict(ppo.logs), finite=bool(np.isfinite(flat).all()))

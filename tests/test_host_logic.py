@@ -97,6 +97,50 @@ def test_python_constructor_errors_mirror_reference():
         K.waypoints_config(dtype="bf16")
 
 
+def _same_config(a, b):
+    import ctypes as C
+    return C.string_at(C.addressof(a), C.sizeof(a)) == C.string_at(C.addressof(b), C.sizeof(b))
+
+
+def test_reference_make_env_keyword_sets_are_accepted():
+    """The exact keyword sets of the reference's make_env() factories (train/train_objlock.py:113-153 and
+    train/train_Fixedwing_Waypoints_ObjLock.py:119-165) build the training configs; what the device env cannot honour
+    raises ValueError instead of TypeError / silent acceptance."""
+    objlock_kw = dict(
+        sparse_reward=False, render_mode="rgb_array", angle_representation="euler", flight_dome_size=200.0,
+        max_duration_seconds=60.0, agent_hz=30, use_egl=False, wind_config=K.TRAIN_OBJLOCK_WIND,
+        num_obstacles=0, obstacle_radius=2.0, obstacle_height_range=(10.0, 30.0), obstacle_safe_distance_m=10.0,
+        obstacle_avoid_reward_scale=1.0, obstacle_avoid_max_penalty=5.0,
+        duck_camera_capture_interval_steps=12, duck_lock_hold_steps=5, duck_strike_distance_m=10.0, duck_strike_reward=400.0,
+        duck_lock_step_reward=0.2, duck_approach_reward_scale=0.1, duck_global_scaling=60.0,
+        duck_vision_history_len=3, duck_vision_use_deltas=True)
+    c = K.objlock_config_from_reference_kwargs(**objlock_kw)
+    assert _same_config(c, K.train_objlock_config()) and c.camera_resolution == 480       # rgb_array => render_resolution (:213-218)
+    assert K.objlock_config_from_reference_kwargs(**{**objlock_kw, "render_mode": None}).camera_resolution == 128
+    c2 = K.objlock_config_from_reference_kwargs(**objlock_kw, camera_profile="cockpit_fpv", camera_position_offset=(0.5, 0.0, 0.2),
+                                                camera_angle_degrees=-10, camera_FOV_degrees=60, camera_resolution=(64, 64),
+                                                duck_urdf_path="duck_vhacd.urdf", flight_mode=0)
+    assert list(c2.camera_offset) == [0.5, 0.0, 0.2] and c2.camera_angle_deg == -10.0 and c2.camera_fov_deg == 60.0
+    assert c2.camera_resolution == 64
+    for bad, match in ((dict(duck_vision_history_len=5), "duck_vision_history_len"), (dict(duck_vision_use_deltas=False), "use_deltas"),
+                       (dict(camera_profile="chase"), "camera_profile"), (dict(flight_mode=-1), "flight_mode"),
+                       (dict(render_mode="human"), "render mode"), (dict(camera_resolution=(64, 48)), "square")):
+        with pytest.raises(ValueError, match=match):
+            K.objlock_config_from_reference_kwargs(**{**objlock_kw, **bad})
+    combined_kw = dict(
+        sparse_reward=False, num_targets=8, goal_reach_distance=8, render_mode="rgb_array", angle_representation="euler",
+        flight_dome_size=100.0, max_duration_seconds=120.0, agent_hz=30, use_egl=False, wind_config=K.TRAIN_COMBINED_WIND,
+        num_obstacles=20, obstacle_radius=2.0, obstacle_height_range=(10.0, 30.0), obstacle_safe_distance_m=5.0,
+        obstacle_avoid_reward_scale=1.0, obstacle_avoid_max_penalty=2.0,
+        duck_camera_capture_interval_steps=6, duck_lock_hold_steps=10, duck_strike_distance_m=8, duck_strike_reward=200.0,
+        duck_lock_step_reward=0.1, duck_approach_reward_scale=0.05, duck_switch_min_consecutive_seen=2,
+        duck_switch_min_area=0.0005, duck_global_scaling=30.0)
+    c = K.waypoint_objlock_config_from_reference_kwargs(context_length=2, **combined_kw)
+    assert _same_config(c, K.train_waypoint_objlock_config())
+    with pytest.raises(ValueError, match="flight_mode"):
+        K.waypoint_objlock_config_from_reference_kwargs(**{**combined_kw, "flight_mode": 4})
+
+
 def test_box_space():
     b = P.Box(-1.0, 1.0, (4,), np.float64)
     assert b.shape == (4,) and b.dtype == np.float64

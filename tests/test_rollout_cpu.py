@@ -229,6 +229,96 @@ def test_update_time_collectives_world_size_2():
         assert all(oks), (rank, oks)
 
 
+# ---------------------------------------------------------------- replicated update of a sharded job (gloo, world_size 2)
+class RecordingVenv(FakeVenv):
+    """FakeVenv that keeps every raw observation batch it handed out (reset and steps), for the statistics check."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw); self.seen = []
+
+    def reset_tensor(self):
+        o = super().reset_tensor(); self.seen.append(o.clone()); return o
+
+    def step_tensor(self, actions):
+        out = super().step_tensor(actions); self.seen.append(out[0].clone()); return out
+
+
+_REPL_CFG = dict(n_steps=4, batch_size=16, n_epochs=3, seed=3)
+
+
+def _worker_replicated(rank, world, port, q, stats_sync):
+    import torch.distributed as td
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        venv = RecordingVenv(n=8, d=5, seed=100 + rank)
+        env = R.VecNormalizeDevice(venv, use_fused_kernel=False, stats_sync=stats_sync)
+        ppo = R.PPO(env, R.PPOConfig(**_REPL_CFG), policy=R.MlpPolicy(5), gae_fn=R.gae_reference)
+        assert ppo._replicated and ppo.perm_gen is not ppo.gen
+        w0 = [p.detach().clone().numpy() for p in ppo.policy.parameters()]
+        ppo.collect_rollouts()
+        shard = {k: getattr(ppo, k).clone().numpy() for k in ("buf_obs", "buf_act", "buf_logp", "adv", "ret")}
+        stats = torch.cat([env.obs_rms.mean, env.obs_rms.var, env.obs_rms.count, env.ret_rms.mean.reshape(1),
+                           env.ret_rms.var.reshape(1), env.ret_rms.count]).numpy()
+        ppo.train()
+        w1 = [p.detach().clone().numpy() for p in ppo.policy.parameters()]
+        chk = ppo.replica_checksum()
+        # two more iterations: the replicas must stay bit-identical with no per-minibatch collective at all
+        ppo.learn(2 * 4 * 8 * world, reset_num_timesteps=False)
+        chk2 = ppo.replica_checksum()
+        seen = torch.cat(venv.seen[:5]).numpy()                  # reset + the 4 steps of the first rollout
+        q.put((rank, w0, shard, stats, w1, chk, chk2, ppo.allgather_bytes, seen, ppo.num_timesteps))
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("stats_sync", ["step", "rollout"])
+def test_replicated_update_world_size_2_equals_single_process_on_concatenated_buffers(stats_sync):
+    """SURVEY section 8(e) / north_star: envs shard across ranks, the rollout shard is all-gathered at update time and every
+    rank runs the same minibatch sequence.  Proven here on the CPU (gloo, torch restatement of the learner): (a) both ranks
+    end with bit-identical weights, (b) those are bit-identical to ONE process running PPO.train() on the concatenated
+    buffers, (c) the normaliser statistics of the ranks agree bit for bit and equal the statistics of the union of all
+    observations, for both exchange cadences (every vec-step / once per rollout)."""
+    import torch.multiprocessing as mp
+    torch.set_num_threads(1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_worker_replicated, args=(r, 2, port, q, stats_sync)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60); assert p.exitcode == 0
+    (_, w0a, sa, sta, w1a, chka, chk2a, nbytes, seen_a, nt_a), (_, w0b, sb, stb, w1b, chkb, chk2b, _, seen_b, nt_b) = res
+    assert all(np.array_equal(x, y) for x, y in zip(w0a, w0b)), "rank 0's initial weights are broadcast"
+    assert all(np.array_equal(x, y) for x, y in zip(w1a, w1b)), "replicas diverged"
+    assert chka == chkb == 0.0 and chk2a == chk2b == 0.0
+    assert nbytes == 4 * 8 * (5 + 7) * 4 and nt_a == nt_b == 3 * 4 * 8 * 2
+    assert np.array_equal(sta, stb), "normaliser statistics differ between ranks"
+    ref = NpRunningMeanStd((5,))
+    if stats_sync == "step":
+        for k in range(5):                                            # one merge per vec-step over the union, as one big VecNormalize
+            ref.update(np.concatenate([seen_a[8 * k:8 * k + 8], seen_b[8 * k:8 * k + 8]]))
+    else:
+        ref.update(np.concatenate([seen_a, seen_b]))                  # one merge of everything since the last exchange
+    np.testing.assert_allclose(sta[:5], ref.mean, rtol=1e-12); np.testing.assert_allclose(sta[5:10], ref.var, rtol=1e-11)
+    assert sta[10] == pytest.approx(1e-4 + 5 * 16)
+    # single process on the concatenated buffers (rank-major env order), same initial weights, same permutation stream
+    one = R.PPO(R.VecNormalizeDevice(FakeVenv(n=16, d=5, seed=0), use_fused_kernel=False), R.PPOConfig(**_REPL_CFG),
+                policy=R.MlpPolicy(5), gae_fn=R.gae_reference)
+    with torch.no_grad():
+        for p, w in zip(one.policy.parameters(), w0a):
+            p.copy_(torch.from_numpy(w))
+    for k in ("buf_obs", "buf_act", "buf_logp"):
+        getattr(one, k).copy_(torch.from_numpy(np.concatenate([sa[k], sb[k]], axis=1)))
+    one.adv = torch.from_numpy(np.concatenate([sa["adv"], sb["adv"]], axis=1)); one.ret = torch.from_numpy(np.concatenate([sa["ret"], sb["ret"]], axis=1))
+    one.perm_gen = torch.Generator().manual_seed(_REPL_CFG["seed"] * 1_000_003 + 12345)
+    one.train()
+    for p, w in zip(one.policy.parameters(), w1a):
+        assert np.array_equal(p.detach().numpy(), w), "sharded replicas != one process on the concatenated buffers"
+
+
 # ---------------------------------------------------------------- configs[0]: CPU plumbing
 class OracleVenv:
     """Test-only adapter: the CPU oracle behind the device-env surface the learner consumes.  (The product has no CPU

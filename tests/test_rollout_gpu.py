@@ -35,9 +35,16 @@ def test_fw_normalize_obs_matches_torch_path(dtype):
         device, num_envs, obs_dim = dev, 4096, 28
     fused = R.VecNormalizeDevice(V(), use_fused_kernel=True)
     plain = R.VecNormalizeDevice(V(), use_fused_kernel=False)
+    # the accumulators a sharded job all-reduces once per rollout (fw_normalize_obs's batch_acc): sums of every UPDATING batch
+    fused._obs_acc = torch.zeros(2 * 28 + 1, dtype=torch.float64, device=dev)
+    want = torch.zeros_like(fused._obs_acc)
     for i in range(6):
         obs = (torch.randn((4096, 28), generator=g, dtype=torch.float64) * (1 + i) + 3 * i).to(dtype).to(dev)
+        if i != 4:
+            x = obs.double()
+            want += torch.cat([x.sum(0), (x * x).sum(0), torch.tensor([4096.0], dtype=torch.float64, device=dev)])
         a = fused._process_obs(obs, update=(i != 4)).clone()
+        torch.testing.assert_close(fused._obs_acc, want, rtol=1e-12, atol=1e-9)
         b = plain._process_obs(obs, update=(i != 4)).clone()
         torch.testing.assert_close(fused.obs_rms.mean, plain.obs_rms.mean, rtol=1e-10, atol=1e-12)
         torch.testing.assert_close(fused.obs_rms.var, plain.obs_rms.var, rtol=1e-9, atol=1e-12)
@@ -168,9 +175,13 @@ def test_fused_ppo_update_rejects_what_it_cannot_run():
     H = R._PpoHyper()
     import ctypes as C
     args = [R._p(z)] * 8 + [R._p(z.to(torch.int32))]
-    assert L.fw_ppo_update(*args, 1, 100, 28, C.byref(H), None, None) == K.FW_EINVAL      # batch not a multiple of 64
-    assert L.fw_ppo_update(*args, 1, 64, 65, C.byref(H), None, None) == K.FW_EINVAL       # obs_dim too large
-    assert L.fw_ppo_update(*args, 0, 64, 28, C.byref(H), None, None) == K.FW_EINVAL
+    ws = torch.zeros(int(L.fw_ppo_update_workspace_bytes(1)), dtype=torch.uint8, device="cuda")
+    assert L.fw_ppo_update(*args, 1, 100, 28, C.byref(H), None, R._p(ws), ws.numel(), None) == K.FW_EINVAL      # batch not a multiple of 64
+    assert L.fw_ppo_update(*args, 1, 64, 65, C.byref(H), None, R._p(ws), ws.numel(), None) == K.FW_EINVAL       # obs_dim too large
+    assert L.fw_ppo_update(*args, 0, 64, 28, C.byref(H), None, R._p(ws), ws.numel(), None) == K.FW_EINVAL
+    assert L.fw_ppo_update(*args, 1, 64, 28, C.byref(H), None, None, 0, None) == K.FW_EINVAL                    # no workspace
+    assert L.fw_ppo_update(*args, 4, 64, 28, C.byref(H), None, R._p(ws), ws.numel(), None) == K.FW_EINVAL       # workspace sized for 1 minibatch
+    assert b"workspace" in L.fw_last_error(None)
 
 
 def _flat_params(pol, d):
@@ -240,6 +251,7 @@ def test_fw_rollout_post_matches_vecnormalize_reward_path():
     ret = torch.zeros(n, dtype=torch.float64, device="cuda")
     mean, var, cnt = (x.clone() for x in (ref.ret_rms.mean, ref.ret_rms.var, ref.ret_rms.count))
     rng = torch.tensor([5, 0], dtype=torch.int64, device="cuda")
+    acc, want_acc = torch.zeros(3, dtype=torch.float64, device="cuda"), torch.zeros(3, dtype=torch.float64, device="cuda")
     for step in range(6):
         rew = (torch.randn(n, generator=g, dtype=torch.float64) * 30).cuda()
         term = (torch.rand(n, generator=g) < 0.1).to(torch.uint8).cuda()
@@ -247,13 +259,16 @@ def test_fw_rollout_post_matches_vecnormalize_reward_path():
         tv = torch.randn(n, generator=g).cuda()
         # reference: the torch statements of VecNormalizeDevice.step + PPO._rollout_body
         ref.returns.mul_(ref.gamma).add_(rew); ref.ret_rms.update(ref.returns)
+        ref_ret_before = ref.returns.clone()
         rn = (rew / torch.sqrt(ref.ret_rms.var + ref.epsilon)).clamp(-10, 10).float()
         done = (term | trunc).bool()
         rn = rn + 0.99 * tv * (trunc.bool() & ~term.bool()).float()
         ref.returns.masked_fill_(done, 0.0)
         out, start = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        want_acc += torch.stack([ref_ret_before.sum(), (ref_ret_before * ref_ret_before).sum(), torch.tensor(float(n), dtype=torch.float64, device="cuda")])
         _lib.check(L.fw_rollout_post(R._p(rew), 1, R._p(term), R._p(trunc), R._p(tv), R._p(ret), R._p(mean), R._p(var), R._p(cnt), n, 1, 1,
-                                     0.99, 10.0, 1e-8, R._p(out), R._p(start), R._p(rng), None))
+                                     0.99, 10.0, 1e-8, R._p(out), R._p(start), R._p(rng), R._p(acc), None))
+        torch.testing.assert_close(acc, want_acc, rtol=1e-12, atol=1e-9)
         torch.testing.assert_close(out, rn, rtol=1e-5, atol=1e-5)
         assert torch.equal(start.bool(), done)
         torch.testing.assert_close(ret, ref.returns, rtol=1e-12, atol=1e-12)

@@ -1,0 +1,26 @@
+"""The multi-GPU half of north_star on the hardware that is available: the per-GPU share of BASELINE.json's configs[3]
+(4096 waypoint envs per rank at global_env_offset = rank * 4096) and configs[4] (2048 combined waypoint -> duck envs per
+rank) as a world_size-2 job -- fused hipGraph collector on every rank, one all-gather of the rollout shard at update time,
+the same fused fw_ppo_update on every rank.  (Two ranks share the one GPU of the box, so the collectives run over gloo;
+with RCCL the same code path issues all_gather_into_tensor / all_reduce on device tensors.)
+Reference callers: train/train_Fixedwing_Waypoints_v3.py:293-337, train/train_Fixedwing_Waypoints_ObjLock.py:287-403."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("task,n_envs,n_steps,batch", [("waypoints", 4096, 4, 128), ("combined", 2048, 4, 128)])
+def test_per_gpu_share_collect_and_replicated_fused_update(two_ranks, task, n_envs, n_steps, batch):
+    a, b = two_ranks("sharded_training", task=task, n_envs=n_envs, n_steps=n_steps, batch_size=batch, n_epochs=2, iterations=3)
+    for r in (a, b):
+        f = r["facts"]
+        assert f["fused_collect"] and f["graphs"] and f["replicated"] and f["fused_update"] and f["use_fused_norm"], f
+        assert f["stats_sync"] == "rollout" and f["graph_captured"]
+        assert r["checks"] == [0.0, 0.0, 0.0], "replicas diverged"
+        assert r["finite"] and r["num_timesteps"] == 3 * n_steps * n_envs * 2
+        assert r["allgather_bytes"] == n_steps * n_envs * (28 + 7) * 4
+        assert r["counters"]["launches"] == 3 * n_steps
+    assert np.array_equal(a["weights"], b["weights"]) and np.array_equal(a["stats"], b["stats"])
+    assert a["stats"][2 * 28] == pytest.approx(1e-4 + (3 * n_steps + 1) * n_envs * 2)          # observations of BOTH ranks counted
+    assert not np.array_equal(a["first_obs"], b["first_obs"]), "the ranks must simulate different env shards"
