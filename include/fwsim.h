@@ -293,10 +293,25 @@ int32_t fw_validate_config(const fw_config* cfg, char* msg, int32_t msg_len);
 int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device,
                   uint64_t seed, int64_t global_env_offset, fw_handle* out);
 
+/* Scenario of the episode a fw_reset starts, supplied by the caller instead of drawn by the env -- e.g. the targets /
+ * duck / obstacles / wind a PyFlyt run sampled, so that reference traces can be replayed without
+ * forging whole state records.  HOST arrays indexed by the handle's local env; any pointer may be NULL = keep the
+ * env's own draw for that item.  Only the episode started by this call is affected (later auto-resets draw again). */
+typedef struct fw_scenario {
+  const double* targets;        /* [N][FW_MAX_TARGETS][3] world waypoints (rows >= num_targets ignored)     WaypointHandler.reset */
+  const double* duck_pos;       /* [N][3] duck base position                         envs/fixedwing_objlock_env.py:472-491 */
+  const double* obstacles;      /* [N][FW_MAX_OBSTACLES][3]  x, y, height            envs/fixedwing_objlock_env.py:528-565 */
+  const int32_t* num_obstacles; /* [N]  cylinders actually placed (required with `obstacles`) */
+  const double* wind_base;      /* [N][3]  wind_enu_mps                              envs/fixedwing_envs/fixedwing_base_env.py:135-143 */
+  const double* gust_amp;       /* [N][3]  gust_amp_enu_mps                          :155-159 */
+  const double* gust_phase;     /* [N]     gust_phase_rad                            :162-165 */
+} fw_scenario;
+
 /* Reset envs.  mask: device u8[N] (non-zero = reset) or NULL = all.
+ * scenario: NULL, or the caller-supplied scenario of the new episodes (see fw_scenario; applied to the reset envs only).
  * obs_out: device T[N,D] or NULL.  Rows of non-reset envs are rewritten with
  * their current observation. */
-int32_t fw_reset(fw_handle h, const uint8_t* mask, void* obs_out, void* hip_stream);
+int32_t fw_reset(fw_handle h, const uint8_t* mask, const fw_scenario* scenario, void* obs_out, void* hip_stream);
 
 /* One agent step for all N envs.
  *   actions       T[N,4]  in [-1,1] (caller clips, as SB3 does)

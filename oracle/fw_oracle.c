@@ -956,7 +956,8 @@ static void flatten_obs(const struct fw_env* h, const oenv* e, double* out) {
 static void reset_duck_state(oenv* e);
 static void objlock_spawn(struct fw_env* h, oenv* e, uint32_t genv, uint32_t ep);
 static void combined_spawn(struct fw_env* h, oenv* e, uint32_t genv, uint32_t ep);
-static void env_reset(struct fw_env* h, oenv* e, uint32_t genv) {
+/* `ov` / `li`: caller-supplied scenario of the new episode (fw_scenario, may be NULL) and the env's local index in it */
+static void env_reset(struct fw_env* h, oenv* e, uint32_t genv, const fw_scenario* ov, int li) {
   const fw_config* c = &h->cfg;
   e->episode += 1;                       /* index of the episode that starts now */
   uint32_t ep = (uint32_t)e->episode;
@@ -984,6 +985,11 @@ static void env_reset(struct fw_env* h, oenv* e, uint32_t genv) {
       if (c->wind_randomize_phase) e->wind_phase = rng_uniform(h->seed, genv, ep, J_WIND_PHASE, 0.0, 2.0 * FWO_PI);
     }
   }
+  if (ov && c->wind_mode != FW_WIND_OFF) {
+    if (ov->wind_base) for (int k = 0; k < 3; ++k) e->wind_base[k] = ov->wind_base[3 * li + k];
+    if (ov->gust_amp) for (int k = 0; k < 3; ++k) e->wind_amp[k] = ov->gust_amp[3 * li + k];
+    if (ov->gust_phase) e->wind_phase = ov->gust_phase[li];
+  }
   /* WaypointHandler.reset: polar sampling */
   e->num_reached = 0; e->new_distance = 0.0; e->old_distance = 0.0;
   memset(e->targets, 0, sizeof(e->targets));
@@ -998,11 +1004,23 @@ static void env_reset(struct fw_env* h, oenv* e, uint32_t genv) {
       e->targets[i][0] = x; e->targets[i][1] = y;
       e->targets[i][2] = z > c->waypoint_min_height ? z : c->waypoint_min_height;
     }
+    if (ov && ov->targets)
+      for (int t = 0; t < c->num_targets; ++t) for (int k = 0; k < 3; ++k) e->targets[t][k] = ov->targets[((size_t)li * FW_MAX_TARGETS + t) * 3 + k];
   }
   memset(e->task, 0, sizeof(e->task));
   e->duck_strike = 0;
   if (c->task == FW_TASK_OBJLOCK) { reset_duck_state(e); objlock_spawn(h, e, genv, ep); }   /* :240-245 */
-  if (c->task == FW_TASK_WAYPOINT_OBJLOCK) { reset_duck_state(e); combined_spawn(h, e, genv, ep); }
+  if (c->task == FW_TASK_WAYPOINT_OBJLOCK) { reset_duck_state(e); combined_spawn(h, e, genv, ep); }   /* duck under the (possibly supplied) last waypoint */
+  if (ov && c->task != FW_TASK_WAYPOINTS) {
+    if (ov->duck_pos) for (int k = 0; k < 3; ++k) TK(e, FW_ST_DUCK_POS + k) = ov->duck_pos[3 * li + k];
+    if (ov->obstacles && ov->num_obstacles) {
+      int n = ov->num_obstacles[li];
+      n = n < 0 ? 0 : (n > FW_MAX_OBSTACLES ? FW_MAX_OBSTACLES : n);
+      for (int o = 0; o < FW_MAX_OBSTACLES; ++o)
+        for (int k = 0; k < 3; ++k) TK(e, FW_ST_OBST + 3 * o + k) = o < n ? ov->obstacles[((size_t)li * FW_MAX_OBSTACLES + o) * 3 + k] : 0.0;
+      TK(e, FW_ST_NUM_OBST) = (double)n;
+    }
+  }
   /* end_reset: 10 warm-up Aviary steps with a zero setpoint, then compute_state */
   for (int i = 0; i < c->warmup_aviary_steps; ++i) aviary_step(h, e, genv);
   compute_state(h, e);
@@ -1087,11 +1105,12 @@ static void write_obs(const struct fw_env* h, const oenv* e, void* obs, size_t r
   for (int k = 0; k < h->obs_dim; ++k) store_T(h, obs, row * (size_t)h->obs_dim + (size_t)k, tmp[k]);
 }
 
-int32_t fwo_reset(fw_handle h, const uint8_t* mask, void* obs_out, void* stream) {
+int32_t fwo_reset(fw_handle h, const uint8_t* mask, const fw_scenario* scenario, void* obs_out, void* stream) {
   (void)stream;
   if (!h) return FW_EINVAL;
+  if (scenario && scenario->obstacles && !scenario->num_obstacles) { snprintf(h->err, sizeof h->err, "fw_scenario: obstacles without num_obstacles"); return FW_EINVAL; }
   for (int i = 0; i < h->n; ++i) {
-    if (!mask || mask[i]) env_reset(h, &h->e[i], (uint32_t)(h->env_offset + i));
+    if (!mask || mask[i]) env_reset(h, &h->e[i], (uint32_t)(h->env_offset + i), scenario, i);
     if (obs_out) write_obs(h, &h->e[i], obs_out, (size_t)i);
   }
   return FW_OK;
@@ -1127,7 +1146,7 @@ int32_t fwo_step(fw_handle h, const void* actions, void* obs, void* reward, uint
     }
     if (done && h->cfg.auto_reset) {
       if (terminal_obs) write_obs(h, e, terminal_obs, (size_t)i);
-      env_reset(h, e, genv);
+      env_reset(h, e, genv, NULL, 0);
     }
     if (obs) write_obs(h, e, obs, (size_t)i);
   }

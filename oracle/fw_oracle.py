@@ -83,7 +83,7 @@ def _bind(L: C.CDLL) -> C.CDLL:
     L.fwo_obs_dim.restype = i32; L.fwo_obs_dim.argtypes = [vp]
     L.fwo_validate_config.restype = i32; L.fwo_validate_config.argtypes = [vp, C.c_char_p, i32]
     L.fwo_create.restype = i32; L.fwo_create.argtypes = [vp, i32, i32, u64, i64, C.POINTER(vp)]
-    L.fwo_reset.restype = i32; L.fwo_reset.argtypes = [vp, vp, vp, vp]
+    L.fwo_reset.restype = i32; L.fwo_reset.argtypes = [vp, vp, vp, vp, vp]
     L.fwo_step.restype = i32; L.fwo_step.argtypes = [vp] * 9
     L.fwo_observe.restype = i32; L.fwo_observe.argtypes = [vp, vp, vp]
     L.fwo_seed.restype = i32; L.fwo_seed.argtypes = [vp, u64]
@@ -142,11 +142,12 @@ class OracleEnv:
         except Exception:
             pass
 
-    def reset(self, mask=None) -> np.ndarray:
+    def reset(self, mask=None, scenario=None) -> np.ndarray:
+        """`scenario`: an fw_scenario-shaped ctypes structure (host arrays; the caller keeps them alive) or None."""
         obs = np.empty((self.num_envs, self.obs_dim), dtype=self.dtype)
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
-        rc = self._L.fwo_reset(self._h, _ptr(m), _ptr(obs), None)
-        assert rc == 0
+        rc = self._L.fwo_reset(self._h, _ptr(m), None if scenario is None else C.byref(scenario), _ptr(obs), None)
+        assert rc == 0, self._L.fwo_last_error(self._h)
         return obs
 
     def step(self, actions):

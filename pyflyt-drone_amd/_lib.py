@@ -57,7 +57,7 @@ def lib() -> C.CDLL:
         L.fw_obs_dim.restype = i32; L.fw_obs_dim.argtypes = [vp]
         L.fw_validate_config.restype = i32; L.fw_validate_config.argtypes = [vp, C.c_char_p, i32]
         L.fw_create.restype = i32; L.fw_create.argtypes = [vp, i32, i32, u64, i64, C.POINTER(vp)]
-        L.fw_reset.restype = i32; L.fw_reset.argtypes = [vp, vp, vp, vp]
+        L.fw_reset.restype = i32; L.fw_reset.argtypes = [vp, vp, vp, vp, vp]
         L.fw_step.restype = i32; L.fw_step.argtypes = [vp] * 9
         L.fw_observe.restype = i32; L.fw_observe.argtypes = [vp, vp, vp]
         L.fw_seed.restype = i32; L.fw_seed.argtypes = [vp, u64]

@@ -245,6 +245,38 @@ def _angle_repr(angle_representation: str) -> int:
         f"angle_representation must be either `euler` or `quaternion`, not {angle_representation}")
 
 
+class FwScenario(C.Structure):
+    """``fw_scenario`` of include/fwsim.h: host arrays of a caller-supplied scenario (NULL = keep the env's own draw)."""
+    _fields_ = [("targets", C.c_void_p), ("duck_pos", C.c_void_p), ("obstacles", C.c_void_p), ("num_obstacles", C.c_void_p),
+                ("wind_base", C.c_void_p), ("gust_amp", C.c_void_p), ("gust_phase", C.c_void_p)]
+
+
+def make_scenario(num_envs: int, *, targets=None, duck_pos=None, obstacles=None, num_obstacles=None, wind_base=None,
+                  gust_amp=None, gust_phase=None):
+    """Build an :class:`FwScenario` from array-likes ``targets[N, <=8, 3]``, ``duck_pos[N,3]``, ``obstacles[N, <=20, 3]``
+    (x, y, height) with ``num_obstacles[N]``, ``wind_base[N,3]``, ``gust_amp[N,3]``, ``gust_phase[N]``.  Returns
+    ``(scenario, keepalive)``: the structure points into the arrays of ``keepalive``."""
+    import numpy as np
+    n, keep, sc = int(num_envs), [], FwScenario()
+
+    def put(field, arr, shape, dtype=np.float64):
+        if arr is None:
+            return
+        a = np.asarray(arr, dtype=dtype)
+        if a.ndim == len(shape) and a.shape[0] == n and len(shape) == 3 and a.shape[1] <= shape[1] and a.shape[2] == 3:
+            full = np.zeros(shape, dtype=dtype); full[:, :a.shape[1]] = a; a = full
+        if a.shape != shape:
+            raise ValueError(f"scenario field {field}: expected shape {shape}, got {a.shape}")
+        a = np.ascontiguousarray(a); keep.append(a)
+        setattr(sc, field, a.ctypes.data)
+    put("targets", targets, (n, FW_MAX_TARGETS, 3)); put("duck_pos", duck_pos, (n, 3))
+    put("obstacles", obstacles, (n, FW_MAX_OBSTACLES, 3)); put("num_obstacles", num_obstacles, (n,), np.int32)
+    put("wind_base", wind_base, (n, 3)); put("gust_amp", gust_amp, (n, 3)); put("gust_phase", gust_phase, (n,))
+    if obstacles is not None and num_obstacles is None:
+        raise ValueError("scenario: obstacles need num_obstacles")
+    return sc, keep
+
+
 def check_agent_hz(agent_hz: int) -> None:
     """envs/fixedwing_envs/fixedwing_base_env.py:48-53."""
     if agent_hz <= 0 or 120 % agent_hz != 0:

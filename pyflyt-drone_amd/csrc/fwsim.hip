@@ -738,11 +738,17 @@ __global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g8(FW_STEP_ARGS) { F
 template <typename T, int TKIND>
 __global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g1(FW_STEP_ARGS) { FW_STEP_RUN(T, true, 1, TKIND); }
 
+// Caller-supplied scenario of the episodes a fw_reset starts (fw_scenario, uploaded to device memory by the host side;
+// doubles indexed by the handle's local env, null = keep the env's own draw).
+struct ScenOv {
+  const double *targets, *duck, *obst, *nob, *wind_base, *gust_amp, *gust_phase;
+};
+
 // K2: reset (masked) + observation.  Same single-tick-site structure (warm-up only).
 template <typename T, int G, int TKIND>
 __global__ __launch_bounds__(kWave)
 void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> Dg,
-                     const uint8_t* __restrict__ mask, T* __restrict__ obs, int do_reset) {
+                     const uint8_t* __restrict__ mask, T* __restrict__ obs, int do_reset, ScenOv ov) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
   const Params<T>& P = *Pp;
@@ -782,16 +788,64 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
   if (resetting) {
     T t_mine[3] = {(T)0, (T)0, (T)0};
     warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase, t_mine);
+    // ---- caller-supplied scenario: replaces what begin_reset drew, before anything depends on it ----
+    if (P.wind_mode != FW_WIND_OFF && (ov.wind_base || ov.gust_amp || ov.gust_phase)) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (ov.wind_base) wb[k] = (T)ov.wind_base[3 * (size_t)env + k];
+        if (ov.gust_amp) wa[k] = (T)ov.gust_amp[3 * (size_t)env + k];
+      }
+      if (ov.gust_phase) wphase = (T)ov.gust_phase[env];
+      if (leader) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { D.r[(RF_WIND + k) * n + env] = wb[k]; D.r[(RF_WIND + 3 + k) * n + env] = wa[k]; }
+        D.r[(RF_WIND + 6) * n + env] = wphase;
+      }
+    }
+    T t_last[3] = {(T)0, (T)0, (T)0};
+    if (!OBJ && ov.targets && P.num_targets > 0) {
+      if (leader)
+        for (int t = 0; t < P.num_targets; ++t)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) D.r[(size_t)(RF_TARGETS + 3 * t + k) * n + env] = (T)ov.targets[((size_t)env * FW_MAX_TARGETS + t) * 3 + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        t_mine[k] = (T)ov.targets[(size_t)env * FW_MAX_TARGETS * 3 + k];                              // waypoint 0, for end_reset
+        t_last[k] = (T)ov.targets[((size_t)env * FW_MAX_TARGETS + (P.num_targets - 1)) * 3 + k];
+      }
+    }
     if (HASOBJ) {
       obj_reset_state<T>(O);
       if (OBJ) obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O); else comb_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
+      if (COMB && ov.targets && P.num_targets > 0) { O.duck[0] = t_last[0]; O.duck[1] = t_last[1]; }   // the duck sits under the last waypoint
+      if (ov.duck) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) O.duck[k] = (T)ov.duck[3 * (size_t)env + k];
+      }
+      if (ov.obst && ov.nob) {
+        int nob = (int)ov.nob[env];
+        nob = nob < 0 ? 0 : (nob > FW_MAX_OBSTACLES ? FW_MAX_OBSTACLES : nob);
+        if (leader)
+          for (int o = 0; o < FW_MAX_OBSTACLES; ++o)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              D.r[(size_t)(RF_TASK + FW_ST_OBST + 3 * o + k) * n + env] = o < nob ? (T)ov.obst[((size_t)env * FW_MAX_OBSTACLES + o) * 3 + k] : (T)0;
+        O.nob = nob;
+      }
       if (G > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
     if (HASOBJ) obj_update_near_mask<T, G>(P, OC, D, envc, O, S);
     if (warm_left == 0) {
       if (OBJ) obj_compute_state<T>(O);
-      else { new_dist = end_reset<T, G>(P, D, env, episode, S); if (COMB) comb_compute_state<T>(OC, O, P.num_targets == 0); }
+      else { new_dist = end_reset<T, G>(P, D, env, episode, S, ov.targets ? t_mine : nullptr); if (COMB) comb_compute_state<T>(OC, O, P.num_targets == 0); }
     }
+  }
+  // waypoint 0 of a supplied scenario, for the end_reset that follows an in-kernel warm-up
+  T t_first[3] = {(T)0, (T)0, (T)0};
+  const bool have_first = resetting && !OBJ && ov.targets && P.num_targets > 0;
+  if (have_first) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t_first[k] = (T)ov.targets[(size_t)env * FW_MAX_TARGETS * 3 + k];
   }
   const T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
   T R[9];
@@ -808,7 +862,7 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
       warm_left -= 1;
       if (warm_left == 0) {
         if (OBJ) obj_compute_state<T>(O);
-        else { new_dist = end_reset<T, G>(P, D, env, episode, S); if (COMB) comb_compute_state<T>(OC, O, P.num_targets == 0); }
+        else { new_dist = end_reset<T, G>(P, D, env, episode, S, have_first ? t_first : nullptr); if (COMB) comb_compute_state<T>(OC, O, P.num_targets == 0); }
       }
     }
   }
@@ -1011,6 +1065,7 @@ struct fw_env {
   unsigned long long* sdone_dev = nullptr;
   uint32_t* lctr_dev = nullptr;             // device-side launch index, one word per workgroup (fwsim_device.hpp: launch_index)
   unsigned long long* stats_dev = nullptr;  // hand-off counters (fw_get_counters)
+  double* scen_dev = nullptr;               // staging of a caller-supplied fw_scenario (allocated on first use)
   long long* prof_dev = nullptr; // FW_PROFILE builds only
   int32_t shadow_on = 0;        // background warm-up of the next episode (see shadow_* kernels)
   std::string err;
@@ -1180,10 +1235,10 @@ int step_T(fw_env* h, const void* actions, void* obs, void* reward, uint8_t* ter
 
 #define FW_LAUNCH_RESET(KERNEL)                                                                                   \
   hipLaunchKernelGGL((KERNEL), grid_of(h), dim3(kWave), tile_bytes<T>(h), st, (const Params<T>*)h->params_dev,    \
-                     (const ObjC<T>*)h->objc_dev, dev_state<T>(h), mask, (T*)obs, do_reset)
+                     (const ObjC<T>*)h->objc_dev, dev_state<T>(h), mask, (T*)obs, do_reset, ov)
 
 template <typename T>
-int reset_T(fw_env* h, const uint8_t* mask, void* obs, int do_reset, hipStream_t st) {
+int reset_T(fw_env* h, const uint8_t* mask, void* obs, int do_reset, hipStream_t st, ScenOv ov = ScenOv{}) {
   const bool g8 = h->lanes_per_env == 8;
   if (h->cfg.task == FW_TASK_OBJLOCK) {
     if (g8) FW_LAUNCH_RESET((fw_reset_kernel<T, 8, FW_TASK_OBJLOCK>)); else FW_LAUNCH_RESET((fw_reset_kernel<T, 1, FW_TASK_OBJLOCK>));
@@ -1317,11 +1372,38 @@ int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64
   return FW_OK;
 }
 
-int32_t fw_reset(fw_handle h, const uint8_t* mask, void* obs_out, void* hip_stream) {
+int32_t fw_reset(fw_handle h, const uint8_t* mask, const fw_scenario* scenario, void* obs_out, void* hip_stream) {
   if (!h) return FW_EINVAL;
   DeviceGuard g(h->device);
   hipStream_t st = (hipStream_t)hip_stream;
-  return (h->cfg.dtype == FW_F64) ? reset_T<double>(h, mask, obs_out, 1, st) : reset_T<float>(h, mask, obs_out, 1, st);
+  ScenOv ov{};
+  if (scenario) {
+    if (scenario->obstacles && !scenario->num_obstacles) { h->err = "fw_scenario: obstacles without num_obstacles"; return FW_EINVAL; }
+    // stage the host arrays in one device buffer owned by the handle (stream-ordered copies, then the reset kernel)
+    const size_t N = (size_t)h->n;
+    const size_t sz[7] = { N * FW_MAX_TARGETS * 3, N * 3, N * FW_MAX_OBSTACLES * 3, N, N * 3, N * 3, N };
+    size_t total = 0;
+    for (size_t v : sz) total += v;
+    if (!h->scen_dev) HIP_TRY(h, hipMalloc((void**)&h->scen_dev, sizeof(double) * total));
+    std::vector<double> nobd;
+    if (scenario->num_obstacles) { nobd.resize(N); for (size_t i = 0; i < N; ++i) nobd[i] = (double)scenario->num_obstacles[i]; }
+    const double* src[7] = { scenario->targets, scenario->duck_pos, scenario->obstacles, scenario->num_obstacles ? nobd.data() : nullptr,
+                             scenario->wind_base, scenario->gust_amp, scenario->gust_phase };
+    const double* dst[7];
+    size_t off = 0;
+    for (int k = 0; k < 7; ++k) {
+      dst[k] = nullptr;
+      if (src[k]) {
+        HIP_TRY(h, hipMemcpyAsync(h->scen_dev + off, src[k], sizeof(double) * sz[k], hipMemcpyHostToDevice, st));
+        dst[k] = h->scen_dev + off;
+      }
+      off += sz[k];
+    }
+    HIP_TRY(h, hipStreamSynchronize(st));          // the host arrays (and `nobd`) may go away as soon as we return
+    ov.targets = dst[0]; ov.duck = dst[1]; ov.obst = dst[2]; ov.nob = dst[3]; ov.wind_base = dst[4]; ov.gust_amp = dst[5]; ov.gust_phase = dst[6];
+    if (!ov.obst) ov.nob = nullptr;
+  }
+  return (h->cfg.dtype == FW_F64) ? reset_T<double>(h, mask, obs_out, 1, st, ov) : reset_T<float>(h, mask, obs_out, 1, st, ov);
 }
 
 int32_t fw_observe(fw_handle h, void* obs_out, void* hip_stream) {
@@ -1551,6 +1633,7 @@ int32_t fw_destroy(fw_handle h) {
   if (h->sdone_dev) (void)hipFree(h->sdone_dev);
   if (h->lctr_dev) (void)hipFree(h->lctr_dev);
   if (h->stats_dev) (void)hipFree(h->stats_dev);
+  if (h->scen_dev) (void)hipFree(h->scen_dev);
   FWP(if (h->prof_dev) (void)hipFree(h->prof_dev);)
   delete h;
   return FW_OK;

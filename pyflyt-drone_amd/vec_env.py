@@ -18,6 +18,7 @@ C ABI (include/fwsim.h).  Two surfaces:
 from __future__ import annotations
 
 import ctypes as C
+from copy import deepcopy
 from typing import Any, List, Optional, Sequence
 
 import numpy as np
@@ -32,8 +33,64 @@ def _devptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-class FixedwingVecEnv:
-    """N fixed-wing envs advanced in lockstep by ``fw_step`` on one MI355X."""
+try:        # Stable-Baselines3 asserts isinstance(env, VecEnv): subclass the real base class when it is importable
+    from stable_baselines3.common.vec_env.base_vec_env import VecEnv as _VecEnvBase
+    HAVE_SB3 = True
+except Exception:
+    HAVE_SB3 = False
+
+    class _VecEnvBase:
+        """In-tree mirror of ``stable_baselines3.common.vec_env.VecEnv`` (constructor contract and the concrete helpers
+        SB3's algorithms call) for images without SB3 -- the build image is one."""
+
+        def __init__(self, num_envs: int, observation_space, action_space):
+            self.num_envs = num_envs
+            self.observation_space, self.action_space = observation_space, action_space
+            self.reset_infos = [{} for _ in range(num_envs)]
+            self._seeds = [None for _ in range(num_envs)]
+            self._options = [{} for _ in range(num_envs)]
+            modes = self.get_attr("render_mode")
+            assert all(m == modes[0] for m in modes), "render_mode mode should be the same for all environments"
+            self.render_mode = modes[0]
+            self.metadata = {"render_modes": [] if self.render_mode is None else [self.render_mode]}
+
+        def step(self, actions):
+            self.step_async(actions)
+            return self.step_wait()
+
+        def seed(self, seed=None):
+            if seed is None:
+                seed = int(np.random.randint(0, np.iinfo(np.uint32).max, dtype=np.uint32))
+            self._seeds = [seed + idx for idx in range(self.num_envs)]
+            return self._seeds
+
+        def set_options(self, options=None):
+            options = {} if options is None else options
+            self._options = deepcopy(options) if isinstance(options, list) else deepcopy([options] * self.num_envs)
+
+        def _reset_seeds(self):
+            self._seeds = [None for _ in range(self.num_envs)]
+
+        def _reset_options(self):
+            self._options = [{} for _ in range(self.num_envs)]
+
+        @property
+        def unwrapped(self):
+            return self
+
+        def getattr_depth_check(self, name: str, already_found: bool):
+            return None
+
+        def _get_indices(self, indices):
+            if indices is None:
+                return range(self.num_envs)
+            return [indices] if isinstance(indices, int) else indices
+
+
+class FixedwingVecEnv(_VecEnvBase):
+    """N fixed-wing envs advanced in lockstep by ``fw_step`` on one MI355X.  A ``stable_baselines3`` ``VecEnv``
+    (subclass of the real base class when SB3 is importable, of its in-tree mirror otherwise) whose spaces are
+    ``gymnasium.spaces.Box`` when gymnasium is importable."""
 
     metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 30}
 
@@ -58,10 +115,9 @@ class FixedwingVecEnv:
         self.obs_dim = K.obs_dim(cfg)
         self.np_dtype = np.float64 if cfg.dtype == K.FW_F64 else np.float32
         self.torch_dtype = torch.float64 if cfg.dtype == K.FW_F64 else torch.float32
-        self.observation_space = Box(-np.inf, np.inf, (self.obs_dim,), self.np_dtype)
-        self.action_space = Box(-1.0, 1.0, (4,), self.np_dtype)
         self.render_mode = None
-        self.reset_infos: List[dict] = [{} for _ in range(self.num_envs)]
+        _VecEnvBase.__init__(self, self.num_envs, Box(-np.inf, np.inf, (self.obs_dim,), self.np_dtype),
+                             Box(-1.0, 1.0, (4,), self.np_dtype))
 
         h = C.c_void_p()
         rc = _lib.lib().fw_create(C.byref(self.cfg), self.num_envs, int(dev.index), int(seed) & (2**64 - 1),
@@ -83,13 +139,17 @@ class FixedwingVecEnv:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def reset_tensor(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Reset all envs (or those with ``mask != 0``) on the device; returns obs[N,D]."""
+    def reset_tensor(self, mask: Optional[torch.Tensor] = None, scenario: Optional[dict] = None) -> torch.Tensor:
+        """Reset all envs (or those with ``mask != 0``) on the device; returns obs[N,D].  ``scenario``: keyword
+        arguments of :func:`config.make_scenario` (targets / duck_pos / obstacles + num_obstacles / wind_base / gust_amp /
+        gust_phase as host arrays) that replace what the env would draw for the episodes started here."""
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             if mask.numel() != self.num_envs:
                 raise ValueError("mask must have num_envs elements")
-        rc = _lib.lib().fw_reset(self._h, _devptr(mask), _devptr(self.obs), self._stream())
+        sc, keep = (None, None) if scenario is None else K.make_scenario(self.num_envs, **scenario)
+        rc = _lib.lib().fw_reset(self._h, _devptr(mask), None if sc is None else C.byref(sc), _devptr(self.obs), self._stream())
+        del keep
         _lib.check(rc, self._h)
         return self.obs
 
@@ -162,7 +222,8 @@ class FixedwingVecEnv:
         s = 0 if seed is None else int(seed)
         _lib.check(_lib.lib().fw_seed(self._h, s & (2**64 - 1)), self._h)
         self.seed_value = s
-        return [s + i for i in range(self.num_envs)]
+        self._seeds = [s + i for i in range(self.num_envs)]
+        return self._seeds
 
     def close(self) -> None:
         h, self._h = getattr(self, "_h", None), None
@@ -182,14 +243,37 @@ class FixedwingVecEnv:
             return [indices]
         return list(indices)
 
+    # Per-env attribute access of the VecEnv API.  The N envs are one kernel launch with one config, so every "per-env"
+    # attribute is the same for all of them: the env object's own attributes first, then the fields of its fw_config
+    # (flight_dome_size, num_targets, ...: what the reference env objects carry as attributes).
     def get_attr(self, attr_name: str, indices=None) -> List[Any]:
-        return [getattr(self, attr_name) for _ in self._indices(indices)]
+        if attr_name == "render_mode":
+            v = self.__dict__.get("render_mode", None)
+        elif attr_name in self.__dict__ or hasattr(type(self), attr_name):
+            v = getattr(self, attr_name)
+        elif "cfg" in self.__dict__ and any(attr_name == f[0] for f in type(self.cfg)._fields_):
+            v = getattr(self.cfg, attr_name)
+        else:
+            raise AttributeError(f"{type(self).__name__} envs have no attribute {attr_name!r}")
+        return [v for _ in self._indices(indices)]
 
     def set_attr(self, attr_name: str, value: Any, indices=None) -> None:
-        raise AttributeError("per-env attributes cannot be set on a fused device env; rebuild it with a new config")
+        """Host-side attributes can be set (for all envs at once: they share one object); anything that is compiled into
+        the device-side constants (an ``fw_config`` field) needs a new env."""
+        if "cfg" in self.__dict__ and any(attr_name == f[0] for f in type(self.cfg)._fields_):
+            raise AttributeError(f"{attr_name!r} is part of the device-side configuration; build a new env with it")
+        if indices is not None and sorted(self._indices(indices)) != list(range(self.num_envs)):
+            raise AttributeError("the envs of a fused device env share their attributes: set them for all envs (indices=None)")
+        setattr(self, attr_name, value)
 
     def env_method(self, method_name: str, *args, indices=None, **kwargs) -> List[Any]:
-        raise AttributeError(f"env_method({method_name!r}) is not available on a fused device env")
+        """Call a method "of each env": methods of this object are called ONCE (they already act on all envs) and the
+        result is repeated per requested index, as ``SubprocVecEnv.env_method`` would return it."""
+        fn = getattr(self, method_name, None)
+        if not callable(fn) or method_name.startswith("_"):
+            raise AttributeError(f"env_method({method_name!r}) is not available on a fused device env")
+        out = fn(*args, **kwargs)
+        return [out for _ in self._indices(indices)]
 
     def env_is_wrapped(self, wrapper_class, indices=None) -> List[bool]:
         return [False for _ in self._indices(indices)]

@@ -141,6 +141,59 @@ def test_reference_make_env_keyword_sets_are_accepted():
         K.waypoint_objlock_config_from_reference_kwargs(**{**combined_kw, "flight_mode": 4})
 
 
+def test_env_is_a_real_sb3_vecenv_with_gymnasium_spaces_when_those_import():
+    """SB3 asserts isinstance(env, VecEnv) and isinstance(space, gymnasium.spaces.Box).  Neither package exists in this
+    image, so two minimal stand-in modules (the classes SB3 / gymnasium export under those names, nothing more) are put
+    on sys.modules and the package is re-imported: the env class must derive from the real VecEnv and Box must be the real
+    Box; without them the in-tree mirrors are used."""
+    import importlib
+    import sys
+    import types
+    from pyflyt_drone_amd import spaces as S0, vec_env as V0
+    assert not S0.HAVE_GYMNASIUM and not V0.HAVE_SB3 and S0.Box is S0.MirrorBox
+
+    class GymBox:
+        def __init__(self, low, high, shape=None, dtype=np.float32, seed=None):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, np.dtype(dtype)
+
+    class SB3VecEnv:
+        def __init__(self, num_envs, observation_space, action_space):
+            self.num_envs, self.observation_space, self.action_space = num_envs, observation_space, action_space
+            self.render_mode = self.get_attr("render_mode")[0]
+
+    fake = {"gymnasium": types.ModuleType("gymnasium"), "gymnasium.spaces": types.ModuleType("gymnasium.spaces"),
+            "stable_baselines3": types.ModuleType("stable_baselines3"), "stable_baselines3.common": types.ModuleType("stable_baselines3.common"),
+            "stable_baselines3.common.vec_env": types.ModuleType("stable_baselines3.common.vec_env"),
+            "stable_baselines3.common.vec_env.base_vec_env": types.ModuleType("stable_baselines3.common.vec_env.base_vec_env")}
+    fake["gymnasium.spaces"].Box = GymBox
+    fake["stable_baselines3.common.vec_env.base_vec_env"].VecEnv = SB3VecEnv
+    try:
+        sys.modules.update(fake)
+        S1 = importlib.reload(S0)
+        V1 = importlib.reload(V0)
+        assert S1.HAVE_GYMNASIUM and S1.Box is GymBox and V1.HAVE_SB3
+        assert issubclass(V1.FixedwingVecEnv, SB3VecEnv) and issubclass(V1.FixedwingObjLockVecEnv, SB3VecEnv)
+        assert V1.Box is GymBox
+    finally:
+        for k in fake:
+            sys.modules.pop(k, None)
+        importlib.reload(S0); importlib.reload(V0)
+    assert S0.Box is S0.MirrorBox and not V0.HAVE_SB3
+    # the per-env attribute API answers from the object and its config (no GPU needed for this part)
+    e = object.__new__(V0.FixedwingVecEnv)
+    e.num_envs, e.cfg = 3, K.train_waypoints_v3_config()
+    assert e.get_attr("render_mode") == [None] * 3 and e.get_attr("flight_dome_size", [0, 2]) == [100.0, 100.0]
+    assert e.get_attr("num_targets", 1) == [8] and e.env_is_wrapped(object) == [False] * 3
+    e.set_attr("note", "x"); assert e.get_attr("note") == ["x"] * 3
+    with pytest.raises(AttributeError, match="device-side configuration"):
+        e.set_attr("flight_dome_size", 50.0)
+    with pytest.raises(AttributeError):
+        e.get_attr("no_such_thing")
+    with pytest.raises(AttributeError):
+        e.env_method("no_such_method")
+    assert e.env_method("get_attr", "num_targets", indices=[0]) == [[8, 8, 8]]
+
+
 def test_box_space():
     b = P.Box(-1.0, 1.0, (4,), np.float64)
     assert b.shape == (4,) and b.dtype == np.float64

@@ -344,7 +344,7 @@ def test_abi_writes_stay_inside_the_buffers(lanes):
     info = torch.full(((n) * K.FW_INFO_DIM + pad,), -7, dtype=torch.int32, device=dev)
     act = torch.zeros((n, 4), dtype=torch.float64, device=dev)
     p = lambda t: C.c_void_p(t.data_ptr())
-    _lib.check(L.fw_reset(h, None, p(obs), None), h)
+    _lib.check(L.fw_reset(h, None, None, p(obs), None), h)
     for _ in range(3):
         _lib.check(L.fw_step(h, p(act), p(obs), p(rew), p(term), p(trunc), p(tobs), p(info), None), h)
     torch.cuda.synchronize()
@@ -428,3 +428,75 @@ def test_ragged_env_counts_match_the_oracle(oracle, lanes, n, task):
     st = hip.get_state()
     hip.set_state(st)
     np.testing.assert_array_equal(hip.get_state(), st)
+
+
+@pytest.mark.parametrize("task", ["waypoints_gust", "objlock", "combined"])
+def test_caller_supplied_scenario_replaces_the_env_draw(oracle, lanes, task):
+    """fw_reset(handle, mask, scenario, obs) of SURVEY section 8(b): targets / duck / obstacles / wind handed in by the caller
+    (e.g. what a PyFlyt run sampled) start the episode instead of the env's own draw -- in the kernel and in the oracle
+    alike: the state shows them, the warm-up and the first observation are computed under them, the lockstep trace that
+    follows agrees, and later auto-resets go back to the env's own streams."""
+    import torch
+    rng = np.random.default_rng(21)
+    n = 130
+    if task == "waypoints_gust":
+        cfg = K.waypoints_config(sparse_reward=False, num_targets=5, goal_reach_distance=10.0, angle_representation="euler",
+                                 wind_config=GUST_FORCE, max_duration_seconds=4.0)
+    elif task == "objlock":
+        cfg = K.objlock_config(flight_dome_size=150.0, max_duration_seconds=4.0, num_obstacles=6, obstacle_safe_distance_m=40.0,
+                               duck_camera_capture_interval_steps=2, angle_representation="euler", camera_resolution=128,
+                               wind_config=GUST_FORCE)
+    else:
+        cfg = K.train_waypoint_objlock_config(goal_reach_distance=25.0, max_duration_seconds=4.0)
+    nt = cfg.num_targets
+    sc = dict(wind_base=rng.uniform(-4, 4, (n, 3)) * [1, 1, 0.05], gust_amp=rng.uniform(0, 2, (n, 3)) * [1, 1, 0.1],
+              gust_phase=rng.uniform(0, 2 * np.pi, n))
+    if nt:
+        sc["targets"] = np.concatenate([rng.uniform(-60, 60, (n, nt, 2)), rng.uniform(5, 40, (n, nt, 1))], axis=2)
+    if cfg.task != K.FW_TASK_WAYPOINTS:
+        nob = rng.integers(0, 7, n).astype(np.int32)
+        ob = np.concatenate([rng.uniform(-70, 70, (n, 20, 2)), rng.uniform(10, 30, (n, 20, 1))], axis=2)
+        ob[np.linalg.norm(ob[:, :, :2], axis=2) < 15] += 40.0            # keep the start area free
+        sc["obstacles"], sc["num_obstacles"] = ob, nob
+        if cfg.task == K.FW_TASK_OBJLOCK:
+            sc["duck_pos"] = np.concatenate([rng.uniform(-70, 70, (n, 2)), np.full((n, 1), 0.05)], axis=1)
+    hip, ora = P.FixedwingVecEnv(cfg, n, seed=31), oracle.OracleEnv(cfg, n, seed=31)
+    osc, keep = K.make_scenario(n, **sc)
+    oh = hip.reset_tensor(scenario=sc).cpu().numpy()
+    oo = ora.reset(scenario=osc)
+    np.testing.assert_allclose(oh, oo, rtol=0, atol=2e-5 if cfg.task == K.FW_TASK_OBJLOCK else 1e-9)
+    st = hip.get_state()
+    np.testing.assert_allclose(st, ora.get_state(), rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(st[:, K.S_WIND:K.S_WIND + 3], sc["wind_base"])
+    np.testing.assert_array_equal(st[:, K.S_WIND + 6], sc["gust_phase"])
+    if nt:
+        np.testing.assert_array_equal(st[:, K.S_TARGETS:K.S_TARGETS + 3 * nt].reshape(n, nt, 3), sc["targets"])
+    if cfg.task != K.FW_TASK_WAYPOINTS:
+        T0 = K.S_TASK
+        np.testing.assert_array_equal(st[:, T0 + K.ST_NUM_OBST], nob)
+        for i in range(n):
+            np.testing.assert_array_equal(st[i, T0 + K.ST_OBST:T0 + K.ST_OBST + 3 * nob[i]].reshape(-1, 3), ob[i, :nob[i]])
+        if cfg.task == K.FW_TASK_OBJLOCK:
+            np.testing.assert_array_equal(st[:, T0:T0 + 3], sc["duck_pos"])
+        else:                                                              # the duck sits under the supplied last waypoint
+            np.testing.assert_array_equal(st[:, T0:T0 + 2], sc["targets"][:, nt - 1, :2])
+    # the trace that follows, through the first auto-resets (which draw their own scenarios again)
+    dones = 0
+    for t in range(150):
+        a = seeded_actions(rng, n, "gentle")
+        o_obs, o_rew, o_term, o_trunc, o_tobs, o_info = ora.step(a)
+        hip.step_tensor(torch.as_tensor(a, device=hip.device))
+        assert np.array_equal(hip.terminated.cpu().numpy(), o_term) and np.array_equal(hip.truncated.cpu().numpy(), o_trunc), t
+        assert np.array_equal(hip.info.cpu().numpy(), o_info), t
+        np.testing.assert_allclose(hip.obs.cpu().numpy(), o_obs, rtol=0, atol=2e-5 if cfg.task == K.FW_TASK_OBJLOCK else 1e-7, err_msg=f"obs {t}")
+        np.testing.assert_allclose(hip.rewards.cpu().numpy(), o_rew, rtol=0, atol=1e-7, err_msg=f"reward {t}")
+        dones += int((o_term | o_trunc).sum())
+    assert dones >= n, "every env was meant to end its supplied episode and auto-reset"
+    # a masked reset with a scenario only touches the masked envs
+    mask = (rng.uniform(size=n) < 0.4).astype(np.uint8)
+    before = hip.get_state()
+    hip.reset_tensor(torch.as_tensor(mask), scenario=sc); ora.reset(mask, scenario=osc)
+    after = hip.get_state()
+    np.testing.assert_array_equal(after[mask == 0], before[mask == 0])
+    np.testing.assert_allclose(after, ora.get_state(), rtol=0, atol=1e-9)
+    del keep
