@@ -648,45 +648,96 @@ static int occluded(const struct fw_env* h, const oenv* e, const double cam[3], 
   return 0;
 }
 
-/* Camera.capture_image() replaced: fills the frame (visible, cx, cy, area, depth_m, d_left, d_center, d_right) */
+/* PyBullet depth-buffer value (float32, as in Camera.depthImg) of a fragment at view-axis depth t: the inverse of
+ * _depth_buffer_to_meters (:691-696), z = far*near / (far - (far-near)*d)  <=>  d = far*(t-near) / (t*(far-near)). */
+static double depth_buffer_of(double t, double near, double far) {
+  if (t < near) t = near;
+  if (t > far) t = far;
+  return (double)(float)(far * (t - near) / (t * (far - near)));
+}
+static double depth_buffer_to_meters(double d) {           /* :691-696 */
+  const double near = 0.1, far = 255.0;
+  double denom = far - (far - near) * d;
+  if (fabs(denom) < 1e-9) return far;
+  return (far * near) / denom;
+}
+
+/* Camera.capture_image() replaced by an analytic render of the scene (duck = sphere resting on the ground, obstacles =
+ * vertical cylinders, ground = plane z = 0, sky = depth buffer 1.0), pixel centres at (x, y), x to the right, y down.
+ * The frame holds the 8 numbers the reference computes FROM THE IMAGES, by the same functionals:
+ *   duck mask (seg == duck id)            = the pixels whose ray hits the sphere between the clip planes, unless the line
+ *                                           of sight to the sphere's centre is blocked by a cylinder (then no duck pixel)
+ *   cx, cy   = mean(xs)/(w-1), mean(ys)/(h-1) over the mask                                           :670-674
+ *   area     = count_nonzero(mask)/(h*w)                                                              :675
+ *   depth_m  = metres(min of the depth buffer over the mask)                                          :731-743
+ *   d_left / d_center / d_right = metres(mean of the DEPTH-BUFFER values of the non-duck pixels of the thirds
+ *              [0, w//3), [w//3, 2w//3), [2w//3, w) of row h//2), 0.0 for an empty third or a zero mean  :698-729 */
 static void camera_capture(const struct fw_env* h, oenv* e) {
   const fw_config* c = &h->cfg;
   double R[9], cam[3], off_w[3];
   mat_from_quat(e->quat, R);
   mat_vec(R, c->camera_offset, off_w);
   for (int k = 0; k < 3; ++k) cam[k] = e->pos[k] + off_w[k];
-  const double W = (double)h->cam_w, H = (double)h->cam_h, F = h->cam_focal;
-  const double u0 = 0.5 * (W - 1.0), v0 = 0.5 * (H - 1.0);
+  const int Wi = h->cam_w, Hi = h->cam_h;
+  const double W = (double)Wi, H = (double)Hi, F = h->cam_focal, near = c->camera_near, far = c->camera_far;
+  const double u0 = 0.5 * (W - 1.0), v0 = 0.5 * (H - 1.0), Rd = h->duck_radius;
   double* fr = &TK(e, FW_ST_FRAME);
-  /* --- duck --- */
-  double C[3] = { TK(e, FW_ST_DUCK_POS), TK(e, FW_ST_DUCK_POS + 1), TK(e, FW_ST_DUCK_POS + 2) + h->duck_radius };
+  /* --- duck mask statistics: literal loop over the pixels of a conservative bounding box --- */
+  double C[3] = { TK(e, FW_ST_DUCK_POS), TK(e, FW_ST_DUCK_POS + 1), TK(e, FW_ST_DUCK_POS + 2) + Rd };
   double relw[3] = { C[0] - cam[0], C[1] - cam[1], C[2] - cam[2] }, relb[3];
   matT_vec(R, relw, relb);
-  double zc = dot3(relb, h->cam_f), xc = dot3(relb, h->cam_r), yc = dot3(relb, h->cam_d);
+  const double zc = dot3(relb, h->cam_f), xc = dot3(relb, h->cam_r), yc = dot3(relb, h->cam_d);
+  const double k2 = zc * zc + xc * xc + yc * yc - Rd * Rd;
   double visible = 0.0, cx = 0.0, cy = 0.0, area = 0.0, depth = 0.0;
-  if (zc - h->duck_radius > c->camera_near && zc - h->duck_radius < c->camera_far) {
-    double u = u0 + F * xc / zc, v = v0 + F * yc / zc, rho = F * h->duck_radius / zc;
-    double x0 = fmax(u - rho, 0.0), x1 = fmin(u + rho, W - 1.0), y0 = fmax(v - rho, 0.0), y1 = fmin(v + rho, H - 1.0);
-    if (x1 > x0 && y1 > y0) {
-      double a = 0.25 * FWO_PI * (x1 - x0) * (y1 - y0);
-      if (a >= 1.0 && !occluded(h, e, cam, C)) {
-        visible = 1.0;
-        cx = 0.5 * (x0 + x1) / fmax(1.0, W - 1.0);        /* mean(xs)/(w-1) :673 */
-        cy = 0.5 * (y0 + y1) / fmax(1.0, H - 1.0);
-        area = fmin(a / (W * H), 1.0);                    /* count/(h*w)   :675 */
-        depth = zc - h->duck_radius;                      /* min depth over the mask, in metres :731-743 */
+  int duck_in_frame = 0;
+  if (zc - Rd > near && zc - Rd < far && !occluded(h, e, cam, C)) {
+    /* |a - xc/zc| <= R sqrt(zc^2 + xc^2) / ((zc - R) zc) for every point of the sphere (a = P_r / P_f) */
+    const double hw = F * Rd * sqrt(zc * zc + xc * xc) / ((zc - Rd) * zc) + 2.0, hh = F * Rd * sqrt(zc * zc + yc * yc) / ((zc - Rd) * zc) + 2.0;
+    const double uc = u0 + F * xc / zc, vc = v0 + F * yc / zc;
+    int xa = (int)floor(fmax(uc - hw, 0.0)), xb = (int)ceil(fmin(uc + hw, W - 1.0));
+    int ya = (int)floor(fmax(vc - hh, 0.0)), yb = (int)ceil(fmin(vc + hh, H - 1.0));
+    double count = 0.0, sx = 0.0, sy = 0.0, dmin = 2.0;
+    for (int y = ya; y <= yb; ++y)
+      for (int x = xa; x <= xb; ++x) {
+        const double a = ((double)x - u0) / F, b = ((double)y - v0) / F;
+        const double q = 1.0 + a * a + b * b, p = zc + a * xc + b * yc, disc = p * p - q * k2;
+        if (disc < 0.0 || p <= 0.0) continue;
+        const double t = (p - sqrt(disc)) / q;               /* view-axis depth of the first hit */
+        if (!(t > near && t < far)) continue;
+        count += 1.0; sx += (double)x; sy += (double)y;
+        const double d = depth_buffer_of(t, near, far);
+        if (d < dmin) dmin = d;
       }
+    if (count > 0.0) {
+      duck_in_frame = 1;
+      visible = 1.0;
+      cx = (sx / count) / fmax(1.0, W - 1.0);               /* mean(xs)/(w-1)  :673 */
+      cy = (sy / count) / fmax(1.0, H - 1.0);
+      area = count / fmax(1.0, H * W);                      /* count/(h*w)     :675 */
+      depth = depth_buffer_to_meters(dmin);                 /* :731-743 */
     }
   }
   fr[0] = visible; fr[1] = cx; fr[2] = cy; fr[3] = area; fr[4] = depth;
-  /* --- obstacle zones: centre column of each third of the middle row :698-729 --- */
-  const double vmid = (double)(h->cam_h / 2);
-  for (int zid = 0; zid < 3; ++zid) {
-    double ucol = (2.0 * zid + 1.0) * W / 6.0 - 0.5;
-    double a = (ucol - u0) / F, b = (vmid - v0) / F, db[3], dw[3];
-    for (int k = 0; k < 3; ++k) db[k] = h->cam_f[k] + a * h->cam_r[k] + b * h->cam_d[k];
+  /* --- obstacle zones: mean depth-buffer value of the non-duck pixels of each third of row h//2  :698-729 --- */
+  const int y_mid = Hi / 2, x_1 = Wi / 3, x_2 = (2 * Wi) / 3;
+  const double bm = ((double)y_mid - v0) / F;
+  double zsum[3] = {0.0, 0.0, 0.0}, zcnt[3] = {0.0, 0.0, 0.0};
+  for (int x = 0; x < Wi; ++x) {
+    const double a = ((double)x - u0) / F;
+    if (duck_in_frame) {                                    /* mask = seg != duck_id */
+      const double q = 1.0 + a * a + bm * bm, p = zc + a * xc + bm * yc, disc = p * p - q * k2;
+      if (disc >= 0.0 && p > 0.0) { const double t = (p - sqrt(disc)) / q; if (t > near && t < far) continue; }
+    }
+    double db[3], dw[3];
+    for (int k = 0; k < 3; ++k) db[k] = h->cam_f[k] + a * h->cam_r[k] + bm * h->cam_d[k];
     mat_vec(R, db, dw);
-    fr[5 + zid] = ray_depth(h, e, cam, dw);
+    const int z = x < x_1 ? 0 : (x < x_2 ? 1 : 2);
+    zsum[z] += depth_buffer_of(ray_depth(h, e, cam, dw), near, far);    /* sky: ray_depth = far -> buffer 1.0 */
+    zcnt[z] += 1.0;
+  }
+  for (int z = 0; z < 3; ++z) {
+    const double mean = zcnt[z] > 0.0 ? (double)(float)(zsum[z] / zcnt[z]) : 0.0;      /* np.mean of float32 values */
+    fr[5 + z] = mean > 0.0 ? depth_buffer_to_meters(mean) : 0.0;
   }
   TK(e, FW_ST_FRAME_HAS) = 1.0;
 }
@@ -1295,9 +1346,4 @@ void fwo_wind_at(const fw_config* c, const double base[3], const double amp[3], 
   wind_at(&h, &e, t, w);
 }
 /* camera depth-buffer -> metres (envs/fixedwing_objlock_env.py:691-696) */
-double fwo_depth_buffer_to_meters(double depth_buffer) {
-  double near = 0.1, far = 255.0;
-  double denom = (far - (far - near) * depth_buffer);
-  if (fabs(denom) < 1e-9) return far;
-  return (far * near) / denom;
-}
+double fwo_depth_buffer_to_meters(double depth_buffer) { return depth_buffer_to_meters(depth_buffer); }

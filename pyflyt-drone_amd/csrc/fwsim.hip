@@ -936,6 +936,7 @@ int validate(const fw_config* c, std::string& msg) {
   if (c->task != FW_TASK_OBJLOCK && (c->context_length < 0 || c->context_length > FW_MAX_TARGETS + 1)) { snprintf(buf, sizeof buf, "bad context_length"); return fail(FW_EINVAL); }
   if (c->n_collision_pts < 0 || c->n_collision_pts > FW_MAX_COLLISION_PTS) { snprintf(buf, sizeof buf, "bad n_collision_pts"); return fail(FW_EINVAL); }
   if (c->num_obstacles < 0 || c->num_obstacles > FW_MAX_OBSTACLES) { snprintf(buf, sizeof buf, "bad num_obstacles"); return fail(FW_EINVAL); }
+  if (c->task != FW_TASK_WAYPOINTS && (c->camera_resolution < 0 || c->camera_resolution > 1024)) { snprintf(buf, sizeof buf, "camera_resolution must be in [1, 1024]"); return fail(FW_EINVAL); }
   if (c->physics_hz <= 0 || c->control_hz <= 0 || c->physics_hz % c->control_hz != 0) { snprintf(buf, sizeof buf, "physics_hz must be a multiple of control_hz"); return fail(FW_EINVAL); }
   if (!(c->mass > 0.0)) { snprintf(buf, sizeof buf, "mass must be > 0"); return fail(FW_EINVAL); }
   if (c->wind_coupling < FW_WIND_COUPLE_NONE || c->wind_coupling > FW_WIND_COUPLE_AIRSPEED) { snprintf(buf, sizeof buf, "bad wind_coupling"); return fail(FW_EINVAL); }
@@ -1120,9 +1121,18 @@ int invalidate_shadow(fw_env* h) {
   return FW_OK;
 }
 
-// LDS bytes of the padded [64/G][D+1] observation tile
+// floats per env of the camera's LDS row buffer: the width padded so that the 4 envs of a half-wave start 8 banks apart
+inline int zrow_stride_of(int res) { return ((res + 31) / 32) * 32 + 8; }
+
+// LDS bytes: the padded [64/G][D+1] observation tile; the camera tasks on the 8-lane mapping alias it (in time) with the
+// float32 row buffer of the analytic camera, 8 envs x zrow_stride floats
 template <typename T> size_t tile_bytes(const fw_env* h) {
-  return sizeof(T) * (size_t)(kWave / h->lanes_per_env) * (size_t)(obs_dim_of(&h->cfg) + 1);
+  size_t b = sizeof(T) * (size_t)(kWave / h->lanes_per_env) * (size_t)(obs_dim_of(&h->cfg) + 1);
+  if (h->cfg.task != FW_TASK_WAYPOINTS && h->lanes_per_env == 8) {
+    const int res = h->cfg.camera_resolution > 0 ? h->cfg.camera_resolution : 128;
+    b = std::max(b, sizeof(float) * 8 * (size_t)zrow_stride_of(res));
+  }
+  return b;
 }
 inline dim3 grid_of(const fw_env* h) { return dim3((unsigned)(h->npad / (kWave / h->lanes_per_env))); }
 
@@ -1137,7 +1147,10 @@ void build_objc(const fw_config& c, ObjC<T>& O) {
   const int res = c.camera_resolution > 0 ? c.camera_resolution : 128;
   O.W = O.H = (T)res; O.vmid = (T)(res / 2);
   O.focal = (T)(0.5 * res / std::tan(0.5 * c.camera_fov_deg * kPi / 180.0));
+  O.inv_focal = (T)(1.0 / (0.5 * res / std::tan(0.5 * c.camera_fov_deg * kPi / 180.0)));
   O.near_ = (T)c.camera_near; O.far_ = (T)c.camera_far;
+  O.inv_near = (T)(1.0 / c.camera_near); O.inv_far = (T)(1.0 / c.camera_far); O.db_c1 = (T)(c.camera_far / (c.camera_far - c.camera_near));
+  O.zrow_stride = zrow_stride_of(res);
   O.duck_radius = (T)(c.duck_radius_per_scale * c.duck_global_scaling); O.half_dome = (T)(c.flight_dome_size / 2.0);
   O.obst_radius = (T)c.obstacle_radius; O.obst_hmin = (T)c.obstacle_height_range[0]; O.obst_hmax = (T)c.obstacle_height_range[1];
   O.safe_dist = (T)c.obstacle_safe_distance_m; O.avoid_scale = (T)c.obstacle_avoid_reward_scale; O.avoid_max = (T)c.obstacle_avoid_max_penalty;

@@ -257,6 +257,7 @@ template <int CTRL> __device__ __forceinline__ double dpp(double v) {
 template <int CTRL> __device__ __forceinline__ float dpp(float v) {
   return __int_as_float(dpp_i32<CTRL>(__float_as_int(v)));
 }
+template <int CTRL> __device__ __forceinline__ int dpp(int v) { return dpp_i32<CTRL>(v); }
 // sum over the 8 lanes of a group; every lane ends with the bit-identical total
 template <int G, typename T> __device__ __forceinline__ T group_sum(T v) {
   if (G == 8) {

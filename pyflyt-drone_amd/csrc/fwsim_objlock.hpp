@@ -17,7 +17,8 @@ constexpr int kHist = FW_VISION_HIST * FW_VISION_FEATS;   // 27
 template <typename T>
 struct ObjC {          // wave-uniform task constants
   T cam_f[3], cam_r[3], cam_d[3], cam_off[3];
-  T focal, W, H, vmid, near_, far_;
+  T focal, inv_focal, W, H, vmid, near_, far_;
+  T inv_near, inv_far, db_c1;   // 1 / near, 1 / far, far / (far - near): depth-buffer value = db_c1 (1 - near / t)
   T duck_radius, half_dome;
   T obst_radius, obst_hmin, obst_hmax, safe_dist, avoid_scale, avoid_max;
   T k_dist, lock_radius, k_center, k_visible, k_area, lost_penalty, approach_clip, k_approach;
@@ -25,6 +26,7 @@ struct ObjC {          // wave-uniform task constants
   T switch_min_area;
   T reach_margin;      // largest |collision point| + slack: how far from the COM a contact can happen
   int32_t hold_steps, decay_steps, num_obstacles, camera_ratio_ticks, switch_min_seen;
+  int32_t zrow_stride;  // floats per env of the LDS row buffer of the camera (8-lane mapping)
 };
 
 template <typename T>
@@ -257,77 +259,285 @@ __device__ __forceinline__ T cyl_hit(const ObjC<T>& OC, T cx, T cy, T hh, const 
   return (z < (T)0 || z > hh) ? inf : t;
 }
 
-// Camera.capture_image() replaced by the analytic frame.  The three zone rays and the line of sight to the
-// duck are tested against every cylinder; G = 8: lane j takes cylinders j, j+8, j+16 and the four minima are
-// combined with DPP (every lane ends with the identical frame).
+// ------------------------------------------------------------------------------------------
+// Camera.capture_image() replaced by an analytic render of the scene, and _compute_vision_features' image statistics
+// (:662-743) computed on it -- the SAME functionals the reference applies to segImg / depthImg:
+//   duck mask = pixels whose ray hits the sphere between the clip planes (none if a cylinder blocks the line of sight to
+//   its centre);  cx, cy = mean(xs)/(w-1), mean(ys)/(h-1);  area = count/(h*w);  depth = metres(min depth-BUFFER value over
+//   the mask);  d_left/center/right = metres(mean depth-BUFFER value (float32, as depthImg) of the non-duck pixels of the
+//   thirds of row h//2), 0 for an empty third.
+// Nothing is rasterised pixel by pixel where a closed form exists:
+//   * a row of the duck mask is the interval between the roots of a quadratic (silhouette of the sphere on that row):
+//     count, sum(x), sum(y) come from the interval's end points; the row's nearest fragment is one of the two pixels
+//     around the closed-form continuous minimiser (the depth along a scan line across a sphere is unimodal);
+//   * the ground's depth-buffer value is linear in the column; a cylinder covers the columns of one interval (the
+//     directions inside its tangent cone), found in closed form (conservatively) and then tested pixel by pixel.
+// G = 8: the env's 8 lanes take every 8th row of the mask, every 8th pixel of row h//2 and every 8th cylinder; row h//2
+// lives in LDS as float32 depth-buffer values (lane j owns the pixels x = j mod 8: no cross-lane hazard), the partial
+// statistics are combined with DPP.  G = 1: one lane does all of it, pixel by pixel against every cylinder (the
+// throughput mapping has no LDS to spare for 64 rows; it serves the camera tasks only above 16 384 envs).
+// ------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T depthbuf_from_inv(const ObjC<T>& OC, T inv_t) {
+  // depth-buffer value far (t - near) / (t (far - near)) = c1 (1 - near / t) of a fragment at view-axis depth t, as float32
+  inv_t = inv_t > OC.inv_near ? OC.inv_near : inv_t;
+  inv_t = inv_t < OC.inv_far ? OC.inv_far : inv_t;
+  return (T)(float)(OC.db_c1 * ((T)1 - OC.near_ * inv_t));
+}
+template <typename T> __device__ __forceinline__ T depthbuf_to_meters(const ObjC<T>& OC, T d) {           // :691-696
+  const T denom = OC.far_ - (OC.far_ - OC.near_) * d;
+  return M<T>::fabs_(denom) < (T)1e-9 ? OC.far_ : M<T>::div_(OC.far_ * OC.near_, denom);
+}
+template <typename T> __device__ __forceinline__ T ceil_(T x) { return ::ceil(x); }
+template <typename T> __device__ __forceinline__ T floor_(T x) { return ::floor(x); }
+
+// 1 / t of the first hit of the ray cam + t dw (t = view-axis depth) with the cylinder (cx, cy, radius, [0, hh]); 0 = miss
+template <typename T>
+__device__ __forceinline__ T cyl_inv_t(const ObjC<T>& OC, T cx, T cy, T hh, const T cam[3], T dwx, T dwy, T dwz) {
+  const T ox = cam[0] - cx, oy = cam[1] - cy;
+  const T a = dwx * dwx + dwy * dwy, hb = ox * dwx + oy * dwy, cc = ox * ox + oy * oy - OC.obst_radius * OC.obst_radius;
+  const T disc = hb * hb - a * cc;                       // (b^2 - 4 a c) / 4 with b = 2 hb
+  if (!(a > (T)0) || disc < (T)0 || hb >= (T)0) return (T)0;      // t = (-hb - sqrt(disc)) / a > 0 needs hb < 0 (outside the cylinder)
+  const T num = -hb - M<T>::sqrt_(disc);
+  if (!(num > (T)0)) return (T)0;
+  const T inv_t = M<T>::div_(a, num);
+  const T z = cam[2] + M<T>::div_(num, a) * dwz;
+  return (z < (T)0 || z > hh) ? (T)0 : inv_t;
+}
+
+template <typename T> struct CamIn { T cam[3]; T R[9]; T duck[3]; int32_t nob; int32_t env; };
+
 template <typename T, int G>
-__device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevState<T>& D, int env, ObjState<T>& O,
-                                                   const Rigid<T>& S, const T R[9]) {
-  T cam[3], offw[3];
-  mv(R, OC.cam_off, offw);
-  cam[0] = S.p[0] + offw[0]; cam[1] = S.p[1] + offw[1]; cam[2] = S.p[2] + offw[2];
-  const T W = OC.W, H = OC.H, F = OC.focal;
-  const T u0 = (T)0.5 * (W - (T)1), v0 = (T)0.5 * (H - (T)1);
-  T Cc[3] = { O.duck[0], O.duck[1], O.duck[2] + OC.duck_radius };
+__device__ __noinline__ void camera_frame(const ObjC<T>* __restrict__ OCp, const T* __restrict__ obst, int npad, const CamIn<T>* in, T* frame, float* zrow) {
+  const ObjC<T>& OC = *OCp;
+  const size_t n = (size_t)npad;
+  const int env = in->env, nob = in->nob;
+  const int sub = (G == 1) ? 0 : (int)(threadIdx.x & (G - 1));
+  const int gbase = (int)threadIdx.x & ~(G - 1);
+  T cam[3], R[9];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) cam[k] = in->cam[k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k] = in->R[k];
+  const T* ob = obst + env;
+  const T W = OC.W, H = OC.H, F = OC.focal, invF = OC.inv_focal;
+  const int Wi = (int)W, Hi = (int)H;
+  const T u0 = (T)0.5 * (W - (T)1), v0 = (T)0.5 * (H - (T)1), Rd = OC.duck_radius;
+  const T inf = (T)1e300;
+  // ---- duck: sphere centre in camera coordinates (zc forward, xc right, yc down) ----
+  T Cc[3] = { in->duck[0], in->duck[1], in->duck[2] + Rd };
   T relw[3] = { Cc[0] - cam[0], Cc[1] - cam[1], Cc[2] - cam[2] }, relb[3];
   mtv(R, relw, relb);
-  // the three zone rays (centre column of each third of the middle row :698-729) in world coordinates
-  T dwz[3][3];
-#pragma unroll
-  for (int zid = 0; zid < 3; ++zid) {
-    T ucol = M<T>::div_((T)(2 * zid + 1) * W, (T)6) - (T)0.5;
-    T a = M<T>::div_(ucol - u0, F), b = M<T>::div_(OC.vmid - v0, F), db[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) db[k] = OC.cam_f[k] + a * OC.cam_r[k] + b * OC.cam_d[k];
-    mv(R, db, dwz[zid]);
-  }
-  // cylinders: per-lane partial minima
-  const T inf = (T)1e300;
-  T best[3] = { inf, inf, inf }, occ_t = inf;
+  const T zc = relb[0] * OC.cam_f[0] + relb[1] * OC.cam_f[1] + relb[2] * OC.cam_f[2];
+  const T xc = relb[0] * OC.cam_r[0] + relb[1] * OC.cam_r[1] + relb[2] * OC.cam_r[2];
+  const T yc = relb[0] * OC.cam_d[0] + relb[1] * OC.cam_d[1] + relb[2] * OC.cam_d[2];
+  const T k2 = zc * zc + xc * xc + yc * yc - Rd * Rd;
+  // row h//2 in world coordinates: dw(a) = g0 + a g1  (forward component 1 => the ray parameter is the view-axis depth)
+  const int y_mid = Hi / 2, x_1 = Wi / 3, x_2 = (2 * Wi) / 3;
+  const T bm = ((T)y_mid - v0) * invF;
+  T g0[3], g1[3];
   {
-    const T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
-    const size_t n = D.npad;
-    const int sub = (G == 1) ? 0 : (int)(threadIdx.x & (G - 1));
-    for (int o = sub; o < O.nob; o += G) {
-      const T cx = ob[(3 * o) * n], cy = ob[(3 * o + 1) * n], hh = ob[(3 * o + 2) * n];
+    T db[3];
 #pragma unroll
-      for (int zid = 0; zid < 3; ++zid) { T t = cyl_hit<T>(OC, cx, cy, hh, cam, dwz[zid]); best[zid] = t < best[zid] ? t : best[zid]; }
-      T t = cyl_hit<T>(OC, cx, cy, hh, cam, relw);
-      occ_t = t < occ_t ? t : occ_t;
-    }
-#pragma unroll
-    for (int zid = 0; zid < 3; ++zid) best[zid] = group_min<G, T>(best[zid]);
-    occ_t = group_min<G, T>(occ_t);
+    for (int k = 0; k < 3; ++k) db[k] = OC.cam_f[k] + bm * OC.cam_d[k];
+    mv(R, db, g0);
+    mv(R, OC.cam_r, g1);
   }
-  // --- duck ---
-  T zc = relb[0] * OC.cam_f[0] + relb[1] * OC.cam_f[1] + relb[2] * OC.cam_f[2];
-  T xc = relb[0] * OC.cam_r[0] + relb[1] * OC.cam_r[1] + relb[2] * OC.cam_r[2];
-  T yc = relb[0] * OC.cam_d[0] + relb[1] * OC.cam_d[1] + relb[2] * OC.cam_d[2];
-  T visible = (T)0, cx = (T)0, cy = (T)0, area = (T)0, depth = (T)0;
-  if (zc - OC.duck_radius > OC.near_ && zc - OC.duck_radius < OC.far_) {
-    T u = u0 + M<T>::div_(F * xc, zc), v = v0 + M<T>::div_(F * yc, zc), rho = M<T>::div_(F * OC.duck_radius, zc);
-    T x0 = M<T>::fmax_(u - rho, (T)0), x1 = -M<T>::fmax_(-(u + rho), -(W - (T)1));
-    T y0 = M<T>::fmax_(v - rho, (T)0), y1 = -M<T>::fmax_(-(v + rho), -(H - (T)1));
-    if (x1 > x0 && y1 > y0) {
-      T a = (T)(0.25 * kPi) * (x1 - x0) * (y1 - y0);
-      if (a >= (T)1 && !(occ_t < (T)1)) {          // occluded <=> a cylinder cuts the segment camera -> duck (0 < t < 1)
-        visible = (T)1;
-        cx = M<T>::div_((T)0.5 * (x0 + x1), M<T>::fmax_((T)1, W - (T)1));
-        cy = M<T>::div_((T)0.5 * (y0 + y1), M<T>::fmax_((T)1, H - (T)1));
-        T af = M<T>::div_(a, W * H);
-        area = af < (T)1 ? af : (T)1;
-        depth = zc - OC.duck_radius;
+  // ---- cylinders: line-of-sight occlusion of the duck + the columns each one can cover on row h//2 (lane-parallel) ----
+  T occ_t = inf;
+  int iv[3] = { 0, 0, 0 };                    // G = 8: packed (lo | hi << 16, hi < lo = empty) of my cylinders sub, sub + 8, sub + 16
+  for (int o = sub, slot = 0; o < nob; o += G, ++slot) {
+    const T cx = ob[(3 * o) * n], cy = ob[(3 * o + 1) * n], hh = ob[(3 * o + 2) * n];
+    {
+      const T it = cyl_inv_t<T>(OC, cx, cy, hh, cam, relw[0], relw[1], relw[2]);
+      if (it > (T)1) occ_t = (T)0.5;          // a hit at 0 < t < 1 on the segment camera -> sphere centre
+    }
+    if (G == 8) {
+      // directions inside the tangent cone of the disc: o.d <= 0 and (o.d)^2 >= |d|^2 (L^2 - r^2), d = p + a q
+      const T ox = cam[0] - cx, oy = cam[1] - cy;
+      const T cc = ox * ox + oy * oy - OC.obst_radius * OC.obst_radius;
+      const T op = ox * g0[0] + oy * g0[1], oq = ox * g1[0] + oy * g1[1];
+      const T pp = g0[0] * g0[0] + g0[1] * g0[1], pq = g0[0] * g1[0] + g0[1] * g1[1], qq = g1[0] * g1[0] + g1[1] * g1[1];
+      const T A2 = oq * oq - qq * cc, B2 = op * oq - pq * cc, C2 = op * op - pp * cc;
+      auto inside = [&](T a) { const T od = op + a * oq; return od <= (T)0 && od * od >= (pp + a * ((T)2 * pq + a * qq)) * cc; };
+      const T amin = ((T)0 - u0) * invF, amax = ((W - (T)1) - u0) * invF;
+      T lo = (T)1, hi = (T)0;                                     // empty
+      const T d2 = B2 * B2 - A2 * C2;
+      if (cc > (T)0) {
+        if (d2 >= (T)0 && M<T>::fabs_(A2) > (T)1e-300) {
+          const T sq = M<T>::sqrt_(d2), ia = M<T>::rcp_(A2);
+          T r1 = (-B2 - sq) * ia, r2 = (-B2 + sq) * ia;
+          if (r1 > r2) { const T t_ = r1; r1 = r2; r2 = t_; }
+          if (inside((T)0.5 * (r1 + r2))) { lo = r1; hi = r2; }
+          else if (inside(r1 - (T)1)) { lo = amin; hi = r1; }
+          else if (inside(r2 + (T)1)) { lo = r2; hi = amax; }
+        } else if (inside((T)0)) { lo = amin; hi = amax; }
+      }
+      int xlo = 1, xhi = 0;
+      if (hi >= lo) {
+        T fl = floor_<T>(u0 + F * lo) - (T)1, fh = ceil_<T>(u0 + F * hi) + (T)1;     // one pixel of slack: the per-pixel test decides
+        fl = fl < (T)0 ? (T)0 : fl; fh = fh > W - (T)1 ? W - (T)1 : fh;
+        if (fh >= fl) { xlo = (int)fl; xhi = (int)fh; }
+      }
+      const int packed = (xhi >= xlo) ? (xlo | (xhi << 16)) : (1 | (0 << 16));
+      iv[0] = slot == 0 ? packed : iv[0]; iv[1] = slot == 1 ? packed : iv[1]; iv[2] = slot == 2 ? packed : iv[2];
+    }
+  }
+  occ_t = group_min<G, T>(occ_t);
+  // ---- duck mask statistics ----
+  T cnt = (T)0, sx = (T)0, sy = (T)0, itmax = (T)0;               // itmax = 1 / (nearest fragment depth)
+  int mid_lo = 1 << 30, mid_hi = -1;                              // duck columns on row h//2
+  const bool duck_ok = (zc - Rd > OC.near_) && (zc - Rd < OC.far_) && !(occ_t < (T)1);
+  const bool straddle = zc + Rd >= OC.far_;                       // some fragments may lie beyond the far plane: test them one by one
+  if (duck_ok) {
+    const T A = Rd * Rd - zc * zc - yc * yc;                      // < 0: the sphere is wholly in front of the near plane
+    const T den = M<T>::rcp_(Rd * Rd - zc * zc);
+    const T sqb = Rd * M<T>::sqrt_(M<T>::fmax_(zc * zc + yc * yc - Rd * Rd, (T)0));
+    T b_lo = (-zc * yc + sqb) * den, b_hi = (-zc * yc - sqb) * den;      // den < 0
+    T fy0 = ceil_<T>(v0 + F * b_lo), fy1 = floor_<T>(v0 + F * b_hi);
+    fy0 = fy0 < (T)0 ? (T)0 : fy0; fy1 = fy1 > H - (T)1 ? H - (T)1 : fy1;
+    const T iA = M<T>::rcp_(A);
+    const int y0 = (int)fy0, y1 = (fy1 >= fy0) ? (int)fy1 : -1;
+    auto inv_hit = [&](T a, T b) {                                // 1 / t of the sphere hit of pixel direction (1, a, b); 0 = miss / clipped
+      const T q = (T)1 + a * a + b * b, p = zc + a * xc + b * yc, disc = p * p - q * k2;
+      if (disc < (T)0 || p <= (T)0) return (T)0;
+      const T num = p - M<T>::sqrt_(disc);
+      const T it = M<T>::div_(q, num);
+      return (it < OC.inv_near && it > OC.inv_far) ? it : (T)0;   // near < t < far
+    };
+#pragma unroll 1
+    for (int y = y0 + sub; y <= y1; y += G) {
+      const T b = ((T)y - v0) * invF;
+      const T e = zc + b * yc, Bh = xc * e, Cq = e * e - ((T)1 + b * b) * k2;
+      const T Dd = Bh * Bh - A * Cq;
+      if (Dd < (T)0) continue;
+      const T sq = M<T>::sqrt_(Dd);
+      const T a_lo = (-Bh + sq) * iA, a_hi = (-Bh - sq) * iA;
+      T fx0 = ceil_<T>(u0 + F * a_lo), fx1 = floor_<T>(u0 + F * a_hi);
+      fx0 = fx0 < (T)0 ? (T)0 : fx0; fx1 = fx1 > W - (T)1 ? W - (T)1 : fx1;
+      if (fx1 < fx0) continue;
+      if (!straddle) {
+        const T nn = fx1 - fx0 + (T)1;
+        cnt += nn; sx += nn * (T)0.5 * (fx0 + fx1); sy += nn * (T)y;
+        if (y == y_mid) { mid_lo = (int)fx0; mid_hi = (int)fx1; }
+        // nearest fragment of the row: around the closed-form minimiser of the scan line's depth profile
+        const T rs = M<T>::rcp_(M<T>::sqrt_((T)1 + b * b));
+        const T s0 = e * rs, rp = M<T>::sqrt_(M<T>::fmax_(s0 * s0 + xc * xc - k2, (T)0));
+        const T xs = u0 + F * M<T>::div_(xc, (s0 - rp) * rs);
+        T xa = floor_<T>(xs); xa = xa < fx0 ? fx0 : (xa > fx1 ? fx1 : xa);
+        T xb = xa + (T)1; xb = xb > fx1 ? fx1 : xb;
+        const T ia = inv_hit((xa - u0) * invF, b), ib = inv_hit((xb - u0) * invF, b);
+        itmax = ia > itmax ? ia : itmax; itmax = ib > itmax ? ib : itmax;
+      } else {
+        for (T x = fx0; x <= fx1; x += (T)1) {
+          const T it = inv_hit((x - u0) * invF, b);
+          if (it > (T)0) { cnt += (T)1; sx += x; sy += (T)y; itmax = it > itmax ? it : itmax; }
+        }
       }
     }
   }
-  O.frame[0] = visible; O.frame[1] = cx; O.frame[2] = cy; O.frame[3] = area; O.frame[4] = depth;
-#pragma unroll
-  for (int zid = 0; zid < 3; ++zid) {
-    T b = OC.far_;
-    if (dwz[zid][2] < (T)0) { T t = M<T>::div_(-cam[2], dwz[zid][2]); if (t > (T)0 && t < b) b = t; }     // ground plane
-    b = best[zid] < b ? best[zid] : b;
-    O.frame[5 + zid] = b < OC.near_ ? OC.near_ : b;
+  cnt = group_sum<G, T>(cnt); sx = group_sum<G, T>(sx); sy = group_sum<G, T>(sy);
+  itmax = -group_min<G, T>(-itmax);
+  if (G == 8) { mid_lo = group_min<G, int>(mid_lo); mid_hi = -group_min<G, int>(-mid_hi); }
+  T visible = (T)0, cxn = (T)0, cyn = (T)0, area = (T)0, depth = (T)0;
+  const bool duck_in = cnt > (T)0;
+  if (duck_in) {
+    visible = (T)1;
+    const T ic = M<T>::rcp_(cnt);
+    cxn = M<T>::div_(M<T>::div_(sx, cnt), M<T>::fmax_((T)1, W - (T)1));
+    cyn = M<T>::div_(M<T>::div_(sy, cnt), M<T>::fmax_((T)1, H - (T)1));
+    (void)ic;
+    area = M<T>::div_(cnt, M<T>::fmax_((T)1, H * W));
+    depth = depthbuf_to_meters<T>(OC, depthbuf_from_inv<T>(OC, itmax));
   }
+  frame[0] = visible; frame[1] = cxn; frame[2] = cyn; frame[3] = area; frame[4] = depth;
+  // ---- obstacle zones: row h//2 as float32 depth-buffer values ----
+  const T inv_camz = cam[2] > (T)0 ? M<T>::rcp_(cam[2]) : (T)0;
+  auto is_duck = [&](int x) {
+    if (!duck_in) return false;
+    if (!straddle) return x >= mid_lo && x <= mid_hi;
+    const T a = ((T)x - u0) * invF;
+    const T q = (T)1 + a * a + bm * bm, p = zc + a * xc + bm * yc, disc = p * p - q * k2;
+    if (disc < (T)0 || p <= (T)0) return false;
+    const T it = M<T>::div_(q, p - M<T>::sqrt_(disc));
+    return it < OC.inv_near && it > OC.inv_far;
+  };
+  T zs[3] = { (T)0, (T)0, (T)0 }, zn[3] = { (T)0, (T)0, (T)0 };
+  if (G == 8) {
+    float* zr = zrow;
+#pragma unroll 1
+    for (int x = sub; x < Wi; x += G) {                           // ground / sky
+      const T a = ((T)x - u0) * invF, dz = g0[2] + a * g1[2];
+      const T it = dz < (T)0 ? -dz * inv_camz : (T)0;
+      zr[x] = (float)depthbuf_from_inv<T>(OC, it);
+    }
+#pragma unroll 1
+    for (int o = 0; o < nob; ++o) {                               // group-uniform: every lane of the env walks the same cylinder
+      const int slot = o >> 3;
+      const int mine = slot == 0 ? iv[0] : (slot == 1 ? iv[1] : iv[2]);
+      const int packed = __shfl(mine, gbase | (o & 7), kWave);
+      const int xlo = packed & 0xFFFF, xhi = packed >> 16;
+      if (xhi < xlo) continue;
+      const T cx = ob[(3 * o) * n], cy = ob[(3 * o + 1) * n], hh = ob[(3 * o + 2) * n];
+      int x = xlo + ((sub - xlo) & 7);                            // my first pixel (x = sub mod 8) inside the interval
+#pragma unroll 1
+      for (; x <= xhi; x += G) {
+        const T a = ((T)x - u0) * invF;
+        const T it = cyl_inv_t<T>(OC, cx, cy, hh, cam, g0[0] + a * g1[0], g0[1] + a * g1[1], g0[2] + a * g1[2]);
+        if (it > (T)0) { const float v = (float)depthbuf_from_inv<T>(OC, it); zr[x] = v < zr[x] ? v : zr[x]; }
+      }
+    }
+#pragma unroll 1
+    for (int x = sub; x < Wi; x += G) {
+      if (is_duck(x)) continue;                                   // mask = seg != duck_id
+      const int z = x < x_1 ? 0 : (x < x_2 ? 1 : 2);
+      const T v = (T)zr[x];
+      zs[0] += z == 0 ? v : (T)0; zs[1] += z == 1 ? v : (T)0; zs[2] += z == 2 ? v : (T)0;
+      zn[0] += z == 0 ? (T)1 : (T)0; zn[1] += z == 1 ? (T)1 : (T)0; zn[2] += z == 2 ? (T)1 : (T)0;
+    }
+  } else {
+#pragma unroll 1
+    for (int x = 0; x < Wi; ++x) {
+      if (is_duck(x)) continue;
+      const T a = ((T)x - u0) * invF;
+      const T dwx = g0[0] + a * g1[0], dwy = g0[1] + a * g1[1], dwz = g0[2] + a * g1[2];
+      T it = dwz < (T)0 ? -dwz * inv_camz : (T)0;
+      it = it > OC.inv_near ? OC.inv_near : it;                   // (the oracle clamps the ground hit before comparing)
+      for (int o = 0; o < nob; ++o) {
+        const T ic = cyl_inv_t<T>(OC, ob[(3 * o) * n], ob[(3 * o + 1) * n], ob[(3 * o + 2) * n], cam, dwx, dwy, dwz);
+        it = ic > it ? ic : it;
+      }
+      const int z = x < x_1 ? 0 : (x < x_2 ? 1 : 2);
+      const T v = depthbuf_from_inv<T>(OC, it);
+      zs[0] += z == 0 ? v : (T)0; zs[1] += z == 1 ? v : (T)0; zs[2] += z == 2 ? v : (T)0;
+      zn[0] += z == 0 ? (T)1 : (T)0; zn[1] += z == 1 ? (T)1 : (T)0; zn[2] += z == 2 ? (T)1 : (T)0;
+    }
+  }
+#pragma unroll
+  for (int z = 0; z < 3; ++z) {
+    const T ssum = group_sum<G, T>(zs[z]), scnt = group_sum<G, T>(zn[z]);
+    const T mean = scnt > (T)0 ? (T)(float)M<T>::div_(ssum, scnt) : (T)0;       // np.mean of float32 values
+    frame[5 + z] = mean > (T)0 ? depthbuf_to_meters<T>(OC, mean) : (T)0;
+  }
+}
+
+template <typename T, int G>
+__device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevState<T>& D, int env, ObjState<T>& O,
+                                                   const Rigid<T>& S, const T R[9]) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  CamIn<T> in;
+  T offw[3];
+  mv(R, OC.cam_off, offw);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { in.cam[k] = S.p[k] + offw[k]; in.duck[k] = O.duck[k]; }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) in.R[k] = R[k];
+  in.nob = O.nob; in.env = env;
+  T fr[8];
+  // G = 8: this env's slice of the row buffer (aliases the observation tile, which is only written after the step loop)
+  float* zrow = (G == 8) ? reinterpret_cast<float*>(smem_raw) + (size_t)((threadIdx.x & (kWave - 1)) / G) * OC.zrow_stride : nullptr;
+  camera_frame<T, G>(&OC, D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad, D.npad, &in, fr, zrow);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) O.frame[k] = fr[k];
   O.frame_has = (T)1;
 }
 

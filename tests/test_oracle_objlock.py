@@ -184,32 +184,183 @@ def test_vision_history_shift_fill_and_deltas(oracle):
     assert np.all(o3[0, 52:56] == 0) and o3[0, 25] == 0 and o3[0, 34] == 1                # deltas only if both visible
 
 
-def test_analytic_camera_geometry(oracle):
-    """Level flight straight at the duck: centred, depth = range - radius, area = pi rho^2 / (W H)."""
-    cfg = quiet(duck_camera_capture_interval_steps=1, camera_resolution=480, flight_dome_size=1e5)
-    env = make(oracle, cfg)
+# ---- the reference's image functionals (:662-743) on the analytic render: an independent numpy restatement as the checker
+def np_render_frame(oracle, cfg, st, res):
+    """Literal numpy version of what _compute_vision_features / _estimate_obstacle_zone_distances_m / _estimate_distance
+    compute from segImg / depthImg, for the analytic scene (sphere duck, cylinder obstacles, ground plane, sky = 1.0)."""
+    near, far = 0.1, 255.0
+    R = oracle.mat_from_quat(st[K.S_QUAT:K.S_QUAT + 4])
+    cam = st[K.S_POS:K.S_POS + 3] + R @ np.array(list(cfg.camera_offset))
+    th = math.radians(cfg.camera_angle_deg)
+    f, r = np.array([math.cos(th), 0.0, math.sin(th)]), np.array([0.0, -1.0, 0.0])
+    d = np.cross(f, r)
+    W = H = res
+    F = 0.5 * res / math.tan(0.5 * math.radians(cfg.camera_fov_deg))
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H))
+    a, b = (xs - 0.5 * (W - 1)) / F, (ys - 0.5 * (H - 1)) / F
+    dirs = (f[None, None, :] + a[..., None] * r + b[..., None] * d) @ R.T          # world ray per pixel, forward component 1
+    depth = np.full((H, W), far)                                                    # metric view-axis depth per pixel
+    seg = np.zeros((H, W), dtype=np.int64)                                          # 0 sky/ground, 1 obstacle, 2 duck
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tg = np.where(dirs[..., 2] < 0, -cam[2] / dirs[..., 2], np.inf)
+    depth = np.minimum(depth, np.where(tg > 0, tg, np.inf))
+    nob = int(st[T0 + K.ST_NUM_OBST])
+    for o in range(nob):
+        ox, oy, hh = st[T0 + K.ST_OBST + 3 * o:T0 + K.ST_OBST + 3 * o + 3]
+        px, py = cam[0] - ox, cam[1] - oy
+        A = dirs[..., 0] ** 2 + dirs[..., 1] ** 2
+        B = 2 * (px * dirs[..., 0] + py * dirs[..., 1])
+        Cc = px * px + py * py - cfg.obstacle_radius ** 2
+        disc = B * B - 4 * A * Cc
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (-B - np.sqrt(np.maximum(disc, 0))) / (2 * A)
+        z = cam[2] + t * dirs[..., 2]
+        hit = (disc >= 0) & (A > 0) & (t > 0) & (z >= 0) & (z <= hh) & (t < depth)
+        depth = np.where(hit, t, depth); seg = np.where(hit, 1, seg)
+    Rd = 0.05 * cfg.duck_global_scaling
+    C = st[T0:T0 + 3] + np.array([0, 0, Rd])
+    rel = C - cam
+    q = (dirs ** 2).sum(-1); pp = dirs @ rel; k2 = rel @ rel - Rd * Rd
+    disc = pp * pp - q * k2
+    with np.errstate(invalid="ignore"):
+        t = (pp - np.sqrt(np.maximum(disc, 0))) / q
+    # line-of-sight occlusion (binary, by the cylinders): the analytic renderer's rule for the whole duck
+    blocked = False
+    for o in range(nob):
+        ox, oy, hh = st[T0 + K.ST_OBST + 3 * o:T0 + K.ST_OBST + 3 * o + 3]
+        px, py = cam[0] - ox, cam[1] - oy
+        A = rel[0] ** 2 + rel[1] ** 2; B = 2 * (px * rel[0] + py * rel[1]); Cc = px * px + py * py - cfg.obstacle_radius ** 2
+        dsc = B * B - 4 * A * Cc
+        if A > 0 and dsc >= 0:
+            tt = (-B - math.sqrt(dsc)) / (2 * A)
+            if 0 < tt < 1 and 0 <= cam[2] + tt * rel[2] <= hh:
+                blocked = True
+    zc = (R.T @ rel) @ f
+    duck = (disc >= 0) & (pp > 0) & (t > near) & (t < far)
+    if blocked or not (near < zc - Rd < far):
+        duck[:] = False
+    depth = np.where(duck, t, depth); seg = np.where(duck, 2, seg)
+    dbuf = (far * (np.clip(depth, near, far) - near) / (np.clip(depth, near, far) * (far - near))).astype(np.float32)   # depthImg
+    to_m = lambda v: far * near / (far - (far - near) * float(v))
+    out = np.zeros(8)
+    mask = seg == 2
+    if mask.any():
+        yy, xx = np.nonzero(mask)
+        out[:5] = [1.0, xx.mean() / (W - 1), yy.mean() / (H - 1), mask.sum() / (H * W), to_m(dbuf[mask].min())]
+    ym, x1, x2 = H // 2, W // 3, 2 * W // 3
+    for zi, (xa, xb) in enumerate(((0, x1), (x1, x2), (x2, W))):
+        zm = ~mask[ym, xa:xb]
+        if zm.any():
+            m = np.float32(dbuf[ym, xa:xb][zm].astype(np.float64).mean())
+            out[5 + zi] = to_m(m) if m > 0 else 0.0
+    return out, mask, dbuf
+
+
+def _pose(env, pos, euler, duck, oracle, obstacles=()):
     s = env.get_state()
-    s[0, K.S_POS:K.S_POS + 3] = [0.0, 0.0, 3.05]; s[0, K.S_QUAT:K.S_QUAT + 4] = [0, 0, 0, 1]
-    s[0, K.S_VEL:K.S_VEL + 3] = [20, 0, 0]; s[0, K.S_OMEGA:K.S_OMEGA + 3] = 0
-    s[0, T0:T0 + 3] = [150.0, 0.0, 0.05]
+    s[0, K.S_POS:K.S_POS + 3] = pos; s[0, K.S_QUAT:K.S_QUAT + 4] = oracle.quat_from_euler(euler)
+    s[0, K.S_VEL:K.S_VEL + 3] = oracle.mat_from_quat(s[0, K.S_QUAT:K.S_QUAT + 4]) @ np.array([20.0, 0, 0]); s[0, K.S_OMEGA:K.S_OMEGA + 3] = 0
+    s[0, T0:T0 + 3] = duck
+    s[0, T0 + K.ST_NUM_OBST] = len(obstacles)
+    for i, ob in enumerate(obstacles):
+        s[0, T0 + K.ST_OBST + 3 * i:T0 + K.ST_OBST + 3 * i + 3] = ob
     env.set_state(s)
-    step0(env)                                                                             # 2 ticks, then a capture
+    return s
+
+
+def test_frame_functionals_match_a_numpy_render(oracle):
+    """cx / cy / area / min-depth of the duck mask and the three zone means of the depth BUFFER (non-duck pixels of row
+    h//2) equal a literal numpy render + the reference's numpy statements, over poses with roll / pitch / yaw, ducks near
+    the image border (clipped masks), ducks crossing the middle row, and cylinders inside the zones."""
+    rng = np.random.default_rng(12)
+    for res, nob in ((128, 3), (480, 0), (96, 6)):
+        cfg = quiet(duck_camera_capture_interval_steps=1, camera_resolution=res, num_obstacles=max(nob, 1), obstacle_radius=2.0,
+                    duck_global_scaling=60.0)
+        env = make(oracle, cfg)
+        seen_vis = seen_clip = seen_mid = 0
+        for trial in range(14):
+            dist = rng.uniform(15, 160)
+            yaw, roll, pitch = rng.uniform(-3, 3), rng.uniform(-0.6, 0.6), rng.uniform(-0.3, 0.3)
+            pos = np.array([rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(4, 40)])
+            bearing = yaw + rng.uniform(-0.75, 0.75)                                  # inside / at the edge of the 90 deg FOV
+            if trial % 3 == 0:                                                        # aimed: the duck lands on / near the middle row
+                bearing = yaw + rng.uniform(-0.2, 0.2); roll = rng.uniform(-0.2, 0.2)
+                pitch = math.atan2(pos[2], dist) - math.radians(5.0) + rng.uniform(-0.01, 0.01)   # positive pitch = nose down
+            duck = np.array([pos[0] + dist * math.cos(bearing), pos[1] + dist * math.sin(bearing), 0.05])
+            obst = [[pos[0] + rng.uniform(12, 90) * math.cos(yaw + rng.uniform(-0.7, 0.7)),
+                     pos[1] + rng.uniform(12, 90) * math.sin(yaw + rng.uniform(-0.7, 0.7)), rng.uniform(10, 30)] for _ in range(nob)]
+            _pose(env, pos, [roll, pitch, yaw], duck, oracle, obst)
+            step0(env)                                                              # 2 ticks, then a capture
+            st = env.get_state()[0]
+            want, mask, _ = np_render_frame(oracle, cfg, st, res)
+            got = st[T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
+            assert got[0] == want[0], (res, trial)
+            np.testing.assert_allclose(got[1:4], want[1:4], rtol=0, atol=1e-15, err_msg=f"mask statistics {res} {trial}")
+            np.testing.assert_allclose(got[4:], want[4:], rtol=1e-6, atol=1e-9, err_msg=f"depths {res} {trial}")   # float32 buffer values
+            seen_vis += int(want[0]); seen_mid += int(mask[res // 2].any())
+            seen_clip += int(mask.any() and (mask[0].any() or mask[-1].any() or mask[:, 0].any() or mask[:, -1].any()))
+        assert seen_vis >= 5 and seen_mid >= 2, (res, seen_vis, seen_clip, seen_mid)
+
+
+def test_level_flight_over_flat_ground_has_closed_form_zone_depths(oracle):
+    """No roll, no obstacles, no duck in view: every ray of row h//2 meets the ground at the same view-axis depth
+    t = cam_z / -(f_z + b d_z), so the buffer mean of each third is that one value and all three zone depths equal t (to
+    the float32 resolution of the depth buffer).  The mean is taken over BUFFER values: put a near cylinder into one third
+    and its zone depth is far from the arithmetic mean of the metric depths."""
+    cfg = quiet(duck_camera_capture_interval_steps=1, camera_resolution=480)
+    env = make(oracle, cfg)
+    _pose(env, [0.0, 0.0, 30.0], [0.0, 0.2, 0.0], [-500.0, 0.0, 0.05], oracle)      # pitched 0.2 rad nose down, duck behind
+    step0(env)
     st = env.get_state()[0]
     fr = st[T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
-    R_d = 0.05 * 60.0
-    cam = st[K.S_POS:K.S_POS + 3] + oracle.mat_from_quat(st[K.S_QUAT:K.S_QUAT + 4]) @ np.array([0.8, 0, 0.12])
-    assert st[T0 + K.ST_FRAME_HAS] == 1 and fr[0] == 1
-    zc_approx = 150.0 - cam[0]
-    assert fr[4] == pytest.approx(zc_approx * math.cos(math.radians(5)) - R_d, rel=2e-2)
-    assert fr[1] == pytest.approx(0.5, abs=0.01) and 0.3 < fr[2] < 0.6
-    rho = 240.0 * R_d / (zc_approx * math.cos(math.radians(5)))
-    assert fr[3] == pytest.approx(math.pi * rho ** 2 / 480 ** 2, rel=5e-2)
-    # obstacle zones see the ground ahead: the centre ray from ~3 m height, pitched 5 deg down
-    assert 20.0 < fr[6] < 60.0 and fr[5] == pytest.approx(fr[7], rel=0.2)
-    # duck behind the aircraft -> not visible
-    s2 = env.get_state(); s2[0, T0:T0 + 3] = [-150.0, 0.0, 0.05]; env.set_state(s2)
-    step0(env)
-    assert env.get_state()[0, T0 + K.ST_FRAME] == 0
+    R = oracle.mat_from_quat(st[K.S_QUAT:K.S_QUAT + 4])
+    cam = st[K.S_POS:K.S_POS + 3] + R @ np.array([0.8, 0.0, 0.12])
+    th = math.radians(-5.0); f = np.array([math.cos(th), 0, math.sin(th)]); d = np.cross(f, [0.0, -1.0, 0.0])
+    b = (480 // 2 - 239.5) / 240.0
+    t = cam[2] / -((R @ (f + b * d))[2])
+    assert fr[0] == 0 and 50.0 < t < 150.0
+    quant = t * t * (255.0 - 0.1) / (255.0 * 0.1) * 6e-8                            # one float32 ulp of the buffer, in metres
+    np.testing.assert_allclose(fr[5:8], [t, t, t], rtol=0, atol=2 * quant)
+
+
+def test_half_clipped_disc_shifts_the_centroid(oracle):
+    """Duck on the optical axis: mask centred, cx = cy = 0.5 (to the float64 rounding of the rotation), count ~ pi rho^2,
+    depth = zc - R within the depth-buffer resolution.  Duck whose centre projects onto the left image border: only the
+    right half of its disc is inside, count ~ pi rho^2 / 2, and mean(xs) sits 4 rho / (3 pi) inside the border (centroid
+    of a half disc) -- the bounding-box centre would sit rho / 2 inside."""
+    res = 480
+    cfg = quiet(duck_camera_capture_interval_steps=1, camera_resolution=res, duck_global_scaling=60.0)
+    env = make(oracle, cfg)
+    Rd, F = 3.0, 240.0
+    th = math.radians(-5.0)
+    cam0 = np.array([0.8, 0.0, 50.0 + 0.12])
+    f = np.array([math.cos(th), 0, math.sin(th)])
+    for case in ("centred", "left_border"):
+        zc = 60.0
+        a_c = 0.0 if case == "centred" else -(239.5 + 0.5) / F                        # image column of the centre: 239.5 / -0.5
+        ctr = cam0 + zc * (f + a_c * np.array([0.0, -1.0, 0.0]))                      # sphere centre in the world (identity attitude)
+        env2 = make(oracle, cfg)
+        s = _pose(env2, [0.0, 0.0, 50.0], [0.0, 0.0, 0.0], ctr - [0, 0, Rd], oracle)
+        s[0, K.S_VEL:K.S_VEL + 3] = 0.0; env2.set_state(s)                            # hover for the two ticks before the capture
+        step0(env2)
+        st = env2.get_state()[0]
+        want, mask, _ = np_render_frame(oracle, cfg, st, res)
+        fr = st[T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
+        np.testing.assert_allclose(fr[:4], want[:4], rtol=0, atol=1e-15)
+        cam = st[K.S_POS:K.S_POS + 3] + oracle.mat_from_quat(st[K.S_QUAT:K.S_QUAT + 4]) @ np.array([0.8, 0.0, 0.12])
+        rel = ctr - cam
+        zc_now = rel @ (oracle.mat_from_quat(st[K.S_QUAT:K.S_QUAT + 4]) @ f)
+        rho = F * Rd / math.sqrt(zc_now ** 2 - Rd ** 2) * math.sqrt(1 + a_c * a_c)   # silhouette half-width at the centre row (perspective)
+        count = fr[3] * res * res
+        if case == "centred":
+            assert abs(fr[1] - 0.5) < 2e-3 and count == pytest.approx(math.pi * (F * Rd / math.sqrt(zc_now ** 2 - Rd ** 2)) ** 2, rel=0.03)
+            assert fr[4] == pytest.approx(zc_now - Rd, abs=5e-3)
+        else:
+            assert mask[:, 0].any() and not mask[:, -1].any()
+            x_mean = fr[1] * (res - 1)
+            assert count == pytest.approx(0.5 * math.pi * rho * (F * Rd / math.sqrt(zc_now ** 2 - Rd ** 2)), rel=0.08)
+            assert x_mean == pytest.approx(-0.5 + 4 * rho / (3 * math.pi), abs=0.9)
+            assert abs(x_mean - 0.5 * rho) > 0.8                                     # not the bounding-box centre
 
 
 def test_obstacle_occludes_and_collides(oracle):
@@ -222,8 +373,14 @@ def test_obstacle_occludes_and_collides(oracle):
     s[0, T0 + K.ST_NUM_OBST] = 1; s[0, T0 + K.ST_OBST:T0 + K.ST_OBST + 3] = [60.0, 0.0, 30.0]     # cylinder on the line of sight
     env.set_state(s)
     _, r, term, *_ = step0(env)
-    fr = env.get_state()[0, T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
-    assert fr[0] == 0 and fr[6] == pytest.approx(60.0 - 2.0 - 0.8 - 20 * 2 / 240, abs=0.5) and not term[0]
+    st = env.get_state()[0]
+    fr = st[T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
+    want, mask, dbuf = np_render_frame(oracle, cfg, st, 128)
+    np.testing.assert_allclose(fr, want, rtol=1e-6, atol=1e-9)
+    assert fr[0] == 0 and not mask.any() and not term[0]                            # the duck is hidden behind the cylinder
+    # the centre third holds the cylinder's columns (about 57 m away) among ground / sky pixels: the zone depth is the depth of
+    # the MEAN BUFFER VALUE (:713-729) -- between the cylinder and the far ground, nowhere near the arithmetic mean of the depths
+    assert 57.0 < fr[6] < 255.0 and fr[5] == pytest.approx(fr[7], rel=1e-3)
     # fly into it: -100 and collision
     s = env.get_state(); s[0, K.S_POS] = 57.0; env.set_state(s)
     for _ in range(20):

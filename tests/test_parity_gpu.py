@@ -500,3 +500,56 @@ def test_caller_supplied_scenario_replaces_the_env_draw(oracle, lanes, task):
     np.testing.assert_array_equal(after[mask == 0], before[mask == 0])
     np.testing.assert_allclose(after, ora.get_state(), rtol=0, atol=1e-9)
     del keep
+
+
+def test_camera_frame_statistics_match_the_oracle_on_directed_poses(oracle, lanes):
+    """The image functionals of envs/fixedwing_objlock_env.py:662-743 (mask mean / pixel count / min depth-buffer value,
+    zone means of the depth BUFFER over the non-duck pixels of row h//2): the kernel's closed-form row intervals against the
+    oracle's literal per-pixel loops, on poses chosen to hit the hard cases -- rolled / pitched cameras, ducks clipped by
+    the image border, ducks crossing the middle row, ducks straddling the far plane (255 m), cylinders inside the zones,
+    in front of the duck and behind the camera."""
+    import math
+    import torch
+    T0 = K.S_TASK
+    rng = np.random.default_rng(77)
+    for res, nobs in ((480, 20), (128, 5), (65, 0)):
+        cfg = K.objlock_config(agent_hz=120, motor_noise=False, auto_reset=False, angle_representation="euler",
+                               duck_camera_capture_interval_steps=1, flight_dome_size=1e5, num_obstacles=max(nobs, 1),
+                               obstacle_radius=2.0, duck_global_scaling=60.0, camera_resolution=res)
+        n = 256
+        hip, ora = P.FixedwingVecEnv(cfg, n, seed=5), oracle.OracleEnv(cfg, n, seed=5)
+        hip.reset_tensor(); ora.reset()
+        s = ora.get_state()
+        for i in range(n):
+            kind = i % 4
+            dist = rng.uniform(12, 200) if kind != 3 else rng.uniform(249.0, 259.0)        # kind 3: around the far plane
+            yaw, roll, pitch = rng.uniform(-3, 3), rng.uniform(-0.7, 0.7), rng.uniform(-0.3, 0.3)
+            pos = np.array([rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(4, 45)])
+            bearing = yaw + rng.uniform(-0.8, 0.8)
+            if kind in (1, 3):                                                              # aimed at the duck: mask on / near row h//2
+                bearing = yaw + rng.uniform(-0.15, 0.15); roll = rng.uniform(-0.3, 0.3)
+                pitch = math.atan2(pos[2], dist) - math.radians(5.0) + rng.uniform(-0.02, 0.02)
+            s[i, K.S_POS:K.S_POS + 3] = pos
+            s[i, K.S_QUAT:K.S_QUAT + 4] = oracle.quat_from_euler([roll, pitch, yaw])
+            s[i, K.S_VEL:K.S_VEL + 3] = oracle.mat_from_quat(s[i, K.S_QUAT:K.S_QUAT + 4]) @ np.array([20.0, 0, 0])
+            s[i, K.S_OMEGA:K.S_OMEGA + 3] = 0
+            s[i, T0:T0 + 3] = [pos[0] + dist * math.cos(bearing), pos[1] + dist * math.sin(bearing), 0.05]
+            k = int(rng.integers(0, nobs + 1))
+            s[i, T0 + K.ST_NUM_OBST] = k
+            for o in range(k):
+                ang, d = yaw + rng.uniform(-math.pi, math.pi) * (1.0 if o % 3 == 0 else 0.25), rng.uniform(8, 120)
+                s[i, T0 + K.ST_OBST + 3 * o:T0 + K.ST_OBST + 3 * o + 3] = [pos[0] + d * math.cos(ang), pos[1] + d * math.sin(ang), rng.uniform(10, 60)]
+        hip.set_state(s); ora.set_state(s)
+        a = np.zeros((n, 4))
+        ora.step(a); hip.step_tensor(torch.as_tensor(a, device=hip.device))                 # 2 ticks, then a capture
+        fh = hip.get_state()[:, T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
+        fo = ora.get_state()[:, T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
+        assert np.array_equal(fh[:, 0], fo[:, 0]), np.nonzero(fh[:, 0] != fo[:, 0])[0]
+        np.testing.assert_allclose(fh[:, 1:4], fo[:, 1:4], rtol=0, atol=1e-15, err_msg=f"mask statistics, res {res}")
+        np.testing.assert_allclose(fh[:, 4:], fo[:, 4:], rtol=1e-6, atol=1e-9, err_msg=f"depths, res {res}")
+        vis = fo[:, 0] > 0
+        assert vis.sum() > n // 4 and (~vis).sum() > 10
+        if nobs:
+            assert (np.abs(fo[:, 5:8] - fo[:, 5:8].mean(1, keepdims=True)).max(1) > 1.0).sum() > 20, "cylinders were meant to change zone depths"
+        far_cases = fo[3::4]
+        assert 0 < (far_cases[:, 0] > 0).sum() < len(far_cases), "far-plane cases must include visible and clipped ducks"
