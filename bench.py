@@ -44,6 +44,24 @@ ENVS_PER_GPU = 4096
 WORDS_PER_ENV_STEP = 94
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 POOL = 64
+# Vector-issue ceiling of the chip for 64-bit lane operations: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-instr/s
+# (one wave64 fp64 VALU instruction occupies its SIMD for 4 cycles).  DESIGN.md section 6 gives the instruction counts.
+VALU_PEAK_TLANE = 256 * 4 * 16 * 2.4e9 / 1e12
+
+# --task: the four step kernels, their config (reference TRAIN_CONFIGs) and algorithmic words per env-step.
+#   waypoints       94 = 40 read + 54 written
+#   waypoints_wind  same state traffic as waypoints (the 7 wind words are already among the 40 read)
+#   objlock         rigid 13 + actuators 6 + action 4 + wind 7 + counters 2 + duck 3 + vision scalars 8 + frame 8 + history 27
+#                   = 78 read; state 23 + vision scalars 8 + frame 8 + history 27 + obs 56 + reward / flags / info 3 = 125
+#                   written => 203 words ("about 190")
+#   combined        waypoints' 94 + duck 3 + vision scalars 8 + frame 8 + phase 2 read (21) + vision scalars 8 + frame 8 +
+#                   phase 2 written (18) + 3 x 20 obstacle words read = 193 words
+TASKS = {
+    "waypoints": ("FixedwingWaypoints-v3 TRAIN_CONFIG (8 targets, sparse, euler, 30 Hz)", lambda K, dt: K.train_waypoints_v3_config(dtype=dt), 94),
+    "waypoints_wind": ("FixedwingWaypoints-v3 TRAIN_CONFIG + gust wind of train_objlock.py:74-85", lambda K, dt: K.train_waypoints_v3_config(dtype=dt, wind_config=K.TRAIN_OBJLOCK_WIND), 94),
+    "objlock": ("FixedwingObjLock TRAIN_CONFIG (train_objlock.py:27-86: dome 200 m, gust wind, camera 480 x 480 every 12 control steps)", lambda K, dt: K.train_objlock_config(dtype=dt), 203),
+    "combined": ("Waypoint+ObjLock TRAIN_CONFIG (train_Fixedwing_Waypoints_ObjLock.py:35-92: 8 targets, 20 obstacles, camera every 6 control steps)", lambda K, dt: K.train_waypoint_objlock_config(dtype=dt), 193),
+}
 
 
 def parse():
@@ -56,6 +74,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also print an N-sweep (stderr) 2^10..2^22")
+    ap.add_argument("--task", default="waypoints", choices=sorted(TASKS),
+                    help="step kernel to time (default: the headline FixedwingWaypoints workload of BASELINE.json)")
     return ap.parse_args()
 
 
@@ -181,7 +201,8 @@ def main():
         else:
             td.init_process_group(backend)
     n = args.envs_per_gpu
-    cfg = K.train_waypoints_v3_config(dtype=args.dtype)
+    task_name, task_cfg, task_words = TASKS[args.task]
+    cfg = task_cfg(K, args.dtype)
     env = P.FixedwingVecEnv(cfg, n, device=local_rank, seed=42, global_env_offset=rank * n)
     env.reset_tensor()
     pool = action_pool(n, env.torch_dtype, env.device)
@@ -242,7 +263,7 @@ def main():
             allgather = {"error": repr(e)}
 
     word = 8 if args.dtype == "float64" else 4
-    bytes_per_launch = WORDS_PER_ENV_STEP * word * n
+    bytes_per_launch = task_words * word * n
     launch_s = dev_ms * 1e-3 / args.steps
     achieved = bytes_per_launch / launch_s / 1e9
 
@@ -269,14 +290,28 @@ def main():
     # process); the committed summary is quoted when it was taken on this very workload, else null.
     traffic, traffic_src = None, None
     pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_pmc_traffic.json")
-    if n == 4096 and args.dtype == "float64" and os.path.exists(pmc_path):
+    if n == 4096 and args.dtype == "float64" and args.task == "waypoints" and os.path.exists(pmc_path):
         with open(pmc_path) as f:
             traffic = json.load(f)["hbm_bytes_per_launch"]["total"]
         traffic_src = "profiles/r01_d_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, calibrated with tools/calib_pmc.hip)"
 
+    # The ceiling that really binds this kernel: 64-bit vector issue.  fp64 lane-instructions per env-step come from the ISA
+    # of the shipped kernel (profiles/r02_valu_count.json, made by tools/count_valu.py: instructions of the tick loop x ticks +
+    # prologue / epilogue, x lanes per env); achieved = that x env-steps per second.
+    valu = None
+    vpath = os.path.join(ROOT, "profiles", "r02_valu_count.json")
+    if os.path.exists(vpath):
+        with open(vpath) as f:
+            vc = json.load(f).get(args.task if args.dtype == "float64" else "", None)
+        if vc:
+            lane_instr = vc["lane_instructions_per_env_step"]
+            ach = lane_instr * n / launch_s / 1e12
+            valu = {"bound": "valu64", "achieved": ach, "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s", "frac": ach / VALU_PEAK_TLANE,
+                    "lane_instructions_per_env_step": lane_instr, "source": "profiles/r02_valu_count.json"}
     if rank == 0:
         out = {
-            "metric": "env-steps/sec at N parallel envs (FixedwingWaypoints)",
+            "metric": "env-steps/sec at N parallel envs (FixedwingWaypoints)" if args.task == "waypoints"
+                      else f"env-steps/sec at N parallel envs ({args.task}: not the BASELINE.json headline)",
             "value": world * n * args.steps / wall,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -288,14 +323,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f64" if args.dtype == "float64" else "f32",
             "data": "synthetic",
-            "config": {"workload": f"FixedwingWaypoints-v3 TRAIN_CONFIG (8 targets, sparse, euler, 30 Hz), "
+            "config": {"workload": f"{task_name}, "
                                    f"{n} envs/GPU x {world} GPU, physics-only step(), motor noise + auto-reset on",
                        "envs_per_gpu": n, "obs_dim": env.obs_dim, "ticks_per_env_step": 8,
                        "launch": stepper.describe(timed), "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "fw_step_kernel", "launch_us": launch_s * 1e6,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "words_per_env_step": task_words,
+                         "valu": valu,
                          "note": "element-wise fp64 physics at N=4096 is latency/VALU-bound, not HBM-bound (DESIGN.md section 6)"},
         }
         if allgather is not None:

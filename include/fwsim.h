@@ -301,7 +301,7 @@ typedef struct fw_scenario {
   const double* targets;        /* [N][FW_MAX_TARGETS][3] world waypoints (rows >= num_targets ignored)     WaypointHandler.reset */
   const double* duck_pos;       /* [N][3] duck base position                         envs/fixedwing_objlock_env.py:472-491 */
   const double* obstacles;      /* [N][FW_MAX_OBSTACLES][3]  x, y, height            envs/fixedwing_objlock_env.py:528-565 */
-  const int32_t* num_obstacles; /* [N]  cylinders actually placed (required with `obstacles`) */
+  const int32_t* num_obstacles; /* [N]  cylinders actually placed (required with `obstacles`; clipped to fw_config.num_obstacles) */
   const double* wind_base;      /* [N][3]  wind_enu_mps                              envs/fixedwing_envs/fixedwing_base_env.py:135-143 */
   const double* gust_amp;       /* [N][3]  gust_amp_enu_mps                          :155-159 */
   const double* gust_phase;     /* [N]     gust_phase_rad                            :162-165 */

@@ -648,12 +648,13 @@ static int occluded(const struct fw_env* h, const oenv* e, const double cam[3], 
   return 0;
 }
 
-/* PyBullet depth-buffer value (float32, as in Camera.depthImg) of a fragment at view-axis depth t: the inverse of
- * _depth_buffer_to_meters (:691-696), z = far*near / (far - (far-near)*d)  <=>  d = far*(t-near) / (t*(far-near)). */
+/* Depth-buffer value of a fragment at view-axis depth t: the inverse of _depth_buffer_to_meters (:691-696),
+ * z = far*near / (far - (far-near)*d)  <=>  d = far*(t-near) / (t*(far-near)).  The analytic depth image is float64 (PyBullet's
+ * depthImg is float32: a quantisation of <= 3e-8 of the buffer value that belongs to the renderer, not to the functionals). */
 static double depth_buffer_of(double t, double near, double far) {
   if (t < near) t = near;
   if (t > far) t = far;
-  return (double)(float)(far * (t - near) / (t * (far - near)));
+  return far * (t - near) / (t * (far - near));
 }
 static double depth_buffer_to_meters(double d) {           /* :691-696 */
   const double near = 0.1, far = 255.0;
@@ -736,8 +737,10 @@ static void camera_capture(const struct fw_env* h, oenv* e) {
     zcnt[z] += 1.0;
   }
   for (int z = 0; z < 3; ++z) {
-    const double mean = zcnt[z] > 0.0 ? (double)(float)(zsum[z] / zcnt[z]) : 0.0;      /* np.mean of float32 values */
-    fr[5 + z] = mean > 0.0 ? depth_buffer_to_meters(mean) : 0.0;
+    const double mean = zcnt[z] > 0.0 ? zsum[z] / zcnt[z] : 0.0;                       /* float(np.mean(vals)) :718 */
+    /* `d_buf > 0.0` (:725-727) with a guard band: a third whose every fragment sits on the near plane has mean buffer exactly 0
+     * here and 1e-16 in an implementation that sums in another order; below 1e-12 (t within 1e-14 m of the near plane) is "0" */
+    fr[5 + z] = mean > 1e-12 ? depth_buffer_to_meters(mean) : 0.0;
   }
   TK(e, FW_ST_FRAME_HAS) = 1.0;
 }
@@ -1066,7 +1069,7 @@ static void env_reset(struct fw_env* h, oenv* e, uint32_t genv, const fw_scenari
     if (ov->duck_pos) for (int k = 0; k < 3; ++k) TK(e, FW_ST_DUCK_POS + k) = ov->duck_pos[3 * li + k];
     if (ov->obstacles && ov->num_obstacles) {
       int n = ov->num_obstacles[li];
-      n = n < 0 ? 0 : (n > FW_MAX_OBSTACLES ? FW_MAX_OBSTACLES : n);
+      n = n < 0 ? 0 : (n > c->num_obstacles ? c->num_obstacles : n);                   /* never more than the config allows */
       for (int o = 0; o < FW_MAX_OBSTACLES; ++o)
         for (int k = 0; k < 3; ++k) TK(e, FW_ST_OBST + 3 * o + k) = o < n ? ov->obstacles[((size_t)li * FW_MAX_OBSTACLES + o) * 3 + k] : 0.0;
       TK(e, FW_ST_NUM_OBST) = (double)n;

@@ -131,9 +131,9 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
     T tm0[3]; (void)begin_reset<T, G>(P, V, env, S0, tick0, episode, nr, wb0, wa0, wph0, tm0);     // shadow_on implies !warm_valid
     if (HASOBJ) {
       ObjState<T> O0;
-      obj_reset_state<T>(O0);
+      obj_reset_state<T, OBJ>(O0);
       if (OBJ) obj_spawn<T>(P, OC, V, env, target, leader, O0); else comb_spawn<T>(P, OC, V, env, target, leader, O0);
-      if (leader) obj_store<T>(V, env, O0);
+      if (leader) obj_store<T, OBJ>(V, env, O0);
     }
     if (leader) { store_rigid<T>(V, env, S0); D.is[env] = 0; D.sdone[env] = pack_done(target, D.epoch, 1); }
   }
@@ -152,7 +152,7 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
   T gust[2];
   gust_init<T>(P, wph, tick, gust);
   ObjState<T> O;
-  if (HASOBJ) { obj_load<T>(V, envc, O); O.near_mask = 0u; }
+  if (HASOBJ) { obj_load<T, OBJ>(V, envc, O); O.near_mask = 0u; }
   const T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
   LaneAct<T> LA; LA.cmd = (T)0; LA.a = (T)0;
   if (G == 8) lane_act_scatter<T>(S, LA);
@@ -168,7 +168,7 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
   if (chunk > 0 && leader) {
     store_rigid<T>(V, env, S);
     D.is[env] = tick;
-    if (HASOBJ) obj_store<T>(V, env, O);
+    if (HASOBJ) obj_store<T, OBJ>(V, env, O);
     D.sdone[env] = pack_done(target, D.epoch, done + chunk);
   }
 }
@@ -299,7 +299,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   rot_from_unit_quat<T>(S.q, R);
   ObjState<T> O;
   const ObjC<T>& OC = *OCp;
-  if (HASOBJ) { obj_load<T>(D, envc, O); obj_update_near_mask<T, G>(P, OC, D, envc, O, S); }
+  if (HASOBJ) { obj_load<T, OBJ>(D, envc, O); obj_update_near_mask<T, G>(P, OC, D, envc, O, S); }
   int32_t out_strike = 0;
   // shadow bookkeeping (kernel-boundary hand-off, see shadow_* above)
   unsigned long long sh_req = ~0ull, sh_done = 0ull;
@@ -359,9 +359,6 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   T nz0 = (T)0, nz1 = (T)0;
   if (pre_noise && !done_at_entry) rng_normal2<T>(P, genv, (uint32_t)episode, astep0 + (uint32_t)sub, nz0, nz1);
 
-  // latched outputs
-  T out_rew = (T)0;
-  int32_t out_flags = 0, out_reached = 0, out_steps = 0, out_strike_latched = 0;
   int phase = active ? PH_STEP : PH_DONE;
   int it = 0, warm_left = 0;
   bool resetting = false;                            // DEFER: auto-reset pending for the epilogue
@@ -375,8 +372,18 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       // ---- end of env.step(): :346, outputs, SB3 worker auto-reset ----
       step_count += 1;
       ep_return += rew;
-      out_rew = rew; out_flags = flags; out_reached = num_reached; out_steps = step_count; out_strike_latched = out_strike;
       phase = PH_DONE;
+      // the outputs of the step leave for memory here (nothing is kept live across the rest of the loop for them)
+      if (leader) {
+        reward[env] = rew;
+        terminated[env] = (uint8_t)((flags & FL_TERM) ? 1 : 0);
+        truncated[env] = (uint8_t)((flags & FL_TRUNC) ? 1 : 0);
+        if (info) {
+          int4* ip = reinterpret_cast<int4*>(info + (size_t)env * FW_INFO_DIM);
+          ip[0] = make_int4(num_reached, (flags & FL_COLLISION) ? 1 : 0, (flags & FL_OOB) ? 1 : 0, (flags & FL_COMPLETE) ? 1 : 0);
+          ip[1] = make_int4(out_strike, OBJ ? out_strike : 0, step_count, 0);
+        }
+      }
       if (DEFER) { resetting = (flags & (FL_TERM | FL_TRUNC)) && P.auto_reset; FWP(if (resetting) p_nreset += 1;) }
       if (!DEFER && (flags & (FL_TERM | FL_TRUNC)) && P.auto_reset) {
         if (G == 8) lane_act_gather<T>(S, LA);          // the terminal observation shows all six actuators
@@ -399,7 +406,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
 #pragma unroll
           for (int k = 0; k < 3; ++k) { wb[k] = V.r[(RF_WIND + k) * n + env]; wa[k] = V.r[(RF_WIND + 3 + k) * n + env]; }
           wphase = V.r[(RF_WIND + 6) * n + env];
-          if (HASOBJ) obj_load<T>(V, env, O);
+          if (HASOBJ) obj_load<T, OBJ>(V, env, O);
           if (!OBJ) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) t_mine[k] = V.r[(size_t)(RF_TARGETS + k) * n + env];     // waypoint 0, for end_reset
@@ -419,7 +426,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
             for (int k = 0; k < 3; ++k) t_mine[k] = __shfl(t_mine[k], src, kWave);
           }
           if (HASOBJ) {
-            obj_reset_state<T>(O);
+            obj_reset_state<T, OBJ>(O);
             if (OBJ) obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
             else comb_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
           }
@@ -579,16 +586,6 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
 
   if ((GENERAL || DEFER) && D.shadow_on && active && leader && (uint32_t)(sh_req >> 32) != (uint32_t)(episode + 1))
     D.sreq[env] = ((unsigned long long)(uint32_t)(episode + 1) << 32) | (unsigned long long)D.epoch;   // ask for the next episode
-  if (active && leader) {
-    reward[env] = out_rew;
-    terminated[env] = (uint8_t)((out_flags & FL_TERM) ? 1 : 0);
-    truncated[env] = (uint8_t)((out_flags & FL_TRUNC) ? 1 : 0);
-    if (info) {
-      int4* ip = reinterpret_cast<int4*>(info + (size_t)env * FW_INFO_DIM);
-      ip[0] = make_int4(out_reached, (out_flags & FL_COLLISION) ? 1 : 0, (out_flags & FL_OOB) ? 1 : 0, (out_flags & FL_COMPLETE) ? 1 : 0);
-      ip[1] = make_int4(out_strike_latched, OBJ ? out_strike_latched : 0, out_steps, 0);
-    }
-  }
   T act_obs[4] = {(T)0, (T)0, (T)0, (T)0};
   if (LANE_T) {
     // every lane runs the pass (same issue cost as one lane), the leader stores; action and waypoints come by shuffle
@@ -689,7 +686,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   }
   if (active && leader) {
     store_rigid<T>(D, env, S);
-    if (HASOBJ) obj_store<T>(D, env, O);
+    if (HASOBJ) obj_store<T, OBJ>(D, env, O);
 #pragma unroll
     for (int k = 0; k < 4; ++k) D.r[(RF_ACTION + k) * n + env] = act_obs[k];
     D.r[RF_NEW_DIST * n + env] = new_dist;
@@ -702,7 +699,9 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   }
   __syncthreads();
   flush_obs_tile<T>(tile, ld, obs, env0, EPW, D.n, Dobs);
+  FWP(long long p_capmax = HASOBJ ? O.p_cap : 0; const int p_ncapw = HASOBJ ? __popcll(__ballot(leader && O.p_ncap > 0)) : 0;)
   FWP(if (D.prof) {
+    for (int o = 32; o > 0; o >>= 1) p_capmax = max(p_capmax, (long long)__shfl_xor((long long)p_capmax, o, kWave));
     const int nr = __popcll(__ballot(leader && p_nreset > 0)), nh = __popcll(__ballot(leader && p_nhit > 0));
     for (int o = 32; o > 0; o >>= 1) {               // the reset split is per lane (divergent region): wave max
       p_r1 = max(p_r1, (long long)__shfl_xor((long long)p_r1, o, kWave));
@@ -713,6 +712,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       long long* w = D.prof + ((size_t)(D.epoch % kProfSlots) * 2 * nblk + blockIdx.x) * kProfWords;
       const long long t3 = FWP_NOW();
       w[0] = t3 - p_t0; w[1] = p_t1 - p_t0; w[2] = p_reset; w[3] = p_avi; w[4] = p_task; w[5] = t3 - p_t2; w[6] = it | (nr << 8) | (nh << 16); w[7] = p_t0; w[8] = p_r1; w[9] = p_r2; w[10] = p_r3;
+      w[11] = p_capmax | ((long long)p_ncapw << 48);
     } })
 }
 
@@ -775,7 +775,7 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
   load_rigid<T>(D, envc, S);
   ObjState<T> O;
   const ObjC<T>& OC = *OCp;
-  if (HASOBJ) obj_load<T>(D, envc, O);
+  if (HASOBJ) obj_load<T, OBJ>(D, envc, O);
   T action[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) action[k] = D.r[(RF_ACTION + k) * n + envc];
@@ -815,7 +815,7 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
       }
     }
     if (HASOBJ) {
-      obj_reset_state<T>(O);
+      obj_reset_state<T, OBJ>(O);
       if (OBJ) obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O); else comb_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
       if (COMB && ov.targets && P.num_targets > 0) { O.duck[0] = t_last[0]; O.duck[1] = t_last[1]; }   // the duck sits under the last waypoint
       if (ov.duck) {
@@ -824,7 +824,7 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
       }
       if (ov.obst && ov.nob) {
         int nob = (int)ov.nob[env];
-        nob = nob < 0 ? 0 : (nob > FW_MAX_OBSTACLES ? FW_MAX_OBSTACLES : nob);
+        nob = nob < 0 ? 0 : (nob > OC.num_obstacles ? OC.num_obstacles : nob);           // never more than the config (and its LDS row) allows
         if (leader)
           for (int o = 0; o < FW_MAX_OBSTACLES; ++o)
 #pragma unroll
@@ -882,7 +882,7 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
       D.i[IF_EPISODE * n + env] = episode;
       D.i[IF_FLAGS * n + env] = 0;
       D.i[IF_NUM_REACHED * n + env] = num_reached;
-      if (HASOBJ) obj_store<T>(D, env, O);
+      if (HASOBJ) obj_store<T, OBJ>(D, env, O);
     }
   }
   if (obs) {
@@ -1121,16 +1121,16 @@ int invalidate_shadow(fw_env* h) {
   return FW_OK;
 }
 
-// floats per env of the camera's LDS row buffer: the width padded so that the 4 envs of a half-wave start 8 banks apart
+// words per env of the camera's LDS row buffer: the width padded so that the 4 envs of a half-wave start on different banks
 inline int zrow_stride_of(int res) { return ((res + 31) / 32) * 32 + 8; }
 
 // LDS bytes: the padded [64/G][D+1] observation tile; the camera tasks on the 8-lane mapping alias it (in time) with the
-// float32 row buffer of the analytic camera, 8 envs x zrow_stride floats
+// row buffer of the analytic camera (1 / t of the nearest cylinder fragment per column), 8 envs x zrow_stride words
 template <typename T> size_t tile_bytes(const fw_env* h) {
   size_t b = sizeof(T) * (size_t)(kWave / h->lanes_per_env) * (size_t)(obs_dim_of(&h->cfg) + 1);
   if (h->cfg.task != FW_TASK_WAYPOINTS && h->lanes_per_env == 8) {
     const int res = h->cfg.camera_resolution > 0 ? h->cfg.camera_resolution : 128;
-    b = std::max(b, sizeof(float) * 8 * (size_t)zrow_stride_of(res));
+    if (h->cfg.num_obstacles > 0) b = std::max(b, sizeof(T) * 8 * (size_t)zrow_stride_of(res));
   }
   return b;
 }

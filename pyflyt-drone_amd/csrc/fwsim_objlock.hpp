@@ -40,11 +40,16 @@ struct ObjState {
   int32_t nob;
   int32_t phase;       // combined task: bit0 duck_phase, bit1 post_waypoints
   T seen_consec;
+#ifdef FW_PROFILE
+  long long p_cap = 0; int p_ncap = 0;    // dev-only: cycles spent in camera captures, number of captures (tools/wave_profile.py)
+#endif
 };
 
 template <typename T> __device__ __forceinline__ T f32r(T x) { return (T)(float)x; }
 
-template <typename T>
+// HIST = false (combined task): the 27-float vision history is not part of that task (its observation has no duck_vision,
+// envs/flatten_waypoint_env.py:68-70) -- it is neither loaded, kept in registers nor stored; its state rows stay zero
+template <typename T, bool HIST = true>
 __device__ __forceinline__ void obj_load(const DevState<T>& D, int env, ObjState<T>& O) {
   const T* b = D.r + (size_t)RF_TASK * D.npad + env;
   const size_t n = D.npad;
@@ -56,12 +61,14 @@ __device__ __forceinline__ void obj_load(const DevState<T>& D, int env, ObjState
   O.frame_has = b[FW_ST_FRAME_HAS * n];
 #pragma unroll
   for (int k = 0; k < 8; ++k) O.frame[k] = b[(FW_ST_FRAME + k) * n];
+  if (HIST) {
 #pragma unroll
-  for (int k = 0; k < kHist; ++k) O.hist[k] = (float)b[(FW_ST_HIST + k) * n];
+    for (int k = 0; k < kHist; ++k) O.hist[k] = (float)b[(FW_ST_HIST + k) * n];
+  }
   O.nob = (int32_t)b[FW_ST_NUM_OBST * n];
   O.phase = (int32_t)b[FW_ST_DUCK_PHASE * n]; O.seen_consec = b[FW_ST_SEEN_CONSEC * n];
 }
-template <typename T>
+template <typename T, bool HIST = true>
 __device__ __forceinline__ void obj_store(const DevState<T>& D, int env, const ObjState<T>& O) {
   T* b = D.r + (size_t)RF_TASK * D.npad + env;
   const size_t n = D.npad;
@@ -73,21 +80,25 @@ __device__ __forceinline__ void obj_store(const DevState<T>& D, int env, const O
   b[FW_ST_FRAME_HAS * n] = O.frame_has;
 #pragma unroll
   for (int k = 0; k < 8; ++k) b[(FW_ST_FRAME + k) * n] = O.frame[k];
+  if (HIST) {
 #pragma unroll
-  for (int k = 0; k < kHist; ++k) b[(FW_ST_HIST + k) * n] = (T)O.hist[k];
+    for (int k = 0; k < kHist; ++k) b[(FW_ST_HIST + k) * n] = (T)O.hist[k];
+  }
   b[FW_ST_NUM_OBST * n] = (T)O.nob;
   b[FW_ST_DUCK_PHASE * n] = (T)O.phase; b[FW_ST_SEEN_CONSEC * n] = O.seen_consec;
 }
 
 // _reset_duck_state :409-419
-template <typename T>
+template <typename T, bool HIST = true>
 __device__ __forceinline__ void obj_reset_state(ObjState<T>& O) {
   O.lock_steps = (T)0; O.prev_est = (T)-1; O.last_cx = (T)0.5; O.last_cy = (T)0.5; O.last_area = (T)0; O.last_depth = (T)0;
   O.since_seen = (T)60; O.filled = (T)0; O.frame_has = (T)0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) O.frame[k] = (T)0;
+  if (HIST) {
 #pragma unroll
-  for (int k = 0; k < kHist; ++k) O.hist[k] = 0.0f;
+    for (int k = 0; k < kHist; ++k) O.hist[k] = 0.0f;
+  }
   O.phase = 0; O.seen_consec = (T)0;
 }
 
@@ -278,10 +289,11 @@ __device__ __forceinline__ T cyl_hit(const ObjC<T>& OC, T cx, T cy, T hh, const 
 // throughput mapping has no LDS to spare for 64 rows; it serves the camera tasks only above 16 384 envs).
 // ------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ T depthbuf_from_inv(const ObjC<T>& OC, T inv_t) {
-  // depth-buffer value far (t - near) / (t (far - near)) = c1 (1 - near / t) of a fragment at view-axis depth t, as float32
+  // depth-buffer value far (t - near) / (t (far - near)) = c1 (1 - near / t) of a fragment at view-axis depth t (clipped to
+  // [near, far]); the analytic depth image is kept in the env dtype (PyBullet's is float32: a renderer property)
   inv_t = inv_t > OC.inv_near ? OC.inv_near : inv_t;
   inv_t = inv_t < OC.inv_far ? OC.inv_far : inv_t;
-  return (T)(float)(OC.db_c1 * ((T)1 - OC.near_ * inv_t));
+  return OC.db_c1 * ((T)1 - OC.near_ * inv_t);
 }
 template <typename T> __device__ __forceinline__ T depthbuf_to_meters(const ObjC<T>& OC, T d) {           // :691-696
   const T denom = OC.far_ - (OC.far_ - OC.near_) * d;
@@ -304,28 +316,53 @@ __device__ __forceinline__ T cyl_inv_t(const ObjC<T>& OC, T cx, T cy, T hh, cons
   return (z < (T)0 || z > hh) ? (T)0 : inv_t;
 }
 
-template <typename T> struct CamIn { T cam[3]; T R[9]; T duck[3]; int32_t nob; int32_t env; };
+// column interval [xlo, xhi] of row h//2 that a cylinder can cover (conservative: one pixel of slack, the per-pixel test
+// decides), in float: the directions inside the tangent cone of its disc, o.d <= 0 and (o.d)^2 >= |d|^2 (L^2 - r^2), d = p + a q
+__device__ __forceinline__ int cyl_columns(float ox, float oy, float r2, float px, float py, float qx, float qy, float u0, float F, float invF, float W) {
+  const float cc = ox * ox + oy * oy - r2;
+  if (!(cc > 0.f)) return 1;                                      // camera inside the cylinder (a contact ends the episode): nothing drawn
+  const float op = ox * px + oy * py, oq = ox * qx + oy * qy;
+  const float pp = px * px + py * py, pq = px * qx + py * qy, qq = qx * qx + qy * qy;
+  const float A2 = oq * oq - qq * cc, B2 = op * oq - pq * cc, C2 = op * op - pp * cc;
+  auto inside = [&](float a) { const float od = op + a * oq; return od <= 0.f && od * od >= (pp + a * (2.f * pq + a * qq)) * cc; };
+  const float amin = (0.f - u0) * invF, amax = ((W - 1.f) - u0) * invF;
+  float lo = 1.f, hi = 0.f;
+  const float d2 = B2 * B2 - A2 * C2;
+  if (d2 >= 0.f && fabsf(A2) > 1e-30f) {
+    const float sq = sqrtf(d2), ia = 1.0f / A2;
+    float r1 = (-B2 - sq) * ia, r2_ = (-B2 + sq) * ia;
+    if (r1 > r2_) { const float t_ = r1; r1 = r2_; r2_ = t_; }
+    if (inside(0.5f * (r1 + r2_))) { lo = r1; hi = r2_; }
+    else if (inside(r1 - 1.f)) { lo = amin; hi = r1; }
+    else if (inside(r2_ + 1.f)) { lo = r2_; hi = amax; }
+  } else if (inside(0.f)) { lo = amin; hi = amax; }
+  if (!(hi >= lo)) return 1;
+  float fl = floorf(u0 + F * lo) - 2.f, fh = ceilf(u0 + F * hi) + 2.f;      // float rounding + one pixel of slack
+  fl = fl < 0.f ? 0.f : fl; fh = fh > W - 1.f ? W - 1.f : fh;
+  return (fh >= fl) ? ((int)fl | ((int)fh << 16)) : 1;            // packed lo | hi << 16; 1 = (lo 1, hi 0) = empty
+}
 
 template <typename T, int G>
-__device__ __noinline__ void camera_frame(const ObjC<T>* __restrict__ OCp, const T* __restrict__ obst, int npad, const CamIn<T>* in, T* frame, float* zrow) {
-  const ObjC<T>& OC = *OCp;
-  const size_t n = (size_t)npad;
-  const int env = in->env, nob = in->nob;
+__device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevState<T>& D, int env, ObjState<T>& O,
+                                                   const Rigid<T>& S, const T R[9]) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const size_t n = D.npad;
+  const int nob = O.nob;
   const int sub = (G == 1) ? 0 : (int)(threadIdx.x & (G - 1));
   const int gbase = (int)threadIdx.x & ~(G - 1);
-  T cam[3], R[9];
+  T cam[3];
+  {
+    T offw[3];
+    mv(R, OC.cam_off, offw);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) cam[k] = in->cam[k];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) R[k] = in->R[k];
-  const T* ob = obst + env;
+    for (int k = 0; k < 3; ++k) cam[k] = S.p[k] + offw[k];
+  }
+  const T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * n + env;
   const T W = OC.W, H = OC.H, F = OC.focal, invF = OC.inv_focal;
   const int Wi = (int)W, Hi = (int)H;
   const T u0 = (T)0.5 * (W - (T)1), v0 = (T)0.5 * (H - (T)1), Rd = OC.duck_radius;
-  const T inf = (T)1e300;
   // ---- duck: sphere centre in camera coordinates (zc forward, xc right, yc down) ----
-  T Cc[3] = { in->duck[0], in->duck[1], in->duck[2] + Rd };
-  T relw[3] = { Cc[0] - cam[0], Cc[1] - cam[1], Cc[2] - cam[2] }, relb[3];
+  T relw[3] = { O.duck[0] - cam[0], O.duck[1] - cam[1], O.duck[2] + Rd - cam[2] }, relb[3];
   mtv(R, relw, relb);
   const T zc = relb[0] * OC.cam_f[0] + relb[1] * OC.cam_f[1] + relb[2] * OC.cam_f[2];
   const T xc = relb[0] * OC.cam_r[0] + relb[1] * OC.cam_r[1] + relb[2] * OC.cam_r[2];
@@ -342,68 +379,56 @@ __device__ __noinline__ void camera_frame(const ObjC<T>* __restrict__ OCp, const
     mv(R, db, g0);
     mv(R, OC.cam_r, g1);
   }
+  const bool duck_front = (zc - Rd > OC.near_) && (zc - Rd < OC.far_);
   // ---- cylinders: line-of-sight occlusion of the duck + the columns each one can cover on row h//2 (lane-parallel) ----
-  T occ_t = inf;
-  int iv[3] = { 0, 0, 0 };                    // G = 8: packed (lo | hi << 16, hi < lo = empty) of my cylinders sub, sub + 8, sub + 16
-  for (int o = sub, slot = 0; o < nob; o += G, ++slot) {
-    const T cx = ob[(3 * o) * n], cy = ob[(3 * o + 1) * n], hh = ob[(3 * o + 2) * n];
-    {
-      const T it = cyl_inv_t<T>(OC, cx, cy, hh, cam, relw[0], relw[1], relw[2]);
-      if (it > (T)1) occ_t = (T)0.5;          // a hit at 0 < t < 1 on the segment camera -> sphere centre
-    }
+  bool occluded = false;
+  int iv0 = 1, iv1 = 1, iv2 = 1;              // G = 8: packed column intervals of my cylinders sub, sub + 8, sub + 16
+  T myc[3][3] = {{(T)0, (T)0, (T)0}, {(T)0, (T)0, (T)0}, {(T)0, (T)0, (T)0}};     // G = 8: (x, y, height) of my cylinders, loaded once
+  if (nob > 0) {
     if (G == 8) {
-      // directions inside the tangent cone of the disc: o.d <= 0 and (o.d)^2 >= |d|^2 (L^2 - r^2), d = p + a q
-      const T ox = cam[0] - cx, oy = cam[1] - cy;
-      const T cc = ox * ox + oy * oy - OC.obst_radius * OC.obst_radius;
-      const T op = ox * g0[0] + oy * g0[1], oq = ox * g1[0] + oy * g1[1];
-      const T pp = g0[0] * g0[0] + g0[1] * g0[1], pq = g0[0] * g1[0] + g0[1] * g1[1], qq = g1[0] * g1[0] + g1[1] * g1[1];
-      const T A2 = oq * oq - qq * cc, B2 = op * oq - pq * cc, C2 = op * op - pp * cc;
-      auto inside = [&](T a) { const T od = op + a * oq; return od <= (T)0 && od * od >= (pp + a * ((T)2 * pq + a * qq)) * cc; };
-      const T amin = ((T)0 - u0) * invF, amax = ((W - (T)1) - u0) * invF;
-      T lo = (T)1, hi = (T)0;                                     // empty
-      const T d2 = B2 * B2 - A2 * C2;
-      if (cc > (T)0) {
-        if (d2 >= (T)0 && M<T>::fabs_(A2) > (T)1e-300) {
-          const T sq = M<T>::sqrt_(d2), ia = M<T>::rcp_(A2);
-          T r1 = (-B2 - sq) * ia, r2 = (-B2 + sq) * ia;
-          if (r1 > r2) { const T t_ = r1; r1 = r2; r2 = t_; }
-          if (inside((T)0.5 * (r1 + r2))) { lo = r1; hi = r2; }
-          else if (inside(r1 - (T)1)) { lo = amin; hi = r1; }
-          else if (inside(r2 + (T)1)) { lo = r2; hi = amax; }
-        } else if (inside((T)0)) { lo = amin; hi = amax; }
+#pragma unroll
+      for (int slot = 0; slot < 3; ++slot) {                      // all loads in flight together: one memory round trip
+        const int o = sub + 8 * slot;
+        if (o < nob) { myc[slot][0] = ob[(3 * o) * n]; myc[slot][1] = ob[(3 * o + 1) * n]; myc[slot][2] = ob[(3 * o + 2) * n]; }
       }
-      int xlo = 1, xhi = 0;
-      if (hi >= lo) {
-        T fl = floor_<T>(u0 + F * lo) - (T)1, fh = ceil_<T>(u0 + F * hi) + (T)1;     // one pixel of slack: the per-pixel test decides
-        fl = fl < (T)0 ? (T)0 : fl; fh = fh > W - (T)1 ? W - (T)1 : fh;
-        if (fh >= fl) { xlo = (int)fl; xhi = (int)fh; }
+#pragma unroll
+      for (int slot = 0; slot < 3; ++slot) {
+        const int o = sub + 8 * slot;
+        if (o < nob) {
+          const T cx = myc[slot][0], cy = myc[slot][1], hh = myc[slot][2];
+          if (duck_front) occluded |= cyl_inv_t<T>(OC, cx, cy, hh, cam, relw[0], relw[1], relw[2]) > (T)1;   // a hit at 0 < t < 1 of the segment camera -> sphere centre
+          const int packed = cyl_columns((float)(cam[0] - cx), (float)(cam[1] - cy), (float)(OC.obst_radius * OC.obst_radius), (float)g0[0], (float)g0[1],
+                                         (float)g1[0], (float)g1[1], (float)u0, (float)F, (float)invF, (float)W);
+          iv0 = slot == 0 ? packed : iv0; iv1 = slot == 1 ? packed : iv1; iv2 = slot == 2 ? packed : iv2;
+        }
       }
-      const int packed = (xhi >= xlo) ? (xlo | (xhi << 16)) : (1 | (0 << 16));
-      iv[0] = slot == 0 ? packed : iv[0]; iv[1] = slot == 1 ? packed : iv[1]; iv[2] = slot == 2 ? packed : iv[2];
+    } else {
+#pragma unroll 1
+      for (int o = 0; o < nob; ++o)
+        if (duck_front) occluded |= cyl_inv_t<T>(OC, ob[(3 * o) * n], ob[(3 * o + 1) * n], ob[(3 * o + 2) * n], cam, relw[0], relw[1], relw[2]) > (T)1;
     }
+    occluded = group_any<G>(occluded);
   }
-  occ_t = group_min<G, T>(occ_t);
   // ---- duck mask statistics ----
   T cnt = (T)0, sx = (T)0, sy = (T)0, itmax = (T)0;               // itmax = 1 / (nearest fragment depth)
   int mid_lo = 1 << 30, mid_hi = -1;                              // duck columns on row h//2
-  const bool duck_ok = (zc - Rd > OC.near_) && (zc - Rd < OC.far_) && !(occ_t < (T)1);
+  const bool duck_ok = duck_front && !occluded;
   const bool straddle = zc + Rd >= OC.far_;                       // some fragments may lie beyond the far plane: test them one by one
+  auto inv_hit = [&](T a, T b) {                                  // 1 / t of the sphere hit of pixel direction (1, a, b); 0 = miss / clipped
+    const T q = (T)1 + a * a + b * b, p = zc + a * xc + b * yc, disc = p * p - q * k2;
+    if (disc < (T)0 || p <= (T)0) return (T)0;
+    const T it = M<T>::div_(q, p - M<T>::sqrt_(disc));
+    return (it < OC.inv_near && it > OC.inv_far) ? it : (T)0;     // near < t < far
+  };
   if (duck_ok) {
     const T A = Rd * Rd - zc * zc - yc * yc;                      // < 0: the sphere is wholly in front of the near plane
     const T den = M<T>::rcp_(Rd * Rd - zc * zc);
     const T sqb = Rd * M<T>::sqrt_(M<T>::fmax_(zc * zc + yc * yc - Rd * Rd, (T)0));
-    T b_lo = (-zc * yc + sqb) * den, b_hi = (-zc * yc - sqb) * den;      // den < 0
+    const T b_lo = (-zc * yc + sqb) * den, b_hi = (-zc * yc - sqb) * den;       // den < 0
     T fy0 = ceil_<T>(v0 + F * b_lo), fy1 = floor_<T>(v0 + F * b_hi);
     fy0 = fy0 < (T)0 ? (T)0 : fy0; fy1 = fy1 > H - (T)1 ? H - (T)1 : fy1;
     const T iA = M<T>::rcp_(A);
     const int y0 = (int)fy0, y1 = (fy1 >= fy0) ? (int)fy1 : -1;
-    auto inv_hit = [&](T a, T b) {                                // 1 / t of the sphere hit of pixel direction (1, a, b); 0 = miss / clipped
-      const T q = (T)1 + a * a + b * b, p = zc + a * xc + b * yc, disc = p * p - q * k2;
-      if (disc < (T)0 || p <= (T)0) return (T)0;
-      const T num = p - M<T>::sqrt_(disc);
-      const T it = M<T>::div_(q, num);
-      return (it < OC.inv_near && it > OC.inv_far) ? it : (T)0;   // near < t < far
-    };
 #pragma unroll 1
     for (int y = y0 + sub; y <= y1; y += G) {
       const T b = ((T)y - v0) * invF;
@@ -419,14 +444,18 @@ __device__ __noinline__ void camera_frame(const ObjC<T>* __restrict__ OCp, const
         const T nn = fx1 - fx0 + (T)1;
         cnt += nn; sx += nn * (T)0.5 * (fx0 + fx1); sy += nn * (T)y;
         if (y == y_mid) { mid_lo = (int)fx0; mid_hi = (int)fx1; }
-        // nearest fragment of the row: around the closed-form minimiser of the scan line's depth profile
+        // nearest fragment of the row: one of the two pixels around the closed-form minimiser of the scan line's depth profile
+        // (rows whose continuous minimum cannot beat the best so far are skipped)
         const T rs = M<T>::rcp_(M<T>::sqrt_((T)1 + b * b));
         const T s0 = e * rs, rp = M<T>::sqrt_(M<T>::fmax_(s0 * s0 + xc * xc - k2, (T)0));
-        const T xs = u0 + F * M<T>::div_(xc, (s0 - rp) * rs);
-        T xa = floor_<T>(xs); xa = xa < fx0 ? fx0 : (xa > fx1 ? fx1 : xa);
-        T xb = xa + (T)1; xb = xb > fx1 ? fx1 : xb;
-        const T ia = inv_hit((xa - u0) * invF, b), ib = inv_hit((xb - u0) * invF, b);
-        itmax = ia > itmax ? ia : itmax; itmax = ib > itmax ? ib : itmax;
+        const T tmin_row = (s0 - rp) * rs;                        // view-axis depth of the row's nearest sphere point
+        if (tmin_row * itmax < (T)1 + (T)1e-9) {
+          const T xs = u0 + F * M<T>::div_(xc, tmin_row);
+          T xa = floor_<T>(xs); xa = xa < fx0 ? fx0 : (xa > fx1 ? fx1 : xa);
+          T xb = xa + (T)1; xb = xb > fx1 ? fx1 : xb;
+          const T ia = inv_hit((xa - u0) * invF, b), ib = inv_hit((xb - u0) * invF, b);
+          itmax = ia > itmax ? ia : itmax; itmax = ib > itmax ? ib : itmax;
+        }
       } else {
         for (T x = fx0; x <= fx1; x += (T)1) {
           const T it = inv_hit((x - u0) * invF, b);
@@ -434,110 +463,180 @@ __device__ __noinline__ void camera_frame(const ObjC<T>* __restrict__ OCp, const
         }
       }
     }
+    cnt = group_sum<G, T>(cnt); sx = group_sum<G, T>(sx); sy = group_sum<G, T>(sy);
+    itmax = -group_min<G, T>(-itmax);
+    if (G == 8) { mid_lo = group_min<G, int>(mid_lo); mid_hi = -group_min<G, int>(-mid_hi); }
   }
-  cnt = group_sum<G, T>(cnt); sx = group_sum<G, T>(sx); sy = group_sum<G, T>(sy);
-  itmax = -group_min<G, T>(-itmax);
-  if (G == 8) { mid_lo = group_min<G, int>(mid_lo); mid_hi = -group_min<G, int>(-mid_hi); }
   T visible = (T)0, cxn = (T)0, cyn = (T)0, area = (T)0, depth = (T)0;
   const bool duck_in = cnt > (T)0;
   if (duck_in) {
     visible = (T)1;
     const T ic = M<T>::rcp_(cnt);
+    (void)ic;
     cxn = M<T>::div_(M<T>::div_(sx, cnt), M<T>::fmax_((T)1, W - (T)1));
     cyn = M<T>::div_(M<T>::div_(sy, cnt), M<T>::fmax_((T)1, H - (T)1));
-    (void)ic;
     area = M<T>::div_(cnt, M<T>::fmax_((T)1, H * W));
     depth = depthbuf_to_meters<T>(OC, depthbuf_from_inv<T>(OC, itmax));
   }
-  frame[0] = visible; frame[1] = cxn; frame[2] = cyn; frame[3] = area; frame[4] = depth;
-  // ---- obstacle zones: row h//2 as float32 depth-buffer values ----
+  O.frame[0] = visible; O.frame[1] = cxn; O.frame[2] = cyn; O.frame[3] = area; O.frame[4] = depth;
+  // ---- obstacle zones: mean depth-buffer value of the non-duck pixels of each third of row h//2 ----
+  // Everything is accumulated as sum of clip(1 / t, 1 / far, 1 / near): the buffer value is c1 (1 - near / t), affine in 1 / t.
+  //  * ground / sky: 1 / t = -(g0z + a g1z) / cam_z is LINEAR in the column, so the sum over a run of columns is an arithmetic
+  //    series between the two columns where it meets the clip planes -- closed form, no per-pixel work.  A third minus the
+  //    duck's columns is at most two runs: six (third, run) pairs, one per lane of the env's group.
+  //  * cylinders: the nearest cylinder fragment of every covered pixel goes to an LDS row (max of 1 / t; lane j owns the
+  //    pixels x = j mod 8, 4 independent pixels in flight per lane), then every lane adds max(cyl, ground) - ground of its
+  //    pixels to the third's sum.  (G = 1: one lane, pixel by pixel against every cylinder.)
   const T inv_camz = cam[2] > (T)0 ? M<T>::rcp_(cam[2]) : (T)0;
-  auto is_duck = [&](int x) {
-    if (!duck_in) return false;
-    if (!straddle) return x >= mid_lo && x <= mid_hi;
-    const T a = ((T)x - u0) * invF;
-    const T q = (T)1 + a * a + bm * bm, p = zc + a * xc + bm * yc, disc = p * p - q * k2;
-    if (disc < (T)0 || p <= (T)0) return false;
-    const T it = M<T>::div_(q, p - M<T>::sqrt_(disc));
-    return it < OC.inv_near && it > OC.inv_far;
+  const T gk1 = -g1[2] * invF * inv_camz, gk0 = -g0[2] * inv_camz - u0 * gk1;       // ground: 1 / t at column x = gk0 + gk1 x
+  auto git = [&](T x) { T it = gk0 + gk1 * x; it = it > OC.inv_near ? OC.inv_near : it; return it < OC.inv_far ? OC.inv_far : it; };
+  // columns where the ground's 1 / t crosses the clip values
+  T xf_ = (T)0, xn_ = (T)0;
+  const bool sloped = gk1 != (T)0;
+  if (sloped) { const T ig = M<T>::rcp_(gk1); xf_ = (OC.inv_far - gk0) * ig; xn_ = (OC.inv_near - gk0) * ig; }
+  auto run_sum = [&](int p_, int q_, T& sum, int& cntr) {         // adds sum of clip(1/t) over the columns [p_, q_)
+    if (q_ <= p_) return;
+    const T p = (T)p_, q = (T)q_;
+    cntr += q_ - p_;
+    if (!sloped) { sum += (q - p) * git((T)0); return; }
+    // linear part [u, w): far-clipped on one side, near-clipped on the other (which side depends on the sign of the slope)
+    T u, w, nlo, nhi;                                             // nlo / nhi: clip value below u / from w on
+    if (gk1 > (T)0) { u = ceil_<T>(xf_); w = floor_<T>(xn_) + (T)1; nlo = OC.inv_far; nhi = OC.inv_near; }
+    else { u = ceil_<T>(xn_); w = floor_<T>(xf_) + (T)1; nlo = OC.inv_near; nhi = OC.inv_far; }
+    u = u < p ? p : (u > q ? q : u); w = w < u ? u : (w > q ? q : w);
+    const T m = w - u;
+    sum += (u - p) * nlo + (q - w) * nhi + gk0 * m + gk1 * ((T)0.5 * m * (u + w - (T)1));
   };
-  T zs[3] = { (T)0, (T)0, (T)0 }, zn[3] = { (T)0, (T)0, (T)0 };
+  // (no runtime-indexed private arrays below: thirds are picked with selects)
+  auto z_lo = [&](int z) { return z == 0 ? 0 : (z == 1 ? x_1 : x_2); };
+  auto z_hi = [&](int z) { return z == 0 ? x_1 : (z == 1 ? x_2 : Wi); };
+  const bool exact_duck = duck_in && straddle;                    // duck columns not one interval: pixel by pixel below
+  const int dlo = (duck_in && !straddle) ? mid_lo : (1 << 30), dhi = (duck_in && !straddle) ? mid_hi : -1;
+  T zsum[3] = { (T)0, (T)0, (T)0 };
+  int zcnt[3] = { 0, 0, 0 };
   if (G == 8) {
-    float* zr = zrow;
-#pragma unroll 1
-    for (int x = sub; x < Wi; x += G) {                           // ground / sky
-      const T a = ((T)x - u0) * invF, dz = g0[2] + a * g1[2];
-      const T it = dz < (T)0 ? -dz * inv_camz : (T)0;
-      zr[x] = (float)depthbuf_from_inv<T>(OC, it);
+    T msum = (T)0; int mcnt = 0;
+    if (sub < 6) {
+      const int z = sub >> 1, r = sub & 1;
+      const int za = z_lo(z), zb = z_hi(z);
+      // run 0: [za, min(zb, max(dlo, za)));  run 1: [max(za, dhi + 1), zb) if the duck starts before the third's end
+      if (r == 0) run_sum(za, dlo < zb ? (dlo > za ? dlo : za) : zb, msum, mcnt);
+      else if (dlo < zb) run_sum((dhi + 1) > za ? (dhi + 1) : za, zb, msum, mcnt);
     }
-#pragma unroll 1
-    for (int o = 0; o < nob; ++o) {                               // group-uniform: every lane of the env walks the same cylinder
-      const int slot = o >> 3;
-      const int mine = slot == 0 ? iv[0] : (slot == 1 ? iv[1] : iv[2]);
-      const int packed = __shfl(mine, gbase | (o & 7), kWave);
-      const int xlo = packed & 0xFFFF, xhi = packed >> 16;
-      if (xhi < xlo) continue;
-      const T cx = ob[(3 * o) * n], cy = ob[(3 * o + 1) * n], hh = ob[(3 * o + 2) * n];
-      int x = xlo + ((sub - xlo) & 7);                            // my first pixel (x = sub mod 8) inside the interval
-#pragma unroll 1
-      for (; x <= xhi; x += G) {
-        const T a = ((T)x - u0) * invF;
-        const T it = cyl_inv_t<T>(OC, cx, cy, hh, cam, g0[0] + a * g1[0], g0[1] + a * g1[1], g0[2] + a * g1[2]);
-        if (it > (T)0) { const float v = (float)depthbuf_from_inv<T>(OC, it); zr[x] = v < zr[x] ? v : zr[x]; }
-      }
-    }
-#pragma unroll 1
-    for (int x = sub; x < Wi; x += G) {
-      if (is_duck(x)) continue;                                   // mask = seg != duck_id
-      const int z = x < x_1 ? 0 : (x < x_2 ? 1 : 2);
-      const T v = (T)zr[x];
-      zs[0] += z == 0 ? v : (T)0; zs[1] += z == 1 ? v : (T)0; zs[2] += z == 2 ? v : (T)0;
-      zn[0] += z == 0 ? (T)1 : (T)0; zn[1] += z == 1 ? (T)1 : (T)0; zn[2] += z == 2 ? (T)1 : (T)0;
+#pragma unroll
+    for (int z = 0; z < 3; ++z) {
+      zsum[z] = group_sum<G, T>((sub >> 1) == z && sub < 6 ? msum : (T)0);
+      zcnt[z] = (int)group_sum<G, float>((sub >> 1) == z && sub < 6 ? (float)mcnt : 0.f);
     }
   } else {
-#pragma unroll 1
-    for (int x = 0; x < Wi; ++x) {
-      if (is_duck(x)) continue;
-      const T a = ((T)x - u0) * invF;
-      const T dwx = g0[0] + a * g1[0], dwy = g0[1] + a * g1[1], dwz = g0[2] + a * g1[2];
-      T it = dwz < (T)0 ? -dwz * inv_camz : (T)0;
-      it = it > OC.inv_near ? OC.inv_near : it;                   // (the oracle clamps the ground hit before comparing)
-      for (int o = 0; o < nob; ++o) {
-        const T ic = cyl_inv_t<T>(OC, ob[(3 * o) * n], ob[(3 * o + 1) * n], ob[(3 * o + 2) * n], cam, dwx, dwy, dwz);
-        it = ic > it ? ic : it;
-      }
-      const int z = x < x_1 ? 0 : (x < x_2 ? 1 : 2);
-      const T v = depthbuf_from_inv<T>(OC, it);
-      zs[0] += z == 0 ? v : (T)0; zs[1] += z == 1 ? v : (T)0; zs[2] += z == 2 ? v : (T)0;
-      zn[0] += z == 0 ? (T)1 : (T)0; zn[1] += z == 1 ? (T)1 : (T)0; zn[2] += z == 2 ? (T)1 : (T)0;
+#pragma unroll
+    for (int z = 0; z < 3; ++z) {
+      const int za = z_lo(z), zb = z_hi(z);
+      run_sum(za, dlo < zb ? (dlo > za ? dlo : za) : zb, zsum[z], zcnt[z]);
+      if (dlo < zb) run_sum((dhi + 1) > za ? (dhi + 1) : za, zb, zsum[z], zcnt[z]);
     }
+  }
+  if (exact_duck) {                                               // rare: take the duck's pixels of row h//2 out one by one
+    T dsum[3] = { (T)0, (T)0, (T)0 }; int dcnt[3] = { 0, 0, 0 };
+    for (int x = sub; x < Wi; x += G) {
+      if (inv_hit(((T)x - u0) * invF, bm) > (T)0) {
+        const T v = git((T)x);
+        dsum[0] += x < x_1 ? v : (T)0; dsum[1] += (x >= x_1 && x < x_2) ? v : (T)0; dsum[2] += x >= x_2 ? v : (T)0;
+        dcnt[0] += x < x_1 ? 1 : 0; dcnt[1] += (x >= x_1 && x < x_2) ? 1 : 0; dcnt[2] += x >= x_2 ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int z = 0; z < 3; ++z) { zsum[z] -= group_sum<G, T>(dsum[z]); zcnt[z] -= (int)group_sum<G, float>((float)dcnt[z]); }
+  }
+  if (nob > 0) {
+    const T pp = g0[0] * g0[0] + g0[1] * g0[1], pq = g0[0] * g1[0] + g0[1] * g1[1], qq = g1[0] * g1[0] + g1[1] * g1[1];
+    const T r2 = OC.obst_radius * OC.obst_radius;
+    auto is_duck = [&](int x) {
+      if (!duck_in) return false;
+      if (!straddle) return x >= mid_lo && x <= mid_hi;
+      return inv_hit(((T)x - u0) * invF, bm) > (T)0;
+    };
+    // 1 / t of the cylinder's fragment in column a (0 = none): no division for the hit / height tests
+    auto cyl_it = [&](T a, T ox, T oy, T cc, T op, T oq, T hh) {
+      const T A = pp + a * ((T)2 * pq + a * qq), hb = op + a * oq, disc = hb * hb - A * cc;
+      if (!(A > (T)0) || disc < (T)0 || hb >= (T)0) return (T)0;
+      const T num = -hb - M<T>::sqrt_(disc);
+      const T zA = cam[2] * A + num * (g0[2] + a * g1[2]);         // z of the hit times A
+      if (!(num > (T)0) || zA < (T)0 || zA > hh * A) return (T)0;
+      (void)ox; (void)oy;
+      return M<T>::div_(A, num);
+    };
+    T csum[3] = { (T)0, (T)0, (T)0 };
+    if (G == 8) {
+      T* zr = reinterpret_cast<T*>(smem_raw) + (size_t)((threadIdx.x & (kWave - 1)) / G) * OC.zrow_stride;   // this env's LDS row (aliases
+                                                                  // the observation tile, which is only written after the step loop)
+#pragma unroll 4
+      for (int x = sub; x < Wi; x += G) zr[x] = (T)0;
+#pragma unroll 1
+      for (int o = 0; o < nob; ++o) {                             // group-uniform: every lane of the env walks the same cylinder
+        const int slot = o >> 3;
+        const int mine = slot == 0 ? iv0 : (slot == 1 ? iv1 : iv2);
+        const int packed = __shfl(mine, gbase | (o & 7), kWave);
+        const int xlo = packed & 0xFFFF, xhi = packed >> 16;
+        if (xhi < xlo) continue;
+        const int src = gbase | (o & 7);                          // the lane that loaded this cylinder hands its coordinates over
+        const T cx = __shfl(slot == 0 ? myc[0][0] : (slot == 1 ? myc[1][0] : myc[2][0]), src, kWave);
+        const T cy = __shfl(slot == 0 ? myc[0][1] : (slot == 1 ? myc[1][1] : myc[2][1]), src, kWave);
+        const T hh = __shfl(slot == 0 ? myc[0][2] : (slot == 1 ? myc[1][2] : myc[2][2]), src, kWave);
+        const T ox = cam[0] - cx, oy = cam[1] - cy, cc = ox * ox + oy * oy - r2;
+        const T op = ox * g0[0] + oy * g0[1], oq = ox * g1[0] + oy * g1[1];
+#pragma unroll 1
+        for (int x = xlo + ((sub - xlo) & 7); x <= xhi; x += 4 * G) {       // my pixels (x = sub mod 8) of the interval, 4 at a time
+          T it4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int xx = x + u * G;
+            it4[u] = xx <= xhi ? cyl_it(((T)xx - u0) * invF, ox, oy, cc, op, oq, hh) : (T)0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int xx = x + u * G;
+            if (it4[u] > (T)0) { const T c = zr[xx]; zr[xx] = it4[u] > c ? it4[u] : c; }
+          }
+        }
+      }
+#pragma unroll 2
+      for (int x = sub; x < Wi; x += G) {                          // covered pixels: the nearer of cylinder and ground replaces the ground
+        T c = zr[x];
+        if (c > (T)0 && !is_duck(x)) {
+          c = c > OC.inv_near ? OC.inv_near : c;
+          const T gnd = git((T)x), d = c > gnd ? c - gnd : (T)0;
+          csum[0] += x < x_1 ? d : (T)0; csum[1] += (x >= x_1 && x < x_2) ? d : (T)0; csum[2] += x >= x_2 ? d : (T)0;
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int x = 0; x < Wi; ++x) {
+        if (is_duck(x)) continue;
+        const T a = ((T)x - u0) * invF;
+        T c = (T)0;
+        for (int o = 0; o < nob; ++o) {
+          const T cx = ob[(3 * o) * n], cy = ob[(3 * o + 1) * n], hh = ob[(3 * o + 2) * n];
+          const T ox = cam[0] - cx, oy = cam[1] - cy;
+          const T ic = cyl_it(a, ox, oy, ox * ox + oy * oy - r2, ox * g0[0] + oy * g0[1], ox * g1[0] + oy * g1[1], hh);
+          c = ic > c ? ic : c;
+        }
+        if (c > (T)0) {
+          c = c > OC.inv_near ? OC.inv_near : c;
+          const T gnd = git((T)x), d = c > gnd ? c - gnd : (T)0;
+          csum[0] += x < x_1 ? d : (T)0; csum[1] += (x >= x_1 && x < x_2) ? d : (T)0; csum[2] += x >= x_2 ? d : (T)0;
+        }
+      }
+    }
+#pragma unroll
+    for (int z = 0; z < 3; ++z) zsum[z] += group_sum<G, T>(csum[z]);
   }
 #pragma unroll
   for (int z = 0; z < 3; ++z) {
-    const T ssum = group_sum<G, T>(zs[z]), scnt = group_sum<G, T>(zn[z]);
-    const T mean = scnt > (T)0 ? (T)(float)M<T>::div_(ssum, scnt) : (T)0;       // np.mean of float32 values
-    frame[5 + z] = mean > (T)0 ? depthbuf_to_meters<T>(OC, mean) : (T)0;
+    // mean buffer value = c1 (1 - near * mean(1 / t));  float(np.mean(vals)) :718, then metres unless the mean is 0 :725-727
+    const T mean = zcnt[z] > 0 ? OC.db_c1 * ((T)1 - OC.near_ * M<T>::div_(zsum[z], (T)zcnt[z])) : (T)0;
+    O.frame[5 + z] = mean > (T)1e-12 ? depthbuf_to_meters<T>(OC, mean) : (T)0;       // (guard band of the `> 0.0` test: see the oracle)
   }
-}
-
-template <typename T, int G>
-__device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevState<T>& D, int env, ObjState<T>& O,
-                                                   const Rigid<T>& S, const T R[9]) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  CamIn<T> in;
-  T offw[3];
-  mv(R, OC.cam_off, offw);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { in.cam[k] = S.p[k] + offw[k]; in.duck[k] = O.duck[k]; }
-#pragma unroll
-  for (int k = 0; k < 9; ++k) in.R[k] = R[k];
-  in.nob = O.nob; in.env = env;
-  T fr[8];
-  // G = 8: this env's slice of the row buffer (aliases the observation tile, which is only written after the step loop)
-  float* zrow = (G == 8) ? reinterpret_cast<float*>(smem_raw) + (size_t)((threadIdx.x & (kWave - 1)) / G) * OC.zrow_stride : nullptr;
-  camera_frame<T, G>(&OC, D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad, D.npad, &in, fr, zrow);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) O.frame[k] = fr[k];
   O.frame_has = (T)1;
 }
 
@@ -752,7 +851,15 @@ __device__ __forceinline__ bool aviary_step(const Params<T>& P, const TickC<T>& 
     tick += 1;
     if (WIND) gust_advance<T>(P, gust);
   }
-  if (OBJ && OC.camera_ratio_ticks > 0 && (tick % OC.camera_ratio_ticks) == 0) obj_camera_capture<T, G>(OC, D, env, O, S, R);
+  if (OBJ && OC.camera_ratio_ticks > 0 && (tick % OC.camera_ratio_ticks) == 0) {
+#ifdef FW_PROFILE
+    const long long c0 = (long long)__builtin_readcyclecounter();
+#endif
+    obj_camera_capture<T, G>(OC, D, env, O, S, R);
+#ifdef FW_PROFILE
+    O.p_cap += (long long)__builtin_readcyclecounter() - c0; O.p_ncap += 1;
+#endif
+  }
   return contact;
 }
 

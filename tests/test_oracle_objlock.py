@@ -240,7 +240,7 @@ def np_render_frame(oracle, cfg, st, res):
     if blocked or not (near < zc - Rd < far):
         duck[:] = False
     depth = np.where(duck, t, depth); seg = np.where(duck, 2, seg)
-    dbuf = (far * (np.clip(depth, near, far) - near) / (np.clip(depth, near, far) * (far - near))).astype(np.float32)   # depthImg
+    dbuf = far * (np.clip(depth, near, far) - near) / (np.clip(depth, near, far) * (far - near))     # depthImg (float64 here)
     to_m = lambda v: far * near / (far - (far - near) * float(v))
     out = np.zeros(8)
     mask = seg == 2
@@ -251,8 +251,8 @@ def np_render_frame(oracle, cfg, st, res):
     for zi, (xa, xb) in enumerate(((0, x1), (x1, x2), (x2, W))):
         zm = ~mask[ym, xa:xb]
         if zm.any():
-            m = np.float32(dbuf[ym, xa:xb][zm].astype(np.float64).mean())
-            out[5 + zi] = to_m(m) if m > 0 else 0.0
+            m = float(np.mean(dbuf[ym, xa:xb][zm]))
+            out[5 + zi] = to_m(m) if m > 1e-12 else 0.0                      # (guard band of the `> 0.0` test, see the oracle)
     return out, mask, dbuf
 
 
@@ -296,31 +296,39 @@ def test_frame_functionals_match_a_numpy_render(oracle):
             got = st[T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
             assert got[0] == want[0], (res, trial)
             np.testing.assert_allclose(got[1:4], want[1:4], rtol=0, atol=1e-15, err_msg=f"mask statistics {res} {trial}")
-            np.testing.assert_allclose(got[4:], want[4:], rtol=1e-6, atol=1e-9, err_msg=f"depths {res} {trial}")   # float32 buffer values
+            np.testing.assert_allclose(got[4:], want[4:], rtol=1e-9, atol=1e-9, err_msg=f"depths {res} {trial}")
             seen_vis += int(want[0]); seen_mid += int(mask[res // 2].any())
             seen_clip += int(mask.any() and (mask[0].any() or mask[-1].any() or mask[:, 0].any() or mask[:, -1].any()))
         assert seen_vis >= 5 and seen_mid >= 2, (res, seen_vis, seen_clip, seen_mid)
 
 
-def test_level_flight_over_flat_ground_has_closed_form_zone_depths(oracle):
-    """No roll, no obstacles, no duck in view: every ray of row h//2 meets the ground at the same view-axis depth
-    t = cam_z / -(f_z + b d_z), so the buffer mean of each third is that one value and all three zone depths equal t (to
-    the float32 resolution of the depth buffer).  The mean is taken over BUFFER values: put a near cylinder into one third
-    and its zone depth is far from the arithmetic mean of the metric depths."""
+def test_flight_over_flat_ground_has_closed_form_zone_depths(oracle):
+    """No obstacles, no duck in view: along row h//2 the ground's depth-BUFFER value is linear in the column
+    (1/t = -dw_z / cam_z and dw is affine in the column), so the mean of a third is the buffer value at its mean column and
+    its zone depth is the ground depth of that one ray -- for level flight all three are equal, with roll they differ
+    exactly as the closed form says.  (A mean of METRIC depths would not have this property.)"""
     cfg = quiet(duck_camera_capture_interval_steps=1, camera_resolution=480)
-    env = make(oracle, cfg)
-    _pose(env, [0.0, 0.0, 30.0], [0.0, 0.2, 0.0], [-500.0, 0.0, 0.05], oracle)      # pitched 0.2 rad nose down, duck behind
-    step0(env)
-    st = env.get_state()[0]
-    fr = st[T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
-    R = oracle.mat_from_quat(st[K.S_QUAT:K.S_QUAT + 4])
-    cam = st[K.S_POS:K.S_POS + 3] + R @ np.array([0.8, 0.0, 0.12])
-    th = math.radians(-5.0); f = np.array([math.cos(th), 0, math.sin(th)]); d = np.cross(f, [0.0, -1.0, 0.0])
-    b = (480 // 2 - 239.5) / 240.0
-    t = cam[2] / -((R @ (f + b * d))[2])
-    assert fr[0] == 0 and 50.0 < t < 150.0
-    quant = t * t * (255.0 - 0.1) / (255.0 * 0.1) * 6e-8                            # one float32 ulp of the buffer, in metres
-    np.testing.assert_allclose(fr[5:8], [t, t, t], rtol=0, atol=2 * quant)
+    for roll in (0.0, 0.08, -0.1):                                                   # (small enough that no ray of the row reaches the far plane)
+        env = make(oracle, cfg)
+        _pose(env, [0.0, 0.0, 30.0], [roll, 0.2, 0.3], [-500.0, 0.0, 0.05], oracle)   # pitched 0.2 rad nose down, duck behind
+        step0(env)
+        st = env.get_state()[0]
+        fr = st[T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
+        R = oracle.mat_from_quat(st[K.S_QUAT:K.S_QUAT + 4])
+        cam = st[K.S_POS:K.S_POS + 3] + R @ np.array([0.8, 0.0, 0.12])
+        th = math.radians(-5.0); f = np.array([math.cos(th), 0, math.sin(th)]); r = np.array([0.0, -1.0, 0.0]); d = np.cross(f, r)
+        b = (480 // 2 - 239.5) / 240.0
+        want = []
+        for xa, xb in ((0, 160), (160, 320), (320, 480)):
+            a = (0.5 * (xa + xb - 1) - 239.5) / 240.0                                  # mean column of the third
+            want.append(cam[2] / -((R @ (f + a * r + b * d))[2]))
+        edge = [cam[2] / -((R @ (f + ((x - 239.5) / 240.0) * r + b * d))[2]) for x in (0, 479)]
+        assert fr[0] == 0 and all(30.0 < t < 250.0 for t in want + edge)
+        np.testing.assert_allclose(fr[5:8], want, rtol=1e-10, atol=0)
+        if roll == 0.0:
+            assert abs(want[0] - want[2]) < 0.05 * want[1]
+        else:
+            assert abs(want[0] - want[2]) > 0.05 * want[1]                             # roll tilts the row: left and right thirds differ
 
 
 def test_half_clipped_disc_shifts_the_centroid(oracle):
@@ -376,7 +384,7 @@ def test_obstacle_occludes_and_collides(oracle):
     st = env.get_state()[0]
     fr = st[T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
     want, mask, dbuf = np_render_frame(oracle, cfg, st, 128)
-    np.testing.assert_allclose(fr, want, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(fr, want, rtol=1e-9, atol=1e-9)
     assert fr[0] == 0 and not mask.any() and not term[0]                            # the duck is hidden behind the cylinder
     # the centre third holds the cylinder's columns (about 57 m away) among ground / sky pixels: the zone depth is the depth of
     # the MEAN BUFFER VALUE (:713-729) -- between the cylinder and the far ground, nowhere near the arithmetic mean of the depths

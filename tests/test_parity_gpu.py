@@ -546,7 +546,7 @@ def test_camera_frame_statistics_match_the_oracle_on_directed_poses(oracle, lane
         fo = ora.get_state()[:, T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
         assert np.array_equal(fh[:, 0], fo[:, 0]), np.nonzero(fh[:, 0] != fo[:, 0])[0]
         np.testing.assert_allclose(fh[:, 1:4], fo[:, 1:4], rtol=0, atol=1e-15, err_msg=f"mask statistics, res {res}")
-        np.testing.assert_allclose(fh[:, 4:], fo[:, 4:], rtol=1e-6, atol=1e-9, err_msg=f"depths, res {res}")
+        np.testing.assert_allclose(fh[:, 4:], fo[:, 4:], rtol=1e-9, atol=1e-9, err_msg=f"depths, res {res}")
         vis = fo[:, 0] > 0
         assert vis.sum() > n // 4 and (~vis).sum() > 10
         if nobs:

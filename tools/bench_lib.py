@@ -7,7 +7,11 @@ import pyflyt_drone_amd as P
 from pyflyt_drone_amd import config as K, _lib
 if len(sys.argv) > 1 and sys.argv[1] != "-": _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 CFG = {"waypoints": K.train_waypoints_v3_config, "objlock": K.train_objlock_config, "combined": K.train_waypoint_objlock_config,
-       "waypoints_wind": lambda: K.train_waypoints_v3_config(wind_config=K.TRAIN_OBJLOCK_WIND)}
+       "waypoints_wind": lambda: K.train_waypoints_v3_config(wind_config=K.TRAIN_OBJLOCK_WIND),
+       "combined_noobst": lambda: K.train_waypoint_objlock_config(num_obstacles=0),
+       "combined_nocam": lambda: K.train_waypoint_objlock_config(duck_camera_capture_interval_steps=10 ** 6),
+       "combined_noobst_nocam": lambda: K.train_waypoint_objlock_config(num_obstacles=0, duck_camera_capture_interval_steps=10 ** 6),
+       "objlock_nocam": lambda: K.train_objlock_config(duck_camera_capture_interval_steps=10 ** 6)}
 N = int(os.environ.get("N", 4096))
 for which in sys.argv[2:] or ["waypoints"]:
     e = P.FixedwingVecEnv(CFG[which](), N, seed=42); e.reset_tensor()

@@ -37,5 +37,9 @@ print(f"  slowest wave reset split: terminal obs {S[:, 8].mean():.0f}  swap-in /
 print(f"  loop iterations: mean {it.mean():.2f}  slowest-wave mean {(S[:, 6] & 0xFF).mean():.2f}  max {it.max()}")
 print(f"  env resets/launch {nr.sum(axis=1).mean():.1f}  of which swapped-in shadows {nh.sum(axis=1).mean():.1f}")
 print(f"  waves with a reset: {100.0 * (nr > 0).mean():.1f}%   with an in-kernel (fallback) reset: {100.0 * ((nr - nh) > 0).mean():.1f}%")
+cap = st[:, :, 11] & ((1 << 48) - 1); ncap = st[:, :, 11] >> 48
+if cap.any():
+    print(f"  camera: envs capturing per wave-step {ncap.mean():.2f} of {N // nblk}; cycles in captures per wave-step: mean {cap.mean():.0f}  "
+          f"slowest wave {(S[:, 11] & ((1 << 48) - 1)).mean():.0f}; waves with a capture {100.0 * (ncap > 0).mean():.1f}%")
 if wk.any():
     print(f"  shadow worker waves: busy {100.0 * (wk > 2000).mean():.1f}%  mean busy cycles {wk[wk > 2000].mean() if (wk > 2000).any() else 0:.0f}  max {wk.max()}")
