@@ -14,7 +14,7 @@ from . import config as K
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libfwsim_hip.so")
+LIB_PATH = os.environ.get("FWSIM_LIB") or os.path.join(CSRC, "libfwsim_hip.so")      # FWSIM_LIB: A/B builds of the same ABI (dev tools)
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 EXPORTS = (

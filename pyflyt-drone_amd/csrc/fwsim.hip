@@ -139,7 +139,7 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
   }
   if (__ballot(left > 0) == 0ull) return;
   TickC<T> C; SurfC<T> mine; T wmask;
-  load_tick_constants<T, G>(Pp, C, mine, wmask);
+  load_tick_constants<T, G, false>(Pp, C, mine, wmask);
   Rigid<T> S;
   load_rigid<T>(V, envc, S);
   T R[9];
@@ -292,7 +292,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   T ep_return = D.r[RF_EP_RETURN * n + envc];
   // tick constants + this lane's lifting surface (G = 8: resident in VGPRs for the whole launch)
   TickC<T> C; SurfC<T> mine; T wmask;
-  load_tick_constants<T, G>(Pp, C, mine, wmask);
+  load_tick_constants<T, G, DEFER && G == 8>(Pp, C, mine, wmask);
 
   normalize_quat<T>(S.q);
   T R[9];
@@ -769,7 +769,7 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
   const int Dobs = P.obs_dim;
   const int ld = Dobs + 1;
   TickC<T> C; SurfC<T> mine; T wmask;
-  load_tick_constants<T, G>(Pp, C, mine, wmask);
+  load_tick_constants<T, G, false>(Pp, C, mine, wmask);
 
   Rigid<T> S;
   load_rigid<T>(D, envc, S);
@@ -1130,7 +1130,8 @@ template <typename T> size_t tile_bytes(const fw_env* h) {
   size_t b = sizeof(T) * (size_t)(kWave / h->lanes_per_env) * (size_t)(obs_dim_of(&h->cfg) + 1);
   if (h->cfg.task != FW_TASK_WAYPOINTS && h->lanes_per_env == 8) {
     const int res = h->cfg.camera_resolution > 0 ? h->cfg.camera_resolution : 128;
-    if (h->cfg.num_obstacles > 0) b = std::max(b, sizeof(T) * 8 * (size_t)zrow_stride_of(res));
+    if (h->cfg.num_obstacles > 0)                      // 8 rows + the per-env table of 8 words per cylinder
+      b = std::max(b, sizeof(T) * 8 * ((size_t)zrow_stride_of(res) + (size_t)FW_MAX_OBSTACLES * 8));
   }
   return b;
 }

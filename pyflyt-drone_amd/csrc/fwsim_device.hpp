@@ -514,10 +514,15 @@ __device__ __forceinline__ int opaque_zero() {
   return z;
 }
 
-template <typename T, int G>
+// RESIDENT = true (wind-free waypoints kernel on the 8-lane mapping): the shared constants are loaded through a per-lane
+// address and stay in VGPRs.  The wind / camera kernels keep far more per-env state in registers; there the shared
+// constants stay wave-uniform (scalar loads), which takes ~80 VGPRs off the peak (their spills went 84 -> 38) at no cost
+// in time (measured: waypoints + wind 27.2 us either way, ObjLock 41.6 -> 39.2 us).  This lane's surface is per-lane data
+// in both cases.
+template <typename T, int G, bool RESIDENT = (G == 8)>
 __device__ __forceinline__ void load_tick_constants(const Params<T>* Pp, TickC<T>& C, SurfC<T>& mine, T& wmask) {
   const int sub = (G == 1) ? 0 : (int)(threadIdx.x & (G - 1));
-  const Params<T>* Q = (G == 1) ? Pp : Pp + opaque_zero();     // per-lane address => vector loads => VGPR residency
+  const Params<T>* Q = (G == 1 || !RESIDENT) ? Pp : Pp + opaque_zero();     // per-lane address => vector loads => VGPR residency
 #pragma unroll
   for (int s = 0; s < FW_NUM_SURFACES; ++s) C.dt_tau[s] = Q->s[s].dt_tau;
   C.motor_dt_tau = Q->motor_dt_tau; C.noise_ratio = Q->noise_ratio;

@@ -382,26 +382,42 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
   const bool duck_front = (zc - Rd > OC.near_) && (zc - Rd < OC.far_);
   // ---- cylinders: line-of-sight occlusion of the duck + the columns each one can cover on row h//2 (lane-parallel) ----
   bool occluded = false;
-  int iv0 = 1, iv1 = 1, iv2 = 1;              // G = 8: packed column intervals of my cylinders sub, sub + 8, sub + 16
-  T myc[3][3] = {{(T)0, (T)0, (T)0}, {(T)0, (T)0, (T)0}, {(T)0, (T)0, (T)0}};     // G = 8: (x, y, height) of my cylinders, loaded once
+  uint32_t vis = 0u;                          // G = 8: cylinders that can show on row h//2 (group-uniform after the OR below)
+  // G = 8: LDS of this env -- the row buffer (1 / t of the nearest cylinder fragment per column; aliases the observation tile,
+  // which is only written after the step loop) and, behind the 8 rows, a table of 8 words per cylinder filled by the lane
+  // that screened it: ox, oy, cc, hh, op, oq, first column, last column
+  const int erow = (int)((threadIdx.x & (kWave - 1)) / G);
+  T* zr = (G == 8) ? reinterpret_cast<T*>(smem_raw) + (size_t)erow * OC.zrow_stride : nullptr;
+  T* ctab = (G == 8) ? reinterpret_cast<T*>(smem_raw) + (size_t)8 * OC.zrow_stride + (size_t)erow * (FW_MAX_OBSTACLES * 8) : nullptr;
   if (nob > 0) {
     if (G == 8) {
+      T myc[3][3];
 #pragma unroll
       for (int slot = 0; slot < 3; ++slot) {                      // all loads in flight together: one memory round trip
         const int o = sub + 8 * slot;
+        myc[slot][0] = myc[slot][1] = myc[slot][2] = (T)0;
         if (o < nob) { myc[slot][0] = ob[(3 * o) * n]; myc[slot][1] = ob[(3 * o + 1) * n]; myc[slot][2] = ob[(3 * o + 2) * n]; }
       }
+      const T r2 = OC.obst_radius * OC.obst_radius;
 #pragma unroll
       for (int slot = 0; slot < 3; ++slot) {
         const int o = sub + 8 * slot;
         if (o < nob) {
           const T cx = myc[slot][0], cy = myc[slot][1], hh = myc[slot][2];
           if (duck_front) occluded |= cyl_inv_t<T>(OC, cx, cy, hh, cam, relw[0], relw[1], relw[2]) > (T)1;   // a hit at 0 < t < 1 of the segment camera -> sphere centre
-          const int packed = cyl_columns((float)(cam[0] - cx), (float)(cam[1] - cy), (float)(OC.obst_radius * OC.obst_radius), (float)g0[0], (float)g0[1],
+          const T ox = cam[0] - cx, oy = cam[1] - cy;
+          const int packed = cyl_columns((float)ox, (float)oy, (float)r2, (float)g0[0], (float)g0[1],
                                          (float)g1[0], (float)g1[1], (float)u0, (float)F, (float)invF, (float)W);
-          iv0 = slot == 0 ? packed : iv0; iv1 = slot == 1 ? packed : iv1; iv2 = slot == 2 ? packed : iv2;
+          const int xlo = packed & 0xFFFF, xhi = packed >> 16;
+          if (xhi >= xlo) {
+            vis |= 1u << o;
+            T* e = ctab + o * 8;
+            e[0] = ox; e[1] = oy; e[2] = ox * ox + oy * oy - r2; e[3] = hh;
+            e[4] = ox * g0[0] + oy * g0[1]; e[5] = ox * g1[0] + oy * g1[1]; e[6] = (T)xlo; e[7] = (T)xhi;
+          }
         }
       }
+      vis = group_or<G>(vis);
     } else {
 #pragma unroll 1
       for (int o = 0; o < nob; ++o)
@@ -557,34 +573,44 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
       return inv_hit(((T)x - u0) * invF, bm) > (T)0;
     };
     // 1 / t of the cylinder's fragment in column a (0 = none): no division for the hit / height tests
-    auto cyl_it = [&](T a, T ox, T oy, T cc, T op, T oq, T hh) {
+    auto cyl_it = [&](T a, T ox, T oy, T cc, T op, T oq, T hh) {     // branch-free: four of these are in flight per lane
       const T A = pp + a * ((T)2 * pq + a * qq), hb = op + a * oq, disc = hb * hb - A * cc;
+#ifdef FW_DBG_BRANCHY
       if (!(A > (T)0) || disc < (T)0 || hb >= (T)0) return (T)0;
-      const T num = -hb - M<T>::sqrt_(disc);
+      { const T num = -hb - M<T>::sqrt_(disc);
+        const T zA = cam[2] * A + num * (g0[2] + a * g1[2]);
+        if (!(num > (T)0) || zA < (T)0 || zA > hh * A) return (T)0;
+        return M<T>::div_(A, num); }
+#endif
+      bool ok = A > (T)0 && disc >= (T)0 && hb < (T)0;
+      const T num = -hb - M<T>::sqrt_(disc > (T)0 ? disc : (T)0);
       const T zA = cam[2] * A + num * (g0[2] + a * g1[2]);         // z of the hit times A
-      if (!(num > (T)0) || zA < (T)0 || zA > hh * A) return (T)0;
+      ok = ok && num > (T)0 && zA >= (T)0 && zA <= hh * A;
       (void)ox; (void)oy;
-      return M<T>::div_(A, num);
+      const T it = M<T>::div_(A, ok ? num : (T)1);
+      return ok ? it : (T)0;
+    };
+    // a pixel whose nearest cylinder fragment moves from 1/t = c_old to c_new adds this to its third's sum of clip(1/t)
+    // (the ground value g stays underneath: the pixel shows max(cylinder, ground)); telescopes over successive updates
+    auto delta = [&](T c_old, T c_new, T g) {
+      const T hi = c_new > OC.inv_near ? OC.inv_near : c_new, lo = c_old > OC.inv_near ? OC.inv_near : c_old;
+      return (hi > g ? hi : g) - (lo > g ? lo : g);
     };
     T csum[3] = { (T)0, (T)0, (T)0 };
     if (G == 8) {
-      T* zr = reinterpret_cast<T*>(smem_raw) + (size_t)((threadIdx.x & (kWave - 1)) / G) * OC.zrow_stride;   // this env's LDS row (aliases
-                                                                  // the observation tile, which is only written after the step loop)
 #pragma unroll 4
       for (int x = sub; x < Wi; x += G) zr[x] = (T)0;
+      __builtin_amdgcn_wave_barrier();                            // the table entries written by my sibling lanes are read below
+      // every env walks ITS OWN visible cylinders (k-th iteration = k-th set bit of its mask): the wave runs max-over-envs
+      // iterations instead of one per cylinder index that any env can see
+      uint32_t m = vis;
 #pragma unroll 1
-      for (int o = 0; o < nob; ++o) {                             // group-uniform: every lane of the env walks the same cylinder
-        const int slot = o >> 3;
-        const int mine = slot == 0 ? iv0 : (slot == 1 ? iv1 : iv2);
-        const int packed = __shfl(mine, gbase | (o & 7), kWave);
-        const int xlo = packed & 0xFFFF, xhi = packed >> 16;
-        if (xhi < xlo) continue;
-        const int src = gbase | (o & 7);                          // the lane that loaded this cylinder hands its coordinates over
-        const T cx = __shfl(slot == 0 ? myc[0][0] : (slot == 1 ? myc[1][0] : myc[2][0]), src, kWave);
-        const T cy = __shfl(slot == 0 ? myc[0][1] : (slot == 1 ? myc[1][1] : myc[2][1]), src, kWave);
-        const T hh = __shfl(slot == 0 ? myc[0][2] : (slot == 1 ? myc[1][2] : myc[2][2]), src, kWave);
-        const T ox = cam[0] - cx, oy = cam[1] - cy, cc = ox * ox + oy * oy - r2;
-        const T op = ox * g0[0] + oy * g0[1], oq = ox * g1[0] + oy * g1[1];
+      while (m) {
+        const int o = __ffs((int)m) - 1;
+        m &= m - 1u;
+        const T* e = ctab + o * 8;                                // same address in the 8 lanes of the env: LDS broadcast
+        const T ox = e[0], oy = e[1], cc = e[2], hh = e[3], op = e[4], oq = e[5];
+        const int xlo = (int)e[6], xhi = (int)e[7];
 #pragma unroll 1
         for (int x = xlo + ((sub - xlo) & 7); x <= xhi; x += 4 * G) {       // my pixels (x = sub mod 8) of the interval, 4 at a time
           T it4[4];
@@ -596,17 +622,17 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int xx = x + u * G;
-            if (it4[u] > (T)0) { const T c = zr[xx]; zr[xx] = it4[u] > c ? it4[u] : c; }
+            if (it4[u] > (T)0) {
+              const T c = zr[xx];
+              if (it4[u] > c) {
+                zr[xx] = it4[u];
+                if (!is_duck(xx)) {
+                  const T d = delta(c, it4[u], git((T)xx));
+                  csum[0] += xx < x_1 ? d : (T)0; csum[1] += (xx >= x_1 && xx < x_2) ? d : (T)0; csum[2] += xx >= x_2 ? d : (T)0;
+                }
+              }
+            }
           }
-        }
-      }
-#pragma unroll 2
-      for (int x = sub; x < Wi; x += G) {                          // covered pixels: the nearer of cylinder and ground replaces the ground
-        T c = zr[x];
-        if (c > (T)0 && !is_duck(x)) {
-          c = c > OC.inv_near ? OC.inv_near : c;
-          const T gnd = git((T)x), d = c > gnd ? c - gnd : (T)0;
-          csum[0] += x < x_1 ? d : (T)0; csum[1] += (x >= x_1 && x < x_2) ? d : (T)0; csum[2] += x >= x_2 ? d : (T)0;
         }
       }
     } else {
@@ -622,8 +648,7 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
           c = ic > c ? ic : c;
         }
         if (c > (T)0) {
-          c = c > OC.inv_near ? OC.inv_near : c;
-          const T gnd = git((T)x), d = c > gnd ? c - gnd : (T)0;
+          const T d = delta((T)0, c, git((T)x));
           csum[0] += x < x_1 ? d : (T)0; csum[1] += (x >= x_1 && x < x_2) ? d : (T)0; csum[2] += x >= x_2 ? d : (T)0;
         }
       }
