@@ -286,14 +286,16 @@ def main():
                   f"{WORDS_PER_ENV_STEP * word * m / us / 1e3:.1f} GB/s algorithmic", file=sys.stderr, flush=True)
             e2.close()
 
-    # HBM bytes per launch from the PMC counters are collected offline (rocprofv3 --pmc cannot run inside this
-    # process); the committed summary is quoted when it was taken on this very workload, else null.
+    # HBM bytes per launch from the PMC counters are collected offline (rocprofv3 --pmc cannot run inside this process:
+    # tools/collect_profiles.sh); the committed summary is quoted when it was taken on this very workload, else null.
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_pmc_traffic.json")
-    if n == 4096 and args.dtype == "float64" and args.task == "waypoints" and os.path.exists(pmc_path):
+    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if n == 4096 and args.dtype == "float64" and os.path.exists(pmc_path):
         with open(pmc_path) as f:
-            traffic = json.load(f)["hbm_bytes_per_launch"]["total"]
-        traffic_src = "profiles/r01_d_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, calibrated with tools/calib_pmc.hip)"
+            tt = json.load(f).get("tasks", {}).get(args.task)
+        if tt:
+            traffic = tt["total"]
+            traffic_src = "profiles/r02_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes; gfx950 FETCH_SIZE correction x 2)"
 
     # The ceiling that really binds this kernel: 64-bit vector issue.  fp64 lane-instructions per env-step come from the ISA
     # of the shipped kernel (profiles/r02_valu_count.json, made by tools/count_valu.py: instructions of the tick loop x ticks +
@@ -302,7 +304,7 @@ def main():
     vpath = os.path.join(ROOT, "profiles", "r02_valu_count.json")
     if os.path.exists(vpath):
         with open(vpath) as f:
-            vc = json.load(f).get(args.task if args.dtype == "float64" else "", None)
+            vc = json.load(f).get(args.task if (args.dtype == "float64" and n == 4096) else "", None)
         if vc:
             lane_instr = vc["lane_instructions_per_env_step"]
             ach = lane_instr * n / launch_s / 1e12
