@@ -428,6 +428,29 @@ int32_t fw_rollout_post(const void* reward, int32_t rew_is_f64, const uint8_t* t
                         int32_t N, int32_t training, int32_t norm_reward, double gamma, float clip_reward, float epsilon,
                         float* rew_out, float* start_out, uint64_t* rng, double* ret_acc, void* hip_stream);
 
+/* The same collection in THREE launches per vec-step (fw_collect_act -> fw_step -> fw_collect_stats) instead of seven:
+ * fw_collect_act  = fw_policy_act reading the env's RAW observation buffer and normalising it on load with (obs_mean, obs_var,
+ *   clip_obs, eps_obs) -- the normalised rows still go to obs_copy -- whose value block also FINALISES THE PREVIOUS STEP for its
+ *   rows when prev_reward != NULL: rew_out = clip(prev_reward / sqrt(ret_var + eps_reward), +-clip_reward) (if norm_reward)
+ *   + gamma * V(normalised prev_terminal_obs) where prev_truncated && !prev_terminated (a second pass through the value network in
+ *   the blocks that hold such a row), start_out = prev_terminated | prev_truncated.  It runs BEFORE the next fw_step, while the
+ *   env's reward / flag / terminal-observation buffers still hold the previous step.
+ * fw_collect_stats = VecNormalize.step_wait's statistics after an env step, one launch: observation moments -> (obs_mean, obs_var,
+ *   obs_count) if update_obs; returns = returns * gamma + reward, their moments -> (ret_mean, ret_var, ret_count) if update_ret,
+ *   returns = 0 where the episode ended; rng[1] += 1 (rng may be NULL); obs_acc / ret_acc as batch_acc / ret_acc above.
+ *   workspace: caller-owned, fw_collect_stats_workspace_bytes(D) bytes, zero-initialised once. */
+int32_t fw_collect_act(const float* params, const void* raw_obs, int32_t obs_is_f64, int32_t N, int32_t obs_dim, const double* obs_mean,
+                       const double* obs_var, float clip_obs, float eps_obs, int32_t nets, int32_t deterministic, const uint64_t* rng,
+                       int64_t env_offset, float* obs_copy, float* act_raw, void* act_env, int32_t act_is_f64, float* logp, float* value,
+                       const void* prev_reward, const uint8_t* prev_terminated, const uint8_t* prev_truncated, const void* prev_terminal_obs,
+                       const double* ret_var, int32_t norm_reward, float clip_reward, float eps_reward, float gamma, float* rew_out,
+                       float* start_out, void* hip_stream);
+int64_t fw_collect_stats_workspace_bytes(int32_t D);
+int32_t fw_collect_stats(const void* obs, int32_t obs_is_f64, int32_t N, int32_t D, double* obs_mean, double* obs_var, double* obs_count,
+                         int32_t update_obs, const void* reward, int32_t rew_is_f64, const uint8_t* terminated, const uint8_t* truncated,
+                         double* returns, double* ret_mean, double* ret_var, double* ret_count, int32_t update_ret, double gamma,
+                         uint64_t* rng, void* workspace, double* obs_acc, double* ret_acc, void* hip_stream);
+
 int32_t fw_num_envs(fw_handle h);
 const char* fw_last_error(fw_handle h); /* h may be NULL: last create/validate error */
 int32_t fw_destroy(fw_handle h);

@@ -88,6 +88,8 @@ def save(path: str, ppo, include_env_state: bool = True) -> str:
         if hasattr(venv, "cfg"):
             sd["config_sha256"] = config_fingerprint(venv.cfg)
         sd["env_returns"] = ppo.env.returns.detach().cpu()
+        if hasattr(venv, "obs") and torch.is_tensor(venv.obs):
+            sd["env_obs"] = venv.obs.detach().cpu()               # the raw observation the next rollout's first step reads
         if getattr(ppo, "last_obs", None) is not None:
             sd["last_obs"] = ppo.last_obs.detach().cpu()
             sd["last_starts"] = ppo.last_starts.detach().cpu()
@@ -127,6 +129,8 @@ def load(path: str, ppo, reset_num_timesteps: bool = True, restore_env_state: bo
                                  "the episodes that follow would not be those of the interrupted run")
         ppo.env.venv.set_state(sd["env_state"].numpy())
         ppo.env.returns.copy_(sd["env_returns"].to(ppo.env.returns.device))
+        if "env_obs" in sd and hasattr(venv, "obs"):
+            venv.obs.copy_(sd["env_obs"].to(venv.obs.device))
         if "last_obs" in sd:
             if ppo.last_obs is None:
                 ppo.last_obs = sd["last_obs"].to(ppo.device).clone()

@@ -1584,10 +1584,63 @@ int32_t fw_policy_act(const float* params, const float* obs, int32_t N, int32_t 
   DeviceGuard g(dev);
   if (int rc = ensure_learner_lds(dev, 1, lds)) return rc;
   ActArgs A;
+  std::memset(&A, 0, sizeof A);
   A.params = params; A.obs = obs; A.N = N; A.D = obs_dim; A.nets = nets; A.deterministic = deterministic; A.act_is_f64 = act_is_f64;
   A.rng = rng; A.env_offset = env_offset; A.obs_copy = obs_copy; A.act_raw = act_raw; A.act_env = act_env; A.logp = logp; A.value = value;
   A.raw = nullptr; A.raw_is_f64 = 0; A.mean = A.var = nullptr; A.clip = A.eps = 0.f; A.terminated = A.truncated = nullptr;
   hipLaunchKernelGGL(fw_policy_act_kernel, dim3((N + kPChunk - 1) / kPChunk, 2), dim3(kPThreads), lds, (hipStream_t)hip_stream, A);
+  HIP_TRY((fw_env*)nullptr, hipGetLastError());
+  return FW_OK;
+}
+
+int32_t fw_collect_act(const float* params, const void* raw_obs, int32_t obs_is_f64, int32_t N, int32_t obs_dim, const double* obs_mean,
+                       const double* obs_var, float clip_obs, float eps_obs, int32_t nets, int32_t deterministic, const uint64_t* rng,
+                       int64_t env_offset, float* obs_copy, float* act_raw, void* act_env, int32_t act_is_f64, float* logp, float* value,
+                       const void* prev_reward, const uint8_t* prev_terminated, const uint8_t* prev_truncated, const void* prev_terminal_obs,
+                       const double* ret_var, int32_t norm_reward, float clip_reward, float eps_reward, float gamma, float* rew_out,
+                       float* start_out, void* hip_stream) {
+  if (!params || !raw_obs || !obs_mean || !obs_var || N <= 0 || obs_dim <= 0 || obs_dim > 64 || (nets & ~3) || !nets) { g_err = "fw_collect_act: bad arguments"; return FW_EINVAL; }
+  if ((nets & 1) && (!act_raw || !act_env || !logp || (!deterministic && !rng))) { g_err = "fw_collect_act: policy outputs missing"; return FW_EINVAL; }
+  if ((nets & 2) && !value) { g_err = "fw_collect_act: value output missing"; return FW_EINVAL; }
+  if (prev_reward && (!(nets & 2) || !prev_terminated || !prev_truncated || !prev_terminal_obs || !ret_var || !rew_out || !start_out)) {
+    g_err = "fw_collect_act: finalising the previous step needs the value network and all of its buffers"; return FW_EINVAL;
+  }
+  const size_t lds = act_lds_bytes(obs_dim);
+  const int dev = device_of(params);
+  DeviceGuard g(dev);
+  if (int rc = ensure_learner_lds(dev, 1, lds)) return rc;
+  ActArgs A;
+  std::memset(&A, 0, sizeof A);
+  A.params = params; A.N = N; A.D = obs_dim; A.nets = nets; A.deterministic = deterministic; A.act_is_f64 = act_is_f64;
+  A.rng = rng; A.env_offset = env_offset; A.obs_copy = obs_copy; A.act_raw = act_raw; A.act_env = act_env; A.logp = logp; A.value = value;
+  A.raw = raw_obs; A.raw_is_f64 = obs_is_f64; A.mean = obs_mean; A.var = obs_var; A.clip = clip_obs; A.eps = eps_obs;
+  A.prev_reward = prev_reward; A.prev_term = prev_terminated; A.prev_trunc = prev_truncated; A.prev_tobs = prev_terminal_obs;
+  A.ret_var = ret_var; A.norm_reward = norm_reward; A.clip_reward = clip_reward; A.rew_eps = eps_reward; A.gamma = gamma;
+  A.rew_out = rew_out; A.start_out = start_out;
+  hipLaunchKernelGGL(fw_policy_act_kernel, dim3((N + kPChunk - 1) / kPChunk, 2), dim3(kPThreads), lds, (hipStream_t)hip_stream, A);
+  HIP_TRY((fw_env*)nullptr, hipGetLastError());
+  return FW_OK;
+}
+
+static int collect_stats_blocks(int N) { return N >= 64 * 64 ? 64 : (N + 63) / 64; }
+int64_t fw_collect_stats_workspace_bytes(int32_t D) { return D > 0 ? (int64_t)(sizeof(double) * 64 * (2 * (size_t)D + 2) + 64) : FW_EINVAL; }
+
+int32_t fw_collect_stats(const void* obs, int32_t obs_is_f64, int32_t N, int32_t D, double* obs_mean, double* obs_var, double* obs_count,
+                         int32_t update_obs, const void* reward, int32_t rew_is_f64, const uint8_t* terminated, const uint8_t* truncated,
+                         double* returns, double* ret_mean, double* ret_var, double* ret_count, int32_t update_ret, double gamma,
+                         uint64_t* rng, void* workspace, double* obs_acc, double* ret_acc, void* hip_stream) {
+  if (!obs || !obs_mean || !obs_var || !obs_count || !reward || !terminated || !truncated || !returns || !ret_mean || !ret_var || !ret_count ||
+      !workspace || N <= 0 || D <= 0 || D > 256) { g_err = "fw_collect_stats: bad arguments"; return FW_EINVAL; }
+  DeviceGuard g(device_of(obs));
+  StatsArgs A;
+  A.obs = obs; A.obs_is_f64 = obs_is_f64; A.N = N; A.D = D; A.mean = obs_mean; A.var = obs_var; A.count = obs_count; A.update_obs = update_obs;
+  A.reward = reward; A.rew_is_f64 = rew_is_f64; A.terminated = terminated; A.truncated = truncated; A.returns = returns;
+  A.ret_mean = ret_mean; A.ret_var = ret_var; A.ret_count = ret_count; A.update_ret = update_ret; A.gamma = gamma; A.rng = rng;
+  A.part = (double*)workspace; A.ticket = (unsigned int*)((char*)workspace + sizeof(double) * 64 * (2 * (size_t)D + 2));
+  A.obs_acc = obs_acc; A.ret_acc = ret_acc;
+  const int nb = collect_stats_blocks(N);
+  if (obs_is_f64) hipLaunchKernelGGL(fw_collect_stats_kernel<double>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, A);
+  else hipLaunchKernelGGL(fw_collect_stats_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, A);
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;
 }

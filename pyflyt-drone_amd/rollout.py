@@ -163,6 +163,9 @@ class VecNormalizeDevice:
         if self.use_fused:
             nbytes = int(_lib.lib().fw_normalize_obs_workspace_bytes(self.obs_dim))
             self._ws = torch.zeros(nbytes // 8, dtype=torch.float64, device=self.device)       # caller-owned scratch of fw_normalize_obs
+            nb2 = int(_lib.lib().fw_collect_stats_workspace_bytes(self.obs_dim))
+            self._ws_stats = torch.zeros((nb2 + 7) // 8, dtype=torch.float64, device=self.device)   # ... and of fw_collect_stats (zeroed once)
+
         if _dist() is not None and self.stats_sync == "rollout":
             self._obs_acc = torch.zeros(2 * self.obs_dim + 1, dtype=torch.float64, device=self.device)
             self._ret_acc = torch.zeros(3, dtype=torch.float64, device=self.device)
@@ -630,28 +633,55 @@ class PPO:
                                    int(self._act_env.dtype == torch.float64), bl, _p(val), _stream(self.device)))
 
     def _rollout_body_fused(self):
-        """collect_rollouts with the between-steps work in two kernels (fw_policy_act, fw_rollout_post) around fw_step and
-        fw_normalize_obs: 5 launches per vec-step instead of ~70 framework ops.  Same data flow as _rollout_body."""
+        """collect_rollouts as THREE launches per vec-step:  fw_collect_act -> fw_step -> fw_collect_stats.
+        fw_collect_act reads the env's raw observation buffer, normalises it on load with the current statistics (the policy
+        sees what VecNormalize.step_wait would have returned), samples, writes the rollout-buffer rows of step t and the env's
+        action -- and its value block first finalises step t-1 for its rows (normalised + bootstrapped reward, episode starts),
+        while the env's output buffers still hold that step.  fw_collect_stats folds the step's observations and rewards into
+        both normalisers.  Same data flow as _rollout_body; SB3 OnPolicyAlgorithm.collect_rollouts + VecNormalize semantics."""
         cfg, env, L = self.cfg, self.env, _lib.lib()
-        venv, T = env.venv, cfg.n_steps
+        venv, T, N, D = env.venv, cfg.n_steps, env.num_envs, env.obs_dim
         st = _stream(self.device)
+        f64 = int(venv.obs.dtype == torch.float64)
         self.buf_start[0].copy_(self.last_starts)
-        obs = self.last_obs
+        track = int(env.training and env.norm_reward)
+
+        def act(t, nets, value_out, prev_t):
+            """prev_t: index of the step to finalise (its rewards go to buf_rew[prev_t], the starts of the NEXT step to
+            buf_start[prev_t + 1] / last_starts), or None."""
+            bo = _p(self.buf_obs[t]) if t is not None else None
+            ba = _p(self.buf_act[t]) if t is not None else None
+            bl = _p(self.buf_logp[t]) if t is not None else None
+            if prev_t is None:
+                prev = (None, None, None, None, None, 0, 0.0, 0.0, 0.0, None, None)
+            else:
+                nxt = self.buf_start[prev_t + 1] if prev_t + 1 < T else self.last_starts
+                prev = (_p(venv.rewards), _p(venv.terminated), _p(venv.truncated), _p(venv.terminal_obs), _p(env.ret_rms.var),
+                        int(env.norm_reward), float(env.clip_reward), float(env.epsilon), float(cfg.gamma), _p(self.buf_rew[prev_t]), _p(nxt))
+            _lib.check(L.fw_collect_act(_p(self._fused.flat), _p(venv.obs), f64, N, D, _p(env.obs_rms.mean), _p(env.obs_rms.var),
+                                        float(env.clip_obs), float(env.epsilon), nets, 0, _p(self._rng),
+                                        int(getattr(venv, "global_env_offset", 0)), bo, ba, _p(self._act_env),
+                                        int(self._act_env.dtype == torch.float64), bl, _p(value_out), *prev, st))
+
         for t in range(T):
-            self._act(obs, 3, t=t)                                                   # buffers of step t, clipped action for the env
-            raw_obs, rew, term, trunc = venv.step_tensor(self._act_env)
-            obs = env._process_obs(raw_obs, update=env.training)                     # fw_normalize_obs -> env.obs_out
-            _lib.check(L.fw_policy_terminal_value(_p(self._fused.flat), _p(venv.terminal_obs), int(venv.terminal_obs.dtype == torch.float64),
-                                                  env.num_envs, env.obs_dim, _p(env.obs_rms.mean), _p(env.obs_rms.var),
-                                                  float(env.clip_obs), float(env.epsilon), _p(term), _p(trunc), _p(self._tval), st))
-            nxt = self.buf_start[t + 1] if t + 1 < T else self.last_starts
-            _lib.check(L.fw_rollout_post(_p(rew), int(rew.dtype == torch.float64), _p(term), _p(trunc), _p(self._tval),
-                                         _p(env.returns), _p(env.ret_rms.mean), _p(env.ret_rms.var), _p(env.ret_rms.count),
-                                         env.num_envs, int(env.training), int(env.norm_reward), float(env.gamma),
-                                         float(env.clip_reward), float(env.epsilon), _p(self.buf_rew[t]), _p(nxt), _p(self._rng),
-                                         _p(env._ret_acc), st))
-        self.last_obs.copy_(obs)
-        self._act(self.last_obs, 2, value_out=self.last_values)
+            act(t, 3, self.buf_val[t], t - 1 if t > 0 else None)
+            venv.step_tensor(self._act_env)
+            _lib.check(L.fw_collect_stats(_p(venv.obs), f64, N, D, _p(env.obs_rms.mean), _p(env.obs_rms.var), _p(env.obs_rms.count),
+                                          int(env.training and env.norm_obs), _p(venv.rewards), int(venv.rewards.dtype == torch.float64),
+                                          _p(venv.terminated), _p(venv.truncated), _p(env.returns), _p(env.ret_rms.mean),
+                                          _p(env.ret_rms.var), _p(env.ret_rms.count), track, float(env.gamma), _p(self._rng),
+                                          _p(env._ws_stats), _p(env._obs_acc) if env.training and env.norm_obs else None,
+                                          _p(env._ret_acc) if track else None, st))
+        # V(last observation) for GAE + the finalisation of step T-1 (nothing is sampled; the normalised last observation lands
+        # in last_obs for callers that look at it)
+        _lib.check(L.fw_collect_act(_p(self._fused.flat), _p(venv.obs), f64, N, D, _p(env.obs_rms.mean), _p(env.obs_rms.var),
+                                    float(env.clip_obs), float(env.epsilon), 2, 0, _p(self._rng), int(getattr(venv, "global_env_offset", 0)),
+                                    None, None, None, 0, None, _p(self.last_values),
+                                    _p(venv.rewards), _p(venv.terminated), _p(venv.truncated), _p(venv.terminal_obs), _p(env.ret_rms.var),
+                                    int(env.norm_reward), float(env.clip_reward), float(env.epsilon), float(cfg.gamma),
+                                    _p(self.buf_rew[T - 1]), _p(self.last_starts), st))
+        _lib.check(L.fw_normalize_obs(_p(venv.obs), f64, N, D, _p(env.obs_rms.mean), _p(env.obs_rms.var), _p(env.obs_rms.count), 0,
+                                      float(env.clip_obs), float(env.epsilon), _p(self.last_obs), None, None, st))
 
     @torch.no_grad()
     def collect_rollouts(self):

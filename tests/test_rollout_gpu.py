@@ -347,3 +347,107 @@ def test_objlock_training_learns_to_strike():
     s0, s1 = float(np.mean(before.duck_strike)), float(np.mean(after.duck_strike))
     assert s0 <= 0.2 and s1 >= 0.5, (s0, s1)
     assert after.mean_reward > before.mean_reward + 500.0
+
+
+@pytest.mark.parametrize("dtype,n,d", [(torch.float64, 4096, 28), (torch.float32, 1000, 56), (torch.float64, 65, 27)])
+def test_fw_collect_stats_matches_the_torch_statistics(dtype, n, d):
+    """fw_collect_stats (one launch: observation moments + discounted-return tracker + both Chan merges, last block folds in
+    a fixed order) against the torch statements of VecNormalizeDevice.step, over several steps; the accumulators a sharded job
+    all-reduces hold the batch sums; the action sampler's draw counter advances; flags off = statistics untouched."""
+    from pyflyt_drone_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(n + d)
+
+    class V:
+        device, num_envs, obs_dim = torch.device("cuda"), n, d
+    ref = R.VecNormalizeDevice(V(), use_fused_kernel=False)
+    dev = V()
+    me = R.VecNormalizeDevice(dev, use_fused_kernel=True)
+    oacc, racc = torch.zeros(2 * d + 1, dtype=torch.float64, device="cuda"), torch.zeros(3, dtype=torch.float64, device="cuda")
+    want_o, want_r = torch.zeros_like(oacc), torch.zeros_like(racc)
+    rng = torch.tensor([5, 0], dtype=torch.int64, device="cuda")
+    for step in range(6):
+        obs = (torch.randn((n, d), generator=g, dtype=torch.float64) * (1 + step) + 2 * step).to(dtype).cuda()
+        rew = (torch.randn(n, generator=g, dtype=torch.float64) * 30).to(dtype).cuda()
+        term = (torch.rand(n, generator=g) < 0.1).to(torch.uint8).cuda(); trunc = (torch.rand(n, generator=g) < 0.1).to(torch.uint8).cuda()
+        upd = step != 4
+        if upd:
+            ref.obs_rms.update(obs)
+            ref.returns.mul_(ref.gamma).add_(rew.double()); ref.ret_rms.update(ref.returns)
+            x = obs.double()
+            want_o += torch.cat([x.sum(0), (x * x).sum(0), torch.tensor([float(n)], dtype=torch.float64, device="cuda")])
+            want_r += torch.stack([ref.returns.sum(), (ref.returns ** 2).sum(), torch.tensor(float(n), dtype=torch.float64, device="cuda")])
+        ref.returns.masked_fill_((term | trunc).bool(), 0.0)
+        _lib.check(L.fw_collect_stats(R._p(obs), int(dtype == torch.float64), n, d, R._p(me.obs_rms.mean), R._p(me.obs_rms.var), R._p(me.obs_rms.count),
+                                      int(upd), R._p(rew), int(dtype == torch.float64), R._p(term), R._p(trunc), R._p(me.returns),
+                                      R._p(me.ret_rms.mean), R._p(me.ret_rms.var), R._p(me.ret_rms.count), int(upd), 0.99, R._p(rng),
+                                      R._p(me._ws_stats), R._p(oacc) if upd else None, R._p(racc) if upd else None, None))
+        torch.testing.assert_close(me.obs_rms.mean, ref.obs_rms.mean, rtol=1e-10, atol=1e-10)
+        torch.testing.assert_close(me.obs_rms.var, ref.obs_rms.var, rtol=1e-9, atol=1e-10)
+        torch.testing.assert_close(me.obs_rms.count, ref.obs_rms.count)
+        torch.testing.assert_close(me.returns, ref.returns, rtol=1e-12, atol=1e-9)
+        torch.testing.assert_close(me.ret_rms.var, ref.ret_rms.var, rtol=1e-10, atol=0)
+        torch.testing.assert_close(me.ret_rms.mean, ref.ret_rms.mean, rtol=1e-10, atol=1e-12)
+        torch.testing.assert_close(me.ret_rms.count, ref.ret_rms.count)
+        torch.testing.assert_close(oacc, want_o, rtol=1e-12, atol=1e-6); torch.testing.assert_close(racc, want_r, rtol=1e-12, atol=1e-6)
+    assert int(rng[1]) == 6
+    assert int(me._ws_stats.view(torch.int32)[-16:].abs().sum()) == 0            # the ticket is left at zero for the next launch
+
+
+def test_fw_collect_act_normalises_on_load_and_finalises_the_previous_step():
+    """fw_collect_act = fw_policy_act on observations normalised on load (bit-identical to fw_normalize_obs followed by
+    fw_policy_act), and its value block applies VecNormalize's reward path + SB3's truncation bootstrap to the previous step:
+    checked against fw_rollout_post fed with fw_policy_terminal_value."""
+    from pyflyt_drone_amd import _lib
+    L = _lib.lib()
+    d, n = 28, 1000
+    torch.manual_seed(11)
+    pol = R.MlpPolicy(d).cuda()
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    flat = _flat_params(pol, d)
+    raw = torch.randn((n, d), device="cuda", dtype=torch.float64) * 4 + 1
+    mean, var = torch.randn(d, device="cuda", dtype=torch.float64), torch.rand(d, device="cuda", dtype=torch.float64) * 4 + 0.1
+    cnt = torch.ones(1, device="cuda", dtype=torch.float64)
+    rng = torch.tensor([77, 3], dtype=torch.int64, device="cuda")
+    # reference: normalise, then act
+    obs_n = torch.zeros((n, d), device="cuda")
+    _lib.check(L.fw_normalize_obs(R._p(raw), 1, n, d, R._p(mean), R._p(var), R._p(cnt), 0, 10.0, 1e-8, R._p(obs_n), None, None, None))
+    oc0, ar0, ae0 = torch.zeros_like(obs_n), torch.zeros((n, 4), device="cuda"), torch.zeros((n, 4), device="cuda", dtype=torch.float64)
+    lp0, v0 = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    _lib.check(L.fw_policy_act(R._p(flat), R._p(obs_n), n, d, 3, 0, R._p(rng), 512, R._p(oc0), R._p(ar0), R._p(ae0), 1, R._p(lp0), R._p(v0), None))
+    # previous step: rewards, flags, terminal observations
+    g = torch.Generator().manual_seed(2)
+    rew = (torch.randn(n, generator=g, dtype=torch.float64) * 20).cuda()
+    term = (torch.rand(n, generator=g) < 0.05).to(torch.uint8).cuda(); trunc = (torch.rand(n, generator=g) < 0.03).to(torch.uint8).cuda()
+    trunc[64:128] = 0; term[64:128] = 0                                           # one block without any episode end
+    tobs = torch.randn((n, d), device="cuda", dtype=torch.float64) * 3
+    ret_var = torch.tensor([7.5], dtype=torch.float64, device="cuda")
+    tv = torch.zeros(n, device="cuda")
+    _lib.check(L.fw_policy_terminal_value(R._p(flat), R._p(tobs), 1, n, d, R._p(mean), R._p(var), 10.0, 1e-8, R._p(term), R._p(trunc), R._p(tv), None))
+    ret, rm, rc = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros(1, dtype=torch.float64, device="cuda"), torch.ones(1, dtype=torch.float64, device="cuda")
+    rew0, st0 = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    _lib.check(L.fw_rollout_post(R._p(rew), 1, R._p(term), R._p(trunc), R._p(tv), R._p(ret), R._p(rm), R._p(ret_var.clone()), R._p(rc), n, 0, 1,
+                                 0.99, 10.0, 1e-8, R._p(rew0), R._p(st0), None, None, None))
+    oc1, ar1, ae1 = torch.zeros_like(obs_n), torch.zeros((n, 4), device="cuda"), torch.zeros((n, 4), device="cuda", dtype=torch.float64)
+    lp1, v1 = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    rew1, st1 = torch.full((n,), -9.0, device="cuda"), torch.full((n,), -9.0, device="cuda")
+    _lib.check(L.fw_collect_act(R._p(flat), R._p(raw), 1, n, d, R._p(mean), R._p(var), 10.0, 1e-8, 3, 0, R._p(rng), 512, R._p(oc1), R._p(ar1),
+                                R._p(ae1), 1, R._p(lp1), R._p(v1), R._p(rew), R._p(term), R._p(trunc), R._p(tobs), R._p(ret_var), 1, 10.0, 1e-8, 0.99,
+                                R._p(rew1), R._p(st1), None))
+    assert torch.equal(oc1, obs_n) and torch.equal(oc1, oc0)
+    assert torch.equal(ar1, ar0) and torch.equal(ae1, ae0) and torch.equal(lp1, lp0) and torch.equal(v1, v0)
+    assert torch.equal(st1, st0)
+    timeouts = (trunc.bool() & ~term.bool())
+    assert int(timeouts.sum()) >= 5
+    torch.testing.assert_close(rew1, rew0, rtol=1e-6, atol=1e-6)
+    assert torch.equal(rew1[~timeouts], rew0[~timeouts])
+    # without a previous step nothing of it is touched; the policy block alone leaves the value outputs alone
+    rew1.fill_(-9.0); v1.fill_(-9.0)
+    _lib.check(L.fw_collect_act(R._p(flat), R._p(raw), 1, n, d, R._p(mean), R._p(var), 10.0, 1e-8, 1, 0, R._p(rng), 512, R._p(oc1), R._p(ar1),
+                                R._p(ae1), 1, R._p(lp1), None, None, None, None, None, None, 0, 0.0, 0.0, 0.0, None, None, None))
+    assert bool((rew1 == -9.0).all()) and bool((v1 == -9.0).all()) and torch.equal(ar1, ar0)
+    assert L.fw_collect_act(R._p(flat), R._p(raw), 1, n, d, R._p(mean), R._p(var), 10.0, 1e-8, 1, 0, R._p(rng), 512, R._p(oc1), R._p(ar1),
+                            R._p(ae1), 1, R._p(lp1), None, R._p(rew), R._p(term), R._p(trunc), R._p(tobs), R._p(ret_var), 1, 10.0, 1e-8, 0.99,
+                            R._p(rew1), R._p(st1), None) == K.FW_EINVAL           # finalisation needs the value block
