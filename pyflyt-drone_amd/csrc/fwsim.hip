@@ -165,6 +165,28 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
     }
   }
   if (G == 8) lane_act_gather<T>(S, LA);
+  if (chunk > 0 && done + chunk == total) {
+    // warm-up complete: end_reset()'s first compute_state and the observation reset() returns (zero action) are part of the
+    // shadow, so that the reset that takes it is a copy (state rows, observation row) and nothing else.  The rows of the
+    // shadow the worker never writes (stored action, episode return) are zero from the allocation: what a fresh episode holds.
+    T nd = (T)0;
+    if (OBJ) obj_compute_state<T>(O);
+    else {
+      T t0[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t0[k] = V.r[(size_t)(RF_TARGETS + k) * n + envc];
+      nd = end_reset<T, G>(P, V, envc, (int32_t)target, S, t0);
+      if (COMB) comb_compute_state<T>(OC, O, P.num_targets == 0);
+    }
+    if (leader) {
+      const T a0[4] = {(T)0, (T)0, (T)0, (T)0};
+      T* orow = D.sobs + (size_t)env * P.obs_dim;
+      if (OBJ) obj_write_obs<T>(P, O, S, a0, [&](int k, T v) { orow[k] = v; });
+      else if (COMB) comb_write_obs<T>(P, V, env, O, S, a0, 0, [&](int k, T v) { orow[k] = v; });
+      else write_obs<T>(P, V, env, S, a0, 0, [&](int k, T v) { orow[k] = v; });
+      V.r[RF_NEW_DIST * n + env] = nd;
+    }
+  }
   if (chunk > 0 && leader) {
     store_rigid<T>(V, env, S);
     D.is[env] = tick;
@@ -385,7 +407,13 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
         }
       }
       if (DEFER) { resetting = (flags & (FL_TERM | FL_TRUNC)) && P.auto_reset; FWP(if (resetting) p_nreset += 1;) }
-      if (!DEFER && (flags & (FL_TERM | FL_TRUNC)) && P.auto_reset) {
+      // GENERAL: a reset whose pre-simulated episode is ready is a copy, done in the epilogue (the observation pass there writes
+      // the terminal observation); only a reset without one runs here, with its warm-up in the loop
+      const bool take_shadow = GENERAL && (flags & (FL_TERM | FL_TRUNC)) && P.auto_reset && D.shadow_on &&
+                               (int)(sh_done & 0xFF) == P.warmup_aviary_steps + 1 && (uint32_t)(sh_done >> 32) == (uint32_t)(episode + 1) &&
+                               (uint32_t)((sh_done >> 8) & 0xFFFFFFu) != (D.epoch & 0xFFFFFFu);
+      if (take_shadow) { resetting = true; FWP(p_nreset += 1; p_nhit += 1;) }
+      if (!DEFER && !take_shadow && (flags & (FL_TERM | FL_TRUNC)) && P.auto_reset) {
         if (G == 8) lane_act_gather<T>(S, LA);          // the terminal observation shows all six actuators
         if (terminal_obs && leader) {
           T* trow = terminal_obs + (size_t)env * Dobs;
@@ -397,27 +425,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
         }
         T t_mine[3] = {(T)0, (T)0, (T)0};            // first waypoint of the new episode
         FWP(const long long p_ra = FWP_NOW(); p_r1 += p_ra - p_a;)
-        if (GENERAL && D.shadow_on && (int)(sh_done & 0xFF) == P.warmup_aviary_steps + 1 &&
-            (uint32_t)(sh_done >> 32) == (uint32_t)(episode + 1) && (uint32_t)((sh_done >> 8) & 0xFFFFFFu) != (D.epoch & 0xFFFFFFu)) {
-          // swap the pre-simulated episode in: a copy instead of 10 Aviary steps
-          const DevState<T> V = shadow_view<T>(D);
-          load_rigid<T>(V, env, S);
-          tick = D.is[env];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) { wb[k] = V.r[(RF_WIND + k) * n + env]; wa[k] = V.r[(RF_WIND + 3 + k) * n + env]; }
-          wphase = V.r[(RF_WIND + 6) * n + env];
-          if (HASOBJ) obj_load<T, OBJ>(V, env, O);
-          if (!OBJ) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) t_mine[k] = V.r[(size_t)(RF_TARGETS + k) * n + env];     // waypoint 0, for end_reset
-          }
-          copy_words<T, G>(D.r, V.r, RF_WIND, 7, n, env);
-          if (!OBJ) copy_words<T, G>(D.r, V.r, RF_TARGETS, 3 * P.num_targets, n, env);
-          if (HASOBJ) copy_words<T, G>(D.r, V.r, RF_TASK + FW_ST_OBST, 3 * FW_MAX_OBSTACLES, n, env);
-          episode += 1; num_reached = 0; warm_left = 0;
-          if (leader) stat_add(D.stats, FW_CTR_SHADOW_HITS);
-          FWP(p_nhit += 1;)
-        } else {
+        {
           if (leader) stat_add(D.stats, FW_CTR_FALLBACKS);
           warm_left = begin_reset<T, G>(P, D, env, S, tick, episode, num_reached, wb, wa, wphase, t_mine);
           if (G > 1) {                                          // the group's lane 0 sampled waypoint 0
@@ -584,8 +592,24 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     for (int k = 0; k < 3; ++k) tpre[k] = D.rs[(size_t)(RF_TARGETS + 3 * sub + k) * n + env];
   }
 
-  if ((GENERAL || DEFER) && D.shadow_on && active && leader && (uint32_t)(sh_req >> 32) != (uint32_t)(episode + 1))
-    D.sreq[env] = ((unsigned long long)(uint32_t)(episode + 1) << 32) | (unsigned long long)D.epoch;   // ask for the next episode
+  // GENERAL: the rows of a shadow that is being taken, fetched by the env's G lanes before the observation pass (their round
+  // trip hides behind it): word w of the [RF_COUNT] state column goes to lane w % G; the first observation likewise
+  constexpr int kCW = GENERAL ? (RF_COUNT + G - 1) / G : 1, kOW = GENERAL ? (kMaxObs + G - 1) / G : 1;
+  constexpr bool SWAP_REGS = GENERAL && G == 8;       // G = 1: one lane would hold all 123 words; it copies through memory below
+  T cw[kCW], ow[kOW];
+  int32_t tick_new = 0;
+  if (GENERAL && resetting) {
+    if (SWAP_REGS) {
+#pragma unroll
+      for (int j = 0; j < kCW; ++j) { const int w = sub + j * G; cw[j] = (w < RF_COUNT) ? D.rs[(size_t)w * n + env] : (T)0; }
+#pragma unroll
+      for (int j = 0; j < kOW; ++j) { const int k = sub + j * G; ow[j] = (k < Dobs) ? Dg.sobs[(size_t)env * Dobs + k] : (T)0; }
+    }
+    tick_new = D.is[env];
+  }
+  const int ep_want = episode + 1 + ((GENERAL && resetting) ? 1 : 0);     // a reset taken below asks for the episode after next
+  if ((GENERAL || DEFER) && D.shadow_on && active && leader && (uint32_t)(sh_req >> 32) != (uint32_t)ep_want)
+    D.sreq[env] = ((unsigned long long)(uint32_t)ep_want << 32) | (unsigned long long)D.epoch;   // ask for the next episode
   T act_obs[4] = {(T)0, (T)0, (T)0, (T)0};
   if (LANE_T) {
     // every lane runs the pass (same issue cost as one lane), the leader stores; action and waypoints come by shuffle
@@ -684,13 +708,36 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
 #pragma unroll
     for (int k = 0; k < 4; ++k) act_obs[k] = (T)0;
   }
-  if (active && leader) {
-    store_rigid<T>(D, env, S);
-    if (HASOBJ) obj_store<T, OBJ>(D, env, O);
+  if (GENERAL && resetting) {                        // group-uniform: all G lanes of the env take part
+    // the row just written is the terminal observation: move it out, then the new episode's row and state replace the old
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (terminal_obs) {
+      T* trow = terminal_obs + (size_t)env * Dobs;
+      for (int k = sub; k < Dobs; k += G) trow[k] = tile[row * ld + k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (SWAP_REGS) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) D.r[(RF_ACTION + k) * n + env] = act_obs[k];
-    D.r[RF_NEW_DIST * n + env] = new_dist;
-    D.r[RF_EP_RETURN * n + env] = ep_return;
+      for (int j = 0; j < kOW; ++j) { const int k = sub + j * G; if (k < Dobs) tile[row * ld + k] = ow[j]; }
+#pragma unroll
+      for (int j = 0; j < kCW; ++j) { const int w = sub + j * G; if (w < RF_COUNT) D.r[(size_t)w * n + env] = cw[j]; }
+    } else {
+      for (int k = 0; k < Dobs; ++k) tile[row * ld + k] = Dg.sobs[(size_t)env * Dobs + k];
+      copy_words<T, G>(D.r, D.rs, 0, RF_COUNT, n, env);
+    }
+    if (leader) { stat_add(D.stats, FW_CTR_RESETS); stat_add(D.stats, FW_CTR_SHADOW_HITS); }
+    episode += 1; tick = tick_new;
+    step_count = 0; flags = 0; tgt_obs = 0; num_reached = 0;
+  }
+  if (active && leader) {
+    if (!(GENERAL && resetting)) {
+      store_rigid<T>(D, env, S);
+      if (HASOBJ) obj_store<T, OBJ>(D, env, O);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) D.r[(RF_ACTION + k) * n + env] = act_obs[k];
+      D.r[RF_NEW_DIST * n + env] = new_dist;
+      D.r[RF_EP_RETURN * n + env] = ep_return;
+    }
     D.i[IF_STEP * n + env] = step_count;
     D.i[IF_TICK * n + env] = tick;
     D.i[IF_EPISODE * n + env] = episode;
@@ -1062,6 +1109,7 @@ struct fw_env {
   int32_t* i_dev = nullptr;     // i32[IF_COUNT][npad]
   void* rs_dev = nullptr;       // shadow T[RF_COUNT][npad]   (only when shadow_on)
   int32_t* is_dev = nullptr;    // shadow ticks i32[npad]
+  void* sobs_dev = nullptr;     // shadow first observations T[npad][obs_dim]
   unsigned long long* sreq_dev = nullptr;   // shadow requests / progress words, u64[npad] each
   unsigned long long* sdone_dev = nullptr;
   uint32_t* lctr_dev = nullptr;             // device-side launch index, one word per workgroup (fwsim_device.hpp: launch_index)
@@ -1107,7 +1155,7 @@ int ensure_learner_lds(int dev, int which /*0: fw_ppo_update, 1: fw_policy_act*/
 
 template <typename T> DevState<T> dev_state(fw_env* h) {
   DevState<T> D; D.r = (T*)h->r_dev; D.i = h->i_dev; D.n = h->n; D.npad = h->npad;
-  D.rs = (T*)h->rs_dev; D.is = h->is_dev; D.sreq = h->sreq_dev; D.sdone = h->sdone_dev; D.epoch = 0; D.shadow_on = h->shadow_on;
+  D.rs = (T*)h->rs_dev; D.is = h->is_dev; D.sobs = (T*)h->sobs_dev; D.sreq = h->sreq_dev; D.sdone = h->sdone_dev; D.epoch = 0; D.shadow_on = h->shadow_on;
   D.lctr = h->lctr_dev; D.stats = h->stats_dev;
   FWP(D.prof = h->prof_dev;)
   return D;
@@ -1211,6 +1259,8 @@ int create_T(fw_env* h) {
     HIP_TRY(h, hipMalloc(&h->rs_dev, sizeof(T) * RF_COUNT * npad));
     HIP_TRY(h, hipMemset(h->rs_dev, 0, sizeof(T) * RF_COUNT * npad));
     HIP_TRY(h, hipMalloc((void**)&h->is_dev, sizeof(int32_t) * npad));
+    HIP_TRY(h, hipMalloc(&h->sobs_dev, sizeof(T) * (size_t)npad * (size_t)obs_dim_of(&h->cfg)));
+    HIP_TRY(h, hipMemset(h->sobs_dev, 0, sizeof(T) * (size_t)npad * (size_t)obs_dim_of(&h->cfg)));
     HIP_TRY(h, hipMalloc((void**)&h->sreq_dev, sizeof(unsigned long long) * npad));
     HIP_TRY(h, hipMalloc((void**)&h->sdone_dev, sizeof(unsigned long long) * npad));
     rc = invalidate_shadow(h);
@@ -1375,6 +1425,8 @@ int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64
     if (h->i_dev) (void)hipFree(h->i_dev);
     if (h->rs_dev) (void)hipFree(h->rs_dev);
     if (h->is_dev) (void)hipFree(h->is_dev);
+  if (h->sobs_dev) (void)hipFree(h->sobs_dev);
+    if (h->sobs_dev) (void)hipFree(h->sobs_dev);
     if (h->sreq_dev) (void)hipFree(h->sreq_dev);
     if (h->sdone_dev) (void)hipFree(h->sdone_dev);
     if (h->lctr_dev) (void)hipFree(h->lctr_dev);

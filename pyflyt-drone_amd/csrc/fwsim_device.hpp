@@ -96,6 +96,7 @@ struct DevState {
   // "shadow" = the pre-simulated start of each env's NEXT episode (see shadow_* in fwsim.hip)
   T* rs;                     // [RF_COUNT][npad]  same layout as r; written ONLY by shadow workers
   int32_t* is;               // [npad]            physics ticks of the shadow state
+  T* sobs;                   // [npad][obs_dim]   the observation the finished shadow's episode starts with (zero action)
   unsigned long long* sreq;  // [npad]  live -> worker:  (episode wanted << 32) | launch index of the request
   unsigned long long* sdone; // [npad]  worker -> live:  (episode built << 32) | (launch index & 0xFFFFFF) << 8 | progress
   uint32_t epoch;            // launch index of this fw_step: set IN the kernel from `lctr` (launch_index below)
