@@ -159,10 +159,12 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
   const int chunk = left;
 #pragma unroll 1
   while (__ballot(left > 0) != 0ull) {
-    if (left > 0) {
+    const bool stepped = left > 0;
+    if (stepped) {
       (void)aviary_step<T, true, G, HASOBJ>(P, C, OC, V, envc, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, gust, mine, wmask, LA);
       left -= 1;
     }
+    if (HASOBJ) obj_capture_step<T, G>(OC, V, stepped, envc, O, S, R, tick);
   }
   if (G == 8) lane_act_gather<T>(S, LA);
   if (chunk > 0 && done + chunk == total) {
@@ -465,11 +467,12 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       const int src = (lane & ~(G - 1)) | (it & (G - 1));
       z0 = __shfl(nz0, src, kWave); z1 = __shfl(nz1, src, kWave);
     }
-    if (phase != PH_DONE) {
-      const bool stepping = !GENERAL || phase == PH_STEP;
+    const bool stepped = phase != PH_DONE;
+    const bool stepping = stepped && (!GENERAL || phase == PH_STEP);
+    bool contact = false;
+    if (stepped) {
       if (P.has_noise && !pre_noise && stepping)
         rng_normal2<T>(P, genv, (uint32_t)episode, (uint32_t)(tick / P.ticks_per_aviary), z0, z1);
-      bool contact;
       if (GENERAL) {
         T c_eff[FW_NUM_ACTUATORS];
 #pragma unroll
@@ -480,7 +483,10 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       } else {
         contact = aviary_step<T, false, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd, tick, z0, z1, wb, wa, gust, mine, wmask, LA);    // :339
       }
-      FWP(const long long p_c = FWP_NOW(); p_avi += p_c - p_b;)
+    }
+    if (HASOBJ) obj_capture_step<T, G>(OC, D, stepped, envc, O, S, R, tick);     // the camera, by the whole wave
+    FWP(const long long p_c = FWP_NOW(); p_avi += p_c - p_b;)
+    if (stepped) {
       if (stepping && OBJ) {
         obj_compute_state<T>(O);                                                                   // :342
         // compute_base_term_trunc_reward(): :296-312
@@ -760,6 +766,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       const long long t3 = FWP_NOW();
       w[0] = t3 - p_t0; w[1] = p_t1 - p_t0; w[2] = p_reset; w[3] = p_avi; w[4] = p_task; w[5] = t3 - p_t2; w[6] = it | (nr << 8) | (nh << 16); w[7] = p_t0; w[8] = p_r1; w[9] = p_r2; w[10] = p_r3;
       w[11] = p_capmax | ((long long)p_ncapw << 48);
+      if (HASOBJ) { w[8] = O.p_capm[0]; w[9] = O.p_capm[1]; w[10] = O.p_capm[2]; w[2] = O.p_capm[3]; }     // (the reset split is unused by these kernels)
     } })
 }
 
@@ -904,8 +911,10 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
   if (G == 8) lane_act_scatter<T>(S, LA);
 #pragma unroll 1
   while (__ballot(warm_left > 0) != 0ull) {
-    if (warm_left > 0) {
-      (void)aviary_step<T, true, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, gust, mine, wmask, LA);
+    const bool stepped = warm_left > 0;
+    if (stepped) (void)aviary_step<T, true, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd0, tick, (T)0, (T)0, wb, wa, gust, mine, wmask, LA);
+    if (HASOBJ) obj_capture_step<T, G>(OC, D, stepped, env, O, S, R, tick);
+    if (stepped) {
       warm_left -= 1;
       if (warm_left == 0) {
         if (OBJ) obj_compute_state<T>(O);
@@ -1178,8 +1187,8 @@ template <typename T> size_t tile_bytes(const fw_env* h) {
   size_t b = sizeof(T) * (size_t)(kWave / h->lanes_per_env) * (size_t)(obs_dim_of(&h->cfg) + 1);
   if (h->cfg.task != FW_TASK_WAYPOINTS && h->lanes_per_env == 8) {
     const int res = h->cfg.camera_resolution > 0 ? h->cfg.camera_resolution : 128;
-    if (h->cfg.num_obstacles > 0)                      // 8 rows + the per-env table of 8 words per cylinder
-      b = std::max(b, sizeof(T) * 8 * ((size_t)zrow_stride_of(res) + (size_t)FW_MAX_OBSTACLES * 8));
+    if (h->cfg.num_obstacles > 0)                      // 8 rows + the per-env cylinder table: 38.9 KB at 480 columns, so that FOUR workgroups (the step and worker blocks a CU gets) fit its 160 KB
+      b = std::max(b, sizeof(T) * 8 * ((size_t)zrow_stride_of(res) + (size_t)FW_MAX_OBSTACLES * kCtabWords));
   }
   return b;
 }

@@ -8,6 +8,7 @@
 // penalty, dense lock / approach shaping, strike) follows the reference line by line.
 // The task state of one env lives in registers for the whole launch.
 #pragma once
+#include <type_traits>
 #include "fwsim_device.hpp"
 
 namespace fwsim {
@@ -42,6 +43,7 @@ struct ObjState {
   T seen_consec;
 #ifdef FW_PROFILE
   long long p_cap = 0; int p_ncap = 0;    // dev-only: cycles spent in camera captures, number of captures (tools/wave_profile.py)
+  long long p_capm[4] = {0, 0, 0, 0};     // dev-only, wave-level: cycles (low 40 bits) | episodes << 40 of capture steps with 1 / 2 / 3-4 / 5+ envs due
 #endif
 };
 
@@ -342,27 +344,56 @@ __device__ __forceinline__ int cyl_columns(float ox, float oy, float r2, float p
   return (fh >= fl) ? ((int)fl | ((int)fh << 16)) : 1;            // packed lo | hi << 16; 1 = (lo 1, hi 0) = empty
 }
 
+// The capture of ONE env, run by a SET of `VG` lanes (G = 8: VG = 8, 16, 32 or 64 consecutive lanes of the wave, lane `vsub` of the
+// set; G = 1: one lane): all of them are handed the owner env's pose / duck / obstacle count and compute the same scalars; rows of
+// the duck mask, cylinders and pixels of row h//2 are dealt out modulo VG; partial statistics are combined inside the set (DPP
+// inside 8 lanes, xor-butterflies above), after which every lane of the set holds the same `frame`.  `work` = false: a lane set
+// without an env this time (it only takes part in the cross-lane steps).
+constexpr int kCtabWords = 6;      // LDS table of the screened cylinders, per cylinder: cc, hh, op, oq, first column, last column
 template <typename T, int G>
-__device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevState<T>& D, int env, ObjState<T>& O,
-                                                   const Rigid<T>& S, const T R[9]) {
+__device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T>& D, int env, const T duck[3], int nob_in,
+                                             const T Sp[3], const T R[9], int vsub, int VG, int erow, bool work, T frame[8]) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const size_t n = D.npad;
-  const int nob = O.nob;
-  const int sub = (G == 1) ? 0 : (int)(threadIdx.x & (G - 1));
-  const int gbase = (int)threadIdx.x & ~(G - 1);
+  const int nob = work ? nob_in : 0;
+  const int sub = vsub & (G - 1);                     // lane within its 8-lane group
+  // reductions over the set (every lane gets the result)
+  auto ssum = [&](T v) {
+    v = group_sum<G, T>(v);
+    if (G == 8) { if (VG >= 16) v += __shfl_xor(v, 8, kWave); if (VG >= 32) v += __shfl_xor(v, 16, kWave); if (VG >= 64) v += __shfl_xor(v, 32, kWave); }
+    return v;
+  };
+  auto smin = [&](auto v) {
+    v = group_min<G>(v);
+    if (G == 8) {
+      if (VG >= 16) { auto o = __shfl_xor(v, 8, kWave); v = o < v ? o : v; }
+      if (VG >= 32) { auto o = __shfl_xor(v, 16, kWave); v = o < v ? o : v; }
+      if (VG >= 64) { auto o = __shfl_xor(v, 32, kWave); v = o < v ? o : v; }
+    }
+    return v;
+  };
+  auto sor = [&](uint32_t v) {
+    v = group_or<G>(v);
+    if (G == 8) {
+      if (VG >= 16) v |= (uint32_t)__shfl_xor((int)v, 8, kWave);
+      if (VG >= 32) v |= (uint32_t)__shfl_xor((int)v, 16, kWave);
+      if (VG >= 64) v |= (uint32_t)__shfl_xor((int)v, 32, kWave);
+    }
+    return v;
+  };
   T cam[3];
   {
     T offw[3];
     mv(R, OC.cam_off, offw);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) cam[k] = S.p[k] + offw[k];
+    for (int k = 0; k < 3; ++k) cam[k] = Sp[k] + offw[k];
   }
   const T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * n + env;
   const T W = OC.W, H = OC.H, F = OC.focal, invF = OC.inv_focal;
   const int Wi = (int)W, Hi = (int)H;
   const T u0 = (T)0.5 * (W - (T)1), v0 = (T)0.5 * (H - (T)1), Rd = OC.duck_radius;
   // ---- duck: sphere centre in camera coordinates (zc forward, xc right, yc down) ----
-  T relw[3] = { O.duck[0] - cam[0], O.duck[1] - cam[1], O.duck[2] + Rd - cam[2] }, relb[3];
+  T relw[3] = { duck[0] - cam[0], duck[1] - cam[1], duck[2] + Rd - cam[2] }, relb[3];
   mtv(R, relw, relb);
   const T zc = relb[0] * OC.cam_f[0] + relb[1] * OC.cam_f[1] + relb[2] * OC.cam_f[2];
   const T xc = relb[0] * OC.cam_r[0] + relb[1] * OC.cam_r[1] + relb[2] * OC.cam_r[2];
@@ -384,24 +415,23 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
   bool occluded = false;
   uint32_t vis = 0u;                          // G = 8: cylinders that can show on row h//2 (group-uniform after the OR below)
   // G = 8: LDS of this env -- the row buffer (1 / t of the nearest cylinder fragment per column; aliases the observation tile,
-  // which is only written after the step loop) and, behind the 8 rows, a table of 8 words per cylinder filled by the lane
+  // which is only written after the step loop) and, behind the 8 rows, a table of kCtabWords words per cylinder filled by the lane
   // that screened it: ox, oy, cc, hh, op, oq, first column, last column
-  const int erow = (int)((threadIdx.x & (kWave - 1)) / G);
   T* zr = (G == 8) ? reinterpret_cast<T*>(smem_raw) + (size_t)erow * OC.zrow_stride : nullptr;
-  T* ctab = (G == 8) ? reinterpret_cast<T*>(smem_raw) + (size_t)8 * OC.zrow_stride + (size_t)erow * (FW_MAX_OBSTACLES * 8) : nullptr;
+  T* ctab = (G == 8) ? reinterpret_cast<T*>(smem_raw) + (size_t)8 * OC.zrow_stride + (size_t)erow * (FW_MAX_OBSTACLES * kCtabWords) : nullptr;
   if (nob > 0) {
     if (G == 8) {
       T myc[3][3];
 #pragma unroll
       for (int slot = 0; slot < 3; ++slot) {                      // all loads in flight together: one memory round trip
-        const int o = sub + 8 * slot;
+        const int o = vsub + VG * slot;
         myc[slot][0] = myc[slot][1] = myc[slot][2] = (T)0;
         if (o < nob) { myc[slot][0] = ob[(3 * o) * n]; myc[slot][1] = ob[(3 * o + 1) * n]; myc[slot][2] = ob[(3 * o + 2) * n]; }
       }
       const T r2 = OC.obst_radius * OC.obst_radius;
 #pragma unroll
       for (int slot = 0; slot < 3; ++slot) {
-        const int o = sub + 8 * slot;
+        const int o = vsub + VG * slot;
         if (o < nob) {
           const T cx = myc[slot][0], cy = myc[slot][1], hh = myc[slot][2];
           if (duck_front) occluded |= cyl_inv_t<T>(OC, cx, cy, hh, cam, relw[0], relw[1], relw[2]) > (T)1;   // a hit at 0 < t < 1 of the segment camera -> sphere centre
@@ -411,19 +441,20 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
           const int xlo = packed & 0xFFFF, xhi = packed >> 16;
           if (xhi >= xlo) {
             vis |= 1u << o;
-            T* e = ctab + o * 8;
-            e[0] = ox; e[1] = oy; e[2] = ox * ox + oy * oy - r2; e[3] = hh;
-            e[4] = ox * g0[0] + oy * g0[1]; e[5] = ox * g1[0] + oy * g1[1]; e[6] = (T)xlo; e[7] = (T)xhi;
+            T* e = ctab + o * kCtabWords;
+            e[0] = ox * ox + oy * oy - r2; e[1] = hh;
+            e[2] = ox * g0[0] + oy * g0[1]; e[3] = ox * g1[0] + oy * g1[1]; e[4] = (T)xlo; e[5] = (T)xhi;
           }
         }
       }
-      vis = group_or<G>(vis);
+      // one cross-lane step for both results of the screening
+      const uint32_t pk = sor(vis | (occluded ? 0x80000000u : 0u));
+      vis = pk & 0x7FFFFFFFu; occluded = (pk >> 31) != 0u;
     } else {
 #pragma unroll 1
       for (int o = 0; o < nob; ++o)
         if (duck_front) occluded |= cyl_inv_t<T>(OC, ob[(3 * o) * n], ob[(3 * o + 1) * n], ob[(3 * o + 2) * n], cam, relw[0], relw[1], relw[2]) > (T)1;
     }
-    occluded = group_any<G>(occluded);
   }
   // ---- duck mask statistics ----
   T cnt = (T)0, sx = (T)0, sy = (T)0, itmax = (T)0;               // itmax = 1 / (nearest fragment depth)
@@ -444,9 +475,9 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
     T fy0 = ceil_<T>(v0 + F * b_lo), fy1 = floor_<T>(v0 + F * b_hi);
     fy0 = fy0 < (T)0 ? (T)0 : fy0; fy1 = fy1 > H - (T)1 ? H - (T)1 : fy1;
     const T iA = M<T>::rcp_(A);
-    const int y0 = (int)fy0, y1 = (fy1 >= fy0) ? (int)fy1 : -1;
+    const int y0 = (int)fy0, y1 = (work && fy1 >= fy0) ? (int)fy1 : -1;
 #pragma unroll 1
-    for (int y = y0 + sub; y <= y1; y += G) {
+    for (int y = y0 + vsub; y <= y1; y += VG) {
       const T b = ((T)y - v0) * invF;
       const T e = zc + b * yc, Bh = xc * e, Cq = e * e - ((T)1 + b * b) * k2;
       const T Dd = Bh * Bh - A * Cq;
@@ -479,9 +510,9 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
         }
       }
     }
-    cnt = group_sum<G, T>(cnt); sx = group_sum<G, T>(sx); sy = group_sum<G, T>(sy);
-    itmax = -group_min<G, T>(-itmax);
-    if (G == 8) { mid_lo = group_min<G, int>(mid_lo); mid_hi = -group_min<G, int>(-mid_hi); }
+    cnt = ssum(cnt); sx = ssum(sx); sy = ssum(sy);
+    itmax = -smin(-itmax);
+    if (G == 8) { mid_lo = smin(mid_lo); mid_hi = -smin(-mid_hi); }
   }
   T visible = (T)0, cxn = (T)0, cyn = (T)0, area = (T)0, depth = (T)0;
   const bool duck_in = cnt > (T)0;
@@ -494,7 +525,7 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
     area = M<T>::div_(cnt, M<T>::fmax_((T)1, H * W));
     depth = depthbuf_to_meters<T>(OC, depthbuf_from_inv<T>(OC, itmax));
   }
-  O.frame[0] = visible; O.frame[1] = cxn; O.frame[2] = cyn; O.frame[3] = area; O.frame[4] = depth;
+  frame[0] = visible; frame[1] = cxn; frame[2] = cyn; frame[3] = area; frame[4] = depth;
   // ---- obstacle zones: mean depth-buffer value of the non-duck pixels of each third of row h//2 ----
   // Everything is accumulated as sum of clip(1 / t, 1 / far, 1 / near): the buffer value is c1 (1 - near / t), affine in 1 / t.
   //  * ground / sky: 1 / t = -(g0z + a g1z) / cam_z is LINEAR in the column, so the sum over a run of columns is an arithmetic
@@ -554,7 +585,7 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
   }
   if (exact_duck) {                                               // rare: take the duck's pixels of row h//2 out one by one
     T dsum[3] = { (T)0, (T)0, (T)0 }; int dcnt[3] = { 0, 0, 0 };
-    for (int x = sub; x < Wi; x += G) {
+    for (int x = work ? vsub : Wi; x < Wi; x += VG) {
       if (inv_hit(((T)x - u0) * invF, bm) > (T)0) {
         const T v = git((T)x);
         dsum[0] += x < x_1 ? v : (T)0; dsum[1] += (x >= x_1 && x < x_2) ? v : (T)0; dsum[2] += x >= x_2 ? v : (T)0;
@@ -562,7 +593,7 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
       }
     }
 #pragma unroll
-    for (int z = 0; z < 3; ++z) { zsum[z] -= group_sum<G, T>(dsum[z]); zcnt[z] -= (int)group_sum<G, float>((float)dcnt[z]); }
+    for (int z = 0; z < 3; ++z) { zsum[z] -= ssum(dsum[z]); zcnt[z] -= (int)ssum((T)dcnt[z]); }
   }
   if (nob > 0) {
     const T pp = g0[0] * g0[0] + g0[1] * g0[1], pq = g0[0] * g1[0] + g0[1] * g1[1], qq = g1[0] * g1[0] + g1[1] * g1[1];
@@ -573,7 +604,7 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
       return inv_hit(((T)x - u0) * invF, bm) > (T)0;
     };
     // 1 / t of the cylinder's fragment in column a (0 = none): no division for the hit / height tests
-    auto cyl_it = [&](T a, T ox, T oy, T cc, T op, T oq, T hh) {     // branch-free: four of these are in flight per lane
+    auto cyl_it = [&](T a, T cc, T op, T oq, T hh) {     // branch-free: four of these are in flight per lane
       const T A = pp + a * ((T)2 * pq + a * qq), hb = op + a * oq, disc = hb * hb - A * cc;
 #ifdef FW_DBG_BRANCHY
       if (!(A > (T)0) || disc < (T)0 || hb >= (T)0) return (T)0;
@@ -586,7 +617,6 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
       const T num = -hb - M<T>::sqrt_(disc > (T)0 ? disc : (T)0);
       const T zA = cam[2] * A + num * (g0[2] + a * g1[2]);         // z of the hit times A
       ok = ok && num > (T)0 && zA >= (T)0 && zA <= hh * A;
-      (void)ox; (void)oy;
       const T it = M<T>::div_(A, ok ? num : (T)1);
       return ok ? it : (T)0;
     };
@@ -599,7 +629,7 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
     T csum[3] = { (T)0, (T)0, (T)0 };
     if (G == 8) {
 #pragma unroll 4
-      for (int x = sub; x < Wi; x += G) zr[x] = (T)0;
+      for (int x = work ? vsub : Wi; x < Wi; x += VG) zr[x] = (T)0;
       __builtin_amdgcn_wave_barrier();                            // the table entries written by my sibling lanes are read below
       // every env walks ITS OWN visible cylinders (k-th iteration = k-th set bit of its mask): the wave runs max-over-envs
       // iterations instead of one per cylinder index that any env can see
@@ -608,32 +638,40 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
       while (m) {
         const int o = __ffs((int)m) - 1;
         m &= m - 1u;
-        const T* e = ctab + o * 8;                                // same address in the 8 lanes of the env: LDS broadcast
-        const T ox = e[0], oy = e[1], cc = e[2], hh = e[3], op = e[4], oq = e[5];
-        const int xlo = (int)e[6], xhi = (int)e[7];
+        const T* e = ctab + o * kCtabWords;                       // same address in all lanes of the set: LDS broadcast
+        const T cc = e[0], hh = e[1], op = e[2], oq = e[3];
+        const int xlo = (int)e[4], xhi = (int)e[5];
+        // my pixels (x = vsub mod VG: a pixel always belongs to the same lane, so the row buffer needs no atomics), U at a time:
+        // independent chains in flight per lane where a lane has several pixels of a segment, one where 32+ lanes share it
+        auto pixels = [&](auto UC) {
+          constexpr int U = decltype(UC)::value;
 #pragma unroll 1
-        for (int x = xlo + ((sub - xlo) & 7); x <= xhi; x += 4 * G) {       // my pixels (x = sub mod 8) of the interval, 4 at a time
-          T it4[4];
+          for (int x = xlo + ((vsub - xlo) & (VG - 1)); x <= xhi; x += U * VG) {
+            T itu[U];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int xx = x + u * G;
-            it4[u] = xx <= xhi ? cyl_it(((T)xx - u0) * invF, ox, oy, cc, op, oq, hh) : (T)0;
-          }
+            for (int u = 0; u < U; ++u) {
+              const int xx = x + u * VG;
+              itu[u] = xx <= xhi ? cyl_it(((T)xx - u0) * invF, cc, op, oq, hh) : (T)0;
+            }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int xx = x + u * G;
-            if (it4[u] > (T)0) {
-              const T c = zr[xx];
-              if (it4[u] > c) {
-                zr[xx] = it4[u];
-                if (!is_duck(xx)) {
-                  const T d = delta(c, it4[u], git((T)xx));
-                  csum[0] += xx < x_1 ? d : (T)0; csum[1] += (xx >= x_1 && xx < x_2) ? d : (T)0; csum[2] += xx >= x_2 ? d : (T)0;
+            for (int u = 0; u < U; ++u) {
+              const int xx = x + u * VG;
+              if (itu[u] > (T)0) {
+                const T c = zr[xx];
+                if (itu[u] > c) {
+                  zr[xx] = itu[u];
+                  if (!is_duck(xx)) {
+                    const T d = delta(c, itu[u], git((T)xx));
+                    csum[0] += xx < x_1 ? d : (T)0; csum[1] += (xx >= x_1 && xx < x_2) ? d : (T)0; csum[2] += xx >= x_2 ? d : (T)0;
+                  }
                 }
               }
             }
           }
-        }
+        };
+        if (VG <= 8) pixels(std::integral_constant<int, 4>{});
+        else if (VG == 16) pixels(std::integral_constant<int, 2>{});
+        else pixels(std::integral_constant<int, 1>{});
       }
     } else {
 #pragma unroll 1
@@ -644,7 +682,7 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
         for (int o = 0; o < nob; ++o) {
           const T cx = ob[(3 * o) * n], cy = ob[(3 * o + 1) * n], hh = ob[(3 * o + 2) * n];
           const T ox = cam[0] - cx, oy = cam[1] - cy;
-          const T ic = cyl_it(a, ox, oy, ox * ox + oy * oy - r2, ox * g0[0] + oy * g0[1], ox * g1[0] + oy * g1[1], hh);
+          const T ic = cyl_it(a, ox * ox + oy * oy - r2, ox * g0[0] + oy * g0[1], ox * g1[0] + oy * g1[1], hh);
           c = ic > c ? ic : c;
         }
         if (c > (T)0) {
@@ -654,15 +692,63 @@ __device__ __forceinline__ void obj_camera_capture(const ObjC<T>& OC, const DevS
       }
     }
 #pragma unroll
-    for (int z = 0; z < 3; ++z) zsum[z] += group_sum<G, T>(csum[z]);
+    for (int z = 0; z < 3; ++z) zsum[z] += ssum(csum[z]);
   }
 #pragma unroll
   for (int z = 0; z < 3; ++z) {
     // mean buffer value = c1 (1 - near * mean(1 / t));  float(np.mean(vals)) :718, then metres unless the mean is 0 :725-727
     const T mean = zcnt[z] > 0 ? OC.db_c1 * ((T)1 - OC.near_ * M<T>::div_(zsum[z], (T)zcnt[z])) : (T)0;
-    O.frame[5 + z] = mean > (T)1e-12 ? depthbuf_to_meters<T>(OC, mean) : (T)0;       // (guard band of the `> 0.0` test: see the oracle)
+    frame[5 + z] = mean > (T)1e-12 ? depthbuf_to_meters<T>(OC, mean) : (T)0;       // (guard band of the `> 0.0` test: see the oracle)
   }
-  O.frame_has = (T)1;
+}
+
+// A capture step of the WAVE.  G = 8: the envs whose camera is due hand their pose to sets of 8 * k lanes, k = 8 / 4 / 2 / 2 / 1
+// for 1 / 2 / 3 / 4 / 5+ envs due (only a few of the wave's 8 envs capture at the same sub-step, and the launch lasts as long as
+// its slowest wave): set j = lanes [j VG, (j + 1) VG) works for the j-th due env, whichever env's state those lanes hold
+// themselves; the frame travels back by shuffle.  Must be called by all 64 lanes (wave-uniform control flow).
+template <typename T, int G>
+__device__ __forceinline__ void obj_capture_wave(const ObjC<T>& OC, const DevState<T>& D, bool due, int env, ObjState<T>& O,
+                                                 const Rigid<T>& S, const T R[9]) {
+  T fr[8];
+  if (G != 8) {
+    if (due) {
+      capture_body<T, G>(OC, D, env, O.duck, O.nob, S.p, R, 0, 1, 0, true, fr);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) O.frame[i] = fr[i];
+      O.frame_has = (T)1;
+    }
+    return;
+  }
+  const unsigned long long db = __ballot(due);
+  if (db == 0ull) return;
+  uint32_t dmask = 0u;                                  // bit g: the env of lanes 8 g .. 8 g + 7 is due (wave-uniform)
+#pragma unroll
+  for (int g = 0; g < 8; ++g) dmask |= (uint32_t)((db >> (8 * g)) & 1ull) << g;
+  const int m = __popc(dmask);
+  const int k = m == 1 ? 8 : (m == 2 ? 4 : (m <= 4 ? 2 : 1));
+  const int VG = 8 * k;
+  const int lane = (int)threadIdx.x & (kWave - 1), sub = lane & 7, grp = lane >> 3;
+  const int j = lane / VG;
+  const bool work = j < m;
+  int og = 0;                                           // group of the j-th due env
+  {
+    uint32_t mm = dmask;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) mm = (i < (work ? j : 0)) ? (mm & (mm - 1u)) : mm;
+    og = __ffs((int)mm) - 1;
+  }
+  const int src = og * 8 + sub;
+  T oduck[3], oSp[3], oR[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { oduck[i] = __shfl(O.duck[i], src, kWave); oSp[i] = __shfl(S.p[i], src, kWave); }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) oR[i] = __shfl(R[i], src, kWave);
+  const int onob = __shfl(O.nob, src, kWave), oenv = __shfl(env, src, kWave);
+  capture_body<T, G>(OC, D, oenv, oduck, onob, oSp, oR, lane & (VG - 1), VG, j, work, fr);
+  const int back = __popc(dmask & ((1u << grp) - 1u)) * VG + sub;      // a lane of the set that worked for my env
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const T v = __shfl(fr[i], back, kWave); if (due) O.frame[i] = v; }
+  if (due) O.frame_has = (T)1;
 }
 
 // compute_state (:253-287) side effects: _compute_vision_features (:643-689) on the latest frame,
@@ -859,8 +945,8 @@ __device__ __forceinline__ void obj_write_obs(const Params<T>& P, const ObjState
 
 // Aviary.step(): ticks_per_aviary ticks; returns any-contact.  (z0, z1) are the two ticks'
 // motor-noise normals (zero for warm-up lanes: their throttle is exactly 0).  OBJ adds the
-// duck / cylinder contacts per tick and the camera capture every physics_camera_ratio ticks
-// (envs/fixedwing_objlock_env.py:631-641).
+// duck / cylinder contacts per tick; the camera capture every physics_camera_ratio ticks
+// (envs/fixedwing_objlock_env.py:631-641) is the caller's next call: obj_capture_step, by the whole wave.
 template <typename T, bool WIND, int G, bool OBJ>
 __device__ __forceinline__ bool aviary_step(const Params<T>& P, const TickC<T>& C, const ObjC<T>& OC, const DevState<T>& D,
                                             int env, ObjState<T>& O, Rigid<T>& S, T R[9], const T cmd[FW_NUM_ACTUATORS],
@@ -876,16 +962,29 @@ __device__ __forceinline__ bool aviary_step(const Params<T>& P, const TickC<T>& 
     tick += 1;
     if (WIND) gust_advance<T>(P, gust);
   }
-  if (OBJ && OC.camera_ratio_ticks > 0 && (tick % OC.camera_ratio_ticks) == 0) {
-#ifdef FW_PROFILE
-    const long long c0 = (long long)__builtin_readcyclecounter();
-#endif
-    obj_camera_capture<T, G>(OC, D, env, O, S, R);
-#ifdef FW_PROFILE
-    O.p_cap += (long long)__builtin_readcyclecounter() - c0; O.p_ncap += 1;
-#endif
-  }
   return contact;
+}
+
+// the capture that follows an Aviary step (`stepped`: this lane's env ran one); all lanes of the wave call it
+template <typename T, int G>
+__device__ __forceinline__ void obj_capture_step(const ObjC<T>& OC, const DevState<T>& D, bool stepped, int env, ObjState<T>& O,
+                                                 const Rigid<T>& S, const T R[9], int32_t tick) {
+  const bool due = stepped && OC.camera_ratio_ticks > 0 && (tick % OC.camera_ratio_ticks) == 0;
+#ifdef FW_PROFILE
+  const long long c0 = (long long)__builtin_readcyclecounter();
+#endif
+  obj_capture_wave<T, G>(OC, D, due, env, O, S, R);
+#ifdef FW_PROFILE
+  const long long c1 = (long long)__builtin_readcyclecounter();
+  if (due) { O.p_cap += c1 - c0; O.p_ncap += 1; }
+  if (G == 8) {
+    const unsigned long long db = __ballot(due);
+    int m = 0;
+    for (int g = 0; g < 8; ++g) m += (int)((db >> (8 * g)) & 1ull);
+    if (m > 0) { const int b = m == 1 ? 0 : (m == 2 ? 1 : (m <= 4 ? 2 : 3)); const long long add = (c1 - c0) + (1ll << 40);
+      O.p_capm[0] += b == 0 ? add : 0; O.p_capm[1] += b == 1 ? add : 0; O.p_capm[2] += b == 2 ? add : 0; O.p_capm[3] += b == 3 ? add : 0; }
+  }
+#endif
 }
 
 }  // namespace fwsim

@@ -41,5 +41,12 @@ cap = st[:, :, 11] & ((1 << 48) - 1); ncap = st[:, :, 11] >> 48
 if cap.any():
     print(f"  camera: envs capturing per wave-step {ncap.mean():.2f} of {N // nblk}; cycles in captures per wave-step: mean {cap.mean():.0f}  "
           f"slowest wave {(S[:, 11] & ((1 << 48) - 1)).mean():.0f}; waves with a capture {100.0 * (ncap > 0).mean():.1f}%")
+    names_m = ["1 env due", "2", "3-4", "5+"]
+    for idx, nm in zip((8, 9, 10, 2), names_m):
+        v = st[:, :, idx]; cyc = v & ((1 << 40) - 1); ne = v >> 40
+        vs = S[:, idx]; cs = vs & ((1 << 40) - 1); ns = vs >> 40
+        if ne.sum():
+            print(f"    capture steps with {nm}: {ne.mean():.2f} per wave-step, {cyc.sum() / max(1, ne.sum()):.0f} cycles each (all waves); "
+                  f"slowest wave: {ns.mean():.2f} per step, {cs.sum() / max(1, ns.sum()):.0f} cycles each")
 if wk.any():
     print(f"  shadow worker waves: busy {100.0 * (wk > 2000).mean():.1f}%  mean busy cycles {wk[wk > 2000].mean() if (wk > 2000).any() else 0:.0f}  max {wk.max()}")
