@@ -1187,8 +1187,8 @@ template <typename T> size_t tile_bytes(const fw_env* h) {
   size_t b = sizeof(T) * (size_t)(kWave / h->lanes_per_env) * (size_t)(obs_dim_of(&h->cfg) + 1);
   if (h->cfg.task != FW_TASK_WAYPOINTS && h->lanes_per_env == 8) {
     const int res = h->cfg.camera_resolution > 0 ? h->cfg.camera_resolution : 128;
-    if (h->cfg.num_obstacles > 0)                      // 8 rows + the per-env cylinder table: 38.9 KB at 480 columns, so that FOUR workgroups (the step and worker blocks a CU gets) fit its 160 KB
-      b = std::max(b, sizeof(T) * 8 * ((size_t)zrow_stride_of(res) + (size_t)FW_MAX_OBSTACLES * kCtabWords));
+    if (h->cfg.num_obstacles > 0)                      // the camera's rows, tables and work list (camera_lds_bytes): 45 KB at 480 columns
+      b = std::max(b, camera_lds_bytes(sizeof(T), zrow_stride_of(res), res));
   }
   return b;
 }

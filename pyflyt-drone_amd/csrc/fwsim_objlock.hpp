@@ -349,7 +349,16 @@ __device__ __forceinline__ int cyl_columns(float ox, float oy, float r2, float p
 // the duck mask, cylinders and pixels of row h//2 are dealt out modulo VG; partial statistics are combined inside the set (DPP
 // inside 8 lanes, xor-butterflies above), after which every lane of the set holds the same `frame`.  `work` = false: a lane set
 // without an env this time (it only takes part in the cross-lane steps).
-constexpr int kCtabWords = 6;      // LDS table of the screened cylinders, per cylinder: cc, hh, op, oq, first column, last column
+// LDS map of the analytic camera on the 8-lane mapping (aliases the observation tile, which is only written after the step
+// loop), in words of T:  8 row buffers of zrow_stride words (1 / t of the nearest cylinder fragment per column, one per lane set)
+// | 8 tables of FW_MAX_OBSTACLES x kCtabWords (the screened cylinders of a set: cc, hh, op, oq, first column, last column, 1 / cc)
+// | 8 x kSetWords (constants of a set's row h//2: pp, pq, qq, g0z, g1z, cam z) | u32: slice count, pad, 8 x (first, last covered
+// column) | u16 slice list: set << 10 | cylinder << 5 | index of the 32-column slice inside the cylinder's interval
+constexpr int kCtabWords = 7, kSetWords = 8, kSliceCols = 32;
+__host__ __device__ inline size_t camera_lds_bytes(size_t word, int zrow_stride, int res) {
+  const size_t slices = (size_t)8 * FW_MAX_OBSTACLES * (size_t)((res + kSliceCols - 1) / kSliceCols);
+  return word * ((size_t)8 * zrow_stride + (size_t)8 * FW_MAX_OBSTACLES * kCtabWords + (size_t)8 * kSetWords) + 4 * 18 + 2 * slices + 8;
+}
 template <typename T, int G>
 __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T>& D, int env, const T duck[3], int nob_in,
                                              const T Sp[3], const T R[9], int vsub, int VG, int erow, bool work, T frame[8]) {
@@ -417,8 +426,21 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
   // G = 8: LDS of this env -- the row buffer (1 / t of the nearest cylinder fragment per column; aliases the observation tile,
   // which is only written after the step loop) and, behind the 8 rows, a table of kCtabWords words per cylinder filled by the lane
   // that screened it: ox, oy, cc, hh, op, oq, first column, last column
-  T* zr = (G == 8) ? reinterpret_cast<T*>(smem_raw) + (size_t)erow * OC.zrow_stride : nullptr;
-  T* ctab = (G == 8) ? reinterpret_cast<T*>(smem_raw) + (size_t)8 * OC.zrow_stride + (size_t)erow * (FW_MAX_OBSTACLES * kCtabWords) : nullptr;
+  using UB = std::conditional_t<sizeof(T) == 8, unsigned long long, unsigned int>;      // T as ordered bits (positive values)
+  T* const lbase = reinterpret_cast<T*>(smem_raw);
+  UB* zr = (G == 8) ? reinterpret_cast<UB*>(lbase) + (size_t)erow * OC.zrow_stride : nullptr;
+  T* ctab_all = lbase + (size_t)8 * OC.zrow_stride;
+  T* ctab = ctab_all + (size_t)erow * (FW_MAX_OBSTACLES * kCtabWords);
+  T* sconst_all = ctab_all + (size_t)8 * FW_MAX_OBSTACLES * kCtabWords;
+  uint32_t* lu = reinterpret_cast<uint32_t*>(sconst_all + 8 * kSetWords);      // [0] slice count, [2 + 2 s], [3 + 2 s]: covered columns of set s
+  uint16_t* slist = reinterpret_cast<uint16_t*>(lu + 18);
+  const T pp = g0[0] * g0[0] + g0[1] * g0[1], pq = g0[0] * g1[0] + g0[1] * g1[1], qq = g1[0] * g1[0] + g1[1] * g1[1];
+  const bool cyl_on = G == 8 && OC.num_obstacles > 0;   // (the handle's LDS holds the camera map only then)
+  if (cyl_on) {
+    if ((threadIdx.x & (kWave - 1)) == 0) lu[0] = 0u;
+    if (vsub == 0) { lu[2 + 2 * erow] = 0x7FFFFFFFu; lu[3 + 2 * erow] = 0u; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
   if (nob > 0) {
     if (G == 8) {
       T myc[3][3];
@@ -442,14 +464,25 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
           if (xhi >= xlo) {
             vis |= 1u << o;
             T* e = ctab + o * kCtabWords;
-            e[0] = ox * ox + oy * oy - r2; e[1] = hh;
-            e[2] = ox * g0[0] + oy * g0[1]; e[3] = ox * g1[0] + oy * g1[1]; e[4] = (T)xlo; e[5] = (T)xhi;
+            const T cc = ox * ox + oy * oy - r2;
+            e[0] = cc; e[1] = hh;
+            e[2] = ox * g0[0] + oy * g0[1]; e[3] = ox * g1[0] + oy * g1[1]; e[4] = (T)xlo; e[5] = (T)xhi; e[6] = M<T>::rcp_(cc);
+            // the interval joins the wave's work list in slices of kSliceCols columns
+            (void)__hip_atomic_fetch_min(lu + 2 + 2 * erow, (uint32_t)xlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            (void)__hip_atomic_fetch_max(lu + 3 + 2 * erow, (uint32_t)xhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int nsl = (xhi - xlo) / kSliceCols + 1;
+            const uint32_t pos = __hip_atomic_fetch_add(lu, (uint32_t)nsl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int i = 0; i < nsl; ++i) slist[pos + i] = (uint16_t)((erow << 10) | (o << 5) | i);
           }
         }
       }
       // one cross-lane step for both results of the screening
       const uint32_t pk = sor(vis | (occluded ? 0x80000000u : 0u));
       vis = pk & 0x7FFFFFFFu; occluded = (pk >> 31) != 0u;
+      if (vsub == 0 && vis) {
+        T* sc = sconst_all + erow * kSetWords;
+        sc[0] = pp; sc[1] = pq; sc[2] = qq; sc[3] = g0[2]; sc[4] = g1[2]; sc[5] = cam[2];
+      }
     } else {
 #pragma unroll 1
       for (int o = 0; o < nob; ++o)
@@ -595,85 +628,94 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
 #pragma unroll
     for (int z = 0; z < 3; ++z) { zsum[z] -= ssum(dsum[z]); zcnt[z] -= (int)ssum((T)dcnt[z]); }
   }
-  if (nob > 0) {
-    const T pp = g0[0] * g0[0] + g0[1] * g0[1], pq = g0[0] * g1[0] + g0[1] * g1[1], qq = g1[0] * g1[0] + g1[1] * g1[1];
-    const T r2 = OC.obst_radius * OC.obst_radius;
+  {
     auto is_duck = [&](int x) {
       if (!duck_in) return false;
       if (!straddle) return x >= mid_lo && x <= mid_hi;
       return inv_hit(((T)x - u0) * invF, bm) > (T)0;
     };
-    // 1 / t of the cylinder's fragment in column a (0 = none): no division for the hit / height tests
-    auto cyl_it = [&](T a, T cc, T op, T oq, T hh) {     // branch-free: four of these are in flight per lane
-      const T A = pp + a * ((T)2 * pq + a * qq), hb = op + a * oq, disc = hb * hb - A * cc;
-#ifdef FW_DBG_BRANCHY
-      if (!(A > (T)0) || disc < (T)0 || hb >= (T)0) return (T)0;
-      { const T num = -hb - M<T>::sqrt_(disc);
-        const T zA = cam[2] * A + num * (g0[2] + a * g1[2]);
-        if (!(num > (T)0) || zA < (T)0 || zA > hh * A) return (T)0;
-        return M<T>::div_(A, num); }
-#endif
+    // 1 / t of a cylinder's fragment in the column of direction g0 + a g1 (0 = none).  t = (-hb - sqrt(disc)) / A and
+    // hb^2 - disc = A cc, so 1 / t = (sqrt(disc) - hb) / cc: no division per pixel (cc = |o|^2 - r^2 > 0 is the cylinder's), and no
+    // cancellation (hb < 0).  Branch-free: several of these are in flight per lane.
+    auto cyl_it = [&](T a, T cc, T icc, T op, T oq, T hh, T pp_, T pq_, T qq_, T g0z, T g1z, T camz) {
+      const T A = pp_ + a * ((T)2 * pq_ + a * qq_), hb = op + a * oq, disc = hb * hb - A * cc;
       bool ok = A > (T)0 && disc >= (T)0 && hb < (T)0;
-      const T num = -hb - M<T>::sqrt_(disc > (T)0 ? disc : (T)0);
-      const T zA = cam[2] * A + num * (g0[2] + a * g1[2]);         // z of the hit times A
+      const T sq = M<T>::sqrt_(disc > (T)0 ? disc : (T)0);
+      const T num = -hb - sq;
+      const T zA = camz * A + num * (g0z + a * g1z);               // z of the hit times A
       ok = ok && num > (T)0 && zA >= (T)0 && zA <= hh * A;
-      const T it = M<T>::div_(A, ok ? num : (T)1);
-      return ok ? it : (T)0;
+      return ok ? (sq - hb) * icc : (T)0;
     };
-    // a pixel whose nearest cylinder fragment moves from 1/t = c_old to c_new adds this to its third's sum of clip(1/t)
-    // (the ground value g stays underneath: the pixel shows max(cylinder, ground)); telescopes over successive updates
-    auto delta = [&](T c_old, T c_new, T g) {
-      const T hi = c_new > OC.inv_near ? OC.inv_near : c_new, lo = c_old > OC.inv_near ? OC.inv_near : c_old;
-      return (hi > g ? hi : g) - (lo > g ? lo : g);
-    };
+    // what a pixel whose nearest cylinder fragment is at 1 / t = c adds to its third's sum of clip(1 / t): the ground value g
+    // stays underneath (the pixel shows max(cylinder, ground))
+    auto over_ground = [&](T c, T g) { const T hi = c > OC.inv_near ? OC.inv_near : c; return (hi > g ? hi : g) - g; };
     T csum[3] = { (T)0, (T)0, (T)0 };
-    if (G == 8) {
+    if (cyl_on) {
+      // (1) my set clears the covered columns of its row buffer
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const bool drawn = work && vis != 0u;                       // set-uniform
+      const int xmin = drawn ? (int)lu[2 + 2 * erow] : 1, xmax = drawn ? (int)lu[3 + 2 * erow] : 0;
 #pragma unroll 4
-      for (int x = work ? vsub : Wi; x < Wi; x += VG) zr[x] = (T)0;
-      __builtin_amdgcn_wave_barrier();                            // the table entries written by my sibling lanes are read below
-      // every env walks ITS OWN visible cylinders (k-th iteration = k-th set bit of its mask): the wave runs max-over-envs
-      // iterations instead of one per cylinder index that any env can see
-      uint32_t m = vis;
+      for (int x = xmin + vsub; x <= xmax; x += VG) zr[x] = (UB)0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // (2) the WAVE draws all sets' intervals: slice s of the list goes to 8-lane group s mod 8, 4 pixels per lane in flight;
+      // the nearest fragment of a pixel is a max of 1 / t, kept with an LDS atomic on the ordered bit pattern, so who draws
+      // what -- and in which order -- does not change a bit of the result
+      const uint32_t total = lu[0];
+      const int grp = (int)(threadIdx.x & (kWave - 1)) >> 3, s8 = (int)threadIdx.x & 7;
 #pragma unroll 1
-      while (m) {
-        const int o = __ffs((int)m) - 1;
-        m &= m - 1u;
-        const T* e = ctab + o * kCtabWords;                       // same address in all lanes of the set: LDS broadcast
-        const T cc = e[0], hh = e[1], op = e[2], oq = e[3];
-        const int xlo = (int)e[4], xhi = (int)e[5];
-        // my pixels (x = vsub mod VG: a pixel always belongs to the same lane, so the row buffer needs no atomics), U at a time:
-        // independent chains in flight per lane where a lane has several pixels of a segment, one where 32+ lanes share it
-        auto pixels = [&](auto UC) {
-          constexpr int U = decltype(UC)::value;
+      for (uint32_t si = (uint32_t)grp; si < total; si += 8u) {
+        const uint32_t ent = slist[si];
+        const int es = (int)(ent >> 10), eo = (int)(ent >> 5) & 31, ei = (int)ent & 31;
+        const T* e = ctab_all + ((size_t)es * FW_MAX_OBSTACLES + eo) * kCtabWords;      // same address in the 8 lanes: LDS broadcast
+        const T* sc = sconst_all + es * kSetWords;
+        const T cc = e[0], hh = e[1], op = e[2], oq = e[3], icc = e[6];
+        const int xhi = (int)e[5];
+        const int x0 = (int)e[4] + ei * kSliceCols + s8;
+        const T c0 = sc[0], c1 = sc[1], c2 = sc[2], c3 = sc[3], c4 = sc[4], c5 = sc[5];
+        UB* zrow = reinterpret_cast<UB*>(lbase) + (size_t)es * OC.zrow_stride;
+        T itu[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int xx = x0 + 8 * u;
+          itu[u] = xx <= xhi ? cyl_it(((T)xx - u0) * invF, cc, icc, op, oq, hh, c0, c1, c2, c3, c4, c5) : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int xx = x0 + 8 * u;
+          if (itu[u] > (T)0) {
+            UB bits;
+            __builtin_memcpy(&bits, &itu[u], sizeof(T));
+            (void)__hip_atomic_fetch_max(zrow + xx, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // (3) my set sums its row: pixel x belongs to lane x mod VG of the set
+      if (drawn) {
 #pragma unroll 1
-          for (int x = xlo + ((vsub - xlo) & (VG - 1)); x <= xhi; x += U * VG) {
-            T itu[U];
+        for (int x = xmin + vsub; x <= xmax; x += 4 * VG) {
+          T v[4];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-              const int xx = x + u * VG;
-              itu[u] = xx <= xhi ? cyl_it(((T)xx - u0) * invF, cc, op, oq, hh) : (T)0;
-            }
+          for (int u = 0; u < 4; ++u) {
+            const int xx = x + u * VG;
+            const UB bits = xx <= xmax ? zr[xx] : (UB)0;
+            __builtin_memcpy(&v[u], &bits, sizeof(T));
+          }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-              const int xx = x + u * VG;
-              if (itu[u] > (T)0) {
-                const T c = zr[xx];
-                if (itu[u] > c) {
-                  zr[xx] = itu[u];
-                  if (!is_duck(xx)) {
-                    const T d = delta(c, itu[u], git((T)xx));
-                    csum[0] += xx < x_1 ? d : (T)0; csum[1] += (xx >= x_1 && xx < x_2) ? d : (T)0; csum[2] += xx >= x_2 ? d : (T)0;
-                  }
-                }
-              }
+          for (int u = 0; u < 4; ++u) {
+            const int xx = x + u * VG;
+            if (v[u] > (T)0 && !is_duck(xx)) {
+              const T d = over_ground(v[u], git((T)xx));
+              csum[0] += xx < x_1 ? d : (T)0; csum[1] += (xx >= x_1 && xx < x_2) ? d : (T)0; csum[2] += xx >= x_2 ? d : (T)0;
             }
           }
-        };
-        if (VG <= 8) pixels(std::integral_constant<int, 4>{});
-        else if (VG == 16) pixels(std::integral_constant<int, 2>{});
-        else pixels(std::integral_constant<int, 1>{});
+        }
+#pragma unroll
+        for (int z = 0; z < 3; ++z) zsum[z] += ssum(csum[z]);
       }
-    } else {
+    } else if (nob > 0) {
+      const T r2 = OC.obst_radius * OC.obst_radius;
 #pragma unroll 1
       for (int x = 0; x < Wi; ++x) {
         if (is_duck(x)) continue;
@@ -682,17 +724,18 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
         for (int o = 0; o < nob; ++o) {
           const T cx = ob[(3 * o) * n], cy = ob[(3 * o + 1) * n], hh = ob[(3 * o + 2) * n];
           const T ox = cam[0] - cx, oy = cam[1] - cy;
-          const T ic = cyl_it(a, ox * ox + oy * oy - r2, ox * g0[0] + oy * g0[1], ox * g1[0] + oy * g1[1], hh);
+          const T cc = ox * ox + oy * oy - r2;
+          const T ic = cc > (T)0 ? cyl_it(a, cc, M<T>::rcp_(cc), ox * g0[0] + oy * g0[1], ox * g1[0] + oy * g1[1], hh, pp, pq, qq, g0[2], g1[2], cam[2]) : (T)0;
           c = ic > c ? ic : c;
         }
         if (c > (T)0) {
-          const T d = delta((T)0, c, git((T)x));
+          const T d = over_ground(c, git((T)x));
           csum[0] += x < x_1 ? d : (T)0; csum[1] += (x >= x_1 && x < x_2) ? d : (T)0; csum[2] += x >= x_2 ? d : (T)0;
         }
       }
-    }
 #pragma unroll
-    for (int z = 0; z < 3; ++z) zsum[z] += ssum(csum[z]);
+      for (int z = 0; z < 3; ++z) zsum[z] += csum[z];
+    }
   }
 #pragma unroll
   for (int z = 0; z < 3; ++z) {
