@@ -132,7 +132,7 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
     if (HASOBJ) {
       ObjState<T> O0;
       obj_reset_state<T, OBJ>(O0);
-      if (OBJ) obj_spawn<T>(P, OC, V, env, target, leader, O0); else comb_spawn<T>(P, OC, V, env, target, leader, O0);
+      if (OBJ) obj_spawn<T, G>(P, OC, V, env, target, leader, O0); else comb_spawn<T, G>(P, OC, V, env, target, leader, O0);
       if (leader) obj_store<T, OBJ>(V, env, O0);
     }
     if (leader) { store_rigid<T>(V, env, S0); D.is[env] = 0; D.sdone[env] = pack_done(target, D.epoch, 1); }
@@ -152,7 +152,7 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
   T gust[2];
   gust_init<T>(P, wph, tick, gust);
   ObjState<T> O;
-  if (HASOBJ) { obj_load<T, OBJ>(V, envc, O); O.near_mask = 0u; }
+  if (HASOBJ) { obj_load<T, OBJ>(V, envc, O); O.near_mask = 0u; O.near_n = 0; }
   const T cmd0[FW_NUM_ACTUATORS] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
   LaneAct<T> LA; LA.cmd = (T)0; LA.a = (T)0;
   if (G == 8) lane_act_scatter<T>(S, LA);
@@ -437,11 +437,12 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
           }
           if (HASOBJ) {
             obj_reset_state<T, OBJ>(O);
-            if (OBJ) obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
-            else comb_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
+            if (OBJ) obj_spawn<T, G>(P, OC, D, env, (uint32_t)episode, leader, O);
+            else comb_spawn<T, G>(P, OC, D, env, (uint32_t)episode, leader, O);
           }
         }
         if (G > 1 && warm_left > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the warm-up's camera reads the obstacles
+        if (HASOBJ) obj_update_near_mask<T, G>(P, OC, D, env, O, S);                          // new position, new cylinders
         if (GENERAL) gust_init<T>(P, wphase, tick, gust);                                  // new clock, new phase
         if (G == 8) lane_act_scatter<T>(S, LA);                                             // new episode's actuator state
         FWP(const long long p_rb = FWP_NOW(); p_r2 += p_rb - p_ra;)
@@ -870,7 +871,7 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
     }
     if (HASOBJ) {
       obj_reset_state<T, OBJ>(O);
-      if (OBJ) obj_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O); else comb_spawn<T>(P, OC, D, env, (uint32_t)episode, leader, O);
+      if (OBJ) obj_spawn<T, G>(P, OC, D, env, (uint32_t)episode, leader, O); else comb_spawn<T, G>(P, OC, D, env, (uint32_t)episode, leader, O);
       if (COMB && ov.targets && P.num_targets > 0) { O.duck[0] = t_last[0]; O.duck[1] = t_last[1]; }   // the duck sits under the last waypoint
       if (ov.duck) {
 #pragma unroll
@@ -1188,7 +1189,7 @@ template <typename T> size_t tile_bytes(const fw_env* h) {
   if (h->cfg.task != FW_TASK_WAYPOINTS && h->lanes_per_env == 8) {
     const int res = h->cfg.camera_resolution > 0 ? h->cfg.camera_resolution : 128;
     if (h->cfg.num_obstacles > 0)                      // the camera's rows, tables and work list (camera_lds_bytes): 45 KB at 480 columns
-      b = std::max(b, camera_lds_bytes(sizeof(T), zrow_stride_of(res), res));
+      b = std::max(b, camera_lds_bytes(sizeof(T), zrow_stride_of(res), res) + near_lds_bytes(sizeof(T)));
   }
   return b;
 }

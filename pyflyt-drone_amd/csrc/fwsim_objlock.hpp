@@ -37,7 +37,8 @@ struct ObjState {
   T frame[8];          // visible, cx, cy, area, depth_m, d_left, d_center, d_right
   float hist[kHist];   // float32 by construction (np.float32 feature vectors)
   float cur_z[3];      // combined task: obstacle-zone depths of the current feature vector (transient)
-  uint32_t near_mask;  // obstacles the aircraft can touch during this agent step (transient, conservative)
+  uint32_t near_mask;  // obstacles the aircraft can touch during this agent step (transient, conservative) that are NOT in the LDS table
+  int32_t near_n;      // ... and how many of them are (G = 8: obj_update_near_mask)
   int32_t nob;
   int32_t phase;       // combined task: bit0 duck_phase, bit1 post_waypoints
   T seen_consec;
@@ -104,32 +105,68 @@ __device__ __forceinline__ void obj_reset_state(ObjState<T>& O) {
   O.phase = 0; O.seen_consec = (T)0;
 }
 
-// _spawn_duck :461-491, _spawn_obstacles :507-565.  Every lane computes the scenario; only the
-// leader writes the obstacle list to HBM.
-template <typename T>
+// Obstacle list of episode `ep`: candidate i = (height, x, y) from its own three Philox blocks, kept unless `reject(x, y)`;
+// the kept ones are stored in candidate order.  G = 8: lane j of the env's group draws candidates j, j + 8, j + 16 and the
+// positions in the list come from ballots (60 Philox blocks: 9 per lane instead of 60 -- the start of an episode is the longest
+// chunk of a worker wave, and with it of the launch); all 8 lanes of the group must call.  G = 1 / `leader`: one lane stores.
+template <typename T, int G, typename Rej>
+__device__ __forceinline__ int sample_obstacles(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env, uint32_t ep,
+                                                bool leader, Rej&& reject) {
+  const uint32_t genv = (uint32_t)(P.env_offset + env);
+  const double r = (double)OC.half_dome;
+  T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
+  const size_t n = D.npad;
+  int nob = 0;
+  if (G == 8) {
+    const int sub = (int)(threadIdx.x & 7), gsh = (int)(threadIdx.x & (kWave - 1)) & ~7;
+#pragma unroll 1
+    for (int i0 = 0; i0 < OC.num_obstacles; i0 += 8) {
+      const int i = i0 + sub;
+      double hh = 0.0, x = 0.0, y = 0.0;
+      bool keep = false;
+      if (i < OC.num_obstacles) {
+        hh = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 0, (double)OC.obst_hmin, (double)OC.obst_hmax);
+        x = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 1, -r, r);
+        y = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 2, -r, r);
+        keep = !reject(x, y);
+      }
+      const uint32_t gm = (uint32_t)(__ballot(keep) >> gsh) & 0xFFu;
+      if (keep) {
+        const int at = nob + __popc(gm & ((1u << sub) - 1u));
+        ob[(3 * at + 0) * n] = (T)x; ob[(3 * at + 1) * n] = (T)y; ob[(3 * at + 2) * n] = (T)hh;
+      }
+      nob += __popc(gm);
+    }
+    for (int i = nob + sub; i < FW_MAX_OBSTACLES; i += 8) { ob[(3 * i + 0) * n] = (T)0; ob[(3 * i + 1) * n] = (T)0; ob[(3 * i + 2) * n] = (T)0; }
+    return nob;
+  }
+#pragma unroll 1
+  for (int i = 0; i < OC.num_obstacles; ++i) {
+    double hh = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 0, (double)OC.obst_hmin, (double)OC.obst_hmax);
+    double x = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 1, -r, r);
+    double y = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 2, -r, r);
+    if (reject(x, y)) continue;
+    if (leader) { ob[(3 * nob + 0) * n] = (T)x; ob[(3 * nob + 1) * n] = (T)y; ob[(3 * nob + 2) * n] = (T)hh; }
+    ++nob;
+  }
+  if (leader)
+    for (int i = nob; i < FW_MAX_OBSTACLES; ++i) { ob[(3 * i + 0) * n] = (T)0; ob[(3 * i + 1) * n] = (T)0; ob[(3 * i + 2) * n] = (T)0; }
+  return nob;
+}
+
+// _spawn_duck :461-491, _spawn_obstacles :507-565.  Every lane computes the duck; the obstacle list is sampled by the env's lanes
+// together (sample_obstacles).
+template <typename T, int G>
 __device__ __forceinline__ void obj_spawn_impl(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env, uint32_t ep,
                                           bool leader, ObjState<T>& O) {
   const uint32_t genv = (uint32_t)(P.env_offset + env);
   const double r = (double)OC.half_dome;
   const double dx = rng_uniform<T>(P, genv, ep, J_DUCK_X, -r, r), dy = rng_uniform<T>(P, genv, ep, J_DUCK_Y, -r, r);
   O.duck[0] = (T)dx; O.duck[1] = (T)dy; O.duck[2] = (T)0.05;
-  int nob = 0;
-  T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
-  const size_t n = D.npad;
-#pragma unroll 1
-  for (int i = 0; i < OC.num_obstacles; ++i) {
-    double hh = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 0, (double)OC.obst_hmin, (double)OC.obst_hmax);
-    double x = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 1, -r, r);
-    double y = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 2, -r, r);
-    double ex = x - dx, ey = y - dy;
-    if (M<double>::sqrt_(ex * ex + ey * ey) < 10.0) continue;
-    if (x * x + y * y < 100.0) continue;
-    if (leader) { ob[(3 * nob + 0) * n] = (T)x; ob[(3 * nob + 1) * n] = (T)y; ob[(3 * nob + 2) * n] = (T)hh; }
-    ++nob;
-  }
-  if (leader)
-    for (int i = nob; i < FW_MAX_OBSTACLES; ++i) { ob[(3 * i + 0) * n] = (T)0; ob[(3 * i + 1) * n] = (T)0; ob[(3 * i + 2) * n] = (T)0; }
-  O.nob = nob;
+  O.nob = sample_obstacles<T, G>(P, OC, D, env, ep, leader, [&](double x, double y) {
+    const double ex = x - dx, ey = y - dy;
+    return M<double>::sqrt_(ex * ex + ey * ey) < 10.0 || x * x + y * y < 100.0;
+  });
 }
 
 // i-th waypoint of episode `ep`, regenerated from the RNG (WaypointHandler.reset polar sampling)
@@ -148,7 +185,7 @@ __device__ __forceinline__ void nth_target(const Params<T>& P, uint32_t genv, ui
 
 // combined task: duck at the last waypoint's x,y (envs/fixedwing_waypoint_objlock_env.py:394-436), obstacles
 // with the origin rejection only (:452-503)
-template <typename T>
+template <typename T, int G>
 __device__ __forceinline__ void comb_spawn_impl(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env, uint32_t ep,
                                            bool leader, ObjState<T>& O) {
   const uint32_t genv = (uint32_t)(P.env_offset + env);
@@ -158,46 +195,44 @@ __device__ __forceinline__ void comb_spawn_impl(const Params<T>& P, const ObjC<T
     O.duck[0] = tl[0]; O.duck[1] = tl[1];
   } else { O.duck[0] = (T)10; O.duck[1] = (T)0; }
   O.duck[2] = (T)0.05;
-  const double r = (double)OC.half_dome;
-  int nob = 0;
-  T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
-  const size_t n = D.npad;
-#pragma unroll 1
-  for (int i = 0; i < OC.num_obstacles; ++i) {
-    double hh = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 0, (double)OC.obst_hmin, (double)OC.obst_hmax);
-    double x = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 1, -r, r);
-    double y = rng_uniform<T>(P, genv, ep, J_OBST + 3 * i + 2, -r, r);
-    if (x * x + y * y < 100.0) continue;
-    if (leader) { ob[(3 * nob + 0) * n] = (T)x; ob[(3 * nob + 1) * n] = (T)y; ob[(3 * nob + 2) * n] = (T)hh; }
-    ++nob;
-  }
-  if (leader)
-    for (int i = nob; i < FW_MAX_OBSTACLES; ++i) { ob[(3 * i + 0) * n] = (T)0; ob[(3 * i + 1) * n] = (T)0; ob[(3 * i + 2) * n] = (T)0; }
-  O.nob = nob;
+  O.nob = sample_obstacles<T, G>(P, OC, D, env, ep, leader, [&](double x, double y) { return x * x + y * y < 100.0; });
 }
 
 // Out-of-line entry points of the spawners (cold path: keeps their live ranges out of the step loop's register budget).
 template <typename T> struct Spawned { T duck[3]; int32_t nob; };
-template <typename T, int TKIND>
+template <typename T, int TKIND, int G>
 __device__ __noinline__ void spawn_task(const Params<T>* Pp, const ObjC<T>* OCp, T* r, int npad, int env, uint32_t ep, bool leader, Spawned<T>* out) {
   DevState<T> D; D.r = r; D.npad = npad;
   ObjState<T> O;
-  if (TKIND == FW_TASK_OBJLOCK) obj_spawn_impl<T>(*Pp, *OCp, D, env, ep, leader, O); else comb_spawn_impl<T>(*Pp, *OCp, D, env, ep, leader, O);
+  if (TKIND == FW_TASK_OBJLOCK) obj_spawn_impl<T, G>(*Pp, *OCp, D, env, ep, leader, O); else comb_spawn_impl<T, G>(*Pp, *OCp, D, env, ep, leader, O);
   out->duck[0] = O.duck[0]; out->duck[1] = O.duck[1]; out->duck[2] = O.duck[2]; out->nob = O.nob;
 }
-template <typename T>
+template <typename T, int G>
 __device__ __forceinline__ void obj_spawn(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env, uint32_t ep, bool leader, ObjState<T>& O) {
   Spawned<T> sp;
-  spawn_task<T, FW_TASK_OBJLOCK>(&P, &OC, D.r, D.npad, env, ep, leader, &sp);
+  spawn_task<T, FW_TASK_OBJLOCK, G>(&P, &OC, D.r, D.npad, env, ep, leader, &sp);
   O.duck[0] = sp.duck[0]; O.duck[1] = sp.duck[1]; O.duck[2] = sp.duck[2]; O.nob = sp.nob;
 }
-template <typename T>
+template <typename T, int G>
 __device__ __forceinline__ void comb_spawn(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env, uint32_t ep, bool leader, ObjState<T>& O) {
   Spawned<T> sp;
-  spawn_task<T, FW_TASK_WAYPOINT_OBJLOCK>(&P, &OC, D.r, D.npad, env, ep, leader, &sp);
+  spawn_task<T, FW_TASK_WAYPOINT_OBJLOCK, G>(&P, &OC, D.r, D.npad, env, ep, leader, &sp);
   O.duck[0] = sp.duck[0]; O.duck[1] = sp.duck[1]; O.duck[2] = sp.duck[2]; O.nob = sp.nob;
 }
 
+// LDS map of the analytic camera on the 8-lane mapping (aliases the observation tile, which is only written after the step
+// loop), in words of T:  8 row buffers of zrow_stride words (1 / t of the nearest cylinder fragment per column, one per lane set)
+// | 8 tables of FW_MAX_OBSTACLES x kCtabWords (the screened cylinders of a set: cc, hh, op, oq, first column, last column, 1 / cc)
+// | 8 x kSetWords (constants of a set's row h//2: pp, pq, qq, g0z, g1z, cam z) | u32: slice count, pad, 8 x (first, last covered
+// column) | u16 slice list: set << 10 | cylinder << 5 | index of the 32-column slice inside the cylinder's interval
+// Behind it: the cylinders an env can touch during this agent step (obj_update_near_mask): 8 x u32 counts, 8 x kNearSlots x (x, y, height).
+constexpr int kCtabWords = 7, kSetWords = 8, kSliceCols = 32, kNearSlots = 4;
+__host__ __device__ inline size_t camera_lds_bytes(size_t word, int zrow_stride, int res) {
+  const size_t slices = (size_t)8 * FW_MAX_OBSTACLES * (size_t)((res + kSliceCols - 1) / kSliceCols);
+  const size_t b = word * ((size_t)8 * zrow_stride + (size_t)8 * FW_MAX_OBSTACLES * kCtabWords + (size_t)8 * kSetWords) + 4 * 18 + 2 * slices;
+  return (b + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t near_lds_bytes(size_t word) { return 32 + word * 8 * kNearSlots * 3; }
 // Which cylinders can be touched during this agent step?  Conservative: horizontal distance of the COM to
 // the axis below radius + reach of the airframe + 1.25 x the distance flown in one agent step (+ slack).
 // The per-tick contact test then only visits these (usually none) instead of all 20.
@@ -205,16 +240,49 @@ __device__ __forceinline__ void comb_spawn(const Params<T>& P, const ObjC<T>& OC
 template <typename T, int G>
 __device__ __forceinline__ void obj_update_near_mask(const Params<T>& P, const ObjC<T>& OC, const DevState<T>& D, int env,
                                                      ObjState<T>& O, const Rigid<T>& S) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
   const T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
   const size_t n = D.npad;
   const T speed = M<T>::sqrt_(S.v[0] * S.v[0] + S.v[1] * S.v[1] + S.v[2] * S.v[2]);
   const T t_step = (T)(P.step_ratio * P.ticks_per_aviary) * P.dt;
   const T reach = OC.obst_radius + OC.reach_margin + (speed + (T)5) * t_step * (T)1.25 + (T)0.5;
   uint32_t m = 0u;
-  const int sub = (G == 1) ? 0 : (int)(threadIdx.x & (G - 1));
-  for (int o = sub; o < O.nob; o += G) {
-    T ox = S.p[0] - ob[(3 * o) * n], oy = S.p[1] - ob[(3 * o + 1) * n];
-    if (ox * ox + oy * oy <= reach * reach) m |= 1u << o;
+  O.near_n = 0;
+  if (G == 8 && OC.num_obstacles > 0) {
+    // the first kNearSlots of them go to an LDS table of the env (x, y, height): the contact test of every tick then costs LDS
+    // reads instead of a dependent memory round trip per cylinder; any further ones stay in the mask (read from memory)
+    const int sub = (int)(threadIdx.x & 7), row = (int)(threadIdx.x & (kWave - 1)) >> 3;
+    unsigned char* nb = smem_raw + camera_lds_bytes(sizeof(T), OC.zrow_stride, (int)OC.W);
+    uint32_t* ncnt = reinterpret_cast<uint32_t*>(nb) + row;
+    T* ntab = reinterpret_cast<T*>(nb + 32) + (size_t)row * kNearSlots * 3;
+    if (sub == 0) *ncnt = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    T cx[3], cy[3];
+#pragma unroll
+    for (int slot = 0; slot < 3; ++slot) {                        // all loads in flight together
+      const int o = sub + 8 * slot;
+      cx[slot] = cy[slot] = (T)0;
+      if (o < O.nob) { cx[slot] = ob[(3 * o) * n]; cy[slot] = ob[(3 * o + 1) * n]; }
+    }
+#pragma unroll
+    for (int slot = 0; slot < 3; ++slot) {
+      const int o = sub + 8 * slot;
+      const T ox = S.p[0] - cx[slot], oy = S.p[1] - cy[slot];
+      if (o < O.nob && ox * ox + oy * oy <= reach * reach) {
+        const uint32_t pos = __hip_atomic_fetch_add(ncnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (pos < (uint32_t)kNearSlots) { T* e = ntab + pos * 3; e[0] = cx[slot]; e[1] = cy[slot]; e[2] = ob[(3 * o + 2) * n]; }
+        else m |= 1u << o;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint32_t c = *ncnt;
+    O.near_n = (int)(c < (uint32_t)kNearSlots ? c : (uint32_t)kNearSlots);
+  } else {
+    const int sub = (G == 1) ? 0 : (int)(threadIdx.x & (G - 1));
+    for (int o = sub; o < O.nob; o += G) {
+      T ox = S.p[0] - ob[(3 * o) * n], oy = S.p[1] - ob[(3 * o + 1) * n];
+      if (ox * ox + oy * oy <= reach * reach) m |= 1u << o;
+    }
   }
   O.near_mask = group_or<G>(m);
 }
@@ -222,8 +290,17 @@ __device__ __forceinline__ void obj_update_near_mask(const Params<T>& P, const O
 // is world point pw inside the duck sphere or a (near) obstacle cylinder?
 template <typename T>
 __device__ __forceinline__ bool obj_point_hit(const ObjC<T>& OC, const DevState<T>& D, int env, const ObjState<T>& O, const T pw[3]) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
   T dx = pw[0] - O.duck[0], dy = pw[1] - O.duck[1], dz = pw[2] - (O.duck[2] + OC.duck_radius);
   bool hit = dx * dx + dy * dy + dz * dz <= OC.duck_radius * OC.duck_radius;
+  if (O.near_n > 0) {
+    const T* ntab = reinterpret_cast<const T*>(smem_raw + camera_lds_bytes(sizeof(T), OC.zrow_stride, (int)OC.W) + 32) +
+                    (size_t)((int)(threadIdx.x & (kWave - 1)) >> 3) * kNearSlots * 3;
+    for (int k = 0; k < O.near_n; ++k) {
+      const T ox = pw[0] - ntab[3 * k], oy = pw[1] - ntab[3 * k + 1];
+      hit |= (ox * ox + oy * oy <= OC.obst_radius * OC.obst_radius) && (pw[2] <= ntab[3 * k + 2]);
+    }
+  }
   const T* ob = D.r + (size_t)(RF_TASK + FW_ST_OBST) * D.npad + env;
   const size_t n = D.npad;
   uint32_t m = O.near_mask;
@@ -349,16 +426,6 @@ __device__ __forceinline__ int cyl_columns(float ox, float oy, float r2, float p
 // the duck mask, cylinders and pixels of row h//2 are dealt out modulo VG; partial statistics are combined inside the set (DPP
 // inside 8 lanes, xor-butterflies above), after which every lane of the set holds the same `frame`.  `work` = false: a lane set
 // without an env this time (it only takes part in the cross-lane steps).
-// LDS map of the analytic camera on the 8-lane mapping (aliases the observation tile, which is only written after the step
-// loop), in words of T:  8 row buffers of zrow_stride words (1 / t of the nearest cylinder fragment per column, one per lane set)
-// | 8 tables of FW_MAX_OBSTACLES x kCtabWords (the screened cylinders of a set: cc, hh, op, oq, first column, last column, 1 / cc)
-// | 8 x kSetWords (constants of a set's row h//2: pp, pq, qq, g0z, g1z, cam z) | u32: slice count, pad, 8 x (first, last covered
-// column) | u16 slice list: set << 10 | cylinder << 5 | index of the 32-column slice inside the cylinder's interval
-constexpr int kCtabWords = 7, kSetWords = 8, kSliceCols = 32;
-__host__ __device__ inline size_t camera_lds_bytes(size_t word, int zrow_stride, int res) {
-  const size_t slices = (size_t)8 * FW_MAX_OBSTACLES * (size_t)((res + kSliceCols - 1) / kSliceCols);
-  return word * ((size_t)8 * zrow_stride + (size_t)8 * FW_MAX_OBSTACLES * kCtabWords + (size_t)8 * kSetWords) + 4 * 18 + 2 * slices + 8;
-}
 template <typename T, int G>
 __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T>& D, int env, const T duck[3], int nob_in,
                                              const T Sp[3], const T R[9], int vsub, int VG, int erow, bool work, T frame[8]) {
