@@ -224,6 +224,11 @@ __device__ __forceinline__ void scenario_worker(const Params<T>* __restrict__ Pp
 #define FWP_NOW() ((long long)__builtin_readcyclecounter())
 #define FWP(...) __VA_ARGS__
 constexpr int kProfSlots = 256, kProfWords = 12;
+#ifdef FW_PROFILE_PHASES
+constexpr bool getenv_ph = true;     // the words of the wave split carry the phases of capture_body instead (tools/wave_profile.py --phases)
+#else
+constexpr bool getenv_ph = false;
+#endif
 #else
 #define FWP(...)
 #endif
@@ -767,7 +772,8 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       const long long t3 = FWP_NOW();
       w[0] = t3 - p_t0; w[1] = p_t1 - p_t0; w[2] = p_reset; w[3] = p_avi; w[4] = p_task; w[5] = t3 - p_t2; w[6] = it | (nr << 8) | (nh << 16); w[7] = p_t0; w[8] = p_r1; w[9] = p_r2; w[10] = p_r3;
       w[11] = p_capmax | ((long long)p_ncapw << 48);
-      if (HASOBJ) { w[8] = O.p_capm[0]; w[9] = O.p_capm[1]; w[10] = O.p_capm[2]; w[2] = O.p_capm[3]; }     // (the reset split is unused by these kernels)
+      if (HASOBJ) { w[8] = O.p_capm[0]; w[9] = O.p_capm[1]; w[10] = O.p_capm[2]; w[2] = O.p_capm[3];
+        if (getenv_ph) { w[1] = O.p_ph[0]; w[3] = O.p_ph[1]; w[4] = O.p_ph[2]; w[5] = O.p_ph[3]; w[7] = O.p_ph[4]; w[6] = O.p_ph[5]; } }     // (the reset split is unused by these kernels)
     } })
 }
 

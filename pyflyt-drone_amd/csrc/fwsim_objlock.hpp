@@ -44,6 +44,7 @@ struct ObjState {
   T seen_consec;
 #ifdef FW_PROFILE
   long long p_cap = 0; int p_ncap = 0;    // dev-only: cycles spent in camera captures, number of captures (tools/wave_profile.py)
+  long long p_ph[6] = {0, 0, 0, 0, 0, 0};  // dev-only: phases of capture_body in capture steps with 5+ envs due, [5] = how many
   long long p_capm[4] = {0, 0, 0, 0};     // dev-only, wave-level: cycles (low 40 bits) | episodes << 40 of capture steps with 1 / 2 / 3-4 / 5+ envs due
 #endif
 };
@@ -223,13 +224,18 @@ __device__ __forceinline__ void comb_spawn(const Params<T>& P, const ObjC<T>& OC
 // LDS map of the analytic camera on the 8-lane mapping (aliases the observation tile, which is only written after the step
 // loop), in words of T:  8 row buffers of zrow_stride words (1 / t of the nearest cylinder fragment per column, one per lane set)
 // | 8 tables of FW_MAX_OBSTACLES x kCtabWords (the screened cylinders of a set: cc, hh, op, oq, first column, last column, 1 / cc)
-// | 8 x kSetWords (constants of a set's row h//2: pp, pq, qq, g0z, g1z, cam z) | u32: slice count, pad, 8 x (first, last covered
-// column) | u16 slice list: set << 10 | cylinder << 5 | index of the 32-column slice inside the cylinder's interval
+// | 8 x kSetWords (constants of a set's row h//2: pp, pq, qq, g0z, g1z, cam z, ground gk0, gk1, duck columns first, last)
+// | 8 x 3 x chunks-per-third partial sums | u32: slice count, chunk count, 8 x (first, last covered column)
+// | u16 slice list: set << 10 | cylinder << 5 | index of the 32-column slice inside the cylinder's interval
+// | u16 chunk list: set << 8 | third << 6 | index of the 32-column chunk inside (covered columns of the set) x (third)
 // Behind it: the cylinders an env can touch during this agent step (obj_update_near_mask): 8 x u32 counts, 8 x kNearSlots x (x, y, height).
-constexpr int kCtabWords = 7, kSetWords = 8, kSliceCols = 32, kNearSlots = 4;
+constexpr int kCtabWords = 7, kSetWords = 12, kSliceCols = 32, kNearSlots = 4;
+__host__ __device__ inline int chunks_per_third(int res) { return ((res + 2) / 3 + kSliceCols - 1) / kSliceCols + 1; }
 __host__ __device__ inline size_t camera_lds_bytes(size_t word, int zrow_stride, int res) {
   const size_t slices = (size_t)8 * FW_MAX_OBSTACLES * (size_t)((res + kSliceCols - 1) / kSliceCols);
-  const size_t b = word * ((size_t)8 * zrow_stride + (size_t)8 * FW_MAX_OBSTACLES * kCtabWords + (size_t)8 * kSetWords) + 4 * 18 + 2 * slices;
+  const size_t chunks = (size_t)8 * 3 * (size_t)chunks_per_third(res);
+  const size_t b = word * ((size_t)8 * zrow_stride + (size_t)8 * FW_MAX_OBSTACLES * kCtabWords + (size_t)8 * kSetWords + chunks) + 4 * 18 +
+                   2 * slices + 2 * chunks;
   return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t near_lds_bytes(size_t word) { return 32 + word * 8 * kNearSlots * 3; }
@@ -428,8 +434,15 @@ __device__ __forceinline__ int cyl_columns(float ox, float oy, float r2, float p
 // without an env this time (it only takes part in the cross-lane steps).
 template <typename T, int G>
 __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T>& D, int env, const T duck[3], int nob_in,
-                                             const T Sp[3], const T R[9], int vsub, int VG, int erow, bool work, T frame[8]) {
+                                             const T Sp[3], const T R[9], int vsub, int VG, int erow, bool work, T frame[8],
+                                             long long* ph = nullptr /* dev-only: cycles per phase (FW_PROFILE) */) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
+#ifdef FW_PROFILE
+  long long ph_t = (long long)__builtin_readcyclecounter();
+#define FW_PH(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); if (ph) ph[i] += t_ - ph_t; ph_t = t_; } while (0)
+#else
+#define FW_PH(i) do { } while (0)
+#endif
   const size_t n = D.npad;
   const int nob = work ? nob_in : 0;
   const int sub = vsub & (G - 1);                     // lane within its 8-lane group
@@ -499,12 +512,15 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
   T* ctab_all = lbase + (size_t)8 * OC.zrow_stride;
   T* ctab = ctab_all + (size_t)erow * (FW_MAX_OBSTACLES * kCtabWords);
   T* sconst_all = ctab_all + (size_t)8 * FW_MAX_OBSTACLES * kCtabWords;
-  uint32_t* lu = reinterpret_cast<uint32_t*>(sconst_all + 8 * kSetWords);      // [0] slice count, [2 + 2 s], [3 + 2 s]: covered columns of set s
+  const int cpz = chunks_per_third(Wi);
+  T* cpart_all = sconst_all + 8 * kSetWords;                                   // [set][third][chunk] partial sums of the row
+  uint32_t* lu = reinterpret_cast<uint32_t*>(cpart_all + 8 * 3 * cpz);        // [0] slices, [1] chunks, [2 + 2 s], [3 + 2 s]: covered columns of set s
   uint16_t* slist = reinterpret_cast<uint16_t*>(lu + 18);
+  uint16_t* clist = slist + (size_t)8 * FW_MAX_OBSTACLES * ((Wi + kSliceCols - 1) / kSliceCols);
   const T pp = g0[0] * g0[0] + g0[1] * g0[1], pq = g0[0] * g1[0] + g0[1] * g1[1], qq = g1[0] * g1[0] + g1[1] * g1[1];
   const bool cyl_on = G == 8 && OC.num_obstacles > 0;   // (the handle's LDS holds the camera map only then)
   if (cyl_on) {
-    if ((threadIdx.x & (kWave - 1)) == 0) lu[0] = 0u;
+    if ((threadIdx.x & (kWave - 1)) == 0) { lu[0] = 0u; lu[1] = 0u; }
     if (vsub == 0) { lu[2 + 2 * erow] = 0x7FFFFFFFu; lu[3 + 2 * erow] = 0u; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
@@ -556,6 +572,7 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
         if (duck_front) occluded |= cyl_inv_t<T>(OC, ob[(3 * o) * n], ob[(3 * o + 1) * n], ob[(3 * o + 2) * n], cam, relw[0], relw[1], relw[2]) > (T)1;
     }
   }
+  FW_PH(0);                                                       // set-up + screening
   // ---- duck mask statistics ----
   T cnt = (T)0, sx = (T)0, sy = (T)0, itmax = (T)0;               // itmax = 1 / (nearest fragment depth)
   int mid_lo = 1 << 30, mid_hi = -1;                              // duck columns on row h//2
@@ -626,6 +643,7 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
     depth = depthbuf_to_meters<T>(OC, depthbuf_from_inv<T>(OC, itmax));
   }
   frame[0] = visible; frame[1] = cxn; frame[2] = cyn; frame[3] = area; frame[4] = depth;
+  FW_PH(1);                                                       // duck rows + statistics
   // ---- obstacle zones: mean depth-buffer value of the non-duck pixels of each third of row h//2 ----
   // Everything is accumulated as sum of clip(1 / t, 1 / far, 1 / near): the buffer value is c1 (1 - near / t), affine in 1 / t.
   //  * ground / sky: 1 / t = -(g0z + a g1z) / cam_z is LINEAR in the column, so the sum over a run of columns is an arithmetic
@@ -717,6 +735,7 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
     // stays underneath (the pixel shows max(cylinder, ground))
     auto over_ground = [&](T c, T g) { const T hi = c > OC.inv_near ? OC.inv_near : c; return (hi > g ? hi : g) - g; };
     T csum[3] = { (T)0, (T)0, (T)0 };
+    FW_PH(2);                                                     // ground runs
     if (cyl_on) {
       // (1) my set clears the covered columns of its row buffer
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -758,24 +777,70 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      // (3) my set sums its row: pixel x belongs to lane x mod VG of the set
-      if (drawn) {
+      FW_PH(3);                                                   // clear + draw
+      // (3) the row sums, again by the wave: the covered columns of a set, cut at the thirds, in chunks of 32 columns; chunk c of
+      // the list goes to 8-lane group c mod 8 (4 pixels per lane), its sum to a slot that belongs to (set, third, chunk), and
+      // the set's lanes 0..2 add the slots of their third in chunk order -- so a sum is built the same way whoever computed
+      // its parts.  (A duck that straddles the far plane is not one run of columns: such a set sums its row itself.)
+      const bool by_wave = drawn && !exact_duck;
+      const int my_lo = vsub < 3 ? (xmin > z_lo(vsub) ? xmin : z_lo(vsub)) : 1, my_hi = vsub < 3 ? (xmax < z_hi(vsub) - 1 ? xmax : z_hi(vsub) - 1) : 0;
+      const int my_nch = (by_wave && vsub < 3 && my_hi >= my_lo) ? (my_hi - my_lo) / kSliceCols + 1 : 0;
+      if (my_nch > 0) {
+        const uint32_t pos = __hip_atomic_fetch_add(lu + 1, (uint32_t)my_nch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int i = 0; i < my_nch; ++i) clist[pos + i] = (uint16_t)((erow << 8) | (vsub << 6) | i);
+      }
+      if (by_wave && vsub == 0) {
+        T* sc = sconst_all + erow * kSetWords;
+        sc[6] = gk0; sc[7] = gk1; sc[8] = (T)dlo; sc[9] = (T)dhi;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const uint32_t totalc = lu[1];
 #pragma unroll 1
-        for (int x = xmin + vsub; x <= xmax; x += 4 * VG) {
-          T v[4];
+      for (uint32_t ci = (uint32_t)grp; ci < totalc; ci += 8u) {
+        const uint32_t ent = clist[ci];
+        const int es = (int)(ent >> 8), ez = (int)(ent >> 6) & 3, ei = (int)ent & 63;
+        const T* sc = sconst_all + es * kSetWords;
+        const T k0 = sc[6], k1 = sc[7];
+        const int e_dlo = (int)sc[8], e_dhi = (int)sc[9];
+        const int e_min = (int)lu[2 + 2 * es], e_max = (int)lu[3 + 2 * es];
+        const int lo = e_min > z_lo(ez) ? e_min : z_lo(ez), hi = e_max < z_hi(ez) - 1 ? e_max : z_hi(ez) - 1;
+        const UB* zrow = reinterpret_cast<const UB*>(lbase) + (size_t)es * OC.zrow_stride;
+        const int x0 = lo + ei * kSliceCols + s8;
+        T v[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int xx = x + u * VG;
-            const UB bits = xx <= xmax ? zr[xx] : (UB)0;
-            __builtin_memcpy(&v[u], &bits, sizeof(T));
-          }
+        for (int u = 0; u < 4; ++u) {
+          const int xx = x0 + 8 * u;
+          const UB bits = xx <= hi ? zrow[xx] : (UB)0;
+          __builtin_memcpy(&v[u], &bits, sizeof(T));
+        }
+        T acc = (T)0;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int xx = x + u * VG;
-            if (v[u] > (T)0 && !is_duck(xx)) {
-              const T d = over_ground(v[u], git((T)xx));
-              csum[0] += xx < x_1 ? d : (T)0; csum[1] += (xx >= x_1 && xx < x_2) ? d : (T)0; csum[2] += xx >= x_2 ? d : (T)0;
-            }
+        for (int u = 0; u < 4; ++u) {
+          const int xx = x0 + 8 * u;
+          T g = k0 + k1 * (T)xx;
+          g = g > OC.inv_near ? OC.inv_near : g; g = g < OC.inv_far ? OC.inv_far : g;
+          const bool on = v[u] > (T)0 && !(xx >= e_dlo && xx <= e_dhi);
+          acc += on ? over_ground(v[u], g) : (T)0;
+        }
+        acc = group_sum<G, T>(acc);
+        if (s8 == 0) cpart_all[(es * 3 + ez) * cpz + ei] = acc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (by_wave) {
+        T zs = (T)0;
+        for (int i = 0; i < my_nch; ++i) zs += cpart_all[(erow * 3 + vsub) * cpz + i];
+        const int first = (int)(threadIdx.x & (kWave - 1)) & ~(VG - 1);
+#pragma unroll
+        for (int z = 0; z < 3; ++z) zsum[z] += __shfl(zs, first + z, kWave);
+      } else if (drawn) {
+#pragma unroll 1
+        for (int x = xmin + vsub; x <= xmax; x += VG) {
+          UB bits = zr[x];
+          T v;
+          __builtin_memcpy(&v, &bits, sizeof(T));
+          if (v > (T)0 && !is_duck(x)) {
+            const T d = over_ground(v, git((T)x));
+            csum[0] += x < x_1 ? d : (T)0; csum[1] += (x >= x_1 && x < x_2) ? d : (T)0; csum[2] += x >= x_2 ? d : (T)0;
           }
         }
 #pragma unroll
@@ -810,6 +875,8 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
     const T mean = zcnt[z] > 0 ? OC.db_c1 * ((T)1 - OC.near_ * M<T>::div_(zsum[z], (T)zcnt[z])) : (T)0;
     frame[5 + z] = mean > (T)1e-12 ? depthbuf_to_meters<T>(OC, mean) : (T)0;       // (guard band of the `> 0.0` test: see the oracle)
   }
+  FW_PH(4);                                                       // row sums + zone means
+#undef FW_PH
 }
 
 // A capture step of the WAVE.  G = 8: the envs whose camera is due hand their pose to sets of 8 * k lanes, k = 8 / 4 / 2 / 2 / 1
@@ -854,7 +921,12 @@ __device__ __forceinline__ void obj_capture_wave(const ObjC<T>& OC, const DevSta
 #pragma unroll
   for (int i = 0; i < 9; ++i) oR[i] = __shfl(R[i], src, kWave);
   const int onob = __shfl(O.nob, src, kWave), oenv = __shfl(env, src, kWave);
+#ifdef FW_PROFILE
+  capture_body<T, G>(OC, D, oenv, oduck, onob, oSp, oR, lane & (VG - 1), VG, j, work, fr, m >= 5 ? O.p_ph : nullptr);
+  if (m >= 5) O.p_ph[5] += 1;
+#else
   capture_body<T, G>(OC, D, oenv, oduck, onob, oSp, oR, lane & (VG - 1), VG, j, work, fr);
+#endif
   const int back = __popc(dmask & ((1u << grp) - 1u)) * VG + sub;      // a lane of the set that worked for my env
 #pragma unroll
   for (int i = 0; i < 8; ++i) { const T v = __shfl(fr[i], back, kWave); if (due) O.frame[i] = v; }

@@ -11,6 +11,9 @@ from pyflyt_drone_amd import config as K, _lib
 _lib.LIB_PATH = os.path.join(ROOT, "tools", "_build", "libfwsim_prof.so")
 CFG = {"waypoints": K.train_waypoints_v3_config, "objlock": K.train_objlock_config, "combined": K.train_waypoint_objlock_config,
        "waypoints_wind": lambda: K.train_waypoints_v3_config(wind_config=K.TRAIN_OBJLOCK_WIND)}
+PHASES = "--phases" in sys.argv
+if PHASES:
+    sys.argv.remove("--phases"); _lib.LIB_PATH = os.path.join(ROOT, "tools", "_build", "libfwsim_prof_ph.so")
 which = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 N = int(os.environ.get("N", 4096))
@@ -28,6 +31,11 @@ st, wk = buf[:, :nblk, :], buf[:, nblk:, 0]
 tot = st[:, :, 0]
 slow = tot.argmax(axis=1)
 S = st[np.arange(256), slow]                      # slowest step wave of each launch
+if PHASES:     # built with -DFW_PROFILE -DFW_PROFILE_PHASES: phases of capture_body in capture steps with 5+ envs due
+    ne = st[:, :, 6].sum()
+    print(f"{which}: capture steps with 5+ envs due: {ne / st[:, :, 6].size:.3f} per wave-step; cycles each: " + "  ".join(
+        f"{nm} {st[:, :, k].sum() / max(1, ne):.0f}" for nm, k in (("set-up+screening", 1), ("duck", 3), ("ground", 4), ("clear+draw", 5), ("sums+means", 7))))
+    sys.exit(0)
 names = ["total", "prologue", "reset", "aviary", "task", "epilogue"]
 print(f"{which} N={N}: {nblk} step waves/launch, last 256 of {steps} launches; cycles (s_memtime)")
 print("  mean over all waves : " + "  ".join(f"{n} {st[:, :, k].mean():8.0f}" for k, n in enumerate(names)))
