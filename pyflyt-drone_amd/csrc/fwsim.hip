@@ -603,6 +603,13 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
 #pragma unroll
     for (int k = 0; k < 3; ++k) tpre[k] = D.rs[(size_t)(RF_TARGETS + 3 * sub + k) * n + env];
   }
+  // ... and so is the cached attitude block of the observation a reset returns (lane `sub` holds its words sub, sub + G, ...)
+  constexpr int kWO = DEFER ? (32 + G - 1) / G : 1;
+  T wo[kWO];
+  if (DEFER && resetting) {
+#pragma unroll
+    for (int j = 0; j < kWO; ++j) { const int k = sub + j * G; wo[j] = (k < P.att_dim) ? Pp->warm_obs[k] : (T)0; }
+  }
 
   // GENERAL: the rows of a shadow that is being taken, fetched by the env's G lanes before the observation pass (their round
   // trip hides behind it): word w of the [RF_COUNT] state column goes to lane w % G; the first observation likewise
@@ -696,7 +703,9 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       }
       if (leader) { tile[row * ld + P.att_dim + 3 * i] = b[0]; tile[row * ld + P.att_dim + 3 * i + 1] = b[1]; tile[row * ld + P.att_dim + 3 * i + 2] = b[2]; }
     }
-    for (int k = sub; k < P.att_dim; k += G) tile[row * ld + k] = Pp->warm_obs[k];      // the env's lanes share the cached attitude block
+#pragma unroll
+    for (int j = 0; j < kWO; ++j) { const int k = sub + j * G; if (k < P.att_dim) tile[row * ld + k] = wo[j]; }   // the env's lanes share the cached attitude block
+    for (int k = sub + kWO * G; k < P.att_dim; k += G) tile[row * ld + k] = Pp->warm_obs[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { S.p[k] = P.warm[k]; S.v[k] = P.warm[7 + k]; S.w[k] = P.warm[10 + k]; }
 #pragma unroll
