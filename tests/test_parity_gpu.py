@@ -264,6 +264,43 @@ def test_sharding_is_world_size_independent(lanes):
         assert torch.equal(big.terminated[3072:], shard.terminated) and torch.equal(big.info[3072:], shard.info)
 
 
+@pytest.mark.parametrize("task", ["objlock", "combined"])
+def test_camera_frame_does_not_depend_on_the_wave_neighbours(task, monkeypatch):
+    """8-lane mapping: the camera is run by the whole wave -- the envs due at a sub-step share the 64 lanes (lane sets), the
+    cylinder slices and the row chunks go to whichever 8-lane group is free.  What an env sees must not depend on that:
+    an env alone in its wave (all 64 lanes work for it) and the same env among 63 others produce the same bits, through
+    captures, strikes / collisions and auto-resets (the pre-simulated episodes are built by the same code)."""
+    import torch
+    monkeypatch.setenv("FWSIM_LANES_PER_ENV", "8")
+    if task == "objlock":
+        cfg = K.train_objlock_config(num_obstacles=14, obstacle_radius=2.0, duck_camera_capture_interval_steps=1)
+    else:
+        cfg = K.train_waypoint_objlock_config(duck_camera_capture_interval_steps=1)
+    n, seed, picks = 64, 5, (0, 5, 17, 42, 63)
+    big = P.FixedwingVecEnv(cfg, n, seed=seed)
+    ones = {k: P.FixedwingVecEnv(cfg, 1, seed=seed, global_env_offset=k) for k in picks}
+    ob = big.reset_tensor().clone()
+    for k, e in ones.items():
+        assert torch.equal(e.reset_tensor()[0], ob[k]), k
+    g = torch.Generator(device="cpu").manual_seed(3)
+    ends = 0
+    for t in range(150):
+        a = (torch.rand((n, 4), generator=g, dtype=torch.float64) * 2 - 1)
+        a[:, 3] = a[:, 3].abs()                                      # keep them flying: more frames with something in view
+        a = a.to(big.device)
+        big.step_tensor(a)
+        for k, e in ones.items():
+            e.step_tensor(a[k:k + 1].contiguous())
+            assert torch.equal(e.obs[0], big.obs[k]) and torch.equal(e.rewards[0], big.rewards[k]), (t, k)
+            assert torch.equal(e.terminated[0], big.terminated[k]) and torch.equal(e.info[0], big.info[k]), (t, k)
+        ends += int((big.terminated | big.truncated).bool()[list(picks)].sum())
+    sb = big.get_state()
+    for k, e in ones.items():
+        assert np.array_equal(e.get_state()[0], sb[k]), k
+    c = big.get_counters()
+    assert c["resets"] > 0 and c["shadow_hits"] > 0
+
+
 def test_properties_at_baseline_size(lanes):
     """Size-independent invariants at N=4096 over 300 steps of random actions."""
     import torch
