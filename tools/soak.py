@@ -7,7 +7,10 @@ t0 = time.time()
 for name, cfg, n, steps in (("objlock g1", K.train_objlock_config(), 65536, 1500),
                             ("combined g1", K.train_waypoint_objlock_config(), 32768, 1500),
                             ("waypoints_wind g1", K.train_waypoints_v3_config(wind_config=K.TRAIN_OBJLOCK_WIND), 131072, 1500),
-                            ("waypoints g8 odd n", K.train_waypoints_v3_config(), 4099, 5000)):
+                            ("waypoints g8 odd n", K.train_waypoints_v3_config(), 4099, 5000),
+                            ("combined g8 (wave-level camera), largest latency-mapped n", K.train_waypoint_objlock_config(), 16384, 2500),
+                            ("combined g8 odd n", K.train_waypoint_objlock_config(duck_camera_capture_interval_steps=1), 4099, 2500),
+                            ("objlock + obstacles g8 odd n", K.train_objlock_config(num_obstacles=20, duck_camera_capture_interval_steps=2), 4099, 2500)):
     e = P.FixedwingVecEnv(cfg, n, seed=3); e.reset_tensor()
     g = torch.Generator().manual_seed(1)
     acts = [(torch.rand((n, 4), generator=g, dtype=torch.float64) * 2 - 1).cuda() for _ in range(8)]
