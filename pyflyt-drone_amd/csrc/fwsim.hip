@@ -1291,6 +1291,17 @@ int create_T(fw_env* h) {
     rc = invalidate_shadow(h);
     if (rc != FW_OK) return rc;
   }
+  // the camera's LDS map outgrows the 64 KB a workgroup gets without asking from ~700 columns on: opt in once per handle
+  if (const size_t lds = tile_bytes<T>(h); lds > 48 * 1024) {
+    if (lds > 160 * 1024) { h->err = "camera_resolution x num_obstacles needs more LDS than a CU has"; return FW_EINVAL; }
+    if (h->cfg.task == FW_TASK_OBJLOCK) {
+      HIP_TRY(h, hipFuncSetAttribute((const void*)fw_step_kernel_obj_g8<T, FW_TASK_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(h, hipFuncSetAttribute((const void*)fw_reset_kernel<T, 8, FW_TASK_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else {
+      HIP_TRY(h, hipFuncSetAttribute((const void*)fw_step_kernel_obj_g8<T, FW_TASK_WAYPOINT_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(h, hipFuncSetAttribute((const void*)fw_reset_kernel<T, 8, FW_TASK_WAYPOINT_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+  }
   hipLaunchKernelGGL(fw_init_kernel<T>, dim3((h->npad + 255) / 256), dim3(256), 0, 0, dev_state<T>(h), kWave / h->lanes_per_env);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipDeviceSynchronize());

@@ -549,7 +549,7 @@ def test_camera_frame_statistics_match_the_oracle_on_directed_poses(oracle, lane
     import torch
     T0 = K.S_TASK
     rng = np.random.default_rng(77)
-    for res, nobs in ((480, 20), (128, 5), (65, 0)):
+    for res, nobs in ((480, 20), (128, 5), (65, 0), (1024, 20)):        # 1024 columns: the camera's LDS map is 89 KB (opt-in above 64 KB)
         cfg = K.objlock_config(agent_hz=120, motor_noise=False, auto_reset=False, angle_representation="euler",
                                duck_camera_capture_interval_steps=1, flight_dome_size=1e5, num_obstacles=max(nobs, 1),
                                obstacle_radius=2.0, duck_global_scaling=60.0, camera_resolution=res)
