@@ -1203,8 +1203,7 @@ template <typename T> size_t tile_bytes(const fw_env* h) {
   size_t b = sizeof(T) * (size_t)(kWave / h->lanes_per_env) * (size_t)(obs_dim_of(&h->cfg) + 1);
   if (h->cfg.task != FW_TASK_WAYPOINTS && h->lanes_per_env == 8) {
     const int res = h->cfg.camera_resolution > 0 ? h->cfg.camera_resolution : 128;
-    if (h->cfg.num_obstacles > 0)                      // the camera's rows, tables and work list (camera_lds_bytes): 45 KB at 480 columns
-      b = std::max(b, camera_lds_bytes(sizeof(T), zrow_stride_of(res), res) + near_lds_bytes(sizeof(T)));
+    b = std::max(b, cam_lds(sizeof(T), zrow_stride_of(res), res, h->cfg.num_obstacles > 0).total);   // camera map (fwsim_objlock.hpp): 2 KB without, 48 KB with cylinders at 480 columns
   }
   return b;
 }

@@ -222,23 +222,45 @@ __device__ __forceinline__ void comb_spawn(const Params<T>& P, const ObjC<T>& OC
 }
 
 // LDS map of the analytic camera on the 8-lane mapping (aliases the observation tile, which is only written after the step
-// loop), in words of T:  8 row buffers of zrow_stride words (1 / t of the nearest cylinder fragment per column, one per lane set)
-// | 8 tables of FW_MAX_OBSTACLES x kCtabWords (the screened cylinders of a set: cc, hh, op, oq, first column, last column, 1 / cc)
-// | 8 x kSetWords (constants of a set's row h//2: pp, pq, qq, g0z, g1z, cam z, ground gk0, gk1, duck columns first, last)
-// | 8 x 3 x chunks-per-third partial sums | u32: slice count, chunk count, 8 x (first, last covered column)
-// | u16 slice list: set << 10 | cylinder << 5 | index of the 32-column slice inside the cylinder's interval
-// | u16 chunk list: set << 8 | third << 6 | index of the 32-column chunk inside (covered columns of the set) x (third)
-// Behind it: the cylinders an env can touch during this agent step (obj_update_near_mask): 8 x u32 counts, 8 x kNearSlots x (x, y, height).
-constexpr int kCtabWords = 7, kSetWords = 12, kSliceCols = 32, kNearSlots = 4;
+// loop).  FRONT (every camera handle), bytes from the start of dynamic LDS:
+//   8 x kSetWords words of T   constants of a lane set's env: row h//2 (pp, pq, qq, g0z, g1z, cam z; ground gk0, gk1; duck columns
+//                              first, last) and duck mask (zc, xc, yc, k2, A, 1 / A, first row, rows)
+//   8 x 4 words                duck mask accumulators of a set: count, sum x, sum y (exact sums: order-free), max 1 / t (bits)
+//   40 x u32                   [0] slices, [1] chunks, [2] mask rows of the wave, [4 + 2 s], [5 + 2 s] covered columns of set s,
+//                              [20 + 2 s], [21 + 2 s] duck columns on row h//2 of set s
+// CYLINDERS (handles with num_obstacles > 0), behind it:
+//   8 row buffers of zrow_stride words (1 / t of the nearest cylinder fragment per column, one per lane set)
+//   8 tables of FW_MAX_OBSTACLES x kCtabWords (the screened cylinders of a set: cc, hh, op, oq, first column, last column, 1 / cc)
+//   8 x 3 x chunks-per-third partial sums of the rows
+//   u16 slice list: set << 10 | cylinder << 5 | index of the 32-column slice inside the cylinder's interval
+//   u16 chunk list: set << 8 | third << 6 | index of the 32-column chunk inside (covered columns of the set) x (third)
+//   the cylinders an env can touch during this agent step (obj_update_near_mask): 8 x u32 counts, 8 x kNearSlots x (x, y, height)
+constexpr int kCtabWords = 7, kSetWords = 20, kSliceCols = 32, kNearSlots = 4, kCamU32 = 40;
 __host__ __device__ inline int chunks_per_third(int res) { return ((res + 2) / 3 + kSliceCols - 1) / kSliceCols + 1; }
-__host__ __device__ inline size_t camera_lds_bytes(size_t word, int zrow_stride, int res) {
-  const size_t slices = (size_t)8 * FW_MAX_OBSTACLES * (size_t)((res + kSliceCols - 1) / kSliceCols);
-  const size_t chunks = (size_t)8 * 3 * (size_t)chunks_per_third(res);
-  const size_t b = word * ((size_t)8 * zrow_stride + (size_t)8 * FW_MAX_OBSTACLES * kCtabWords + (size_t)8 * kSetWords + chunks) + 4 * 18 +
-                   2 * slices + 2 * chunks;
-  return (b + 15) & ~(size_t)15;
+struct CamLds { size_t sconst, dacc, lu, zr, ctab, cpart, slist, clist, near_cnt, near_tab, total; };     // byte offsets
+__host__ __device__ inline CamLds cam_lds(size_t word, int zrow_stride, int res, bool cylinders) {
+  CamLds L;
+  size_t o = 0;
+  L.sconst = o; o += word * 8 * kSetWords;
+  L.dacc = o; o += word * 8 * 4;
+  L.lu = o; o += 4 * kCamU32;
+  o = (o + 15) & ~(size_t)15;
+  L.zr = L.ctab = L.cpart = L.slist = L.clist = L.near_cnt = L.near_tab = o;
+  if (cylinders) {
+    const size_t slices = (size_t)8 * FW_MAX_OBSTACLES * (size_t)((res + kSliceCols - 1) / kSliceCols);
+    const size_t chunks = (size_t)8 * 3 * (size_t)chunks_per_third(res);
+    L.zr = o; o += word * 8 * (size_t)zrow_stride;
+    L.ctab = o; o += word * 8 * FW_MAX_OBSTACLES * kCtabWords;
+    L.cpart = o; o += word * chunks;
+    L.slist = o; o += 2 * slices;
+    L.clist = o; o += 2 * chunks;
+    o = (o + 15) & ~(size_t)15;
+    L.near_cnt = o; o += 32;
+    L.near_tab = o; o += word * 8 * kNearSlots * 3;
+  }
+  L.total = o;
+  return L;
 }
-__host__ __device__ inline size_t near_lds_bytes(size_t word) { return 32 + word * 8 * kNearSlots * 3; }
 // Which cylinders can be touched during this agent step?  Conservative: horizontal distance of the COM to
 // the axis below radius + reach of the airframe + 1.25 x the distance flown in one agent step (+ slack).
 // The per-tick contact test then only visits these (usually none) instead of all 20.
@@ -258,9 +280,9 @@ __device__ __forceinline__ void obj_update_near_mask(const Params<T>& P, const O
     // the first kNearSlots of them go to an LDS table of the env (x, y, height): the contact test of every tick then costs LDS
     // reads instead of a dependent memory round trip per cylinder; any further ones stay in the mask (read from memory)
     const int sub = (int)(threadIdx.x & 7), row = (int)(threadIdx.x & (kWave - 1)) >> 3;
-    unsigned char* nb = smem_raw + camera_lds_bytes(sizeof(T), OC.zrow_stride, (int)OC.W);
-    uint32_t* ncnt = reinterpret_cast<uint32_t*>(nb) + row;
-    T* ntab = reinterpret_cast<T*>(nb + 32) + (size_t)row * kNearSlots * 3;
+    const CamLds L = cam_lds(sizeof(T), OC.zrow_stride, (int)OC.W, true);
+    uint32_t* ncnt = reinterpret_cast<uint32_t*>(smem_raw + L.near_cnt) + row;
+    T* ntab = reinterpret_cast<T*>(smem_raw + L.near_tab) + (size_t)row * kNearSlots * 3;
     if (sub == 0) *ncnt = 0u;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     T cx[3], cy[3];
@@ -300,7 +322,7 @@ __device__ __forceinline__ bool obj_point_hit(const ObjC<T>& OC, const DevState<
   T dx = pw[0] - O.duck[0], dy = pw[1] - O.duck[1], dz = pw[2] - (O.duck[2] + OC.duck_radius);
   bool hit = dx * dx + dy * dy + dz * dz <= OC.duck_radius * OC.duck_radius;
   if (O.near_n > 0) {
-    const T* ntab = reinterpret_cast<const T*>(smem_raw + camera_lds_bytes(sizeof(T), OC.zrow_stride, (int)OC.W) + 32) +
+    const T* ntab = reinterpret_cast<const T*>(smem_raw + cam_lds(sizeof(T), OC.zrow_stride, (int)OC.W, true).near_tab) +
                     (size_t)((int)(threadIdx.x & (kWave - 1)) >> 3) * kNearSlots * 3;
     for (int k = 0; k < O.near_n; ++k) {
       const T ox = pw[0] - ntab[3 * k], oy = pw[1] - ntab[3 * k + 1];
@@ -507,21 +529,28 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
   // which is only written after the step loop) and, behind the 8 rows, a table of kCtabWords words per cylinder filled by the lane
   // that screened it: ox, oy, cc, hh, op, oq, first column, last column
   using UB = std::conditional_t<sizeof(T) == 8, unsigned long long, unsigned int>;      // T as ordered bits (positive values)
-  T* const lbase = reinterpret_cast<T*>(smem_raw);
-  UB* zr = (G == 8) ? reinterpret_cast<UB*>(lbase) + (size_t)erow * OC.zrow_stride : nullptr;
-  T* ctab_all = lbase + (size_t)8 * OC.zrow_stride;
+  const bool cyl_on = G == 8 && OC.num_obstacles > 0;   // (the handle's LDS holds the cylinder part of the camera map only then)
+  const CamLds L = cam_lds(sizeof(T), OC.zrow_stride, Wi, cyl_on);
+  UB* const zr_all = reinterpret_cast<UB*>(smem_raw + L.zr);
+  UB* zr = zr_all + (size_t)erow * OC.zrow_stride;
+  T* ctab_all = reinterpret_cast<T*>(smem_raw + L.ctab);
   T* ctab = ctab_all + (size_t)erow * (FW_MAX_OBSTACLES * kCtabWords);
-  T* sconst_all = ctab_all + (size_t)8 * FW_MAX_OBSTACLES * kCtabWords;
+  T* sconst_all = reinterpret_cast<T*>(smem_raw + L.sconst);
+  T* dacc_all = reinterpret_cast<T*>(smem_raw + L.dacc);
   const int cpz = chunks_per_third(Wi);
-  T* cpart_all = sconst_all + 8 * kSetWords;                                   // [set][third][chunk] partial sums of the row
-  uint32_t* lu = reinterpret_cast<uint32_t*>(cpart_all + 8 * 3 * cpz);        // [0] slices, [1] chunks, [2 + 2 s], [3 + 2 s]: covered columns of set s
-  uint16_t* slist = reinterpret_cast<uint16_t*>(lu + 18);
-  uint16_t* clist = slist + (size_t)8 * FW_MAX_OBSTACLES * ((Wi + kSliceCols - 1) / kSliceCols);
+  T* cpart_all = reinterpret_cast<T*>(smem_raw + L.cpart);                     // [set][third][chunk] partial sums of the row
+  uint32_t* lu = reinterpret_cast<uint32_t*>(smem_raw + L.lu);
+  uint16_t* slist = reinterpret_cast<uint16_t*>(smem_raw + L.slist);
+  uint16_t* clist = reinterpret_cast<uint16_t*>(smem_raw + L.clist);
   const T pp = g0[0] * g0[0] + g0[1] * g0[1], pq = g0[0] * g1[0] + g0[1] * g1[1], qq = g1[0] * g1[0] + g1[1] * g1[1];
-  const bool cyl_on = G == 8 && OC.num_obstacles > 0;   // (the handle's LDS holds the camera map only then)
-  if (cyl_on) {
-    if ((threadIdx.x & (kWave - 1)) == 0) { lu[0] = 0u; lu[1] = 0u; }
-    if (vsub == 0) { lu[2 + 2 * erow] = 0x7FFFFFFFu; lu[3 + 2 * erow] = 0u; }
+  if (G == 8) {
+    if ((threadIdx.x & (kWave - 1)) == 0) { lu[0] = 0u; lu[1] = 0u; lu[2] = 0u; }
+    if ((threadIdx.x & (kWave - 1)) < 8) sconst_all[(threadIdx.x & 7) * kSetWords + 17] = (T)0;     // no mask rows listed (also for sets without lanes this time)
+    if (vsub == 0) {
+      lu[4 + 2 * erow] = 0x7FFFFFFFu; lu[5 + 2 * erow] = 0u; lu[20 + 2 * erow] = 0x7FFFFFFFu; lu[21 + 2 * erow] = 0u;
+      T* da = dacc_all + erow * 4;
+      da[0] = da[1] = da[2] = da[3] = (T)0;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
   if (nob > 0) {
@@ -551,8 +580,8 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
             e[0] = cc; e[1] = hh;
             e[2] = ox * g0[0] + oy * g0[1]; e[3] = ox * g1[0] + oy * g1[1]; e[4] = (T)xlo; e[5] = (T)xhi; e[6] = M<T>::rcp_(cc);
             // the interval joins the wave's work list in slices of kSliceCols columns
-            (void)__hip_atomic_fetch_min(lu + 2 + 2 * erow, (uint32_t)xlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            (void)__hip_atomic_fetch_max(lu + 3 + 2 * erow, (uint32_t)xhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            (void)__hip_atomic_fetch_min(lu + 4 + 2 * erow, (uint32_t)xlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            (void)__hip_atomic_fetch_max(lu + 5 + 2 * erow, (uint32_t)xhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const int nsl = (xhi - xlo) / kSliceCols + 1;
             const uint32_t pos = __hip_atomic_fetch_add(lu, (uint32_t)nsl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             for (int i = 0; i < nsl; ++i) slist[pos + i] = (uint16_t)((erow << 10) | (o << 5) | i);
@@ -578,49 +607,129 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
   int mid_lo = 1 << 30, mid_hi = -1;                              // duck columns on row h//2
   const bool duck_ok = duck_front && !occluded;
   const bool straddle = zc + Rd >= OC.far_;                       // some fragments may lie beyond the far plane: test them one by one
-  auto inv_hit = [&](T a, T b) {                                  // 1 / t of the sphere hit of pixel direction (1, a, b); 0 = miss / clipped
-    const T q = (T)1 + a * a + b * b, p = zc + a * xc + b * yc, disc = p * p - q * k2;
+  // 1 / t of the sphere hit of pixel direction (1, a, b) for a sphere at (zc_, xc_, yc_) with k2_ = |c|^2 - R^2; 0 = miss / clipped
+  auto inv_hit_c = [&](T a, T b, T zc_, T xc_, T yc_, T k2_) {
+    const T q = (T)1 + a * a + b * b, p = zc_ + a * xc_ + b * yc_, disc = p * p - q * k2_;
     if (disc < (T)0 || p <= (T)0) return (T)0;
     const T it = M<T>::div_(q, p - M<T>::sqrt_(disc));
     return (it < OC.inv_near && it > OC.inv_far) ? it : (T)0;     // near < t < far
   };
+  auto inv_hit = [&](T a, T b) { return inv_hit_c(a, b, zc, xc, yc, k2); };
+  // One row of a mask that lies wholly inside the far plane: the silhouette's interval [fx0, fx1] on image row y (empty:
+  // fx1 < fx0), and 1 / t of the row's nearest fragment -- one of the two pixels around the closed-form minimiser of the scan
+  // line's depth profile -- unless the row's continuous minimum cannot beat `best` (then 0)
+  auto mask_row = [&](int y, T zc_, T xc_, T yc_, T k2_, T A_, T iA_, T best, T& fx0, T& fx1) {
+    fx0 = (T)1; fx1 = (T)0;
+    const T b = ((T)y - v0) * invF;
+    const T e = zc_ + b * yc_, Bh = xc_ * e, Cq = e * e - ((T)1 + b * b) * k2_;
+    const T Dd = Bh * Bh - A_ * Cq;
+    if (Dd < (T)0) return (T)0;
+    const T sq = M<T>::sqrt_(Dd);
+    const T a_lo = (-Bh + sq) * iA_, a_hi = (-Bh - sq) * iA_;
+    T f0 = ceil_<T>(u0 + F * a_lo), f1 = floor_<T>(u0 + F * a_hi);
+    f0 = f0 < (T)0 ? (T)0 : f0; f1 = f1 > W - (T)1 ? W - (T)1 : f1;
+    fx0 = f0; fx1 = f1;
+    if (f1 < f0) return (T)0;
+    const T rs = M<T>::rcp_(M<T>::sqrt_((T)1 + b * b));
+    const T s0 = e * rs, rp = M<T>::sqrt_(M<T>::fmax_(s0 * s0 + xc_ * xc_ - k2_, (T)0));
+    const T tmin_row = (s0 - rp) * rs;                            // view-axis depth of the row's nearest sphere point
+    if (!(tmin_row * best < (T)1 + (T)1e-9)) return (T)0;
+    const T xs = u0 + F * M<T>::div_(xc_, tmin_row);
+    T xa = floor_<T>(xs); xa = xa < f0 ? f0 : (xa > f1 ? f1 : xa);
+    T xb = xa + (T)1; xb = xb > f1 ? f1 : xb;
+    const T ia = inv_hit_c((xa - u0) * invF, b, zc_, xc_, yc_, k2_), ib = inv_hit_c((xb - u0) * invF, b, zc_, xc_, yc_, k2_);
+    return ia > ib ? ia : ib;
+  };
+  T A = (T)0, iA = (T)0;
+  int y0 = 0, y1 = -1;
   if (duck_ok) {
-    const T A = Rd * Rd - zc * zc - yc * yc;                      // < 0: the sphere is wholly in front of the near plane
+    A = Rd * Rd - zc * zc - yc * yc;                              // < 0: the sphere is wholly in front of the near plane
     const T den = M<T>::rcp_(Rd * Rd - zc * zc);
     const T sqb = Rd * M<T>::sqrt_(M<T>::fmax_(zc * zc + yc * yc - Rd * Rd, (T)0));
     const T b_lo = (-zc * yc + sqb) * den, b_hi = (-zc * yc - sqb) * den;       // den < 0
     T fy0 = ceil_<T>(v0 + F * b_lo), fy1 = floor_<T>(v0 + F * b_hi);
     fy0 = fy0 < (T)0 ? (T)0 : fy0; fy1 = fy1 > H - (T)1 ? H - (T)1 : fy1;
-    const T iA = M<T>::rcp_(A);
-    const int y0 = (int)fy0, y1 = (work && fy1 >= fy0) ? (int)fy1 : -1;
+    iA = M<T>::rcp_(A);
+    y0 = (int)fy0; y1 = (work && fy1 >= fy0) ? (int)fy1 : -1;
+  }
+  if (G == 8) {
+    // The rows of ALL sets' masks are dealt to the wave's 64 lanes (a near duck covers 10x the rows of a far one, and the
+    // capture step lasts as long as its longest set).  Count, sum x, sum y are sums of integers and half-integers -- exact in
+    // floating point, so LDS atomic adds in any order give the same bits; the nearest fragment is a max.
+    const bool listed = duck_ok && !straddle && y1 >= y0;
+    if (vsub == 0) {
+      T* sc = sconst_all + erow * kSetWords;
+      int base = 0;
+      if (listed) base = (int)__hip_atomic_fetch_add(lu + 2, (uint32_t)(y1 - y0 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      sc[10] = zc; sc[11] = xc; sc[12] = yc; sc[13] = k2; sc[14] = A; sc[15] = iA; sc[16] = (T)y0;
+      sc[17] = listed ? (T)(y1 - y0 + 1) : (T)0; sc[18] = (T)base;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int total_rows = (int)lu[2];
+    if (total_rows > 0) {
+      const int wl = (int)(threadIdx.x & (kWave - 1));
+      T best = (T)0;                                              // this lane's running max within the current set (only steers which rows are evaluated)
+      int best_of = -1;
+#pragma unroll 1
+      for (int i = wl; i < total_rows; i += kWave) {
+        int es = 0;
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {                             // the set whose [base, base + rows) holds item i
+          const T* scq = sconst_all + q * kSetWords;
+          const int bq = (int)scq[18], nq = (int)scq[17];
+          es = (nq > 0 && i >= bq && i < bq + nq) ? q : es;
+        }
+        const T* sc = sconst_all + es * kSetWords;
+        const int y = (int)sc[16] + (i - (int)sc[18]);
+        if (es != best_of) { best = (T)0; best_of = es; }
+        T fx0, fx1;
+        const T it = mask_row(y, sc[10], sc[11], sc[12], sc[13], sc[14], sc[15], best, fx0, fx1);
+        if (fx1 >= fx0) {
+          const T nn = fx1 - fx0 + (T)1;
+          T* da = dacc_all + es * 4;
+          (void)__hip_atomic_fetch_add(da + 0, nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          (void)__hip_atomic_fetch_add(da + 1, nn * (T)0.5 * (fx0 + fx1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          (void)__hip_atomic_fetch_add(da + 2, nn * (T)y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (y == y_mid) { lu[20 + 2 * es] = (uint32_t)(int)fx0; lu[21 + 2 * es] = (uint32_t)(int)fx1; }
+          if (it > (T)0) {
+            best = it > best ? it : best;
+            UB bits;
+            __builtin_memcpy(&bits, &it, sizeof(T));
+            (void)__hip_atomic_fetch_max(reinterpret_cast<UB*>(da + 3), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (listed) {
+      const T* da = dacc_all + erow * 4;
+      cnt = da[0]; sx = da[1]; sy = da[2];
+      UB bits = reinterpret_cast<const UB*>(da)[3];
+      __builtin_memcpy(&itmax, &bits, sizeof(T));
+      if (lu[20 + 2 * erow] != 0x7FFFFFFFu) { mid_lo = (int)lu[20 + 2 * erow]; mid_hi = (int)lu[21 + 2 * erow]; }
+    }
+  }
+  if (duck_ok && (G == 1 || straddle)) {
+    // one lane (G = 1), or a mask that straddles the far plane (its fragments are tested one by one; it is <= 7 pixels wide there)
 #pragma unroll 1
     for (int y = y0 + vsub; y <= y1; y += VG) {
-      const T b = ((T)y - v0) * invF;
-      const T e = zc + b * yc, Bh = xc * e, Cq = e * e - ((T)1 + b * b) * k2;
-      const T Dd = Bh * Bh - A * Cq;
-      if (Dd < (T)0) continue;
-      const T sq = M<T>::sqrt_(Dd);
-      const T a_lo = (-Bh + sq) * iA, a_hi = (-Bh - sq) * iA;
-      T fx0 = ceil_<T>(u0 + F * a_lo), fx1 = floor_<T>(u0 + F * a_hi);
-      fx0 = fx0 < (T)0 ? (T)0 : fx0; fx1 = fx1 > W - (T)1 ? W - (T)1 : fx1;
-      if (fx1 < fx0) continue;
       if (!straddle) {
+        T fx0, fx1;
+        const T it = mask_row(y, zc, xc, yc, k2, A, iA, itmax, fx0, fx1);
+        if (fx1 < fx0) continue;
         const T nn = fx1 - fx0 + (T)1;
         cnt += nn; sx += nn * (T)0.5 * (fx0 + fx1); sy += nn * (T)y;
         if (y == y_mid) { mid_lo = (int)fx0; mid_hi = (int)fx1; }
-        // nearest fragment of the row: one of the two pixels around the closed-form minimiser of the scan line's depth profile
-        // (rows whose continuous minimum cannot beat the best so far are skipped)
-        const T rs = M<T>::rcp_(M<T>::sqrt_((T)1 + b * b));
-        const T s0 = e * rs, rp = M<T>::sqrt_(M<T>::fmax_(s0 * s0 + xc * xc - k2, (T)0));
-        const T tmin_row = (s0 - rp) * rs;                        // view-axis depth of the row's nearest sphere point
-        if (tmin_row * itmax < (T)1 + (T)1e-9) {
-          const T xs = u0 + F * M<T>::div_(xc, tmin_row);
-          T xa = floor_<T>(xs); xa = xa < fx0 ? fx0 : (xa > fx1 ? fx1 : xa);
-          T xb = xa + (T)1; xb = xb > fx1 ? fx1 : xb;
-          const T ia = inv_hit((xa - u0) * invF, b), ib = inv_hit((xb - u0) * invF, b);
-          itmax = ia > itmax ? ia : itmax; itmax = ib > itmax ? ib : itmax;
-        }
+        itmax = it > itmax ? it : itmax;
       } else {
+        const T b = ((T)y - v0) * invF;
+        const T e = zc + b * yc, Bh = xc * e, Cq = e * e - ((T)1 + b * b) * k2;
+        const T Dd = Bh * Bh - A * Cq;
+        if (Dd < (T)0) continue;
+        const T sq = M<T>::sqrt_(Dd);
+        const T a_lo = (-Bh + sq) * iA, a_hi = (-Bh - sq) * iA;
+        T fx0 = ceil_<T>(u0 + F * a_lo), fx1 = floor_<T>(u0 + F * a_hi);
+        fx0 = fx0 < (T)0 ? (T)0 : fx0; fx1 = fx1 > W - (T)1 ? W - (T)1 : fx1;
         for (T x = fx0; x <= fx1; x += (T)1) {
           const T it = inv_hit((x - u0) * invF, b);
           if (it > (T)0) { cnt += (T)1; sx += x; sy += (T)y; itmax = it > itmax ? it : itmax; }
@@ -629,7 +738,6 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
     }
     cnt = ssum(cnt); sx = ssum(sx); sy = ssum(sy);
     itmax = -smin(-itmax);
-    if (G == 8) { mid_lo = smin(mid_lo); mid_hi = -smin(-mid_hi); }
   }
   T visible = (T)0, cxn = (T)0, cyn = (T)0, area = (T)0, depth = (T)0;
   const bool duck_in = cnt > (T)0;
@@ -740,7 +848,7 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
       // (1) my set clears the covered columns of its row buffer
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       const bool drawn = work && vis != 0u;                       // set-uniform
-      const int xmin = drawn ? (int)lu[2 + 2 * erow] : 1, xmax = drawn ? (int)lu[3 + 2 * erow] : 0;
+      const int xmin = drawn ? (int)lu[4 + 2 * erow] : 1, xmax = drawn ? (int)lu[5 + 2 * erow] : 0;
 #pragma unroll 4
       for (int x = xmin + vsub; x <= xmax; x += VG) zr[x] = (UB)0;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -759,7 +867,7 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
         const int xhi = (int)e[5];
         const int x0 = (int)e[4] + ei * kSliceCols + s8;
         const T c0 = sc[0], c1 = sc[1], c2 = sc[2], c3 = sc[3], c4 = sc[4], c5 = sc[5];
-        UB* zrow = reinterpret_cast<UB*>(lbase) + (size_t)es * OC.zrow_stride;
+        UB* zrow = zr_all + (size_t)es * OC.zrow_stride;
         T itu[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -802,9 +910,9 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
         const T* sc = sconst_all + es * kSetWords;
         const T k0 = sc[6], k1 = sc[7];
         const int e_dlo = (int)sc[8], e_dhi = (int)sc[9];
-        const int e_min = (int)lu[2 + 2 * es], e_max = (int)lu[3 + 2 * es];
+        const int e_min = (int)lu[4 + 2 * es], e_max = (int)lu[5 + 2 * es];
         const int lo = e_min > z_lo(ez) ? e_min : z_lo(ez), hi = e_max < z_hi(ez) - 1 ? e_max : z_hi(ez) - 1;
-        const UB* zrow = reinterpret_cast<const UB*>(lbase) + (size_t)es * OC.zrow_stride;
+        const UB* zrow = zr_all + (size_t)es * OC.zrow_stride;
         const int x0 = lo + ei * kSliceCols + s8;
         T v[4];
 #pragma unroll
