@@ -781,8 +781,8 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       const long long t3 = FWP_NOW();
       w[0] = t3 - p_t0; w[1] = p_t1 - p_t0; w[2] = p_reset; w[3] = p_avi; w[4] = p_task; w[5] = t3 - p_t2; w[6] = it | (nr << 8) | (nh << 16); w[7] = p_t0; w[8] = p_r1; w[9] = p_r2; w[10] = p_r3;
       w[11] = p_capmax | ((long long)p_ncapw << 48);
-      if (HASOBJ) { w[8] = O.p_capm[0]; w[9] = O.p_capm[1]; w[10] = O.p_capm[2]; w[2] = O.p_capm[3];
-        if (getenv_ph) { w[1] = O.p_ph[0]; w[3] = O.p_ph[1]; w[4] = O.p_ph[2]; w[5] = O.p_ph[3]; w[7] = O.p_ph[4]; w[6] = O.p_ph[5]; } }     // (the reset split is unused by these kernels)
+      if (HASOBJ) { w[8] = O.p_capm[0]; w[9] = O.p_capm[1]; w[10] = O.p_capm[2]; w[7] = O.p_capm[3];
+        if (getenv_ph) { w[1] = O.p_ph[0]; w[3] = O.p_ph[1]; w[4] = O.p_ph[2]; w[5] = O.p_ph[3]; w[9] = O.p_ph[4]; w[6] = O.p_ph[5]; } }     // (the reset split is unused by these kernels)
     } })
 }
 

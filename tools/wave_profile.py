@@ -34,14 +34,16 @@ S = st[np.arange(256), slow]                      # slowest step wave of each la
 if PHASES:     # built with -DFW_PROFILE -DFW_PROFILE_PHASES: phases of capture_body in capture steps with 5+ envs due
     ne = st[:, :, 6].sum()
     print(f"{which}: capture steps with 5+ envs due: {ne / st[:, :, 6].size:.3f} per wave-step; cycles each: " + "  ".join(
-        f"{nm} {st[:, :, k].sum() / max(1, ne):.0f}" for nm, k in (("set-up+screening", 1), ("duck", 3), ("ground", 4), ("clear+draw", 5), ("sums+means", 7))))
+        f"{nm} {st[:, :, k].sum() / max(1, ne):.0f}" for nm, k in (("set-up+screening", 1), ("duck", 3), ("ground", 4), ("clear+draw", 5), ("sums+means", 9))))
     sys.exit(0)
 names = ["total", "prologue", "reset", "aviary", "task", "epilogue"]
+cap_words = which in ("objlock", "combined")
 print(f"{which} N={N}: {nblk} step waves/launch, last 256 of {steps} launches; cycles (s_memtime)")
 print("  mean over all waves : " + "  ".join(f"{n} {st[:, :, k].mean():8.0f}" for k, n in enumerate(names)))
 print("  slowest wave/launch : " + "  ".join(f"{n} {S[:, k].mean():8.0f}" for k, n in enumerate(names)))
 it = st[:, :, 6] & 0xFF; nr = (st[:, :, 6] >> 8) & 0xFF; nh = (st[:, :, 6] >> 16) & 0xFF
-print(f"  slowest wave reset split: terminal obs {S[:, 8].mean():.0f}  swap-in / begin_reset {S[:, 9].mean():.0f}  first compute_state {S[:, 10].mean():.0f}")
+if not cap_words:      # (the camera kernels use these words for their capture steps, below)
+    print(f"  slowest wave reset split: terminal obs {S[:, 8].mean():.0f}  swap-in / begin_reset {S[:, 9].mean():.0f}  first compute_state {S[:, 10].mean():.0f}")
 print(f"  loop iterations: mean {it.mean():.2f}  slowest-wave mean {(S[:, 6] & 0xFF).mean():.2f}  max {it.max()}")
 print(f"  env resets/launch {nr.sum(axis=1).mean():.1f}  of which swapped-in shadows {nh.sum(axis=1).mean():.1f}")
 print(f"  waves with a reset: {100.0 * (nr > 0).mean():.1f}%   with an in-kernel (fallback) reset: {100.0 * ((nr - nh) > 0).mean():.1f}%")
@@ -50,7 +52,7 @@ if cap.any():
     print(f"  camera: envs capturing per wave-step {ncap.mean():.2f} of {N // nblk}; cycles in captures per wave-step: mean {cap.mean():.0f}  "
           f"slowest wave {(S[:, 11] & ((1 << 48) - 1)).mean():.0f}; waves with a capture {100.0 * (ncap > 0).mean():.1f}%")
     names_m = ["1 env due", "2", "3-4", "5+"]
-    for idx, nm in zip((8, 9, 10, 2), names_m):
+    for idx, nm in zip((8, 9, 10, 7), names_m):
         v = st[:, :, idx]; cyc = v & ((1 << 40) - 1); ne = v >> 40
         vs = S[:, idx]; cs = vs & ((1 << 40) - 1); ns = vs >> 40
         if ne.sum():
