@@ -448,6 +448,43 @@ def test_f32_throughput_mode_single_step_error(oracle):
     np.testing.assert_allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-6)
 
 
+@pytest.mark.parametrize("task", ["objlock", "combined"])
+def test_f32_throughput_mode_camera_tasks_single_step_error(oracle, task, lanes):
+    """The float instantiation of the camera kernels (the wave-level camera keeps its row buffer and its nearest fragments as
+    ordered 32-bit patterns there, and its exact sums in ds_add_f32): one agent step from the oracle's state, cylinders and
+    ducks in view, stays close to the fp64 oracle; the frame's pixel statistics (centroid, area: sums of integers) agree to
+    float rounding wherever both saw the duck."""
+    import torch
+    kw = dict(motor_noise=False, duck_camera_capture_interval_steps=1, wind_config=None)
+    mk = (lambda **o: K.train_objlock_config(num_obstacles=12, **kw, **o)) if task == "objlock" else (lambda **o: K.train_waypoint_objlock_config(**kw, **o))
+    n = 256
+    ora = oracle.OracleEnv(mk(), n, seed=3); ora.reset()
+    rng = np.random.default_rng(4)
+    for _ in range(30):
+        ora.step(seeded_actions(rng, n, "gentle"))
+    hip = P.FixedwingVecEnv(mk(dtype="float32"), n, seed=3); hip.reset_tensor()
+    hip.set_state(ora.get_state())
+    ora.set_state(hip.get_state())                       # start both from the float32-rounded state
+    a = seeded_actions(rng, n, "gentle").astype(np.float32)
+    oo, ro, te, tr, _, _ = ora.step(a.astype(np.float64))
+    hip.step_tensor(torch.as_tensor(a, device=hip.device))
+    same = (hip.terminated.cpu().numpy() == te) & (hip.truncated.cpu().numpy() == tr) & ~(te | tr).astype(bool)
+    assert same.mean() > 0.95
+    assert torch.isfinite(hip.obs).all() and torch.isfinite(hip.rewards).all()
+    T0 = K.S_TASK
+    sh, so = hip.get_state()[same], ora.get_state()[same]
+    fh, fo = sh[:, T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8], so[:, T0 + K.ST_FRAME:T0 + K.ST_FRAME + 8]
+    both = (fh[:, 0] > 0) & (fo[:, 0] > 0)
+    assert (fh[:, 0] == fo[:, 0]).mean() > 0.97              # visibility agrees (a mask of a few pixels may flip in float)
+    if both.any():
+        assert np.abs(fh[both, 1:4] - fo[both, 1:4]).max() < 2e-2       # centroid / area of the mask
+    zones_h, zones_o = fh[:, 5:8], fo[:, 5:8]
+    ok = (zones_h > 0) & (zones_o > 0)
+    assert ok.any()
+    rel = np.abs(zones_h[ok] - zones_o[ok]) / zones_o[ok]
+    assert np.median(rel) < 1e-2, np.median(rel)                       # zone depths in metres (float depth buffer near the far plane is coarse)
+
+
 @pytest.mark.parametrize("n", [1, 9, 65, 130])
 @pytest.mark.parametrize("task", ["waypoints_wind", "objlock"])
 def test_ragged_env_counts_match_the_oracle(oracle, lanes, n, task):
