@@ -604,9 +604,10 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     for (int k = 0; k < 3; ++k) tpre[k] = D.rs[(size_t)(RF_TARGETS + 3 * sub + k) * n + env];
   }
   // ... and so is the cached attitude block of the observation a reset returns (lane `sub` holds its words sub, sub + G, ...)
-  constexpr int kWO = DEFER ? (32 + G - 1) / G : 1;
+  constexpr bool WO = DEFER && G == 8;               // (one lane per env: the block is copied straight from memory below)
+  constexpr int kWO = WO ? 32 / G : 1;
   T wo[kWO];
-  if (DEFER && resetting) {
+  if (WO && resetting) {
 #pragma unroll
     for (int j = 0; j < kWO; ++j) { const int k = sub + j * G; wo[j] = (k < P.att_dim) ? Pp->warm_obs[k] : (T)0; }
   }
@@ -703,9 +704,11 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       }
       if (leader) { tile[row * ld + P.att_dim + 3 * i] = b[0]; tile[row * ld + P.att_dim + 3 * i + 1] = b[1]; tile[row * ld + P.att_dim + 3 * i + 2] = b[2]; }
     }
+    if (WO) {
 #pragma unroll
-    for (int j = 0; j < kWO; ++j) { const int k = sub + j * G; if (k < P.att_dim) tile[row * ld + k] = wo[j]; }   // the env's lanes share the cached attitude block
-    for (int k = sub + kWO * G; k < P.att_dim; k += G) tile[row * ld + k] = Pp->warm_obs[k];
+      for (int j = 0; j < kWO; ++j) { const int k = sub + j * G; if (k < P.att_dim) tile[row * ld + k] = wo[j]; }   // the env's lanes share the cached attitude block
+    }
+    for (int k = sub + (WO ? kWO * G : 0); k < P.att_dim; k += G) tile[row * ld + k] = Pp->warm_obs[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { S.p[k] = P.warm[k]; S.v[k] = P.warm[7 + k]; S.w[k] = P.warm[10 + k]; }
 #pragma unroll
@@ -1445,7 +1448,11 @@ int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64
   // Lane mapping: below ~1 wave per SIMD of env-per-lane work, split each env over 8 lanes
   // (512 waves for 4096 envs) -- latency-bound regime; above, one lane per env.
   // FWSIM_LANES_PER_ENV=1|8 overrides (used by the benchmark sweep).
-  h->lanes_per_env = (num_envs <= kG8MaxEnvs && cfg->num_targets <= 8 && cfg->n_collision_pts <= 8) ? 8 : 1;
+  // Camera tasks with obstacles stay on the 8-lane mapping at every size: there the cylinders are drawn by the wave from LDS
+  // work lists; one lane per env tests every pixel against every cylinder (combined, 20 cylinders: 330 us vs 7.8 ms per
+  // step at 32 768 envs, tools/crossover.py).
+  const bool cyl_camera = cfg->task != FW_TASK_WAYPOINTS && cfg->num_obstacles > 0;
+  h->lanes_per_env = ((num_envs <= kG8MaxEnvs || cyl_camera) && cfg->num_targets <= 8 && cfg->n_collision_pts <= 8) ? 8 : 1;
   if (const char* ev = getenv("FWSIM_LANES_PER_ENV")) {
     int v = atoi(ev);
     if (v == 1 || (v == 8 && cfg->num_targets <= 8 && cfg->n_collision_pts <= 8)) h->lanes_per_env = v;

@@ -390,10 +390,12 @@ __device__ __forceinline__ T cyl_hit(const ObjC<T>& OC, T cx, T cy, T hh, const 
 //     around the closed-form continuous minimiser (the depth along a scan line across a sphere is unimodal);
 //   * the ground's depth-buffer value is linear in the column; a cylinder covers the columns of one interval (the
 //     directions inside its tangent cone), found in closed form (conservatively) and then tested pixel by pixel.
-// G = 8: the env's 8 lanes take every 8th row of the mask, every 8th pixel of row h//2 and every 8th cylinder; row h//2
-// lives in LDS as float32 depth-buffer values (lane j owns the pixels x = j mod 8: no cross-lane hazard), the partial
-// statistics are combined with DPP.  G = 1: one lane does all of it, pixel by pixel against every cylinder (the
-// throughput mapping has no LDS to spare for 64 rows; it serves the camera tasks only above 16 384 envs).
+// G = 8: a capture step is run by the whole wave (obj_capture_wave): the envs that are due hand their pose to sets of 8-64
+// lanes; the rows of all masks, the cylinder intervals (in 32-column slices) and the row sums (in 32-column chunks) are work
+// lists in LDS dealt to the wave's lanes, combined through LDS atomics whose results do not depend on the order (max of
+// 1 / t on the ordered bit pattern; exact sums of integers) or through slots added in a fixed order -- so a frame is the same
+// bits whatever the neighbours do.  G = 1: one lane does all of it, pixel by pixel against every cylinder (the throughput
+// mapping has no LDS to spare for 64 rows; it serves the camera tasks only without obstacles and above 16 384 envs).
 // ------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ T depthbuf_from_inv(const ObjC<T>& OC, T inv_t) {
   // depth-buffer value far (t - near) / (t (far - near)) = c1 (1 - near / t) of a fragment at view-axis depth t (clipped to

@@ -5,7 +5,7 @@ import pyflyt_drone_amd as P
 from pyflyt_drone_amd import config as K, rollout as R
 t0 = time.time()
 for name, cfg, n, steps in (("objlock g1", K.train_objlock_config(), 65536, 1500),
-                            ("combined g1", K.train_waypoint_objlock_config(), 32768, 1500),
+                            ("combined, 8-lane mapping beyond 16 384 envs (cylinders)", K.train_waypoint_objlock_config(), 32768, 1500),
                             ("waypoints_wind g1", K.train_waypoints_v3_config(wind_config=K.TRAIN_OBJLOCK_WIND), 131072, 1500),
                             ("waypoints g8 odd n", K.train_waypoints_v3_config(), 4099, 5000),
                             ("combined g8 (wave-level camera), largest latency-mapped n", K.train_waypoint_objlock_config(), 16384, 2500),
