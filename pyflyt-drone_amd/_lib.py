@@ -31,12 +31,39 @@ def build(force: bool = False, verbose: bool = False) -> str:
     stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(p) for p in deps)
     if force or stale:
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-o", LIB_PATH, os.path.join(CSRC, "fwsim.hip")]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        # -save-temps (into a scratch directory): the device assembly of exactly this build is checked for a register-allocator
+        # hazard that silently corrupts lanes (tools/check_isa.py) -- a build that has it must not ship
+        import shutil
+        import tempfile
+        tmp = tempfile.mkdtemp(prefix="fwsim_build_")
+        try:
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-save-temps",
+                   "-o", LIB_PATH, os.path.join(CSRC, "fwsim.hip")]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, cwd=tmp)
+            asm = [f for f in os.listdir(tmp) if f.endswith(".s") and "gfx950" in f]
+            if not asm:
+                raise RuntimeError("hipcc left no gfx950 assembly to check")
+            hits = check_isa(open(os.path.join(tmp, asm[0])).read())
+            if hits:
+                os.remove(LIB_PATH)
+                raise RuntimeError("spill stores before the exec restore of a join block (tools/check_isa.py): "
+                                   + "; ".join(f"{n[:60]} {lab}" for n, lab, _ in hits[:6]))
+            if verbose:
+                print("ISA check: no spill store precedes the exec restore of its block")
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
     return LIB_PATH
+
+
+def check_isa(text: str):
+    """tools/check_isa.py, importable from the package's own build step."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fw_check_isa", os.path.join(os.path.dirname(CSRC.rstrip(os.sep)), "..", "tools", "check_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.scan(text)
 
 
 _lib = None

@@ -459,11 +459,11 @@ __device__ __forceinline__ int cyl_columns(float ox, float oy, float r2, float p
 template <typename T, int G>
 __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T>& D, int env, const T duck[3], int nob_in,
                                              const T Sp[3], const T R[9], int vsub, int VG, int erow, bool work, T frame[8],
-                                             long long* ph = nullptr /* dev-only: cycles per phase (FW_PROFILE) */) {
+                                             long long* ph = nullptr, bool ph_on = false /* dev-only: cycles per phase (FW_PROFILE) */) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
 #ifdef FW_PROFILE
   long long ph_t = (long long)__builtin_readcyclecounter();
-#define FW_PH(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); if (ph) ph[i] += t_ - ph_t; ph_t = t_; } while (0)
+#define FW_PH(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); if (ph_on) ph[i] += t_ - ph_t; ph_t = t_; } while (0)
 #else
 #define FW_PH(i) do { } while (0)
 #endif
@@ -745,8 +745,6 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
   const bool duck_in = cnt > (T)0;
   if (duck_in) {
     visible = (T)1;
-    const T ic = M<T>::rcp_(cnt);
-    (void)ic;
     cxn = M<T>::div_(M<T>::div_(sx, cnt), M<T>::fmax_((T)1, W - (T)1));
     cyn = M<T>::div_(M<T>::div_(sy, cnt), M<T>::fmax_((T)1, H - (T)1));
     area = M<T>::div_(cnt, M<T>::fmax_((T)1, H * W));
@@ -1032,7 +1030,7 @@ __device__ __forceinline__ void obj_capture_wave(const ObjC<T>& OC, const DevSta
   for (int i = 0; i < 9; ++i) oR[i] = __shfl(R[i], src, kWave);
   const int onob = __shfl(O.nob, src, kWave), oenv = __shfl(env, src, kWave);
 #ifdef FW_PROFILE
-  capture_body<T, G>(OC, D, oenv, oduck, onob, oSp, oR, lane & (VG - 1), VG, j, work, fr, m >= 5 ? O.p_ph : nullptr);
+  capture_body<T, G>(OC, D, oenv, oduck, onob, oSp, oR, lane & (VG - 1), VG, j, work, fr, O.p_ph, m >= 5);   // (always the array itself: a pointer that may be null keeps it from living in registers)
   if (m >= 5) O.p_ph[5] += 1;
 #else
   capture_body<T, G>(OC, D, oenv, oduck, onob, oSp, oR, lane & (VG - 1), VG, j, work, fr);

@@ -226,3 +226,32 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "fw_oracle" not in text and "libfw_oracle" not in text and "fwo_" not in text, f
+
+
+def test_isa_check_flags_spill_stores_ahead_of_an_exec_restore():
+    """tools/check_isa.py (run on the device assembly of every build by _lib.build): a VGPR saved to an AGPR -- and reloaded
+    later -- between the label of a join block and its `s_or_b64 exec` is saved for the lanes of the branch only.  The sample
+    is the shape hipcc 7.2 produced in a dev build of the combined-task kernel (lane index garbage in 7 of 8 lanes, memory
+    fault in the take-over prefetch); the same block with the store after the restore, a predicated accumulator update of an
+    MFMA kernel and a store staged through AGPRs are not flagged."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "check_isa.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    bad = """
+_Z4kernv:
+\ts_and_saveexec_b64 s[0:1], vcc
+\ts_cbranch_execz .LBB0_2
+\tds_write_b64 v56, v[38:39] offset:144
+.LBB0_2:
+\tv_accvgpr_write_b32 a16, v208
+\ts_or_b64 exec, exec, s[0:1]
+\tds_read_b32 v2, v233 offset:1544
+\tv_accvgpr_read_b32 v208, a16
+\ts_endpgm
+.Lfunc_end0:
+"""
+    good = bad.replace("\tv_accvgpr_write_b32 a16, v208\n\ts_or_b64 exec, exec, s[0:1]", "\ts_or_b64 exec, exec, s[0:1]\n\tv_accvgpr_write_b32 a16, v208")
+    mfma = bad.replace("\tds_read_b32", "\tv_mfma_f32_32x32x2_f32 a[0:15], v0, v1, a[0:15]\n\tds_read_b32")
+    staged = bad.replace("\tv_accvgpr_write_b32 a16, v208\n", "\tv_accvgpr_write_b32 a16, v208\n\tglobal_store_dwordx4 v[82:83], a[16:19], off offset:48\n")
+    assert [h[1] for h in m.scan(bad)] == [".LBB0_2"]
+    assert m.scan(good) == [] and m.scan(mfma) == [] and m.scan(staged) == []

@@ -1,0 +1,56 @@
+"""Build-time guard against a register-allocator hazard seen with hipcc 7.2 on these kernels (DESIGN.md section 3,
+"Spills at divergent joins").
+
+When a VGPR is spilled to an AGPR (or to scratch) at the top of the block where divergent control flow re-joins, the spill
+store must come AFTER the `s_or_b64 exec, exec, ...` that re-enables the lanes which skipped the branch.  The compiler was
+caught placing such stores BEFORE it: only the lanes of the branch save their value, the reload later runs for all lanes, and
+the others read whatever the AGPR held.  The symptom is data-dependent garbage in lanes that did not take a branch -- or a
+memory fault when the value is an address.  Which code is hit changes with every change of the register pressure, so the
+check runs on the ISA of every build:
+
+    python tools/check_isa.py <device assembly (.s) of fwsim.hip>
+
+exits 1 and prints the blocks if a spill store to a register that is reloaded later sits between a block label and the exec
+restore of that block.
+"""
+import re
+import sys
+
+
+def scan(text):
+    hits = []
+    for fn in re.split(r"\n(?=_Z[\w]+:\s)", text):
+        name = fn.split(":", 1)[0]
+        if not name.startswith("_Z"):
+            continue
+        lines = [l for l in fn.split("\n") if l.strip() and not re.match(r"\s*(\.loc|\.Ltmp|\.cfi|;|\.p2align)", l)]
+        # kernels with MFMA keep accumulators in AGPRs on purpose: a predicated v_accvgpr_write there is an assignment, not a spill
+        reloaded = set() if "v_mfma" in fn else set(re.findall(r"v_accvgpr_read_b32 v\d+, (a\d+)", fn))
+        for n, l in enumerate(lines):
+            if not re.match(r"\.LBB\d+_\d+:", l):
+                continue
+            pre = []
+            for x in lines[n + 1:n + 40]:
+                if re.match(r"\.LBB", x) or "s_cbranch" in x or "s_branch" in x or "s_endpgm" in x:
+                    break
+                if re.search(r"s_or_b64 exec, exec,", x):
+                    spills = [p.strip() for p in pre
+                              if (m := re.search(r"v_accvgpr_write_b32 (a\d+),", p)) and m.group(1) in reloaded
+                              or re.search(r"scratch_store", p)]
+                    # values staged in AGPRs as the data operand of a store of the same block are not spills
+                    used_here = set(re.findall(r"a\[(\d+):(\d+)\]", " ".join(pre)))
+                    staged = {f"a{i}" for lo, hi in used_here for i in range(int(lo), int(hi) + 1)}
+                    spills = [p for p in spills if not ((m := re.search(r"v_accvgpr_write_b32 (a\d+),", p)) and m.group(1) in staged)]
+                    if spills:
+                        hits.append((name, l.split(":")[0], spills))
+                    break
+                pre.append(x)
+    return hits
+
+
+if __name__ == "__main__":
+    h = scan(open(sys.argv[1]).read())
+    for name, label, spills in h:
+        print(f"{name[:80]} {label}: spill stores before the exec restore: {spills[:6]}")
+    print(f"{len(h)} suspicious block(s)")
+    sys.exit(1 if h else 0)

@@ -1,6 +1,7 @@
 """Dev tool: where does the slowest wave of each fw_step launch spend its cycles?
 
-Builds nothing itself: expects tools/_build/libfwsim_prof.so (fwsim.hip compiled with -DFW_PROFILE).
+Builds nothing itself: expects tools/_build/libfwsim_prof.so (bash tools/build_prof.sh: fwsim.hip with -DFW_PROFILE, ISA-checked);
+--phases expects libfwsim_prof_ph.so (bash tools/build_prof.sh phases) and splits the capture steps with 5+ envs due.
 usage: python tools/wave_profile.py <waypoints|waypoints_wind|objlock|combined> [steps]
 """
 import ctypes as C, os, sys, numpy as np, torch
