@@ -614,14 +614,15 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
 
   // GENERAL: the rows of a shadow that is being taken, fetched by the env's G lanes before the observation pass (their round
   // trip hides behind it): word w of the [RF_COUNT] state column goes to lane w % G; the first observation likewise
-  constexpr int kCW = GENERAL ? (RF_COUNT + G - 1) / G : 1, kOW = GENERAL ? (kMaxObs + G - 1) / G : 1;
-  constexpr bool SWAP_REGS = GENERAL && G == 8;       // G = 1: one lane would hold all 123 words; it copies through memory below
+  constexpr int kRows = HASOBJ ? RF_COUNT : RF_TASK;  // the waypoint task has no task tail
+  constexpr int kCW = GENERAL ? (kRows + G - 1) / G : 1, kOW = GENERAL ? (kMaxObs + G - 1) / G : 1;
+  constexpr bool SWAP_REGS = GENERAL && G == 8;       // G = 1: one lane would hold all 171 words; it copies through memory below
   T cw[kCW], ow[kOW];
   int32_t tick_new = 0;
   if (GENERAL && resetting) {
     if (SWAP_REGS) {
 #pragma unroll
-      for (int j = 0; j < kCW; ++j) { const int w = sub + j * G; cw[j] = (w < RF_COUNT) ? D.rs[(size_t)w * n + env] : (T)0; }
+      for (int j = 0; j < kCW; ++j) { const int w = sub + j * G; cw[j] = (w < kRows) ? D.rs[(size_t)w * n + env] : (T)0; }
 #pragma unroll
       for (int j = 0; j < kOW; ++j) { const int k = sub + j * G; ow[j] = (k < Dobs) ? Dg.sobs[(size_t)env * Dobs + k] : (T)0; }
     }
@@ -744,10 +745,10 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
 #pragma unroll
       for (int j = 0; j < kOW; ++j) { const int k = sub + j * G; if (k < Dobs) tile[row * ld + k] = ow[j]; }
 #pragma unroll
-      for (int j = 0; j < kCW; ++j) { const int w = sub + j * G; if (w < RF_COUNT) D.r[(size_t)w * n + env] = cw[j]; }
+      for (int j = 0; j < kCW; ++j) { const int w = sub + j * G; if (w < kRows) D.r[(size_t)w * n + env] = cw[j]; }
     } else {
       for (int k = 0; k < Dobs; ++k) tile[row * ld + k] = Dg.sobs[(size_t)env * Dobs + k];
-      copy_words<T, G>(D.r, D.rs, 0, RF_COUNT, n, env);
+      copy_words<T, G>(D.r, D.rs, 0, kRows, n, env);
     }
     if (leader) { stat_add(D.stats, FW_CTR_RESETS); stat_add(D.stats, FW_CTR_SHADOW_HITS); }
     episode += 1; tick = tick_new;

@@ -36,7 +36,7 @@ enum RF : int {
   RF_POS = 0, RF_QUAT = 3, RF_VEL = 7, RF_OMEGA = 10, RF_ACT = 13, RF_ACTION = 19,
   RF_NEW_DIST = 23, RF_WIND = 24, RF_EP_RETURN = 31, RF_TARGETS = 32,
   RF_TASK = 32 + 3 * FW_MAX_TARGETS,              // 56
-  RF_COUNT = RF_TASK + (FW_STATE_DIM - FW_S_TASK) // 56 + 67 = 123
+  RF_COUNT = RF_TASK + (FW_STATE_DIM - FW_S_TASK) // 56 + 115 = 171
 };
 // ---- SoA integer fields ----
 enum IF : int { IF_STEP = 0, IF_TICK = 1, IF_EPISODE = 2, IF_FLAGS = 3, IF_NUM_REACHED = 4, IF_COUNT = 5 };
