@@ -72,14 +72,23 @@ class EvalResult:
 @torch.no_grad()
 def evaluate_policy(policy, env, n_eval_episodes: int = 10, deterministic: bool = True,
                     callback: Optional[Callable[[dict], None]] = None, max_vec_steps: Optional[int] = None,
-                    generator: Optional[torch.Generator] = None) -> EvalResult:
+                    generator: Optional[torch.Generator] = None, use_graph: Optional[bool] = None) -> EvalResult:
     """Run ``policy`` on ``env`` (a :class:`~.rollout.VecNormalizeDevice` over a device env,
     normally with ``training=False, norm_reward=False``) until ``n_eval_episodes`` episodes are
     complete.  ``callback(info_dict)`` is called for every finished episode with the keys the
-    reference's callbacks read (``num_targets_reached``, ``is_success``, ``duck_strike``, ...)."""
+    reference's callbacks read (``num_targets_reached``, ``is_success``, ``duck_strike``, ...).
+
+    Deterministic evaluations on the GPU run as replays of a captured hipGraph of 8 vec-steps with the episode bookkeeping
+    on the device (``use_graph``; default: whenever possible): an evaluation of 16 envs flying 1800-step episodes is ~30
+    framework ops per step, and read back after every step it cost as much wall clock as 0.4 M training steps.  Both paths
+    return the same episodes in the same order; ``callback`` is then called once the evaluation is over."""
     venv = env.venv
     n = env.num_envs
     targets = np.array([(n_eval_episodes + i) // n for i in range(n)], dtype=np.int64)
+    if use_graph is None:
+        use_graph = deterministic and generator is None and torch.device(env.device).type == "cuda" and hasattr(venv, "step_tensor")
+    if use_graph:
+        return _evaluate_replayed(policy, env, targets, callback, max_vec_steps)
     counts = np.zeros(n, dtype=np.int64)
     cur_rew = torch.zeros(n, dtype=torch.float64, device=env.device)
     cur_len = torch.zeros(n, dtype=torch.int64, device=env.device)
@@ -124,6 +133,95 @@ def evaluate_policy(policy, env, n_eval_episodes: int = 10, deterministic: bool 
         steps += 1
         if max_vec_steps is not None and steps >= max_vec_steps:
             break
+    return res
+
+
+def _episode_info(res: "EvalResult", rew: float, length: int, info_row, is_objlock: bool) -> dict:
+    info = {"episode": {"r": rew, "l": length}}
+    if info_row is not None:
+        info["num_targets_reached"] = int(info_row[K.INFO_NUM_TARGETS_REACHED])
+        info["collision"] = bool(info_row[K.INFO_COLLISION])
+        info["out_of_bounds"] = bool(info_row[K.INFO_OUT_OF_BOUNDS])
+        info["env_complete"] = bool(info_row[K.INFO_ENV_COMPLETE])
+        res.num_targets_reached.append(info["num_targets_reached"])
+        if is_objlock:
+            info["duck_strike"] = bool(info_row[K.INFO_DUCK_STRIKE])
+            info["is_success"] = bool(info_row[K.INFO_IS_SUCCESS])
+            res.duck_strike.append(info["duck_strike"])
+        else:
+            info["is_success"] = info["env_complete"]
+        res.is_success.append(info["is_success"])
+    return info
+
+
+_REPLAY_STEPS = 8
+
+
+def _evaluate_replayed(policy, env, targets: np.ndarray, callback, max_vec_steps) -> "EvalResult":
+    """evaluate_policy with the loop body captured: policy forward, env step, normalisation and the per-episode bookkeeping
+    (reward / length accumulators, the slot of the episode that just ended, its info row) are device ops on fixed buffers;
+    the host looks at the episode counters once per replay of ``_REPLAY_STEPS`` steps."""
+    venv, n, dev = env.venv, env.num_envs, env.device
+    E = max(int(targets.max()), 1)
+    has_info = hasattr(venv, "info")
+    is_objlock = getattr(getattr(venv, "cfg", None), "task", K.FW_TASK_WAYPOINTS) != K.FW_TASK_WAYPOINTS
+    tg = torch.as_tensor(targets, device=dev)
+    ar = torch.arange(n, device=dev)
+    obs = env.reset().clone()
+    counts = torch.zeros(n, dtype=torch.int64, device=dev)
+    cur_rew = torch.zeros(n, dtype=torch.float64, device=dev)
+    cur_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    step_ctr = torch.zeros((), dtype=torch.int64, device=dev)
+    fin_rew = torch.zeros((n, E), dtype=torch.float64, device=dev)
+    fin_len = torch.zeros((n, E), dtype=torch.int64, device=dev)
+    fin_step = torch.zeros((n, E), dtype=torch.int64, device=dev)
+    fin_info = torch.zeros((n, E, venv.info.shape[1]), dtype=venv.info.dtype, device=dev) if has_info else None
+
+    def body():
+        actions, _, _ = policy(obs, deterministic=True, generator=None)
+        o, _, dones, _, _ = env.step(actions.clamp(-1.0, 1.0).to(venv.torch_dtype))
+        obs.copy_(o)
+        cur_rew.add_(venv.rewards.to(torch.float64))                 # un-normalised reward of the wrapped env
+        cur_len.add_(1); step_ctr.add_(1)
+        take = dones & (counts < tg)
+        slot = counts.clamp(max=E - 1)
+        fin_rew[ar, slot] = torch.where(take, cur_rew, fin_rew[ar, slot])
+        fin_len[ar, slot] = torch.where(take, cur_len, fin_len[ar, slot])
+        fin_step[ar, slot] = torch.where(take, step_ctr.expand(n), fin_step[ar, slot])
+        if has_info:
+            fin_info[ar, slot] = torch.where(take[:, None], venv.info, fin_info[ar, slot])
+        counts.add_(take.to(torch.int64))
+        cur_rew.masked_fill_(dones, 0.0); cur_len.masked_fill_(dones, 0)
+
+    def unfinished() -> bool:
+        return bool((counts < tg).any().item())
+
+    steps = 0
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(2):                                           # warm-up (these are evaluation steps like any other)
+            body(); steps += 1
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(_REPLAY_STEPS):
+            body()
+    steps += _REPLAY_STEPS                                           # (capture does not execute: the first replay does)
+    graph.replay()
+    while unfinished() and (max_vec_steps is None or steps < max_vec_steps):
+        graph.replay(); steps += _REPLAY_STEPS
+    torch.cuda.synchronize(dev)
+    res = EvalResult([], [])
+    c_h = torch.minimum(counts, tg).cpu().numpy()
+    rew_h, len_h, step_h = fin_rew.cpu().numpy(), fin_len.cpu().numpy(), fin_step.cpu().numpy()
+    info_h = fin_info.cpu().numpy() if has_info else None
+    order = sorted((int(step_h[i, k]), i, k) for i in range(n) for k in range(int(c_h[i])))        # as they ended: by step, then env
+    for _, i, k in order:
+        res.episode_rewards.append(float(rew_h[i, k])); res.episode_lengths.append(int(len_h[i, k]))
+        info = _episode_info(res, float(rew_h[i, k]), int(len_h[i, k]), info_h[i, k] if has_info else None, is_objlock)
+        if callback is not None:
+            callback(info)
     return res
 
 

@@ -42,6 +42,30 @@ def test_eval_harness_waypoints_metrics_are_consistent_with_the_env_info():
     assert sorted(r2.episode_lengths) == sorted(r.episode_lengths)
 
 
+@pytest.mark.parametrize("task", ["waypoints", "objlock"])
+def test_replayed_evaluation_returns_the_episodes_of_the_step_by_step_loop(task):
+    """evaluate_policy's default on the GPU (hipGraph replays of 8 vec-steps, bookkeeping on the device, one look at the
+    counters per replay) against the plain loop that reads back after every step: same episodes, same order, same info,
+    including envs that finish several episodes and the uneven split of n_eval_episodes over the envs."""
+    cfg = _wp_cfg() if task == "waypoints" else K.train_objlock_config(max_duration_seconds=3.0)
+    pol = None
+    out = []
+    for use_graph in (False, True):
+        venv = P.FixedwingVecEnv(cfg, 24, seed=9)
+        env = R.VecNormalizeDevice(venv, training=False, norm_reward=False)
+        if pol is None:
+            torch.manual_seed(0)
+            pol = R.MlpPolicy(env.obs_dim).cuda()
+        infos = []
+        r = evaluate.evaluate_policy(pol, env, n_eval_episodes=61, deterministic=True, callback=infos.append, use_graph=use_graph)
+        out.append((r, infos))
+    (a, ia), (b, ib) = out
+    assert len(a.episode_rewards) == 61 == len(b.episode_rewards)
+    assert a.episode_lengths == b.episode_lengths and a.episode_rewards == b.episode_rewards
+    assert a.num_targets_reached == b.num_targets_reached and a.is_success == b.is_success and a.duck_strike == b.duck_strike
+    assert ia == ib
+
+
 def test_eval_harness_objlock_reports_duck_strike_rate():
     venv = P.FixedwingVecEnv(K.train_objlock_config(max_duration_seconds=3.0), 32, seed=1)
     env = R.VecNormalizeDevice(venv, training=False, norm_reward=False)
