@@ -68,6 +68,13 @@ def _atomic_torch_save(obj, path: str) -> None:
 
 
 def save(path: str, ppo, include_env_state: bool = True) -> str:
+    _atomic_torch_save(snapshot(ppo, include_env_state), path)
+    return path
+
+
+def snapshot(ppo, include_env_state: bool = True) -> dict:
+    """What :func:`save` writes, as host tensors: taken now, written later (:func:`write`) -- the evaluation callback keeps
+    the weights it is evaluating until it knows whether they are the best so far."""
     venv = ppo.env.venv
     sd = {
         "format_version": FORMAT_VERSION,
@@ -96,6 +103,10 @@ def save(path: str, ppo, include_env_state: bool = True) -> str:
         sd["sampler_rng_state"] = ppo.gen.get_state().cpu()        # action-sampling generator: resume draws the same actions
         if getattr(ppo, "_collect_fused", False):
             sd["collect_rng"] = ppo._rng.detach().cpu()             # (seed, draw counter) of fw_policy_act
+    return sd
+
+
+def write(sd: dict, path: str) -> str:
     _atomic_torch_save(sd, path)
     return path
 

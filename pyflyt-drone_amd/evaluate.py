@@ -157,82 +157,139 @@ def _episode_info(res: "EvalResult", rew: float, length: int, info_row, is_objlo
 _REPLAY_STEPS = 8
 
 
-def _evaluate_replayed(policy, env, targets: np.ndarray, callback, max_vec_steps) -> "EvalResult":
+class ReplayedEvaluation:
     """evaluate_policy with the loop body captured: policy forward, env step, normalisation and the per-episode bookkeeping
-    (reward / length accumulators, the slot of the episode that just ended, its info row) are device ops on fixed buffers;
-    the host looks at the episode counters once per replay of ``_REPLAY_STEPS`` steps."""
-    venv, n, dev = env.venv, env.num_envs, env.device
-    E = max(int(targets.max()), 1)
-    has_info = hasattr(venv, "info")
-    is_objlock = getattr(getattr(venv, "cfg", None), "task", K.FW_TASK_WAYPOINTS) != K.FW_TASK_WAYPOINTS
-    tg = torch.as_tensor(targets, device=dev)
-    ar = torch.arange(n, device=dev)
-    obs = env.reset().clone()
-    counts = torch.zeros(n, dtype=torch.int64, device=dev)
-    cur_rew = torch.zeros(n, dtype=torch.float64, device=dev)
-    cur_len = torch.zeros(n, dtype=torch.int64, device=dev)
-    step_ctr = torch.zeros((), dtype=torch.int64, device=dev)
-    fin_rew = torch.zeros((n, E), dtype=torch.float64, device=dev)
-    fin_len = torch.zeros((n, E), dtype=torch.int64, device=dev)
-    fin_step = torch.zeros((n, E), dtype=torch.int64, device=dev)
-    fin_info = torch.zeros((n, E, venv.info.shape[1]), dtype=venv.info.dtype, device=dev) if has_info else None
+    (reward / length accumulators, the slot of the episode that just ended, its info row) are device ops on fixed buffers.
 
-    def body():
-        actions, _, _ = policy(obs, deterministic=True, generator=None)
-        o, _, dones, _, _ = env.step(actions.clamp(-1.0, 1.0).to(venv.torch_dtype))
-        obs.copy_(o)
-        cur_rew.add_(venv.rewards.to(torch.float64))                 # un-normalised reward of the wrapped env
-        cur_len.add_(1); step_ctr.add_(1)
+    ``run()`` drives it from the host (one look at the episode counters per replay of ``_REPLAY_STEPS`` steps).
+    ``launch()`` enqueues the WHOLE evaluation on a side stream -- as many replays as the longest possible episodes need,
+    ``episodes per env x (max_steps + 2)`` vec-steps -- and returns at once: the evaluation (a few envs) then runs beside the
+    training that continues on the main stream (the PPO update keeps four of the 256 CUs busy); ``ready()`` / ``result()``
+    collect it.  The policy handed in must not change while it runs (EvalCallback evaluates a copy of the weights)."""
+
+    def __init__(self, policy, env, targets: np.ndarray, callback=None):
+        self.policy, self.env, self.callback = policy, env, callback
+        venv, n, dev = env.venv, env.num_envs, env.device
+        self.venv, self.n, self.dev, self.targets = venv, n, dev, targets
+        self.E = E = max(int(targets.max()), 1)
+        self.has_info = hasattr(venv, "info")
+        self.is_objlock = getattr(getattr(venv, "cfg", None), "task", K.FW_TASK_WAYPOINTS) != K.FW_TASK_WAYPOINTS
+        self.tg = torch.as_tensor(targets, device=dev)
+        self.ar = torch.arange(n, device=dev)
+        self.counts = torch.zeros(n, dtype=torch.int64, device=dev)
+        self.cur_rew = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.cur_len = torch.zeros(n, dtype=torch.int64, device=dev)
+        self.step_ctr = torch.zeros((), dtype=torch.int64, device=dev)
+        self.fin_rew = torch.zeros((n, E), dtype=torch.float64, device=dev)
+        self.fin_len = torch.zeros((n, E), dtype=torch.int64, device=dev)
+        self.fin_step = torch.zeros((n, E), dtype=torch.int64, device=dev)
+        self.fin_info = torch.zeros((n, E, venv.info.shape[1]), dtype=venv.info.dtype, device=dev) if self.has_info else None
+        self.obs = None
+        self.side = torch.cuda.Stream(device=dev)
+        self.done_event = None
+        self.steps = 0
+
+    def _body(self):
+        venv, ar, tg, E, counts = self.venv, self.ar, self.tg, self.E, self.counts
+        actions, _, _ = self.policy(self.obs, deterministic=True, generator=None)
+        o, _, dones, _, _ = self.env.step(actions.clamp(-1.0, 1.0).to(venv.torch_dtype))
+        self.obs.copy_(o)
+        self.cur_rew.add_(venv.rewards.to(torch.float64))            # un-normalised reward of the wrapped env
+        self.cur_len.add_(1); self.step_ctr.add_(1)
         take = dones & (counts < tg)
         slot = counts.clamp(max=E - 1)
-        fin_rew[ar, slot] = torch.where(take, cur_rew, fin_rew[ar, slot])
-        fin_len[ar, slot] = torch.where(take, cur_len, fin_len[ar, slot])
-        fin_step[ar, slot] = torch.where(take, step_ctr.expand(n), fin_step[ar, slot])
-        if has_info:
-            fin_info[ar, slot] = torch.where(take[:, None], venv.info, fin_info[ar, slot])
+        self.fin_rew[ar, slot] = torch.where(take, self.cur_rew, self.fin_rew[ar, slot])
+        self.fin_len[ar, slot] = torch.where(take, self.cur_len, self.fin_len[ar, slot])
+        self.fin_step[ar, slot] = torch.where(take, self.step_ctr.expand(self.n), self.fin_step[ar, slot])
+        if self.has_info:
+            self.fin_info[ar, slot] = torch.where(take[:, None], venv.info, self.fin_info[ar, slot])
         counts.add_(take.to(torch.int64))
-        cur_rew.masked_fill_(dones, 0.0); cur_len.masked_fill_(dones, 0)
+        self.cur_rew.masked_fill_(dones, 0.0); self.cur_len.masked_fill_(dones, 0)
 
-    def unfinished() -> bool:
-        return bool((counts < tg).any().item())
+    def _begin(self):
+        """reset, two eager steps (they are evaluation steps like any other), capture: on the side stream"""
+        self.side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.side):
+            self.obs = self.env.reset().clone()
+            for _ in range(2):
+                self._body(); self.steps += 1
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.side):
+                for _ in range(_REPLAY_STEPS):
+                    self._body()
 
-    steps = 0
-    side = torch.cuda.Stream(device=dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(side):
-        for _ in range(2):                                           # warm-up (these are evaluation steps like any other)
-            body(); steps += 1
-    torch.cuda.current_stream(dev).wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        for _ in range(_REPLAY_STEPS):
-            body()
-    steps += _REPLAY_STEPS                                           # (capture does not execute: the first replay does)
-    graph.replay()
-    while unfinished() and (max_vec_steps is None or steps < max_vec_steps):
-        graph.replay(); steps += _REPLAY_STEPS
-    torch.cuda.synchronize(dev)
-    res = EvalResult([], [])
-    c_h = torch.minimum(counts, tg).cpu().numpy()
-    rew_h, len_h, step_h = fin_rew.cpu().numpy(), fin_len.cpu().numpy(), fin_step.cpu().numpy()
-    info_h = fin_info.cpu().numpy() if has_info else None
-    order = sorted((int(step_h[i, k]), i, k) for i in range(n) for k in range(int(c_h[i])))        # as they ended: by step, then env
-    for _, i, k in order:
-        res.episode_rewards.append(float(rew_h[i, k])); res.episode_lengths.append(int(len_h[i, k]))
-        info = _episode_info(res, float(rew_h[i, k]), int(len_h[i, k]), info_h[i, k] if has_info else None, is_objlock)
-        if callback is not None:
-            callback(info)
-    return res
+    def run(self, max_vec_steps: Optional[int] = None) -> "EvalResult":
+        self._begin()
+        with torch.cuda.stream(self.side):
+            while True:
+                self.graph.replay(); self.steps += _REPLAY_STEPS
+                if not bool((self.counts < self.tg).any().item()) or (max_vec_steps is not None and self.steps >= max_vec_steps):
+                    break
+        torch.cuda.current_stream(self.dev).wait_stream(self.side)
+        return self.result()
+
+    def launch(self, bound_vec_steps: int) -> "ReplayedEvaluation":
+        self._begin()
+        with torch.cuda.stream(self.side):
+            for _ in range(-(-max(bound_vec_steps - 2, 1) // _REPLAY_STEPS)):
+                self.graph.replay(); self.steps += _REPLAY_STEPS
+            self.done_event = torch.cuda.Event()
+            self.done_event.record(self.side)
+        return self
+
+    def ready(self) -> bool:
+        return self.done_event is None or self.done_event.query()
+
+    def result(self) -> "EvalResult":
+        if self.done_event is not None:
+            self.done_event.synchronize()
+        else:
+            self.side.synchronize()
+        n, has_info = self.n, self.has_info
+        res = EvalResult([], [])
+        c_h = torch.minimum(self.counts, self.tg).cpu().numpy()
+        rew_h, len_h, step_h = self.fin_rew.cpu().numpy(), self.fin_len.cpu().numpy(), self.fin_step.cpu().numpy()
+        info_h = self.fin_info.cpu().numpy() if has_info else None
+        order = sorted((int(step_h[i, k]), i, k) for i in range(n) for k in range(int(c_h[i])))    # as they ended: by step, then env
+        for _, i, k in order:
+            res.episode_rewards.append(float(rew_h[i, k])); res.episode_lengths.append(int(len_h[i, k]))
+            info = _episode_info(res, float(rew_h[i, k]), int(len_h[i, k]), info_h[i, k] if has_info else None, self.is_objlock)
+            if self.callback is not None:
+                self.callback(info)
+        return res
+
+
+def _evaluate_replayed(policy, env, targets: np.ndarray, callback, max_vec_steps) -> "EvalResult":
+    return ReplayedEvaluation(policy, env, targets, callback).run(max_vec_steps)
+
+
+def start_evaluation(policy, env, n_eval_episodes: int = 10, callback=None) -> ReplayedEvaluation:
+    """Asynchronous :func:`evaluate_policy` (deterministic, device envs whose config bounds the episode length): returns a
+    running :class:`ReplayedEvaluation`; ``.result()`` waits for it."""
+    n = env.num_envs
+    targets = np.array([(n_eval_episodes + i) // n for i in range(n)], dtype=np.int64)
+    bound = int(targets.max()) * (K.max_steps(env.venv.cfg) + 2)
+    return ReplayedEvaluation(policy, env, targets, callback).launch(bound)
 
 
 class EvalCallback:
     """``WaypointEvalCallback`` / SB3 ``EvalCallback`` for :meth:`rollout.PPO.learn`: every
     ``eval_freq`` vec-steps of training (the reference passes ``10000 // num_envs``) sync the
-    normaliser, evaluate, append to ``evaluations.npz``, keep ``best_model``."""
+    normaliser, evaluate, append to ``evaluations.npz``, keep ``best_model``.
+
+    ``overlap=True`` (single-process jobs on the GPU; off by default): the evaluation is *launched* -- a copy of the
+    weights, the normaliser statistics, then :func:`start_evaluation` on a side stream -- and the training goes on; its
+    figures are logged (under the timestep count at which it was launched) when a later callback finds it finished, at the
+    latest before the next evaluation starts and when training ends.  ``best_model`` is written from the snapshot taken at
+    launch, so it holds the evaluated weights, not the ones trained since.  Same figures as the synchronous form
+    (tests/test_eval_checkpoint_gpu.py) -- but measured SLOWER on the training examples (combined 208 k -> 186 k,
+    waypoints 209 k -> 202 k env-steps/s over whole runs): without a host in the loop every env is stepped for the longest
+    possible episodes, and those ~1800 small launches on a second queue cost the training stream more than the 0.1 s of
+    waiting they replace.  The default is therefore the synchronous evaluation, replayed as hipGraphs of 8 vec-steps."""
 
     def __init__(self, eval_env, n_eval_episodes: int = 5, eval_freq: int = 10000, log_path: Optional[str] = None,
                  best_model_save_path: Optional[str] = None, deterministic: bool = True, num_targets_total: int = 0,
-                 verbose: int = 0):
+                 verbose: int = 0, overlap: Optional[bool] = None):
         self.eval_env, self.n_eval_episodes, self.eval_freq = eval_env, n_eval_episodes, max(int(eval_freq), 1)
         self.log_path = os.path.join(log_path, "evaluations") if log_path else None
         self.best_model_save_path, self.deterministic = best_model_save_path, deterministic
@@ -245,18 +302,67 @@ class EvalCallback:
         self.last_scalars: Dict[str, float] = {}
         self._next_eval_calls = self.eval_freq
         self.n_evals = 0
+        self.overlap = overlap
+        self._pending = None              # (job, num_timesteps at launch, checkpoint snapshot or None)
+        self._policy_copy = None
+        self._seed0, self._n_launched = None, 0
+
+    def _can_overlap(self, ppo) -> bool:
+        if not self.overlap:
+            return False
+        venv = self.eval_env.venv
+        return (self.deterministic and ppo.world_size == 1 and torch.device(self.eval_env.device).type == "cuda"
+                and hasattr(venv, "step_tensor") and hasattr(venv, "cfg"))
 
     def on_rollout_end(self, ppo) -> bool:
+        if self._pending is not None and self._pending[0].ready():
+            self._finish(ppo)
         n_calls = ppo.num_timesteps // max(ppo.env.num_envs * ppo.world_size, 1)      # vec-steps so far (SB3 n_calls)
         if n_calls < self._next_eval_calls:
             return True
         while self._next_eval_calls <= n_calls:
             self._next_eval_calls += self.eval_freq
         from . import checkpoint
+        if self._pending is not None:
+            self._finish(ppo)                                    # one evaluation at a time: its env and weight copy are reused
         sync_envs_normalization(ppo.env, self.eval_env)
-        r = evaluate_policy(ppo.policy, self.eval_env, self.n_eval_episodes, deterministic=self.deterministic)
+        # the k-th evaluation draws its scenarios from (seed of the eval env + k): its episodes then do not depend on how many
+        # steps the earlier evaluations happened to run past their last episode (the overlapped form runs every env for the
+        # longest possible episodes), and two runs of the same training evaluate on the same scenarios
+        venv = self.eval_env.venv
+        if hasattr(venv, "seed") and hasattr(venv, "seed_value"):
+            if self._seed0 is None:
+                self._seed0 = int(venv.seed_value)
+            venv.seed(self._seed0 + self._n_launched)
+        self._n_launched += 1
+        writer = ppo.rank == 0
+        snap = checkpoint.snapshot(ppo, include_env_state=False) if (self.best_model_save_path is not None and writer) else None
+        if self._can_overlap(ppo):
+            import copy
+            if self._policy_copy is None:
+                self._policy_copy = copy.deepcopy(ppo.policy)
+            else:
+                self._policy_copy.load_state_dict(ppo.policy.state_dict())
+            job = start_evaluation(self._policy_copy, self.eval_env, self.n_eval_episodes)
+            self._pending = (job, ppo.num_timesteps, snap)
+        else:
+            r = evaluate_policy(ppo.policy, self.eval_env, self.n_eval_episodes, deterministic=self.deterministic)
+            self._record(ppo, r, ppo.num_timesteps, snap)
+        return True
+
+    def on_training_end(self, ppo) -> None:
+        if self._pending is not None:
+            self._finish(ppo)
+
+    def _finish(self, ppo) -> None:
+        job, timesteps, snap = self._pending
+        self._pending = None
+        self._record(ppo, job.result(), timesteps, snap)
+
+    def _record(self, ppo, r: EvalResult, timesteps: int, snap) -> None:
+        from . import checkpoint
         self.n_evals += 1
-        self.evaluations_timesteps.append(ppo.num_timesteps)
+        self.evaluations_timesteps.append(timesteps)
         self.evaluations_results.append(r.episode_rewards); self.evaluations_length.append(r.episode_lengths)
         writer = ppo.rank == 0               # multi-process job: every rank evaluates (identical weights), ONE rank writes files
         if ppo.world_size > 1:               # ... and every rank keeps rank 0's figure, so best_mean_reward agrees everywhere
@@ -275,12 +381,11 @@ class EvalCallback:
         self.last_mean_reward = mean_reward
         is_objlock = getattr(getattr(self.eval_env.venv, "cfg", None), "task", 0) != K.FW_TASK_WAYPOINTS
         self.last_scalars = r.scalars(self.num_targets_total, has_duck=is_objlock)
-        self.last_scalars["time/total_timesteps"] = ppo.num_timesteps
+        self.last_scalars["time/total_timesteps"] = timesteps
         if self.verbose and writer:
-            print(f"Eval num_timesteps={ppo.num_timesteps}, episode_reward={r.mean_reward:.2f} +/- {r.std_reward:.2f}")
+            print(f"Eval num_timesteps={timesteps}, episode_reward={r.mean_reward:.2f} +/- {r.std_reward:.2f}")
             print(f"Episode length: {r.mean_ep_length:.2f} +/- {r.std_ep_length:.2f}")
         if mean_reward > self.best_mean_reward:
             self.best_mean_reward = mean_reward
-            if self.best_model_save_path is not None and writer:
-                checkpoint.save(os.path.join(self.best_model_save_path, "best_model.pt"), ppo, include_env_state=False)
-        return True
+            if snap is not None:
+                checkpoint.write(snap, os.path.join(self.best_model_save_path, "best_model.pt"))

@@ -872,6 +872,9 @@ class PPO:
             self.train()
             for cb in callbacks:
                 go = bool(cb.on_rollout_end(self)) and go
+        for cb in callbacks:                               # (an evaluation that runs beside the training is collected here)
+            if hasattr(cb, "on_training_end"):
+                cb.on_training_end(self)
         return self
 
     # ---- checkpoint (model + normaliser), train/train_Fixedwing_Waypoints_v3.py:340-347 ----------

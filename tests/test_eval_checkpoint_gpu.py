@@ -124,3 +124,28 @@ def test_train_script_flow_eval_best_model_checkpoints_and_final_save(tmp_path):
     checkpoint.load_vecnormalize(vn, b.env, training=True, norm_reward=True)
     b.learn(8 * 256)                                                              # fresh counter, pretrained weights
     assert b.num_timesteps == 8 * 256 and all(torch.isfinite(p).all() for p in b.policy.parameters())
+
+
+def test_overlapped_evaluation_reports_what_the_synchronous_one_does(tmp_path):
+    """EvalCallback's default on one GPU launches the evaluation on a side stream (copy of the weights, normaliser statistics,
+    every replay enqueued up front) and lets the training go on; the figures it logs -- and the best_model it writes from the
+    snapshot taken at launch -- are those of the callback that evaluates on the spot, for the same training run."""
+    runs = []
+    for overlap in (False, True):
+        a = _ppo(5, True)
+        eval_env = R.VecNormalizeDevice(P.FixedwingVecEnv(_wp_cfg(), 16, seed=5, global_env_offset=256), training=False, norm_reward=False)
+        d = tmp_path / ("ov" if overlap else "sync")
+        ev = evaluate.EvalCallback(eval_env, n_eval_episodes=20, eval_freq=16, log_path=str(d / "logs"),
+                                   best_model_save_path=str(d / "models"), num_targets_total=8, overlap=overlap)
+        a.learn(6 * 8 * 256, callbacks=[ev])
+        assert ev.n_evals == 3 and ev._pending is None
+        best = torch.load(os.path.join(str(d / "models"), "best_model.pt"), map_location="cpu", weights_only=True)
+        runs.append((ev, best, [p.detach().cpu().clone() for p in a.policy.parameters()]))
+    (e0, b0, p0), (e1, b1, p1) = runs
+    assert e0.evaluations_timesteps == e1.evaluations_timesteps == [2 * 8 * 256, 4 * 8 * 256, 6 * 8 * 256]
+    assert e0.evaluations_results == e1.evaluations_results and e0.evaluations_length == e1.evaluations_length
+    assert e0.best_mean_reward == e1.best_mean_reward and b0["num_timesteps"] == b1["num_timesteps"]
+    for k in b0["policy"]:
+        assert torch.equal(b0["policy"][k], b1["policy"][k]), k
+    for x, y in zip(p0, p1):                                                          # and the training itself did not notice
+        assert torch.equal(x, y)
