@@ -16,6 +16,14 @@ reference's).  A "step" is one fw_step launch over the rank's 4096 envs; envs
 shard across ranks with NO data-path collective (weak scaling, each rank keys
 its RNG on the global env id).
 
+`--gpus N` is honoured whichever way the script is started: under torch.distributed.run (WORLD_SIZE set) it must equal the
+world size (anything else exits non-zero -- a `--gpus 8` request never prints `"n_gpus": 1`); started bare with N > 1 it
+launches its own N rank processes BEFORE this process makes any GPU call and forwards rank 0's line.
+
+Timing: W warm-up steps, then `--repeats` (default 30) timed regions of EXACTLY K steps each, every region bracketed by a
+barrier + torch.cuda.synchronize() on both sides and max-reduced over ranks; `ms_per_step` / `value` are the MEDIAN region
+(a single sub-millisecond sample is fragile), `steps` stays K, `repeats` and the spread are reported beside it.
+
 One JSON line on rank 0.  `roofline` prices the step kernel against HBM:
 algorithmic bytes per env-step = 94 words (40 read + 54
 written) x 8 B = 752 B (376 B in fp32); `achieved` = bytes per launch / mean launch
@@ -69,6 +77,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--repeats", type=int, default=30, help="timed regions of --steps launches each; the median is reported")
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
@@ -136,16 +145,17 @@ class Stepper:
         return f"hipGraph({self.graph_len} launches) x{counts['replays']} replays + {counts['eager']} eager"
 
 
-def cpu_baseline(cfg, n, seconds_target=20.0):
-    """the C restatement of the env step (the PyBullet reference cannot run here) on the host cores
-    of the GPU box, OpenMP over envs, same N / scenarios / action pool as the GPU run; 5 repeats, median.  Bounded to
-    about `seconds_target` seconds of CPU work (the protocol's 2 000 timed vec-steps per repeat is the upper limit)."""
+def cpu_baseline(cfg, n, seconds_target=24.0):
+    """the C restatement of the env step (the PyBullet reference cannot run here) on ALL host cores of
+    the GPU box (threads = the process's CPU affinity), OpenMP over envs, same N / scenarios / action pool as the GPU run;
+    5 repeats, median.  Also timed: the 16-thread share gpurun documents for a one-GPU job (`share16_value`) and one thread
+    (`single_thread_value`, the shape of one reference worker).  Bounded to about `seconds_target` seconds of CPU work (the
+    protocol's 2 000 timed vec-steps per repeat is the upper limit)."""
     from oracle import fw_oracle as O          # checker code used as the reported CPU baseline only
     # (-O3 -march=native build of the same C, made by main() before the GPU was touched; the strict build stays the checker)
-    # the GPU box gives one GPU a 16-CPU share even though it reports every host core
     nproc = os.cpu_count() or 1
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else nproc
-    cores = O.set_threads(max(1, min(avail, int(os.environ.get("FW_BENCH_THREADS", "16")))), fast=True)
+    want = int(os.environ.get("FW_BENCH_THREADS", "0")) or avail
     env = O.OracleEnv(cfg, n, seed=42, fast=True)
     env.reset()
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -159,32 +169,98 @@ def cpu_baseline(cfg, n, seconds_target=20.0):
             env.step_timed_only(acts[(k0 + k) % POOL], obs, rew, te, tr, info); k += 1
         return n * k / (time.perf_counter() - t0), k
 
-    timed(1.0, 100, 0)                                           # warm-up
-    reps = [timed(seconds_target * 0.75 / 5, 2000, 100 + 2000 * r) for r in range(5)]
-    multi = float(np.median([v for v, _ in reps]))
-    O.set_threads(1, fast=True)
-    singles = [timed(seconds_target * 0.25 / 5, 400, 7 * r) for r in range(5)]
-    single = float(np.median([v for v, _ in singles]))
+    def at_threads(threads, share, max_steps):
+        got = O.set_threads(max(1, threads), fast=True)
+        timed(0.5, 50, 0)                                          # warm-up (thread team start, caches)
+        reps = [timed(seconds_target * share / 5, max_steps, 100 + 2000 * r) for r in range(5)]
+        return got, float(np.median([v for v, _ in reps])), reps
+
+    cores, multi, reps = at_threads(want, 0.45, 2000)
+    share = None
+    if cores != 16 and avail >= 16:
+        _, share, _ = at_threads(16, 0.3, 2000)
+    _, single, _ = at_threads(1, 0.2, 400)
     O.set_threads(cores, fast=True)
+    quota = None
+    try:                                                             # cgroup v2 CPU quota of the job, if the box sets one
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q = f.read().split()
+        quota = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except Exception:
+        pass
     return {"value": multi, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"median of 5 repeats x {reps[0][1]} vec-steps x {n} envs, same config / scenarios / action pool, OpenMP over envs; "
+            "sample": f"median of 5 repeats x {reps[0][1]} vec-steps x {n} envs, same config / scenarios / action pool, OpenMP over envs "
+                      f"on all {cores} host cores of the process's affinity mask (BASELINE.md section 3); "
                       f"C restatement built -O3 -march=native (not PyBullet: PyFlyt/pybullet are not installable here)",
-            "single_thread_value": single, "nproc": nproc, "affinity": avail, "cpu_model": O._cpu_model(),
-            "repeats": [v for v, _ in reps]}
+            "share16_value": share if share is not None else (multi if cores == 16 else None),
+            "single_thread_value": single, "nproc": nproc, "affinity": avail, "cgroup_cpu_quota": quota,
+            "cpu_model": O._cpu_model(), "repeats": [v for v, _ in reps]}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started bare (no WORLD_SIZE): start the N rank processes ourselves -- one per GPU, the same
+    env contract torch.distributed.run provides, rendezvous on 127.0.0.1 -- BEFORE this process has made any GPU call (it never
+    makes one: a process that has initialised the GPU must not start other programs on the GPU boxes), forward their output
+    (only rank 0 prints the JSON line) and exit with the worst return code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not os.environ.get("FW_BENCH_SINGLE_DEVICE") and not os.environ.get("FW_BENCH_DRY"):
+        have = torch.cuda.device_count()             # counting devices does not initialise the GPU on this image
+        if have < n:
+            print(json.dumps({"error": f"--gpus {n} requested but only {have} HIP device(s) are visible", "n_gpus_requested": n}), flush=True)
+            return 3
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FW_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p_ in list(pending):
+                code = p_.poll()
+                if code is None:
+                    continue
+                pending.remove(p_)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:                    # a rank died: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+    return rc
 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(self_launch(args))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # never report a different job than the one asked for (e.g. `--gpus 8` under a 1-rank launcher)
+        if rank == 0:
+            print(json.dumps({"error": f"--gpus {args.gpus} does not match WORLD_SIZE={world}: start one rank per GPU "
+                                       f"(torch.distributed.run --nproc-per-node {args.gpus}) or run `python bench.py --gpus {args.gpus}` bare",
+                              "n_gpus_requested": args.gpus, "world_size": world}), flush=True)
+        sys.exit(3)
     dist = world > 1
-    if not args.no_cpu_baseline and world == 1:
+    dry = bool(os.environ.get("FW_BENCH_DRY"))         # launcher rehearsal on a box without a GPU (tests only): no env, no timing
+    if not args.no_cpu_baseline and world == 1 and not dry:
         # the CPU-baseline library is compiled for THIS machine's cores (-march=native); do it before anything touches the
         # GPU: a process that has initialised the GPU must not start other programs (make / gcc) on the GPU boxes
         from oracle import fw_oracle as _O
         _O.build_fast()
-    if not torch.cuda.is_available():
+    if not dry and not torch.cuda.is_available():
         print(json.dumps({"error": "no HIP device: pyflyt_drone_amd has no CPU fallback"}))
         sys.exit(2)
     # Rehearsal knobs for a one-GPU box (never set by the driver): FW_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and
@@ -192,7 +268,8 @@ def main():
     if os.environ.get("FW_BENCH_SINGLE_DEVICE"):
         local_rank = 0
     backend = os.environ.get("FW_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
+    if not dry:
+        torch.cuda.set_device(local_rank)
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -200,6 +277,16 @@ def main():
             td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             td.init_process_group(backend)
+    if dry:
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if dist:
+            td.barrier(); td.all_reduce(t, op=td.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "metric": "launcher rehearsal only (FW_BENCH_DRY): nothing was measured", "value": None,
+                              "n_gpus": world, "max_rank_plus_one": float(t.item()), "steps": args.steps, "warmup": args.warmup}), flush=True)
+        if dist:
+            td.barrier(); td.destroy_process_group()
+        return
     n = args.envs_per_gpu
     task_name, task_cfg, task_words = TASKS[args.task]
     cfg = task_cfg(K, args.dtype)
@@ -215,21 +302,29 @@ def main():
         torch.cuda.synchronize()
 
     stepper.run(args.warmup)
-    barrier()
+    # `repeats` timed regions of EXACTLY `steps` launches, each between two barriers + synchronisations, max over ranks;
+    # the median region is reported.  HIP events on the launch stream bracket the same launches for the kernel's own time.
+    reps = max(1, args.repeats)
+    walls, devs = [], []
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    before = dict(stepper.counts)
-    stepper.run(args.steps)
-    timed = {k: stepper.counts[k] - before[k] for k in before}
-    ev1.record()
-    barrier()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    if dist:
-        t = torch.tensor([wall], dtype=torch.float64, device=env.device if backend == "nccl" else "cpu")
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        wall = float(t.item())
+    timed = None
+    for _ in range(reps):
+        barrier()
+        before = dict(stepper.counts)
+        t0 = time.perf_counter()
+        ev0.record()
+        stepper.run(args.steps)
+        ev1.record()
+        barrier()
+        wall = time.perf_counter() - t0
+        timed = {k: stepper.counts[k] - before[k] for k in before}
+        if dist:
+            t = torch.tensor([wall], dtype=torch.float64, device=env.device if backend == "nccl" else "cpu")
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            wall = float(t.item())
+        walls.append(wall); devs.append(ev0.elapsed_time(ev1))
+    wall = float(np.median(walls))
+    dev_ms = float(np.median(devs))
 
     # Update-time exchange of a sharded training job: ONE all-gather of the rank's rollout shard
     # (obs 28 + action 4 + log-prob + advantage + return = 35 float32 per sample, 16 steps x 4096 envs = 65 536 samples per
@@ -276,40 +371,42 @@ def main():
             for _ in range(10):
                 e2.step_tensor(a2)
             s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 50
+            sreps = 50
             s0.record()
-            for _ in range(reps):
+            for _ in range(sreps):
                 e2.step_tensor(a2)
             s1.record(); torch.cuda.synchronize()
-            us = s0.elapsed_time(s1) * 1e3 / reps
-            print(f"[sweep] N=2^{p}={m}: {us:.1f} us/launch, {m / us:.1f} M env-steps/s, "
-                  f"{WORDS_PER_ENV_STEP * word * m / us / 1e3:.1f} GB/s algorithmic", file=sys.stderr, flush=True)
+            us = s0.elapsed_time(s1) * 1e3 / sreps
+            print(f"[sweep] N=2^{p}={m}: lanes/env {e2.lanes_per_env}, {us:.1f} us/launch, {m / us:.1f} M env-steps/s, "
+                  f"{task_words * word * m / us / 1e3:.1f} GB/s algorithmic", file=sys.stderr, flush=True)
             e2.close()
 
     # HBM bytes per launch from the PMC counters are collected offline (rocprofv3 --pmc cannot run inside this process:
-    # tools/collect_profiles.sh); the committed summary is quoted when it was taken on this very workload, else null.
+    # tools/collect_profiles.sh); the newest committed summary is quoted when it was taken on this very workload, else null.
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if n == 4096 and args.dtype == "float64" and os.path.exists(pmc_path):
-        with open(pmc_path) as f:
-            tt = json.load(f).get("tasks", {}).get(args.task)
-        if tt:
-            traffic = tt["total"]
-            traffic_src = "profiles/r02_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes; gfx950 FETCH_SIZE correction x 2)"
+    for rnd in ("r03", "r02"):
+        pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+        if traffic is None and n == 4096 and args.dtype == "float64" and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                tt = json.load(f).get("tasks", {}).get(args.task)
+            if tt:
+                traffic = tt["total"]
+                traffic_src = f"profiles/{rnd}_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes; gfx950 FETCH_SIZE correction x 2)"
 
-    # The ceiling that really binds this kernel: 64-bit vector issue.  fp64 lane-instructions per env-step come from the ISA
-    # of the shipped kernel (profiles/r02_valu_count.json, made by tools/count_valu.py: instructions of the tick loop x ticks +
-    # prologue / epilogue, x lanes per env); achieved = that x env-steps per second.
+    # The ceiling that really binds this kernel: 64-bit vector issue.  Lane-instructions per env-step come from the
+    # SQ_INSTS_VALU counter of the shipped kernel (profiles/rNN_valu_count.json, made by tools/summarize_profiles.py:
+    # wave-level VALU instructions per launch x 64 lanes / envs); achieved = that x env-steps per second.
     valu = None
-    vpath = os.path.join(ROOT, "profiles", "r02_valu_count.json")
-    if os.path.exists(vpath):
-        with open(vpath) as f:
-            vc = json.load(f).get(args.task if (args.dtype == "float64" and n == 4096) else "", None)
-        if vc:
-            lane_instr = vc["lane_instructions_per_env_step"]
-            ach = lane_instr * n / launch_s / 1e12
-            valu = {"bound": "valu64", "achieved": ach, "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s", "frac": ach / VALU_PEAK_TLANE,
-                    "lane_instructions_per_env_step": lane_instr, "source": "profiles/r02_valu_count.json"}
+    for rnd in ("r03", "r02"):
+        vpath = os.path.join(ROOT, "profiles", f"{rnd}_valu_count.json")
+        if valu is None and os.path.exists(vpath):
+            with open(vpath) as f:
+                vc = json.load(f).get(args.task if (args.dtype == "float64" and n == 4096) else "", None)
+            if vc:
+                lane_instr = vc["lane_instructions_per_env_step"]
+                ach = lane_instr * n / launch_s / 1e12
+                valu = {"bound": "valu64", "achieved": ach, "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s", "frac": ach / VALU_PEAK_TLANE,
+                        "lane_instructions_per_env_step": lane_instr, "source": f"profiles/{rnd}_valu_count.json"}
     if rank == 0:
         out = {
             "metric": "env-steps/sec at N parallel envs (FixedwingWaypoints)" if args.task == "waypoints"
@@ -319,7 +416,10 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "repeats": reps,
             "ms_per_step": wall * 1e3 / args.steps,
+            "ms_per_step_min": min(walls) * 1e3 / args.steps,
+            "ms_per_step_max": max(walls) * 1e3 / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -327,14 +427,16 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{task_name}, "
                                    f"{n} envs/GPU x {world} GPU, physics-only step(), motor noise + auto-reset on",
-                       "envs_per_gpu": n, "obs_dim": env.obs_dim, "ticks_per_env_step": 8,
-                       "launch": stepper.describe(timed), "parallelism": f"env-shard x{world}"},
+                       "envs_per_gpu": n, "obs_dim": env.obs_dim, "ticks_per_env_step": 8, "lanes_per_env": env.lanes_per_env,
+                       "launch": stepper.describe(timed), "timing": f"median of {reps} regions of {args.steps} launches, each between barrier + synchronize",
+                       "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "fw_step_kernel", "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "words_per_env_step": task_words,
                          "valu": valu,
-                         "note": "element-wise fp64 physics at N=4096 is latency/VALU-bound, not HBM-bound (DESIGN.md section 6)"},
+                         "note": "HBM is the nominal roofline of this element-wise path (SURVEY.md section 8d) and stays the primary object; "
+                                 "the ceiling that BINDS is 64-bit vector issue / latency -- see `valu` (DESIGN.md section 6)"},
         }
         if allgather is not None:
             out["update_allgather"] = allgather

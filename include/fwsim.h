@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 5
+#define FW_ABI_VERSION 6
 
 #define FW_NUM_SURFACES 5         /* left aileron, right aileron, h-tail, v-tail, main wing */
 #define FW_NUM_ACTUATORS 6        /* 5 surfaces + throttle (aux_state order) */
@@ -452,6 +452,9 @@ int32_t fw_collect_stats(const void* obs, int32_t obs_is_f64, int32_t N, int32_t
                          uint64_t* rng, void* workspace, double* obs_acc, double* ret_acc, void* hip_stream);
 
 int32_t fw_num_envs(fw_handle h);
+/* Lanes of a wavefront that share one env in this handle's step kernels (8: latency mapping, 4 / 1: throughput mappings;
+ * chosen by fw_create from the env count).  Diagnostic; results do not depend on it. */
+int32_t fw_lanes_per_env(fw_handle h);
 const char* fw_last_error(fw_handle h); /* h may be NULL: last create/validate error */
 int32_t fw_destroy(fw_handle h);
 

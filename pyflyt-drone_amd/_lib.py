@@ -19,7 +19,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 EXPORTS = (
     "fw_sizeof_config", "fw_abi_version", "fw_state_dim", "fw_obs_dim", "fw_validate_config", "fw_create", "fw_reset",
-    "fw_step", "fw_seed", "fw_get_state", "fw_set_state", "fw_get_counters", "fw_observe", "fw_num_envs", "fw_last_error",
+    "fw_step", "fw_seed", "fw_get_state", "fw_set_state", "fw_get_counters", "fw_observe", "fw_num_envs", "fw_lanes_per_env", "fw_last_error",
     "fw_destroy", "fw_gae", "fw_normalize_obs", "fw_normalize_obs_workspace_bytes", "fw_ppo_update_workspace_bytes", "fw_ppo_param_count", "fw_ppo_moment_count", "fw_ppo_moment_map", "fw_ppo_update", "fw_policy_act", "fw_policy_terminal_value", "fw_rollout_post", "fw_collect_act", "fw_collect_stats", "fw_collect_stats_workspace_bytes",
 )
 
@@ -48,10 +48,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
             hits = check_isa(open(os.path.join(tmp, asm[0])).read())
             if hits:
                 os.remove(LIB_PATH)
-                raise RuntimeError("spill stores before the exec restore of a join block (tools/check_isa.py): "
+                raise RuntimeError("ISA check failed (tools/check_isa.py: spill stores before the exec restore of a join block, "
+                                   "or a last-block-done ticket that can overtake its partial sums): "
                                    + "; ".join(f"{n[:60]} {lab}" for n, lab, _ in hits[:6]))
             if verbose:
-                print("ISA check: no spill store precedes the exec restore of its block")
+                print("ISA check: no spill store precedes the exec restore of its block; ticket atomics sit behind a vmcnt(0) wait")
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
     return LIB_PATH
@@ -63,7 +64,7 @@ def check_isa(text: str):
     spec = importlib.util.spec_from_file_location("fw_check_isa", os.path.join(os.path.dirname(CSRC.rstrip(os.sep)), "..", "tools", "check_isa.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.scan(text)
+    return mod.scan(text) + mod.scan_ticket(text)
 
 
 _lib = None
@@ -92,6 +93,7 @@ def lib() -> C.CDLL:
         L.fw_set_state.restype = i32; L.fw_set_state.argtypes = [vp, vp]
         L.fw_get_counters.restype = i32; L.fw_get_counters.argtypes = [vp, vp]
         L.fw_num_envs.restype = i32; L.fw_num_envs.argtypes = [vp]
+        L.fw_lanes_per_env.restype = i32; L.fw_lanes_per_env.argtypes = [vp]
         L.fw_last_error.restype = C.c_char_p; L.fw_last_error.argtypes = [vp]
         L.fw_destroy.restype = i32; L.fw_destroy.argtypes = [vp]
         L.fw_gae.restype = i32

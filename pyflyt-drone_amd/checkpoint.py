@@ -103,6 +103,8 @@ def snapshot(ppo, include_env_state: bool = True) -> dict:
         sd["sampler_rng_state"] = ppo.gen.get_state().cpu()        # action-sampling generator: resume draws the same actions
         if getattr(ppo, "_collect_fused", False):
             sd["collect_rng"] = ppo._rng.detach().cpu()             # (seed, draw counter) of fw_policy_act
+        if getattr(ppo, "perm_gen", None) is not None and ppo.perm_gen is not ppo.gen:
+            sd["perm_rng_state"] = ppo.perm_gen.get_state().cpu()   # replicated update: the shared minibatch-permutation stream
     return sd
 
 
@@ -142,6 +144,8 @@ def load(path: str, ppo, reset_num_timesteps: bool = True, restore_env_state: bo
         ppo.env.returns.copy_(sd["env_returns"].to(ppo.env.returns.device))
         if "env_obs" in sd and hasattr(venv, "obs"):
             venv.obs.copy_(sd["env_obs"].to(venv.obs.device))
+        elif hasattr(venv, "observe_tensor"):
+            venv.observe_tensor()          # older checkpoint: recompute the raw observation of the restored state (fw_observe)
         if "last_obs" in sd:
             if ppo.last_obs is None:
                 ppo.last_obs = sd["last_obs"].to(ppo.device).clone()
@@ -154,6 +158,8 @@ def load(path: str, ppo, reset_num_timesteps: bool = True, restore_env_state: bo
             ppo.gen.set_state(sd["sampler_rng_state"])
         if "collect_rng" in sd and getattr(ppo, "_collect_fused", False):
             ppo._rng.copy_(sd["collect_rng"].to(ppo.device))
+        if "perm_rng_state" in sd and getattr(ppo, "perm_gen", None) is not None and ppo.perm_gen is not ppo.gen:
+            ppo.perm_gen.set_state(sd["perm_rng_state"])
     return sd
 
 

@@ -1198,6 +1198,14 @@ int invalidate_shadow(fw_env* h) {
   return FW_OK;
 }
 
+// every device buffer of a handle, freed once and nulled (fw_destroy and the error path of fw_create)
+void free_device_buffers(fw_env* h) {
+  void** bufs[] = { &h->params_dev, &h->objc_dev, &h->r_dev, (void**)&h->i_dev, &h->rs_dev, (void**)&h->is_dev, &h->sobs_dev,
+                    (void**)&h->sreq_dev, (void**)&h->sdone_dev, (void**)&h->lctr_dev, (void**)&h->stats_dev, (void**)&h->scen_dev,
+                    (void**)&h->prof_dev };
+  for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+}
+
 // words per env of the camera's LDS row buffer: the width padded so that the 4 envs of a half-wave start on different banks
 inline int zrow_stride_of(int res) { return ((res + 31) / 32) * 32 + 8; }
 
@@ -1294,15 +1302,22 @@ int create_T(fw_env* h) {
     rc = invalidate_shadow(h);
     if (rc != FW_OK) return rc;
   }
-  // the camera's LDS map outgrows the 64 KB a workgroup gets without asking from ~700 columns on: opt in once per handle
+  // the camera's LDS map outgrows what a workgroup gets without asking from ~700 columns on.  The attribute belongs to the
+  // (device, kernel) pair, not to the handle: keep the maximum ever asked for and only ever raise it, so a later, smaller
+  // handle cannot lower the cap under an earlier one
   if (const size_t lds = tile_bytes<T>(h); lds > 48 * 1024) {
     if (lds > 160 * 1024) { h->err = "camera_resolution x num_obstacles needs more LDS than a CU has"; return FW_EINVAL; }
-    if (h->cfg.task == FW_TASK_OBJLOCK) {
-      HIP_TRY(h, hipFuncSetAttribute((const void*)fw_step_kernel_obj_g8<T, FW_TASK_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      HIP_TRY(h, hipFuncSetAttribute((const void*)fw_reset_kernel<T, 8, FW_TASK_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    } else {
-      HIP_TRY(h, hipFuncSetAttribute((const void*)fw_step_kernel_obj_g8<T, FW_TASK_WAYPOINT_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      HIP_TRY(h, hipFuncSetAttribute((const void*)fw_reset_kernel<T, 8, FW_TASK_WAYPOINT_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int which = (h->cfg.task == FW_TASK_OBJLOCK ? 0 : 1) + (sizeof(T) == 8 ? 0 : 2);
+    static size_t have[64][4] = {};
+    if (h->device < 64 && lds > have[h->device][which]) {
+      if (h->cfg.task == FW_TASK_OBJLOCK) {
+        HIP_TRY(h, hipFuncSetAttribute((const void*)fw_step_kernel_obj_g8<T, FW_TASK_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)fw_reset_kernel<T, 8, FW_TASK_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      } else {
+        HIP_TRY(h, hipFuncSetAttribute((const void*)fw_step_kernel_obj_g8<T, FW_TASK_WAYPOINT_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)fw_reset_kernel<T, 8, FW_TASK_WAYPOINT_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      }
+      have[h->device][which] = lds;
     }
   }
   hipLaunchKernelGGL(fw_init_kernel<T>, dim3((h->npad + 255) / 256), dim3(256), 0, 0, dev_state<T>(h), kWave / h->lanes_per_env);
@@ -1462,18 +1477,7 @@ int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64
   rc = (cfg->dtype == FW_F64) ? create_T<double>(h) : create_T<float>(h);
   if (rc != FW_OK) {
     g_err = h->err;
-    if (h->params_dev) (void)hipFree(h->params_dev);
-    if (h->objc_dev) (void)hipFree(h->objc_dev);
-    if (h->r_dev) (void)hipFree(h->r_dev);
-    if (h->i_dev) (void)hipFree(h->i_dev);
-    if (h->rs_dev) (void)hipFree(h->rs_dev);
-    if (h->is_dev) (void)hipFree(h->is_dev);
-  if (h->sobs_dev) (void)hipFree(h->sobs_dev);
-    if (h->sobs_dev) (void)hipFree(h->sobs_dev);
-    if (h->sreq_dev) (void)hipFree(h->sreq_dev);
-    if (h->sdone_dev) (void)hipFree(h->sdone_dev);
-    if (h->lctr_dev) (void)hipFree(h->lctr_dev);
-    if (h->stats_dev) (void)hipFree(h->stats_dev);
+    free_device_buffers(h);
     delete h;
     return rc;
   }
@@ -1778,6 +1782,7 @@ int32_t fw_rollout_post(const void* reward, int32_t rew_is_f64, const uint8_t* t
 }
 
 int32_t fw_num_envs(fw_handle h) { return h ? h->n : FW_EINVAL; }
+int32_t fw_lanes_per_env(fw_handle h) { return h ? h->lanes_per_env : FW_EINVAL; }
 
 const char* fw_last_error(fw_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
 
@@ -1785,18 +1790,7 @@ int32_t fw_destroy(fw_handle h) {
   if (!h) return FW_EINVAL;
   DeviceGuard g(h->device);
   (void)hipDeviceSynchronize();
-  if (h->params_dev) (void)hipFree(h->params_dev);
-  if (h->objc_dev) (void)hipFree(h->objc_dev);
-  if (h->r_dev) (void)hipFree(h->r_dev);
-  if (h->i_dev) (void)hipFree(h->i_dev);
-  if (h->rs_dev) (void)hipFree(h->rs_dev);
-  if (h->is_dev) (void)hipFree(h->is_dev);
-  if (h->sreq_dev) (void)hipFree(h->sreq_dev);
-  if (h->sdone_dev) (void)hipFree(h->sdone_dev);
-  if (h->lctr_dev) (void)hipFree(h->lctr_dev);
-  if (h->stats_dev) (void)hipFree(h->stats_dev);
-  if (h->scen_dev) (void)hipFree(h->scen_dev);
-  FWP(if (h->prof_dev) (void)hipFree(h->prof_dev);)
+  free_device_buffers(h);
   delete h;
   return FW_OK;
 }

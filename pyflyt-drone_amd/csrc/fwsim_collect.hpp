@@ -416,8 +416,11 @@ __global__ __launch_bounds__(256) void fw_collect_stats_kernel(StatsArgs A) {
     for (int o = 128; o > 0; o >>= 1) { if (t < o) { sm1[t] += sm1[t + o]; sm2[t] += sm2[t + o]; } __syncthreads(); }
     if (t == 0) { st_sc1(mypart + 2 * D, sm1[0]); st_sc1(mypart + 2 * D + 1, sm2[0]); }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // every wave's write-through stores have left (s_waitcnt vmcnt(0)) ...
-  __syncthreads();                                                // ... before the block takes its ticket
+  // Every wave drains its own write-through stores (an explicit s_waitcnt: a workgroup-scope release fence is not required to
+  // wait on vmcnt and compiles to nothing here) before the barrier, and the ticket is taken behind the barrier -- so no partial
+  // can be overtaken by the ticket that announces it.  tools/check_isa.py asserts the wait is in the ISA of every build.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (t == 0) s_last = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
   __syncthreads();
   if (!s_last) return;

@@ -791,7 +791,11 @@ class PPO:
         self._loss_acc.zero_()          # persistent buffer: the captured update graph holds its address
         nb = 0
         bs = cfg.batch_size
-        if B % bs == 0 and FusedPpoUpdate.applies(self.policy, cfg, self.env.obs_dim, bs, self.device):
+        # the fused kernel walks whole minibatches of the buffer it is handed and has no gradient exchange: a multi-process job
+        # may only take it on the gathered buffer ("replicated"); dist_update="allreduce" stays on the torch path below, whose
+        # minibatch loop all-reduces the gradients (allreduce_grads_)
+        fused_ok = _dist() is None or self._replicated
+        if fused_ok and B % bs == 0 and FusedPpoUpdate.applies(self.policy, cfg, self.env.obs_dim, bs, self.device):
             # the whole minibatch sequence in one kernel; the permutations are drawn exactly like the loop below
             if self._fused is None:
                 self._fused = FusedPpoUpdate(self.policy, self.optimizer, self.env.obs_dim)

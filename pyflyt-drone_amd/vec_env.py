@@ -124,6 +124,7 @@ class FixedwingVecEnv(_VecEnvBase):
                                   int(global_env_offset), C.byref(h))
         _lib.check(rc, None)
         self._h = h
+        self.lanes_per_env = int(_lib.lib().fw_lanes_per_env(h))    # which lane mapping fw_create picked (diagnostic)
         n, d = self.num_envs, self.obs_dim
         kw = dict(device=dev)
         self.obs = torch.zeros((n, d), dtype=self.torch_dtype, **kw)
@@ -177,7 +178,14 @@ class FixedwingVecEnv(_VecEnvBase):
     def reset(self) -> np.ndarray:
         obs = self.reset_tensor()
         self.reset_infos = [{} for _ in range(self.num_envs)]
-        return obs.cpu().numpy()
+        return self._np_obs(obs)
+
+    def _np_obs(self, t: torch.Tensor) -> np.ndarray:
+        """Host copy of an observation tensor in the dtype `observation_space` declares (ObjLock: the reference's flattened
+        observation is float32, envs/flatten_objlock_env.py:29-31,46; the values are already float32-rounded on the device)."""
+        a = t.cpu().numpy()
+        want = self.observation_space.dtype
+        return a if a.dtype == want else a.astype(want)
 
     def step_async(self, actions: np.ndarray) -> None:
         a = torch.as_tensor(np.asarray(actions), dtype=self.torch_dtype).reshape(self.num_envs, 4)
@@ -189,14 +197,14 @@ class FixedwingVecEnv(_VecEnvBase):
         if not self._pending:
             raise RuntimeError("step_wait() called without step_async()")
         self._pending = False
-        obs = self.obs.cpu().numpy()
+        obs = self._np_obs(self.obs)
         rewards = self.rewards.cpu().numpy()
         term = self.terminated.cpu().numpy().astype(bool)
         trunc = self.truncated.cpu().numpy().astype(bool)
         info = self.info.cpu().numpy()
         dones = term | trunc
         infos: List[dict] = []
-        tobs = self.terminal_obs.cpu().numpy() if dones.any() else None
+        tobs = self._np_obs(self.terminal_obs) if dones.any() else None
         for i in range(self.num_envs):
             d = {
                 "out_of_bounds": bool(info[i, K.INFO_OUT_OF_BOUNDS]),

@@ -29,12 +29,14 @@ def pytest_sessionstart(session):
     _MP["res"] = ctx.Queue()
     _MP["jobs"] = [ctx.Queue() for _ in range(2)]
     _MP["procs"] = [ctx.Process(target=mp_jobs.serve, args=(r, 2, _MP["jobs"][r], _MP["res"]), daemon=True) for r in range(2)]
+    _MP["launch_q"], _MP["launch_res"] = ctx.Queue(), ctx.Queue()
+    _MP["procs"].append(ctx.Process(target=mp_jobs.launch_serve, args=(_MP["launch_q"], _MP["launch_res"]), daemon=True))
     for p in _MP["procs"]:
         p.start()
 
 
 def pytest_sessionfinish(session, exitstatus):
-    for q in _MP.get("jobs", []):
+    for q in _MP.get("jobs", []) + ([_MP["launch_q"]] if "launch_q" in _MP else []):
         q.put(None)
     for p in _MP.get("procs", []):
         p.join(timeout=20)
@@ -55,6 +57,21 @@ def two_ranks():
         for rank, status, out in res:
             assert status == "ok", f"rank {rank} failed:\n{out}"
         return [out for _, _, out in res]
+    return run
+
+
+@pytest.fixture
+def launcher():
+    """run(argv, env={}, timeout=600) -> (returncode, stdout, stderr) of a program started by a helper process that never
+    touches the GPU (the pytest process has initialised it and must not start programs itself on the GPU boxes)."""
+    if "launch_q" not in _MP:
+        pytest.skip("the launcher helper is only started for -m gpu sessions")
+
+    def run(argv, env=None, timeout=600):
+        _MP["launch_q"].put((list(argv), dict(env or {}), timeout))
+        status, out = _MP["launch_res"].get(timeout=timeout + 60)
+        assert status == "ok", out
+        return out
     return run
 
 

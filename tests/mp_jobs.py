@@ -25,7 +25,25 @@ def serve(rank, world, job_q, res_q):
             res_q.put((rank, "error", traceback.format_exc()))
 
 
-def sharded_training(rank, world, task, n_envs, n_steps, batch_size, n_epochs, iterations):
+def launch_serve(job_q, res_q):
+    """Third helper: never touches the GPU itself, so it may start other programs for the whole session (e.g. `bench.py
+    --gpus 2`, which launches its own ranks).  Jobs are (argv, extra env, timeout); results (returncode, stdout, stderr)."""
+    import subprocess
+    while True:
+        job = job_q.get()
+        if job is None:
+            return
+        argv, env, timeout = job
+        try:
+            e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+            e.update(env)
+            p = subprocess.run(argv, env=e, capture_output=True, text=True, timeout=timeout)
+            res_q.put(("ok", (p.returncode, p.stdout, p.stderr)))
+        except BaseException:
+            res_q.put(("error", traceback.format_exc()))
+
+
+def sharded_training(rank, world, task, n_envs, n_steps, batch_size, n_epochs, iterations, dist_update="replicated"):
     """One rank of a sharded training job: env shard at global_env_offset = rank * n_envs, fused collector (hipGraph),
     rollout all-gather, fused replicated update."""
     import numpy as np
@@ -37,7 +55,7 @@ def sharded_training(rank, world, task, n_envs, n_steps, batch_size, n_epochs, i
     cfg = {"waypoints": K.train_waypoints_v3_config, "combined": K.train_waypoint_objlock_config}[task]()
     venv = P.FixedwingVecEnv(cfg, n_envs, device=0, seed=42, global_env_offset=rank * n_envs)
     env = R.VecNormalizeDevice(venv)
-    ppo = R.PPO(env, R.PPOConfig(n_steps=n_steps, batch_size=batch_size, n_epochs=n_epochs, seed=42))
+    ppo = R.PPO(env, R.PPOConfig(n_steps=n_steps, batch_size=batch_size, n_epochs=n_epochs, seed=42, dist_update=dist_update))
     facts = dict(fused_collect=bool(ppo._collect_fused), graphs=bool(ppo._graphs), replicated=bool(ppo._replicated),
                  stats_sync=env.stats_sync, use_fused_norm=bool(env.use_fused))
     first_obs = None

@@ -1,0 +1,55 @@
+"""bench.py's launch contract, checked without a GPU: `--gpus N` is honoured whichever way the script
+is started.  FW_BENCH_DRY=1 is the launcher-rehearsal switch: ranks rendezvous, barrier and max-reduce over gloo, nothing is
+measured and the line says so (`"dry_run": true, "value": null`); the measuring path itself needs the HIP device and is covered
+by the -m gpu tests."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=300)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, [json.loads(l) for l in lines], p.stderr
+
+
+def test_bare_gpus_2_self_launches_two_ranks_and_rank_0_prints_one_line():
+    rc, lines, err = _run(["--gpus", "2", "--steps", "20", "--warmup", "5"], FW_BENCH_DRY="1", FW_BENCH_BACKEND="gloo", FW_BENCH_SINGLE_DEVICE="1")
+    assert rc == 0, err
+    assert len(lines) == 1, lines                         # ONE JSON line, from rank 0
+    assert lines[0]["n_gpus"] == 2 and lines[0]["max_rank_plus_one"] == 2.0 and lines[0]["dry_run"] is True
+    assert lines[0]["steps"] == 20 and lines[0]["warmup"] == 5
+
+
+def test_gpus_that_disagrees_with_the_world_size_exits_non_zero():
+    """`--gpus 8` under a launcher that started one rank must never print `"n_gpus": 1`."""
+    rc, lines, _ = _run(["--gpus", "8"], WORLD_SIZE="1", RANK="0", FW_BENCH_DRY="1")
+    assert rc != 0 and len(lines) == 1 and "error" in lines[0] and "n_gpus" not in lines[0]
+    assert lines[0]["n_gpus_requested"] == 8 and lines[0]["world_size"] == 1
+
+
+def test_more_gpus_than_devices_is_refused_before_anything_is_launched():
+    rc, lines, _ = _run(["--gpus", "2"])                 # no GPU in this container: 0 devices visible
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two devices are visible here")
+    assert rc != 0 and "error" in lines[0] and "n_gpus" not in lines[0]
+
+
+def test_under_a_launcher_the_ranks_agree_with_gpus():
+    """The driver's form: torch.distributed.run provides WORLD_SIZE / RANK; --gpus equals the world size."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    e = dict(os.environ, FW_BENCH_DRY="1", FW_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "1"],
+                       env=e, capture_output=True, text=True, timeout=300)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0, p.stderr
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 7

@@ -1,0 +1,46 @@
+"""bench.py end to end on the GPU box: the one JSON line the driver parses, at N = 1 and -- as a rehearsal of the multi-GPU
+launch on the one GPU there is -- `python bench.py --gpus 2` started bare, which launches its own two ranks (both on cuda:0,
+barrier / max-reduce over gloo because RCCL refuses two ranks on one device)."""
+import json
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(out):
+    lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return lines[0]
+
+
+def test_bench_line_n1_carries_the_contract_fields(launcher):
+    rc, out, err = launcher([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--repeats", "30", "--no-cpu-baseline"])
+    assert rc == 0, err
+    b = _line(out)
+    assert b["n_gpus"] == 1 and b["steps"] == 20 and b["warmup"] == 5 and b["repeats"] == 30
+    assert b["unit"] == "env-steps/s" and b["dtype"] == "f64" and b["scaling"] == "weak" and b["vs_baseline"] is None
+    assert b["ms_per_step_min"] <= b["ms_per_step"] <= b["ms_per_step_max"]
+    assert b["value"] == pytest.approx(4096 * 1e3 / b["ms_per_step"], rel=1e-9)
+    r = b["roofline"]
+    assert r["bound"] == "hbm" and r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and r["algorithmic_bytes_per_launch"] == 94 * 8 * 4096
+    assert b["value"] > 1e6                                  # BASELINE.json's target
+
+
+def test_bare_gpus_2_launches_its_own_ranks_on_the_gpu(launcher):
+    rc, out, err = launcher([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "10"],
+                            env={"FW_BENCH_BACKEND": "gloo", "FW_BENCH_SINGLE_DEVICE": "1"})
+    assert rc == 0, err
+    b = _line(out)
+    assert b["n_gpus"] == 2 and "cpu_baseline" not in b and b["config"]["parallelism"] == "env-shard x2"
+    assert b["value"] == pytest.approx(2 * 4096 * 1e3 / b["ms_per_step"], rel=1e-9)
+    assert "update_allgather" in b and b["update_allgather"].get("samples_per_rank") == 16 * 4096
+
+
+def test_gpus_mismatch_is_an_error_not_a_one_gpu_line(launcher):
+    rc, out, _ = launcher([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env={"WORLD_SIZE": "1", "RANK": "0"})
+    b = _line(out)
+    assert rc != 0 and "error" in b and "n_gpus" not in b

@@ -255,3 +255,26 @@ _Z4kernv:
     staged = bad.replace("\tv_accvgpr_write_b32 a16, v208\n", "\tv_accvgpr_write_b32 a16, v208\n\tglobal_store_dwordx4 v[82:83], a[16:19], off offset:48\n")
     assert [h[1] for h in m.scan(bad)] == [".LBB0_2"]
     assert m.scan(good) == [] and m.scan(mfma) == [] and m.scan(staged) == []
+
+
+def test_isa_check_wants_a_vmcnt_wait_between_the_partial_stores_and_the_ticket():
+    """tools/check_isa.py, second guard: in a last-block-done kernel the write-through stores of the partial sums must be
+    drained (`s_waitcnt vmcnt(0)`) before the workgroup barrier behind which the ticket atomic is taken -- otherwise the
+    ticket can overtake the partials and the last block folds stale words."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "check_isa.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    good = """
+_Z23fw_collect_stats_kernelIdEvN5fwsim9StatsArgsE:
+\tglobal_store_dwordx2 v[0:1], v[2:3], off sc1
+\ts_waitcnt vmcnt(0)
+\ts_barrier
+\tglobal_atomic_add v4, v5, v6, s[0:1] sc0
+\ts_endpgm
+.Lfunc_end0:
+"""
+    bad = good.replace("\ts_waitcnt vmcnt(0)\n", "")
+    other = bad.replace("fw_collect_stats_kernel", "fw_something_else_kernel")
+    assert m.scan_ticket(good) == []
+    assert [h[1] for h in m.scan_ticket(bad)] == ["ticket"]
+    assert m.scan_ticket(other) == []

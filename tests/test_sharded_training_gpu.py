@@ -24,3 +24,16 @@ def test_per_gpu_share_collect_and_replicated_fused_update(two_ranks, task, n_en
     assert np.array_equal(a["weights"], b["weights"]) and np.array_equal(a["stats"], b["stats"])
     assert a["stats"][2 * 28] == pytest.approx(1e-4 + (3 * n_steps + 1) * n_envs * 2)          # observations of BOTH ranks counted
     assert not np.array_equal(a["first_obs"], b["first_obs"]), "the ranks must simulate different env shards"
+
+
+def test_allreduce_mode_keeps_the_replicas_identical_on_the_gpu(two_ranks):
+    """with PPOConfig.dist_update = "allreduce" every rank trains on its LOCAL shard and the gradients are
+    all-reduced per minibatch -- that exchange only exists on the torch path, so the fused fw_ppo_update (which has none) must
+    not be taken there even though its shape conditions hold.  Replicas stay bit-identical."""
+    a, b = two_ranks("sharded_training", task="waypoints", n_envs=512, n_steps=4, batch_size=128, n_epochs=2, iterations=2,
+                     dist_update="allreduce")
+    for r in (a, b):
+        assert not r["facts"]["replicated"] and not r["facts"]["fused_update"], r["facts"]
+        assert r["checks"] == [0.0, 0.0], "replicas diverged"
+        assert r["finite"]
+    assert np.array_equal(a["weights"], b["weights"])

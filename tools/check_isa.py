@@ -48,8 +48,41 @@ def scan(text):
     return hits
 
 
+def scan_ticket(text, kernels=("fw_collect_stats_kernel",)):
+    """Second guard: in the last-block-done kernels the ticket atomic must not be able to overtake the partial sums
+    it announces.  The stores are write-through (sc1) and every wave drains them with an explicit `s_waitcnt vmcnt(0)` before
+    the workgroup barrier behind which the ticket is taken.  Assert that shape in the ISA: walking up from the first
+    `global_atomic_add` of the kernel there is an `s_barrier`, and walking up from that barrier a `vmcnt(0)` wait comes
+    before any global store."""
+    hits = []
+    for fn in re.split(r"\n(?=_Z[\w]+:\s)", text):
+        name = fn.split(":", 1)[0]
+        if not name.startswith("_Z") or not any(k in name for k in kernels):
+            continue
+        lines = [l.strip() for l in fn.split("\n") if l.strip() and not re.match(r"\s*(\.loc|\.Ltmp|\.cfi|;|\.p2align)", l)]
+        tick = next((i for i, l in enumerate(lines) if re.match(r"global_atomic_(add|inc)", l)), None)
+        if tick is None:
+            hits.append((name, "ticket", ["no ticket atomic found"]))
+            continue
+        bar = next((i for i in range(tick, -1, -1) if lines[i].startswith("s_barrier")), None)
+        if bar is None:
+            hits.append((name, "ticket", ["no s_barrier ahead of the ticket atomic"]))
+            continue
+        ok = False
+        for i in range(bar - 1, -1, -1):
+            if re.match(r"s_waitcnt\b.*vmcnt\(0\)", lines[i]):
+                ok = True
+                break
+            if re.match(r"(global_store|global_atomic|buffer_store|flat_store)", lines[i]):
+                break
+        if not ok:
+            hits.append((name, "ticket", ["a global store reaches the ticket barrier without s_waitcnt vmcnt(0)"]))
+    return hits
+
+
 if __name__ == "__main__":
-    h = scan(open(sys.argv[1]).read())
+    text = open(sys.argv[1]).read()
+    h = scan(text) + scan_ticket(text)
     for name, label, spills in h:
         print(f"{name[:80]} {label}: spill stores before the exec restore: {spills[:6]}")
     print(f"{len(h)} suspicious block(s)")
