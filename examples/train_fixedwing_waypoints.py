@@ -36,13 +36,16 @@ def main():
     model_dir, log_dir = os.path.join(a.out, "models"), os.path.join(a.out, "logs")
     os.makedirs(model_dir, exist_ok=True); os.makedirs(log_dir, exist_ok=True)
 
-    env = R.VecNormalizeDevice(P.FixedwingWaypointsVecEnv(num_envs=a.num_envs, seed=cfg["seed"], **ENV_KW))
-    eval_env = R.VecNormalizeDevice(P.FixedwingWaypointsVecEnv(num_envs=16, seed=cfg["seed"], global_env_offset=a.num_envs, **ENV_KW),
+    world, rank, local = R.init_distributed_from_env()          # torchrun: one process per GPU (RCCL); (1, 0, 0) otherwise
+    dev = local if world > 1 else None
+    # rank r simulates global envs [r * num_envs, (r + 1) * num_envs): scenario / noise / sampling streams are keyed on the global id
+    env = R.VecNormalizeDevice(P.FixedwingWaypointsVecEnv(num_envs=a.num_envs, seed=cfg["seed"], device=dev, global_env_offset=rank * a.num_envs, **ENV_KW))
+    eval_env = R.VecNormalizeDevice(P.FixedwingWaypointsVecEnv(num_envs=16, seed=cfg["seed"], device=dev, global_env_offset=world * a.num_envs, **ENV_KW),
                                     training=False, norm_reward=False)
     vecnorm = checkpoint.infer_vecnorm_path(a.pretrained_model, a.vecnorm_path, model_dir)
     if vecnorm:
         checkpoint.load_vecnormalize(vecnorm, env, training=True, norm_reward=True)
-    n_steps = max(cfg["samples_per_update"] // a.num_envs, 1)
+    n_steps = R.n_steps_for(cfg["samples_per_update"], a.num_envs, world)      # holds the samples per update: n_steps ~ 1 / (envs x world)
     model = R.PPO(env, R.PPOConfig(n_steps=n_steps, batch_size=cfg["batch_size"], n_epochs=cfg["n_epochs"],
                                    learning_rate=cfg["learning_rate"], gamma=cfg["gamma"], gae_lambda=cfg["gae_lambda"],
                                    clip_range=cfg["clip_range"], ent_coef=cfg["ent_coef"], vf_coef=cfg["vf_coef"],
@@ -56,7 +59,7 @@ def main():
     class Progress:
         t0, last = time.perf_counter(), 0
         def on_rollout_end(self, ppo):
-            if ppo.num_timesteps - self.last >= 20 * n_steps * a.num_envs:
+            if ppo.num_timesteps - self.last >= 20 * n_steps * a.num_envs * world:
                 dt = time.perf_counter() - self.t0
                 print(json.dumps({"timesteps": ppo.num_timesteps, "fps": round(ppo.num_timesteps / dt), **{k: round(v, 5) for k, v in ppo.logs.items()},
                                   **{k: round(float(v), 4) for k, v in ev.last_scalars.items()}}), flush=True)

@@ -6,6 +6,15 @@ reference's FlattenWaypointEnv).  Same PPO hyper-parameters (batch 128, 20 epoch
 become num_envs x (32 768 / num_envs).  The eval callback reports wp{i}_reach_rate, success_rate and duck_strike_rate.
 
     python examples/train_fixedwing_waypoints_objlock.py --total_timesteps 5000000 --num_envs 4096 --out runs/combined
+
+`--detector cnn` (BASELINE.json configs[4]: "PPO with CNN detector head on PyTorch-ROCm") puts a small conv net in front of the
+policy: every agent step the env's FPV image (duck mask + depth buffer of the analytic scene, `fw_render`, `--image_res` pixels
+square) is rendered on the device and its CNN features are concatenated to the 28 observation values.  The reference trains
+`MlpPolicy` only (:349; its CNN is the FastSAM eval path, envs/fixedwing_envs/objlock_yolo_env.py:646-716), so this variant
+and its minibatch size (`--batch_size`, default 1024 with the CNN: a conv net per 128-sample minibatch is launch-bound) are
+build-side.  In a multi-process job (`torchrun`, one process per GPU) the MLP variant all-gathers the rollout shards and
+replicates the update, so `n_steps` is divided by the world size to hold the samples per update; the CNN variant keeps
+local minibatches and all-reduces gradients.
 """
 import argparse
 import json
@@ -39,19 +48,26 @@ def main():
     ap.add_argument("--total_timesteps", type=int, default=None)
     ap.add_argument("--num_envs", type=int, default=4096)
     ap.add_argument("--out", type=str, default="runs/obj_strick_ppo")
+    ap.add_argument("--detector", type=str, default="none", choices=["none", "cnn"])
+    ap.add_argument("--image_res", type=int, default=32)
+    ap.add_argument("--batch_size", type=int, default=None)
     a = ap.parse_args()
     cfg = TRAIN_CONFIG
     model_dir, log_dir = os.path.join(a.out, "models"), os.path.join(a.out, "logs")
     os.makedirs(model_dir, exist_ok=True); os.makedirs(log_dir, exist_ok=True)
 
-    env = R.VecNormalizeDevice(P.FixedwingWaypointObjLockVecEnv(num_envs=a.num_envs, seed=cfg["seed"], **ENV_KW))
-    eval_env = R.VecNormalizeDevice(P.FixedwingWaypointObjLockVecEnv(num_envs=16, seed=cfg["seed"], global_env_offset=a.num_envs, **ENV_KW),
+    world, rank, local = R.init_distributed_from_env()          # torchrun: one process per GPU (RCCL); (1, 0, 0) otherwise
+    dev = local if world > 1 else None
+    # rank r simulates global envs [r * num_envs, (r + 1) * num_envs): scenario / noise / sampling streams are keyed on the global id
+    env = R.VecNormalizeDevice(P.FixedwingWaypointObjLockVecEnv(num_envs=a.num_envs, seed=cfg["seed"], device=dev, global_env_offset=rank * a.num_envs, **ENV_KW))
+    eval_env = R.VecNormalizeDevice(P.FixedwingWaypointObjLockVecEnv(num_envs=16, seed=cfg["seed"], device=dev, global_env_offset=world * a.num_envs, **ENV_KW),
                                     training=False, norm_reward=False)
     vecnorm = checkpoint.infer_vecnorm_path(a.pretrained_model, a.vecnorm_path, model_dir)
     if vecnorm:
         checkpoint.load_vecnormalize(vecnorm, env, training=True, norm_reward=True)
-    n_steps = max(cfg["samples_per_update"] // a.num_envs, 1)
-    model = R.PPO(env, R.PPOConfig(n_steps=n_steps, batch_size=cfg["batch_size"], n_epochs=cfg["n_epochs"], learning_rate=cfg["learning_rate"],
+    n_steps = R.n_steps_for(cfg["samples_per_update"], a.num_envs, world)
+    batch_size = a.batch_size or (1024 if a.detector == "cnn" else cfg["batch_size"])
+    model = R.PPO(env, R.PPOConfig(n_steps=n_steps, batch_size=batch_size, detector=a.detector, image_res=a.image_res, n_epochs=cfg["n_epochs"], learning_rate=cfg["learning_rate"],
                                    gamma=cfg["gamma"], gae_lambda=cfg["gae_lambda"], clip_range=cfg["clip_range"], ent_coef=cfg["ent_coef"],
                                    vf_coef=cfg["vf_coef"], max_grad_norm=cfg["max_grad_norm"], seed=cfg["seed"]))
     if a.pretrained_model:
@@ -63,7 +79,7 @@ def main():
     class Progress:
         t0, last = time.perf_counter(), 0
         def on_rollout_end(self, ppo):
-            if ppo.num_timesteps - self.last >= 20 * n_steps * a.num_envs:
+            if ppo.num_timesteps - self.last >= 20 * n_steps * a.num_envs * world:
                 dt = time.perf_counter() - self.t0
                 print(json.dumps({"timesteps": ppo.num_timesteps, "fps": round(ppo.num_timesteps / dt), **{k: round(v, 5) for k, v in ppo.logs.items()},
                                   **{k: round(float(v), 4) for k, v in ev.last_scalars.items()}}), flush=True)

@@ -23,6 +23,8 @@
  *                  train/train_Fixedwing_Waypoints_v3.py:119
  *   fw_get_state/fw_set_state <- (no reference twin) parity tests + checkpoints
  *   fw_get_counters <- (no reference twin) diagnostics of the auto-reset hand-off
+ *   fw_render   <- Camera.capture_image() as consumed at envs/fixedwing_objlock_env.py:603-622 and replaced by a
+ *                  network's mask at envs/fixedwing_envs/objlock_yolo_env.py:646-716
  *   fw_destroy  <- Env.close()  envs/fixedwing_envs/fixedwing_base_env.py:187-191
  *
  * Conventions
@@ -337,6 +339,14 @@ int32_t fw_get_counters(fw_handle h, uint64_t* out);
 
 /* Recompute the observation from the current state (no dynamics), device T[N,D]. */
 int32_t fw_observe(fw_handle h, void* obs_out, void* hip_stream);
+
+/* FPV image of every env's CURRENT pose, for a network front end (the reference's camera hands the env segImg / depthImg,
+ * envs/fixedwing_objlock_env.py:603-622; its CNN path replaces segImg by a detector's mask,
+ * envs/fixedwing_envs/objlock_yolo_env.py:646-716).  The scene is the analytic one the vision features of the objlock tasks are
+ * functionals of: out = device float32 [N][2][res][res], channel 0 = duck mask (0 / 1), channel 1 =
+ * depth-buffer value in [0, 1] of the nearest fragment (sky 1.0); same camera (offset, tilt, FOV), focal length scaled to `res`.
+ * FW_EUNSUPPORTED for the waypoints task (no camera). */
+int32_t fw_render(fw_handle h, int32_t res, float* out, void* hip_stream);
 
 /* ---- rollout-collector helpers (the caller side of the path: SB3's OnPolicyAlgorithm /
  * RolloutBuffer / VecNormalize as driven by train/train_Fixedwing_Waypoints_v3.py:260,293-337).

@@ -745,6 +745,49 @@ static void camera_capture(const struct fw_env* h, oenv* e) {
   TK(e, FW_ST_FRAME_HAS) = 1.0;
 }
 
+/* FPV image of the SAME analytic scene camera_capture() applies the reference's functionals to, rendered pixel by pixel at
+ * `res` x `res` (focal length scaled with the width: same FOV, same body-fixed camera; res == camera_resolution is the image
+ * a14's numbers are functionals of).  What Camera.capture_image() hands the env in the reference (:603-622): a segmentation
+ * image and a depth-buffer image -- here channel 0 = duck mask (1.0 where seg == duck id), channel 1 = depth-buffer value in
+ * [0, 1] of the nearest fragment (duck pixels: the sphere; others: ground / cylinder; sky 1.0).  A network that consumes it
+ * (the reference's CNN path replaces segImg by a network's mask, envs/fixedwing_envs/objlock_yolo_env.py:646-716) sees the
+ * scene of the env's CURRENT pose.  out: float32 [2][res][res] of env e. */
+static void render_env(const struct fw_env* h, const oenv* e, int res, float* out) {
+  const fw_config* c = &h->cfg;
+  double R[9], cam[3], off_w[3];
+  mat_from_quat(e->quat, R);
+  mat_vec(R, c->camera_offset, off_w);
+  for (int k = 0; k < 3; ++k) cam[k] = e->pos[k] + off_w[k];
+  const double W = (double)res, F = 0.5 * W / tan(0.5 * c->camera_fov_deg * (FWO_PI / 180.0));
+  const double near = c->camera_near, far = c->camera_far, u0 = 0.5 * (W - 1.0), v0 = u0, Rd = h->duck_radius;
+  double C[3] = { TK(e, FW_ST_DUCK_POS), TK(e, FW_ST_DUCK_POS + 1), TK(e, FW_ST_DUCK_POS + 2) + Rd };
+  double relw[3] = { C[0] - cam[0], C[1] - cam[1], C[2] - cam[2] }, relb[3];
+  matT_vec(R, relw, relb);
+  const double zc = dot3(relb, h->cam_f), xc = dot3(relb, h->cam_r), yc = dot3(relb, h->cam_d);
+  const double k2 = zc * zc + xc * xc + yc * yc - Rd * Rd;
+  const int duck_possible = (zc - Rd > near && zc - Rd < far && !occluded(h, e, cam, C));
+  for (int y = 0; y < res; ++y)
+    for (int x = 0; x < res; ++x) {
+      const double a = ((double)x - u0) / F, b = ((double)y - v0) / F;
+      double mask = 0.0, d;
+      int is_duck = 0;
+      double t_duck = 0.0;
+      if (duck_possible) {
+        const double q = 1.0 + a * a + b * b, p = zc + a * xc + b * yc, disc = p * p - q * k2;
+        if (disc >= 0.0 && p > 0.0) { t_duck = (p - sqrt(disc)) / q; if (t_duck > near && t_duck < far) is_duck = 1; }
+      }
+      if (is_duck) { mask = 1.0; d = depth_buffer_of(t_duck, near, far); }
+      else {
+        double db[3], dw[3];
+        for (int k = 0; k < 3; ++k) db[k] = h->cam_f[k] + a * h->cam_r[k] + b * h->cam_d[k];
+        mat_vec(R, db, dw);
+        d = depth_buffer_of(ray_depth(h, e, cam, dw), near, far);
+      }
+      out[(size_t)y * res + x] = (float)mask;
+      out[(size_t)res * res + (size_t)y * res + x] = (float)d;
+    }
+}
+
 /* _compute_vision_features :643-689 on the latest frame; returns the 9 float32 features */
 static void vision_features(oenv* e, double out[FW_VISION_FEATS]) {
   double visible = 0.0, dl = 0.0, dc = 0.0, dr = 0.0;
@@ -1300,6 +1343,19 @@ int32_t fwo_set_state(fw_handle h, const double* s) {
     memcpy(e->target_deltas, tmp.target_deltas, sizeof e->target_deltas);
     e->n_deltas = tmp.n_deltas;
   }
+  return FW_OK;
+}
+
+/* fw_render twin: HOST float32 [N][2][res][res] */
+int32_t fwo_render(fw_handle h, int32_t res, float* out, void* stream) {
+  (void)stream;
+  if (!h || !out) return FW_EINVAL;
+  if (h->cfg.task == FW_TASK_WAYPOINTS) { snprintf(h->err, sizeof h->err, "fw_render: the waypoints task has no camera"); return FW_EUNSUPPORTED; }
+  if (res < 1 || res > 1024) { snprintf(h->err, sizeof h->err, "fw_render: res must be in [1, 1024]"); return FW_EINVAL; }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (int i = 0; i < h->n; ++i) render_env(h, &h->e[i], res, out + (size_t)i * 2 * res * res);
   return FW_OK;
 }
 

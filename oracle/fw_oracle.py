@@ -90,6 +90,7 @@ def _bind(L: C.CDLL) -> C.CDLL:
     L.fwo_get_state.restype = i32; L.fwo_get_state.argtypes = [vp, vp]
     L.fwo_set_state.restype = i32; L.fwo_set_state.argtypes = [vp, vp]
     L.fwo_set_threads.restype = i32; L.fwo_set_threads.argtypes = [i32]
+    L.fwo_render.restype = i32; L.fwo_render.argtypes = [vp, i32, vp, vp]
     L.fwo_num_envs.restype = i32; L.fwo_num_envs.argtypes = [vp]
     L.fwo_last_error.restype = C.c_char_p; L.fwo_last_error.argtypes = [vp]
     L.fwo_destroy.restype = i32; L.fwo_destroy.argtypes = [vp]
@@ -171,6 +172,13 @@ class OracleEnv:
         obs = np.empty((self.num_envs, self.obs_dim), dtype=self.dtype)
         assert self._L.fwo_observe(self._h, _ptr(obs), None) == 0
         return obs
+
+    def render(self, res: int) -> np.ndarray:
+        """fw_render twin: float32 [N, 2, res, res] = (duck mask, depth buffer) of every env's current pose, pixel by pixel."""
+        img = np.empty((self.num_envs, 2, int(res), int(res)), dtype=np.float32)
+        rc = self._L.fwo_render(self._h, int(res), _ptr(img), None)
+        assert rc == 0, self._L.fwo_last_error(self._h)
+        return img
 
     def seed(self, seed: int):
         assert self._L.fwo_seed(self._h, int(seed)) == 0

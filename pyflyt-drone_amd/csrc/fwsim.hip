@@ -16,6 +16,7 @@
 #include "fwsim_ppo.hpp"
 #include "fwsim_collect.hpp"
 #include "fwsim_objlock.hpp"
+#include "fwsim_render.hpp"
 
 using namespace fwsim;
 
@@ -1535,6 +1536,28 @@ int32_t fw_step(fw_handle h, const void* actions, void* obs, void* reward, uint8
   return (h->cfg.dtype == FW_F64)
              ? step_T<double>(h, actions, obs, reward, terminated, truncated, terminal_obs, info_i32, st)
              : step_T<float>(h, actions, obs, reward, terminated, truncated, terminal_obs, info_i32, st);
+}
+
+int32_t fw_render(fw_handle h, int32_t res, float* out, void* hip_stream) {
+  if (!h) return FW_EINVAL;
+  if (!out) { h->err = "fw_render: out is NULL"; return FW_EINVAL; }
+  if (h->cfg.task == FW_TASK_WAYPOINTS) { h->err = "fw_render: the waypoints task has no camera"; return FW_EUNSUPPORTED; }
+  if (res < 1 || res > 1024) { h->err = "fw_render: res must be in [1, 1024]"; return FW_EINVAL; }
+  DeviceGuard g(h->device);
+  const fw_config& c = h->cfg;
+  RenderC K;
+  const double th = c.camera_angle_deg * kPi / 180.0;
+  const double f[3] = { std::cos(th), 0.0, std::sin(th) }, r[3] = { 0.0, -1.0, 0.0 };
+  const double d[3] = { f[1] * r[2] - f[2] * r[1], f[2] * r[0] - f[0] * r[2], f[0] * r[1] - f[1] * r[0] };
+  for (int k = 0; k < 3; ++k) { K.cam_f[k] = f[k]; K.cam_r[k] = r[k]; K.cam_d[k] = d[k]; K.cam_off[k] = c.camera_offset[k]; }
+  K.tan_half_fov = std::tan(0.5 * c.camera_fov_deg * (kPi / 180.0));
+  K.near_ = c.camera_near; K.far_ = c.camera_far; K.duck_radius = c.duck_radius_per_scale * c.duck_global_scaling; K.obst_radius = c.obstacle_radius;
+  const int tile = kWave / h->lanes_per_env;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (c.dtype == FW_F64) hipLaunchKernelGGL(fw_render_kernel<double>, dim3((unsigned)h->n), dim3(256), 0, st, (const double*)h->r_dev, tile, h->n, K, res, out);
+  else hipLaunchKernelGGL(fw_render_kernel<float>, dim3((unsigned)h->n), dim3(256), 0, st, (const float*)h->r_dev, tile, h->n, K, res, out);
+  HIP_TRY(h, hipGetLastError());
+  return FW_OK;
 }
 
 int32_t fw_seed(fw_handle h, uint64_t seed) {

@@ -29,6 +29,7 @@ import numpy as np
 import torch
 
 from . import config as K
+from .rollout import policy_inputs
 
 
 def sync_envs_normalization(train_env, eval_env) -> None:
@@ -86,7 +87,8 @@ def evaluate_policy(policy, env, n_eval_episodes: int = 10, deterministic: bool 
     n = env.num_envs
     targets = np.array([(n_eval_episodes + i) // n for i in range(n)], dtype=np.int64)
     if use_graph is None:
-        use_graph = deterministic and generator is None and torch.device(env.device).type == "cuda" and hasattr(venv, "step_tensor")
+        use_graph = (deterministic and generator is None and torch.device(env.device).type == "cuda" and hasattr(venv, "step_tensor")
+                     and not getattr(policy, "uses_image", False))        # (a CNN front end keeps MIOpen out of captures)
     if use_graph:
         return _evaluate_replayed(policy, env, targets, callback, max_vec_steps)
     counts = np.zeros(n, dtype=np.int64)
@@ -98,7 +100,7 @@ def evaluate_policy(policy, env, n_eval_episodes: int = 10, deterministic: bool 
     obs = env.reset()
     steps = 0
     while (counts < targets).any():
-        actions, _, _ = policy(obs, deterministic=deterministic, generator=generator)
+        actions, _, _ = policy(obs, deterministic=deterministic, generator=generator, **policy_inputs(policy, env))
         clipped = actions.clamp(-1.0, 1.0).to(venv.torch_dtype)
         obs, _, dones, _, _ = env.step(clipped)
         cur_rew += venv.rewards.to(torch.float64)        # un-normalised reward of the wrapped env
@@ -191,7 +193,7 @@ class ReplayedEvaluation:
 
     def _body(self):
         venv, ar, tg, E, counts = self.venv, self.ar, self.tg, self.E, self.counts
-        actions, _, _ = self.policy(self.obs, deterministic=True, generator=None)
+        actions, _, _ = self.policy(self.obs, deterministic=True, generator=None, **policy_inputs(self.policy, self.env))
         o, _, dones, _, _ = self.env.step(actions.clamp(-1.0, 1.0).to(venv.torch_dtype))
         self.obs.copy_(o)
         self.cur_rew.add_(venv.rewards.to(torch.float64))            # un-normalised reward of the wrapped env

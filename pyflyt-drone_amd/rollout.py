@@ -48,6 +48,41 @@ def _dist():
     return td if (td.is_available() and td.is_initialized() and td.get_world_size() > 1) else None
 
 
+def init_distributed_from_env():
+    """One process per GPU, as ``torch.distributed.run`` starts them: read WORLD_SIZE / RANK / LOCAL_RANK, bind this process
+    to its GPU and join the process group -- backend "nccl" (= RCCL over xGMI on ROCm) unless ``FW_DIST_BACKEND`` says
+    otherwise (gloo rehearsals on one device).  Returns ``(world, rank, local_rank)``; ``(1, 0, 0)`` and no process group in a
+    plain single-process run."""
+    import os
+    import torch.distributed as td
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 1, 0, 0
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FW_DIST_SINGLE_DEVICE"):
+        local = 0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not td.is_initialized():
+        backend = os.environ.get("FW_DIST_BACKEND", "nccl")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group(backend)
+    return world, rank, local
+
+
+def n_steps_for(samples_per_update: int, num_envs_per_rank: int, world: int = 1) -> int:
+    """Rollout length that HOLDS the reference's samples per update when the envs multiply: ``samples / (envs per rank x
+    world)`` (at least 1).  The reference collects 32 x 2048 = 65 536 samples per update (train/train_Fixedwing_Waypoints_v3.py:
+    29,35); 4096 envs on one GPU make that 16 steps, 8 GPUs x 4096 envs 2 steps.  It matters twice in a sharded job: the update
+    is replicated on every rank (its time is set by the number of sequential minibatches = samples / batch_size x epochs, so
+    holding the samples holds the update time while the collection time falls with 1 / world), and PPO's sample efficiency
+    is that of the reference's batch."""
+    return max(int(samples_per_update) // max(int(num_envs_per_rank) * max(int(world), 1), 1), 1)
+
+
 def _staged(td, t: torch.Tensor) -> bool:
     """RCCL ("nccl") moves device tensors itself; any other backend (gloo rehearsals) gets a host copy."""
     return t.is_cuda and td.get_backend() != "nccl"
@@ -326,6 +361,59 @@ class MlpPolicy(nn.Module):
         return values, self._log_prob(actions, mean, log_std), entropy
 
 
+class CnnDetectorPolicy(nn.Module):
+    """MlpPolicy with a CNN "detector head" in front: a small conv net turns the FPV render of the env's analytic scene
+    (``fw_render``: duck mask + depth buffer, float32 ``[N, 2, res, res]``) into ``cnn_features`` numbers that are
+    concatenated to the flat observation; the 64-64 tanh policy / value networks, the Gaussian head and the initialisation
+    are SB3's, as in :class:`MlpPolicy`; the extractor is shared by both networks like SB3's ``CnnPolicy`` shares its
+    ``features_extractor``.  BASELINE.json configs[4] ("PPO with CNN detector head on PyTorch-ROCm"); the reference's own CNN
+    path feeds camera images to a network (envs/fixedwing_envs/objlock_yolo_env.py:646-716) -- its trainers use ``MlpPolicy``
+    (train/train_Fixedwing_Waypoints_ObjLock.py:349), so the architecture here is build-owned: conv 4x4 / 2 -> ReLU ->
+    conv 3x3 / 2 -> ReLU -> conv 3x3 / 2 -> ReLU -> linear -> ReLU.  Plain torch-ROCm (MIOpen) -- no hand kernel."""
+
+    uses_image = True
+
+    def __init__(self, obs_dim: int, image_res: int = 32, act_dim: int = 4, hidden=(64, 64), cnn_features: int = 32, channels: int = 2):
+        super().__init__()
+        self.image_res, self.obs_dim = int(image_res), int(obs_dim)
+        self.cnn = nn.Sequential(nn.Conv2d(channels, 16, 4, stride=2, padding=1), nn.ReLU(),
+                                 nn.Conv2d(16, 32, 3, stride=2, padding=1), nn.ReLU(),
+                                 nn.Conv2d(32, 32, 3, stride=2, padding=1), nn.ReLU(), nn.Flatten())
+        with torch.no_grad():
+            n_flat = self.cnn(torch.zeros(1, channels, self.image_res, self.image_res)).shape[1]
+        self.cnn_head = nn.Sequential(nn.Linear(n_flat, cnn_features), nn.ReLU())
+        self.mlp = MlpPolicy(obs_dim + cnn_features, act_dim, hidden)
+        for m in list(self.cnn) + list(self.cnn_head):
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.orthogonal_(m.weight, gain=math.sqrt(2)); nn.init.zeros_(m.bias)
+
+    @property
+    def log_std(self):
+        return self.mlp.log_std
+
+    def features(self, obs, img):
+        if img is None:
+            raise ValueError("CnnDetectorPolicy needs the FPV image of the step (img=...)")
+        return torch.cat([obs, self.cnn_head(self.cnn(img))], dim=-1)
+
+    def forward(self, obs, deterministic: bool = False, generator=None, img=None):
+        return self.mlp(self.features(obs, img), deterministic=deterministic, generator=generator)
+
+    def predict_values(self, obs, img=None):
+        return self.mlp.predict_values(self.features(obs, img))
+
+    def evaluate_actions(self, obs, actions, img=None):
+        return self.mlp.evaluate_actions(self.features(obs, img), actions)
+
+
+def policy_inputs(policy, env, out: Optional[torch.Tensor] = None) -> dict:
+    """Extra inputs of a policy call besides the flat observation: ``{"img": FPV render of env's current state}`` for a policy
+    with a CNN front end (``uses_image``), nothing otherwise."""
+    if not getattr(policy, "uses_image", False):
+        return {}
+    return {"img": env.venv.render_tensor(policy.image_res, out=out)}
+
+
 # ---------------------------------------------------------------------------------------------
 # GAE
 # ---------------------------------------------------------------------------------------------
@@ -416,6 +504,9 @@ class PPOConfig:
     use_graphs: bool = True                # replay the rollout / minibatch update as hipGraphs (single-GPU, device envs)
     fused_update: bool = True              # run the whole minibatch sequence of train() in one HIP kernel (fw_ppo_update) when it applies
     fused_collect: bool = True             # policy forward / sampling / buffer writes and the reward path as fw_policy_act + fw_rollout_post
+    detector: str = "none"                 # "cnn": CnnDetectorPolicy over the FPV render (fw_render) of a camera task -- torch path, gradient all-reduce
+    image_res: int = 32                    #        side of the rendered image
+    cnn_features: int = 32                 #        width of the extractor's output
     dist_update: str = "replicated"        # multi-process job: "replicated" = all-gather the rollout shards, every rank runs the same
                                            # minibatch sequence (no per-minibatch collective); "allreduce" = local minibatches + gradient all-reduce
 
@@ -458,6 +549,8 @@ class FusedPpoUpdate:
     def fits(policy, obs_dim: int, device) -> bool:
         """The kernels are written for the reference's MlpPolicy: two 64-64 tanh nets, 4 actions, obs_dim <= 64 (any number
         of ranks: a sharded job runs them unchanged on every GPU)."""
+        if getattr(policy, "uses_image", False) or not hasattr(policy, "pi_net"):
+            return False                   # CNN front end: torch path (the fused kernels are the MlpPolicy's)
         lin = [m for m in list(policy.pi_net) + list(policy.vf_net) if isinstance(m, nn.Linear)]
         return (device.type == "cuda" and obs_dim <= 64 and len(lin) == 4
                 and all(m.out_features == 64 for m in lin) and policy.action_net.out_features == 4)
@@ -554,20 +647,29 @@ class PPO:
         self.env, self.cfg, self.device = env, cfg, env.device
         self._gae = gae_fn
         torch.manual_seed(cfg.seed)
+        if cfg.detector not in ("none", "cnn"):
+            raise ValueError("detector must be 'none' or 'cnn'")
+        if policy is None and cfg.detector == "cnn":
+            policy = CnnDetectorPolicy(env.obs_dim, image_res=cfg.image_res, cnn_features=cfg.cnn_features)
         self.policy = (policy or MlpPolicy(env.obs_dim)).to(self.device)
+        self._img = bool(getattr(self.policy, "uses_image", False))
+        if self._img and not hasattr(env.venv, "render_tensor"):
+            raise ValueError("a policy with a CNN front end needs an env with render_tensor() (a camera task on the device)")
         td = _dist()
         if td is not None:                 # identical initial weights on every rank
             for p in self.policy.parameters():
                 td.broadcast(p.data, src=0)
         if cfg.dist_update not in ("replicated", "allreduce"):
             raise ValueError("dist_update must be 'replicated' or 'allreduce'")
-        self._replicated = td is not None and cfg.dist_update == "replicated"
+        # CNN front end: data-parallel minibatches + ONE flattened gradient all-reduce each (the images of a rollout are ~30x
+        # the flat observations: gathering every rank's rollout on every rank is the wrong trade there)
+        self._replicated = td is not None and cfg.dist_update == "replicated" and not self._img
         self._fused_collect_ok = (bool(cfg.fused_collect) and FusedPpoUpdate.fits(self.policy, env.obs_dim, self.device)
                                   and getattr(env, "use_fused", False) and env.norm_obs and hasattr(env.venv, "step_tensor")
                                   and hasattr(env.venv, "terminal_obs") and hasattr(env.venv, "torch_dtype"))
         # hipGraph replay needs a collective-free body: always on one GPU; in a sharded job when the collector is fused
         # (its statistics are exchanged BETWEEN rollouts) and the update is replicated (no gradient all-reduce)
-        self._graphs = (bool(cfg.use_graphs) and self.device.type == "cuda"
+        self._graphs = (bool(cfg.use_graphs) and self.device.type == "cuda" and not self._img      # (MIOpen convolutions stay out of captures)
                         and (td is None or (self._fused_collect_ok and self._replicated)))
         self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5,
                                           capturable=self._graphs)
@@ -600,6 +702,11 @@ class PPO:
         self.buf_start = torch.zeros((T, N), **f32)
         self.buf_val = torch.zeros((T, N), **f32)
         self.buf_logp = torch.zeros((T, N), **f32)
+        self.buf_img = self.last_img = None
+        if self._img:
+            r = int(self.policy.image_res)
+            self.buf_img = torch.zeros((T, N, 2, r, r), **f32)
+            self.last_img = torch.zeros((N, 2, r, r), **f32)
         self.last_obs = None
         self.last_starts = torch.ones(N, **f32)
         self.num_timesteps = 0
@@ -609,18 +716,29 @@ class PPO:
     def _rollout_body(self):
         cfg, env = self.cfg, self.env
         act_dtype = env.venv.torch_dtype
+        kw = {}
         for t in range(cfg.n_steps):
-            actions, values, logp = self.policy(self.last_obs, generator=self.gen)
+            if self._img:
+                # the FPV image of the state the policy acts on (fw_render of the env's current pose, refreshed below after the step)
+                kw = {"img": self.last_img}
+                self.buf_img[t].copy_(self.last_img)
+            actions, values, logp = self.policy(self.last_obs, generator=self.gen, **kw)
             clipped = actions.clamp(-1.0, 1.0).to(act_dtype)
             obs_n, rew_n, dones, timeouts, tobs_n = env.step(clipped)
-            # bootstrap truncated episodes with V(terminal_observation)
-            tv = self.policy.predict_values(tobs_n)
+            # bootstrap truncated episodes with V(terminal_observation).  (CNN front end: the env has already auto-reset, so the
+            # terminal pose can no longer be rendered; the image of the step before stands in -- one agent step stale, and only
+            # for the rare episodes that end on the time limit.)
+            tv = self.policy.predict_values(tobs_n, **kw)
             rew_n = rew_n + cfg.gamma * tv * timeouts.to(torch.float32)
             self.buf_obs[t].copy_(self.last_obs); self.buf_act[t].copy_(actions); self.buf_rew[t].copy_(rew_n)
             self.buf_start[t].copy_(self.last_starts); self.buf_val[t].copy_(values); self.buf_logp[t].copy_(logp)
             self.last_obs.copy_(obs_n)
             self.last_starts.copy_(dones.to(torch.float32))
-        self.last_values.copy_(self.policy.predict_values(self.last_obs))
+            if self._img:
+                env.venv.render_tensor(self.policy.image_res, out=self.last_img)
+        if self._img:
+            kw = {"img": self.last_img}
+        self.last_values.copy_(self.policy.predict_values(self.last_obs, **kw))
 
     def _act(self, obs, nets, t=None, value_out=None):
         L, env = _lib.lib(), self.env
@@ -688,6 +806,8 @@ class PPO:
         cfg, env = self.cfg, self.env
         if self.last_obs is None:
             self.last_obs = env.reset().clone()
+            if self._img:
+                env.venv.render_tensor(self.policy.image_res, out=self.last_img)
             self.last_starts.fill_(1.0)
             self.last_values = torch.zeros(env.num_envs, dtype=torch.float32, device=self.device)
         body = self._rollout_body
@@ -724,10 +844,11 @@ class PPO:
     # ---- SB3 PPO.train ------------------------------------------------------------------------
     def _minibatch_step(self, obs, act, old_logp, adv, ret, idx, g_mean, g_std, params):
         cfg = self.cfg
+        kw = {"img": self.buf_img.reshape((-1,) + tuple(self.buf_img.shape[2:]))[idx]} if self._img else {}
         a = adv[idx]
         if cfg.normalize_advantage and a.numel() > 1:
             a = (a - g_mean) / (g_std + 1e-8) if cfg.adv_norm_scope == "global" else (a - a.mean()) / (a.std() + 1e-8)
-        values, logp, entropy = self.policy.evaluate_actions(obs[idx], act[idx])
+        values, logp, entropy = self.policy.evaluate_actions(obs[idx], act[idx], **kw)
         ratio = torch.exp(logp - old_logp[idx])
         policy_loss = -torch.min(a * ratio, a * ratio.clamp(1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
         value_loss = torch.nn.functional.mse_loss(ret[idx], values)

@@ -174,6 +174,19 @@ class FixedwingVecEnv(_VecEnvBase):
         _lib.check(rc, self._h)
         return self.obs
 
+    def render_tensor(self, res: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """FPV image of every env's current pose: float32 ``[N, 2, res, res]`` = (duck mask, depth buffer) of the analytic
+        scene the vision features are functionals of (``fw_render``; what ``Camera.capture_image()`` hands the reference env,
+        envs/fixedwing_objlock_env.py:603-622).  Camera tasks only."""
+        res = int(res)
+        if out is None:
+            out = torch.empty((self.num_envs, 2, res, res), dtype=torch.float32, device=self.device)
+        if out.shape != (self.num_envs, 2, res, res) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("render_tensor: out must be a contiguous float32 [N, 2, res, res] tensor on the env's device")
+        rc = _lib.lib().fw_render(self._h, res, _devptr(out), self._stream())
+        _lib.check(rc, self._h)
+        return out
+
     # ------------------------------------------------------------------ SB3 VecEnv surface (numpy)
     def reset(self) -> np.ndarray:
         obs = self.reset_tensor()

@@ -491,3 +491,50 @@ def test_combined_obstacle_penalty_full_scale_in_waypoint_phase(oracle):
     set_frame(env2, 0.0, zones=(255.0, 2.0, 255.0))
     _, r2, *_ = step0(env2)
     assert r2[0] == pytest.approx(-0.1 - 0.5 * (5 - 2) / 5, rel=1e-12)                     # duck phase: x0.5
+
+
+# ---- FPV image for a CNN front end (fw_render): the literal per-pixel render of the SAME scene
+def test_rendered_image_is_the_scene_the_frame_functionals_are_computed_on(oracle):
+    """`render(res)` = (duck mask, depth buffer) per pixel.  Against the independent numpy render above: the mask is the
+    numpy `seg == duck` bit for bit and the depth channel its depth-buffer image (float32-rounded), at the camera's own
+    resolution -- where the reference's functionals applied to the rendered image give back the frame numbers a14 computes --
+    and at a smaller one (same FOV, focal length scaled with the width), with rolled cameras, border-clipped ducks and
+    cylinders in view."""
+    rng = np.random.default_rng(5)
+    to_m = lambda v: 255.0 * 0.1 / (255.0 - (255.0 - 0.1) * float(v))
+    for res, nob in ((96, 4), (128, 0)):
+        cfg = quiet(duck_camera_capture_interval_steps=1, camera_resolution=res, num_obstacles=max(nob, 1), obstacle_radius=2.0)
+        env = make(oracle, cfg)
+        seen = 0
+        for trial in range(8):
+            dist = rng.uniform(15, 120)
+            yaw, roll, pitch = rng.uniform(-3, 3), rng.uniform(-0.5, 0.5), rng.uniform(-0.2, 0.3)
+            pos = np.array([rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(4, 40)])
+            bearing = yaw + rng.uniform(-0.6, 0.6)
+            duck = np.array([pos[0] + dist * math.cos(bearing), pos[1] + dist * math.sin(bearing), 0.05])
+            obst = [[pos[0] + rng.uniform(12, 90) * math.cos(yaw + rng.uniform(-0.7, 0.7)),
+                     pos[1] + rng.uniform(12, 90) * math.sin(yaw + rng.uniform(-0.7, 0.7)), rng.uniform(10, 30)] for _ in range(nob)]
+            _pose(env, pos, [roll, pitch, yaw], duck, oracle, obst)
+            st = env.get_state()[0]
+            for r in (res, 32):
+                want, mask, dbuf = np_render_frame(oracle, cfg, st, r)
+                img = env.render(r)[0]
+                assert img.shape == (2, r, r) and img.dtype == np.float32
+                np.testing.assert_array_equal(img[0], mask.astype(np.float32), err_msg=f"mask {res} {trial} {r}")
+                np.testing.assert_allclose(img[1], dbuf.astype(np.float32), rtol=0, atol=1.2e-7, err_msg=f"depth {res} {trial} {r}")
+            # the reference's statements (:670-675, :731-743) on the rendered image at the camera's resolution = the numpy frame
+            want, _, _ = np_render_frame(oracle, cfg, st, res)
+            m = env.render(res)[0]
+            if m[0].any():
+                yy, xx = np.nonzero(m[0] > 0.5)
+                got = [1.0, xx.mean() / (res - 1), yy.mean() / (res - 1), (m[0] > 0.5).sum() / (res * res)]
+                np.testing.assert_allclose(got, want[:4], rtol=0, atol=1e-15)
+                assert to_m(m[1][m[0] > 0.5].min()) == pytest.approx(want[4], rel=3e-4)      # float32 depth image: 6e-8 of buffer value is ~1e-4 of 100 m
+                seen += 1
+        assert seen >= 3, (res, seen)
+
+
+def test_render_is_refused_for_the_task_without_a_camera(oracle):
+    env = make(oracle, K.train_waypoints_v3_config(motor_noise=False))
+    with pytest.raises(AssertionError):
+        env.render(32)

@@ -361,3 +361,135 @@ def test_config0_plumbing_oracle_env_driven_by_the_ppo_for_two_updates(oracle, K
     assert all(math.isfinite(v) for v in ppo.logs.values())
     assert float(env.obs_rms.count) == pytest.approx(1e-4 + 513) and torch.isfinite(env.obs_rms.var).all()
     print(f"configs[0] plumbing: {fps:.0f} env-steps/s (1 CPU env, oracle physics, torch PPO)")
+
+
+# ---------------------------------------------------------------- CNN detector head (BASELINE configs[4]) on the torch path
+class ImageVenv(FakeVenv):
+    """FakeVenv with the camera surface (`render_tensor`): the image is a function of the current observation, and the reward
+    pays for steering towards a quantity that is ONLY visible in the image (its bright column)."""
+
+    def _col(self):
+        return (self.obs[:, 2].abs() * 3).long() % 8
+
+    def render_tensor(self, res, out=None):
+        n = self.num_envs
+        img = torch.zeros((n, 2, res, res), dtype=torch.float32) if out is None else out
+        img.zero_()
+        img[torch.arange(n), 0, :, self._col()] = 1.0
+        img[:, 1] = 0.5
+        return img
+
+    def step_tensor(self, actions):
+        want = (self._col().to(torch.float64) - 3.5) / 3.5              # the image's bright column, as an action target
+        obs, rew, term, trunc = super().step_tensor(actions)
+        rew = -(actions[:, 0].to(torch.float64) - want) ** 2
+        return obs, rew, term, trunc
+
+
+def test_cnn_detector_policy_shapes_and_wiring():
+    torch.manual_seed(0)
+    pol = R.CnnDetectorPolicy(6, image_res=16, cnn_features=8)
+    obs, img = torch.randn(5, 6), torch.rand(5, 2, 16, 16)
+    a, v, lp = pol(obs, img=img)
+    assert a.shape == (5, 4) and v.shape == (5,) and lp.shape == (5,)
+    v2, lp2, ent = pol.evaluate_actions(obs, a, img=img)
+    assert torch.allclose(v2, v) and torch.allclose(lp2, lp, atol=1e-6) and ent.shape == (5,)
+    with pytest.raises(ValueError):
+        pol(obs)                                                          # the image is not optional
+    assert not R.FusedPpoUpdate.fits(pol, 6, torch.device("cpu")) and R.policy_inputs(R.MlpPolicy(6), None) == {}
+    # the extractor feeds BOTH networks: a value-only loss reaches the conv weights
+    pol.zero_grad(); pol.predict_values(obs, img=img).sum().backward()
+    assert pol.cnn[0].weight.grad.abs().sum() > 0
+
+
+def test_ppo_with_cnn_front_end_collects_images_and_trains_through_the_extractor():
+    venv = ImageVenv(n=32, d=6, seed=4, horizon=50)
+    env = R.VecNormalizeDevice(venv, use_fused_kernel=False, norm_reward=False)
+    ppo = R.PPO(env, R.PPOConfig(n_steps=8, batch_size=64, n_epochs=4, learning_rate=3e-3, detector="cnn", image_res=8, cnn_features=8, seed=1),
+                gae_fn=R.gae_reference)
+    assert isinstance(ppo.policy, R.CnnDetectorPolicy) and not ppo._collect_fused and not ppo._graphs and ppo._fused is None
+    w0 = ppo.policy.cnn[0].weight.detach().clone()
+    ppo.collect_rollouts()
+    assert ppo.buf_img.shape == (8, 32, 2, 8, 8)
+    assert float(ppo.buf_img[:, :, 0].sum(dim=(-1, -2)).min()) == 8.0     # every stored image holds its bright column
+    first = float(ppo.buf_rew.mean())
+    ppo.train()
+    assert not torch.equal(w0, ppo.policy.cnn[0].weight) and all(np.isfinite(v) for v in ppo.logs.values())
+    ppo.learn(60 * 8 * 32, reset_num_timesteps=False)
+    ppo.collect_rollouts()
+    assert float(ppo.buf_rew.mean()) > first + 0.1, (first, float(ppo.buf_rew.mean()))    # the cue is only in the image: it was used
+
+
+def _worker_cnn(rank, world, port, q):
+    import torch.distributed as td
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        env = R.VecNormalizeDevice(ImageVenv(n=8, d=6, seed=50 + rank, horizon=9), use_fused_kernel=False, stats_sync="step")
+        ppo = R.PPO(env, R.PPOConfig(n_steps=4, batch_size=16, n_epochs=2, detector="cnn", image_res=8, cnn_features=8, seed=2), gae_fn=R.gae_reference)
+        facts = (ppo._replicated, ppo._img)
+        ppo.learn(3 * 4 * 8 * world)
+        flat = torch.cat([p.detach().reshape(-1) for p in ppo.policy.parameters()])
+        q.put((rank, facts, ppo.replica_checksum(), flat.numpy(), ppo.num_timesteps))
+    finally:
+        td.destroy_process_group()
+
+
+def test_cnn_front_end_world_size_2_all_reduces_gradients_and_keeps_the_replicas_identical():
+    """configs[4] shards its envs over GPUs with a CNN policy: that job is data-parallel (local minibatches, one flattened
+    gradient all-reduce each) -- the rollout all-gather of the MLP jobs would move every rank's images to every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_worker_cnn, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60); assert p.exitcode == 0
+    (_, fa, ca, wa, na), (_, fb, cb, wb, nb) = res
+    assert fa == fb == (False, True)
+    assert ca == cb == 0.0 and np.array_equal(wa, wb) and na == nb == 3 * 4 * 8 * 2
+
+
+# ---------------------------------------------------------------- samples per update are held when the envs multiply
+def test_n_steps_for_holds_the_reference_samples_per_update():
+    assert R.n_steps_for(32 * 2048, 4096, 1) == 16 and R.n_steps_for(32 * 2048, 4096, 8) == 2        # configs[3]: 8 x 4096 envs
+    assert R.n_steps_for(32 * 1024, 2048, 8) == 2 and R.n_steps_for(16 * 2048, 4096, 1) == 8        # configs[4] / configs[2]
+    assert R.n_steps_for(100, 4096, 8) == 1                                                         # never below one step
+    assert R.init_distributed_from_env() == (1, 0, 0) or os.environ.get("WORLD_SIZE", "1") != "1"
+
+
+def _worker_samples(rank, world, port, q):
+    import torch.distributed as td
+    torch.set_num_threads(1)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank),
+                      FW_DIST_BACKEND="gloo")
+    w, r, _ = R.init_distributed_from_env()                      # what the examples call first
+    try:
+        S, n = 64, 8                                             # samples per update of the (toy) reference config, envs per rank
+        T = R.n_steps_for(S, n, w)
+        env = R.VecNormalizeDevice(FakeVenv(n=n, d=5, seed=7 + r), use_fused_kernel=False, stats_sync="rollout")
+        ppo = R.PPO(env, R.PPOConfig(n_steps=T, batch_size=16, n_epochs=1, seed=3), policy=R.MlpPolicy(5), gae_fn=R.gae_reference)
+        ppo.collect_rollouts()
+        B = ppo._update_buffers()[0].shape[0]
+        q.put((r, w, T, B, ppo.num_timesteps))
+    finally:
+        td.destroy_process_group()
+
+
+def test_sharded_job_holds_the_samples_per_update_world_size_2():
+    """in a sharded job the update is replicated (every rank walks ALL gathered samples), so the examples
+    divide n_steps by the world size: the update sees the reference's sample count whatever the number of GPUs."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_worker_samples, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)])
+    for p in procs:
+        p.join(timeout=60); assert p.exitcode == 0
+    for r, w, T, B, nt in res:
+        assert w == 2 and T == 4 and B == 64 and nt == 64            # 8 envs x 2 ranks x 4 steps = the 64 samples of one process with 8 steps
