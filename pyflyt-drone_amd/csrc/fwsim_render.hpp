@@ -9,7 +9,7 @@
 // at `res` x `res` pixels of the same body-fixed camera (FOV, tilt, offset of fw_config; the focal length scales with the
 // width), for the env's CURRENT pose.  One workgroup per env: the pose, the duck's camera-frame centre and the occlusion flag are
 // computed once into LDS next to the cylinder table, then the 256 threads walk the pixels (x fastest: coalesced float stores).
-// The arithmetic is double whatever the handle's dtype and follows oracle/fw_oracle.c's statements literally (IEEE sqrt and
+// The arithmetic is double whatever the handle's dtype and is written statement by statement like the CPU checker's render (IEEE sqrt and
 // division, no FMA contraction): the duck mask is an exact comparison against 0 at the silhouette, so the test asks for the
 // same bits, not for a tolerance.
 #pragma once
@@ -26,7 +26,7 @@ struct RenderC {            // camera constants in double (built on the host fro
 template <typename T>
 __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r, int tile, int n_envs, RenderC K, int res,
                                                         float* __restrict__ out) {
-#pragma clang fp contract(off)                    // this kernel only (block scope): multiply-adds stay two roundings, as in the oracle's C
+#pragma clang fp contract(off)                    // this kernel only (block scope): multiply-adds stay two roundings, as in the CPU checker's C
   __shared__ double s_c[24];                      // R[9] cam[3] zc xc yc k2 | flag nob
   __shared__ double s_cyl[FW_MAX_OBSTACLES][3];
   const int env = blockIdx.x, t = threadIdx.x;
