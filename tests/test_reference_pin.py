@@ -3,7 +3,6 @@ made by `tests/golden/make_reference_golden.py` where those packages exist -- on
 (`fw_scenario`), the same actions and motor noise off, and compares position / attitude at BASELINE.json's 1e-4.
 Skipped while no reference fixture is present (the build image cannot produce one: PyFlyt / pybullet are not installable
 there); until it runs green, parity against PyBullet is UNPINNED and every document says so."""
-import ctypes as C
 import glob
 import os
 
@@ -42,21 +41,17 @@ def test_oracle_follows_the_reference_trace_within_1e_4(oracle, path):
         cfg.wind_randomize_on_reset = 0; cfg.wind_randomize_phase = 0
         cfg.gust_freq_hz = float(z["gust_freq_hz"])
     env = oracle.OracleEnv(cfg, 1, seed=int(z["seed"]))
-    sc = K.FwScenario()
-    keep = []
-
-    def put(field, arr):
-        a = np.ascontiguousarray(arr, dtype=np.float64); keep.append(a)
-        setattr(sc, field, a.ctypes.data_as(C.POINTER(C.c_double)))
+    kw = {}
     if "targets" in z.files:
-        t = np.zeros((1, K.FW_MAX_TARGETS, 3)); t[0, :len(z["targets"])] = z["targets"][:, :3]; put("targets", t)
+        kw["targets"] = z["targets"][None, :K.FW_MAX_TARGETS, :3]
     if "duck_pos" in z.files:
-        put("duck_pos", z["duck_pos"].reshape(1, 3))
+        kw["duck_pos"] = z["duck_pos"].reshape(1, 3)
     if "obstacles" in z.files:
-        ob = np.zeros((1, K.FW_MAX_OBSTACLES, 3)); k = min(len(z["obstacles"]), K.FW_MAX_OBSTACLES); ob[0, :k] = z["obstacles"][:k]; put("obstacles", ob)
-        nob = np.array([k], dtype=np.int32); keep.append(nob); sc.num_obstacles = nob.ctypes.data_as(C.POINTER(C.c_int32))
+        k = min(len(z["obstacles"]), K.FW_MAX_OBSTACLES)
+        kw["obstacles"] = z["obstacles"][None, :k]; kw["num_obstacles"] = np.array([k])
     if "wind_base" in z.files:
-        put("wind_base", z["wind_base"].reshape(1, 3)); put("gust_amp", z["gust_amp"].reshape(1, 3)); put("gust_phase", np.array([float(z["gust_phase"])]))
+        kw.update(wind_base=z["wind_base"].reshape(1, 3), gust_amp=z["gust_amp"].reshape(1, 3), gust_phase=np.array([float(z["gust_phase"])]))
+    sc, keep = K.make_scenario(1, **kw)
     obs0 = env.reset(scenario=sc)
     # the state after reset (10 warm-up Aviary steps) is the first thing that must agree: rows of Aviary.state(0) =
     # [ang_vel(body), ang_pos(euler), lin_vel(body), lin_pos(world)] (envs/fixedwing_envs/fixedwing_base_env.py:279-285) = obs[0:12]
