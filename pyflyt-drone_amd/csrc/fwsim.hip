@@ -251,7 +251,10 @@ enum Phase : int { PH_STEP = 0, PH_WARM = 1, PH_DONE = 2 };
 // GENERAL = wind is on (per-env wind registers, and -- if it acts on the dynamics -- the
 // PH_WARM path).  The wind-free instantiation (the headline config) carries none of that.
 // OBJ = the ObjLock task (duck / analytic camera / vision shaping, fwsim_objlock.hpp); its state rides in registers.
-template <typename T, bool GENERAL, int G, int TKIND>
+// WPE = waves per SIMD the instantiation is built for (G = 8 only): 1 = the whole register file (359 registers: shared tick
+// constants resident in VGPRs), 2 = capped at 256 registers so that two waves share a SIMD -- the constants then stay
+// wave-uniform (scalar loads); used between 8 192 and 65 536 envs, where the 1-wave build would run its waves in two rounds.
+template <typename T, bool GENERAL, int G, int TKIND, int WPE = 1>
 __device__ __forceinline__
 void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> Dg,
                const T* __restrict__ actions, T* __restrict__ obs, T* __restrict__ reward,
@@ -322,7 +325,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   T ep_return = D.r[RF_EP_RETURN * n + envc];
   // tick constants + this lane's lifting surface (G = 8: resident in VGPRs for the whole launch)
   TickC<T> C; SurfC<T> mine; T wmask;
-  load_tick_constants<T, G, DEFER && G == 8>(Pp, C, mine, wmask);
+  load_tick_constants<T, G, DEFER && G == 8 && WPE == 1>(Pp, C, mine, wmask);
 
   normalize_quat<T>(S.q);
   T R[9];
@@ -803,6 +806,10 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
 // latency mapping (8 lanes per env): one wave per SIMD by construction, let the allocator use the whole file
 template <typename T, bool GENERAL>
 __global__ __launch_bounds__(kWave) void fw_step_kernel_g8(FW_STEP_ARGS) { FW_STEP_RUN(T, GENERAL, 8, FW_TASK_WAYPOINTS); }
+// ... and the same mapping capped at 256 registers: two waves per SIMD (8 192 < N <= 65 536 envs)
+template <typename T, bool GENERAL>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fw_step_kernel_g8w2(FW_STEP_ARGS) { FW_STEP_RUN(T, GENERAL, 8, FW_TASK_WAYPOINTS, 2); }
 // throughput mapping (one lane per env)
 template <typename T, bool GENERAL>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(FW_G1_WAVES, FW_G1_WAVES)))
@@ -978,6 +985,7 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
 // ======================================================================
 namespace {
 
+constexpr int kG8OneWaveMaxEnvs = 8192;   // 1024 SIMDs x 8 envs per wave: above, the one-wave-per-SIMD build needs a second round
 constexpr int kG8MaxEnvs = 16384;   // measured crossover on MI355X: 8 lanes/env wins up to 2^14 envs (51 vs 70 us), loses at 2^15 (93 vs 76 us)
 thread_local std::string g_err;
 
@@ -1131,6 +1139,7 @@ struct fw_env {
   fw_config cfg;
   int32_t n = 0, npad = 0, device = 0;
   int32_t lanes_per_env = 1;    // 1: throughput mapping, 8: latency mapping (see fwsim_device.hpp)
+  int32_t g8_waves = 1;         // 8-lane mapping, waypoints task: waves per SIMD the step kernel is built for (1 | 2)
   uint64_t seed = 0;
   int64_t env_offset = 0;
   void* params_dev = nullptr;   // Params<T>
@@ -1344,9 +1353,11 @@ int step_T(fw_env* h, const void* actions, void* obs, void* reward, uint8_t* ter
   } else if (h->cfg.task == FW_TASK_WAYPOINT_OBJLOCK) {
     if (g8) FW_LAUNCH_STEP((fw_step_kernel_obj_g8<T, FW_TASK_WAYPOINT_OBJLOCK>)); else FW_LAUNCH_STEP((fw_step_kernel_obj_g1<T, FW_TASK_WAYPOINT_OBJLOCK>));
   } else if (general) {
-    if (g8) FW_LAUNCH_STEP((fw_step_kernel_g8<T, true>)); else FW_LAUNCH_STEP((fw_step_kernel_g1<T, true>));
+    if (g8 && h->g8_waves == 2) FW_LAUNCH_STEP((fw_step_kernel_g8w2<T, true>));
+    else if (g8) FW_LAUNCH_STEP((fw_step_kernel_g8<T, true>)); else FW_LAUNCH_STEP((fw_step_kernel_g1<T, true>));
   } else {
-    if (g8) FW_LAUNCH_STEP((fw_step_kernel_g8<T, false>)); else FW_LAUNCH_STEP((fw_step_kernel_g1<T, false>));
+    if (g8 && h->g8_waves == 2) FW_LAUNCH_STEP((fw_step_kernel_g8w2<T, false>));
+    else if (g8) FW_LAUNCH_STEP((fw_step_kernel_g8<T, false>)); else FW_LAUNCH_STEP((fw_step_kernel_g1<T, false>));
   }
   HIP_TRY(h, hipGetLastError());
   return FW_OK;
@@ -1473,6 +1484,14 @@ int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64
   if (const char* ev = getenv("FWSIM_LANES_PER_ENV")) {
     int v = atoi(ev);
     if (v == 1 || (v == 8 && cfg->num_targets <= 8 && cfg->n_collision_pts <= 8)) h->lanes_per_env = v;
+  }
+  // 8-lane mapping of the waypoints kernels above kG8OneWaveMaxEnvs envs: the build capped at 256 registers, two waves per
+  // SIMD (the full-file build holds one, so N = 16 384 ran as two rounds of 1024 waves: the 8 k -> 16 k cliff).
+  // FWSIM_G8_WAVES=1|2 overrides.
+  h->g8_waves = (h->lanes_per_env == 8 && cfg->task == FW_TASK_WAYPOINTS && num_envs > kG8OneWaveMaxEnvs) ? 2 : 1;
+  if (const char* ev = getenv("FWSIM_G8_WAVES")) {
+    int v = atoi(ev);
+    if ((v == 1 || v == 2) && h->lanes_per_env == 8 && cfg->task == FW_TASK_WAYPOINTS) h->g8_waves = v;
   }
   DeviceGuard g(device);
   rc = (cfg->dtype == FW_F64) ? create_T<double>(h) : create_T<float>(h);

@@ -84,12 +84,24 @@ CASES = {name: (cfg, kind) for name, cfg, kind in lockstep_cases()}
 def lanes(request, monkeypatch):
     """Both lane mappings of the kernel (fwsim_device.hpp) must pass every parity test."""
     monkeypatch.setenv("FWSIM_LANES_PER_ENV", str(request.param))
+    monkeypatch.setenv("FWSIM_G8_WAVES", "1")
+    return request.param
+
+
+@pytest.fixture(params=[1, 8, "8w2"], ids=["lane_per_env", "8_lanes_per_env", "8_lanes_2_waves_per_simd"])
+def lanes3(request, monkeypatch):
+    """... and, for the waypoints kernels, the 8-lane mapping built for two waves per SIMD (256 registers, wave-uniform tick
+    constants): what fw_create picks between 8 192 and 16 384 envs."""
+    monkeypatch.setenv("FWSIM_LANES_PER_ENV", "8" if request.param == "8w2" else str(request.param))
+    monkeypatch.setenv("FWSIM_G8_WAVES", "2" if request.param == "8w2" else "1")
     return request.param
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_lockstep_f64(oracle, name, lanes):
+def test_lockstep_f64(oracle, name, lanes3):
     cfg, kind = CASES[name]
+    if lanes3 == "8w2" and cfg.task != K.FW_TASK_WAYPOINTS:
+        pytest.skip("the two-waves-per-SIMD build exists for the waypoints kernels only")
     n = 192 + 7                                      # deliberately not a multiple of 64
     hip = P.FixedwingVecEnv(cfg, n, seed=1234)
     ora = oracle.OracleEnv(cfg, n, seed=1234)
@@ -140,7 +152,7 @@ def test_objlock_aimed_flights_lock_and_strike(oracle, lanes):
     np.testing.assert_allclose(hip.get_state(), ora.get_state(), rtol=0, atol=1e-6)
 
 
-def test_baseline_size_4096_envs_against_oracle(oracle, lanes):
+def test_baseline_size_4096_envs_against_oracle(oracle, lanes3):
     """configs[1] of BASELINE.json: 4096 envs; 24 steps is what the scalar oracle does in ~2 s."""
     cfg = K.train_waypoints_v3_config()
     hip = P.FixedwingVecEnv(cfg, 4096, seed=42)
@@ -627,3 +639,15 @@ def test_camera_frame_statistics_match_the_oracle_on_directed_poses(oracle, lane
             assert (np.abs(fo[:, 5:8] - fo[:, 5:8].mean(1, keepdims=True)).max(1) > 1.0).sum() > 20, "cylinders were meant to change zone depths"
         far_cases = fo[3::4]
         assert 0 < (far_cases[:, 0] > 0).sum() < len(far_cases), "far-plane cases must include visible and clipped ducks"
+
+
+def test_fw_create_picks_the_two_wave_build_between_8k_and_16k_envs(oracle, monkeypatch):
+    """N = 16 384 waypoint envs (configs[4]'s one-GPU size) on the 8-lane mapping is 2048 waves; the
+    full-register-file build holds one wave per SIMD (two rounds: the 8 k -> 16 k cliff), so fw_create switches to the build capped
+    at 256 registers there.  The choice is visible (lanes_per_env stays 8) and the mapping it picks follows the oracle."""
+    monkeypatch.delenv("FWSIM_LANES_PER_ENV", raising=False); monkeypatch.delenv("FWSIM_G8_WAVES", raising=False)
+    cfg = K.train_waypoints_v3_config()
+    n = 16384
+    hip, ora = P.FixedwingVecEnv(cfg, n, seed=42), oracle.OracleEnv(cfg, n, seed=42)
+    assert hip.lanes_per_env == 8
+    run_lockstep(hip, ora, 6, np.random.default_rng(0), kind="uniform", atol=1e-7, rtol=0)

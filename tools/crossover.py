@@ -1,4 +1,5 @@
-"""Dev tool: step time of both lane mappings over env counts (where should fw_create switch from 8 lanes per env to one?).
+"""Dev tool: step time of the lane mappings over env counts (where should fw_create switch from 8 lanes per env at one wave per
+SIMD to the 256-register build at two, and from there to one lane per env?).
 usage: python tools/crossover.py <waypoints|waypoints_wind|objlock|combined> n1 n2 ..."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,8 +10,9 @@ CFG = {"waypoints": K.train_waypoints_v3_config, "objlock": K.train_objlock_conf
        "waypoints_wind": lambda: K.train_waypoints_v3_config(wind_config=K.TRAIN_OBJLOCK_WIND)}
 which = sys.argv[1]
 for n in map(int, sys.argv[2:]):
-    for lanes in (8, 1):
-        os.environ["FWSIM_LANES_PER_ENV"] = str(lanes)
+    modes = ((8, 1), (8, 2), (1, 1)) if which.startswith("waypoints") else ((8, 1), (1, 1))     # (lanes per env, waves per SIMD of the 8-lane build)
+    for lanes, waves in modes:
+        os.environ["FWSIM_LANES_PER_ENV"] = str(lanes); os.environ["FWSIM_G8_WAVES"] = str(waves)
         e = P.FixedwingVecEnv(CFG[which](), n, seed=42); e.reset_tensor()
         g = torch.Generator().manual_seed(0)
         acts = [(torch.rand((n, 4), generator=g, dtype=torch.float64) * 2 - 1).cuda() for _ in range(4)]
@@ -20,5 +22,5 @@ for n in map(int, sys.argv[2:]):
         for i in range(20): e.step_tensor(acts[i % 4])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 20
-        print(f"{which} N={n} lanes={lanes}: {dt*1e6:.1f} us/step  {n/dt/1e6:.1f} M env-steps/s", flush=True)
+        print(f"{which} N={n} lanes={lanes} waves/SIMD={waves if lanes == 8 else 2}: {dt*1e6:.1f} us/step  {n/dt/1e6:.1f} M env-steps/s", flush=True)
         e.close(); del e
