@@ -383,7 +383,7 @@ def main():
                 e2.step_tensor(a2)
             s1.record(); torch.cuda.synchronize()
             us = s0.elapsed_time(s1) * 1e3 / sreps
-            print(f"[sweep] N=2^{p}={m}: lanes/env {e2.lanes_per_env}, {us:.1f} us/launch, {m / us:.1f} M env-steps/s, "
+            print(f"[sweep] N=2^{p}={m}: lanes/env {e2.lanes_per_env} (waves/SIMD {e2.g8_waves if e2.lanes_per_env == 8 else 2}), {us:.1f} us/launch, {m / us:.1f} M env-steps/s, "
                   f"{task_words * word * m / us / 1e3:.1f} GB/s algorithmic", file=sys.stderr, flush=True)
             e2.close()
 
@@ -433,7 +433,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{task_name}, "
                                    f"{n} envs/GPU x {world} GPU, physics-only step(), motor noise + auto-reset on",
-                       "envs_per_gpu": n, "obs_dim": env.obs_dim, "ticks_per_env_step": 8, "lanes_per_env": env.lanes_per_env,
+                       "envs_per_gpu": n, "obs_dim": env.obs_dim, "ticks_per_env_step": 8, "lanes_per_env": env.lanes_per_env, "waves_per_simd": (env.g8_waves if env.lanes_per_env == 8 else 2),
                        "launch": stepper.describe(timed), "timing": f"median of {reps} regions of {args.steps} launches, each between barrier + synchronize",
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

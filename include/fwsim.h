@@ -461,9 +461,42 @@ int32_t fw_collect_stats(const void* obs, int32_t obs_is_f64, int32_t N, int32_t
                          double* returns, double* ret_mean, double* ret_var, double* ret_count, int32_t update_ret, double gamma,
                          uint64_t* rng, void* workspace, double* obs_acc, double* ret_acc, void* hip_stream);
 
+/* The same collection in ONE launch per vec-step: the policy / value forward of step t (fw_collect_act's work, by "act waves" at
+ * the front of the grid), the env step (fw_step's waves, which wait for their actions inside the launch) and the statistics
+ * of VecNormalize.step_wait (fw_collect_stats' work, folded by the last step waves).  Semantics and arithmetic are those of
+ * fw_collect_act -> fw_step -> fw_collect_stats called with the same buffers: `obs`, `reward`, `terminated`, `truncated`,
+ * `terminal_obs` hold the PREVIOUS step on entry (obs = the observation to act on) and this step on return; rew_out /
+ * start_out (both or neither) receive the finalisation of the previous step; (obs_mean, obs_var, obs_count) and the
+ * return statistics are read at entry and updated at the end.  Serves handles on the 8-lanes-per-env mapping at one wave per
+ * SIMD (FW_EUNSUPPORTED otherwise: use the three calls).  workspace: caller-owned, fw_collect_step_workspace_bytes(h) bytes,
+ * zero-initialised once; its last word block holds a status word that stays 0 (bit 0: a step wave gave up waiting for its
+ * actions -- never expected). */
+typedef struct fw_collect_args {
+  const float* params;                     /* flat parameter image (fw_ppo_update layout) */
+  double *obs_mean, *obs_var, *obs_count;  /* VecNormalize observation statistics (in/out) */
+  double *returns;                         /* [N] discounted-return tracker (in/out) */
+  double *ret_mean, *ret_var, *ret_count;  /* its running statistics (in/out) */
+  double *obs_acc, *ret_acc;               /* sharded jobs: batch-sum accumulators (may be NULL) */
+  uint64_t* rng;                           /* [2] seed, draw counter (advanced by one) */
+  float *obs_copy, *act_raw, *logp, *value;/* rollout-buffer rows of the step being acted (obs_copy may be NULL) */
+  void* act_env;                           /* T[N,4] the clipped actions the envs step with (scratch owned by the caller) */
+  float *rew_out, *start_out;              /* finalisation of the previous step: both or neither */
+  void *obs, *reward;                      /* env buffers, as fw_step (in: previous step, out: this step) */
+  uint8_t *terminated, *truncated;
+  void* terminal_obs;
+  int32_t* info_i32;                       /* may be NULL */
+  void* workspace; int64_t workspace_bytes;
+  double gamma;
+  float clip_obs, eps_obs, clip_reward, eps_reward;
+  int32_t update_obs, update_ret, norm_reward, deterministic;
+} fw_collect_args;
+int64_t fw_collect_step_workspace_bytes(fw_handle h);
+int32_t fw_collect_step(fw_handle h, const fw_collect_args* a, void* hip_stream);
+
 int32_t fw_num_envs(fw_handle h);
-/* Lanes of a wavefront that share one env in this handle's step kernels (8: latency mapping, 4 / 1: throughput mappings;
- * chosen by fw_create from the env count).  Diagnostic; results do not depend on it. */
+/* Lane mapping of this handle's step kernels: 8 = eight lanes of a wavefront share one env (latency mapping, one wave per SIMD),
+ * 16 = the same mapping built for two waves per SIMD (256 registers), 1 = one lane per env (throughput mapping); chosen by
+ * fw_create from the env count.  Diagnostic; results do not depend on it. */
 int32_t fw_lanes_per_env(fw_handle h);
 const char* fw_last_error(fw_handle h); /* h may be NULL: last create/validate error */
 int32_t fw_destroy(fw_handle h);

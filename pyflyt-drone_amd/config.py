@@ -245,6 +245,16 @@ def _angle_repr(angle_representation: str) -> int:
         f"angle_representation must be either `euler` or `quaternion`, not {angle_representation}")
 
 
+class FwCollectArgs(C.Structure):
+    """``fw_collect_args`` of include/fwsim.h (one-launch vec-step of the rollout collector)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("params", "obs_mean", "obs_var", "obs_count", "returns", "ret_mean", "ret_var", "ret_count",
+                                           "obs_acc", "ret_acc", "rng", "obs_copy", "act_raw", "logp", "value", "act_env", "rew_out",
+                                           "start_out", "obs", "reward", "terminated", "truncated", "terminal_obs", "info_i32", "workspace")]
+                + [("workspace_bytes", C.c_int64), ("gamma", C.c_double)]
+                + [(n, C.c_float) for n in ("clip_obs", "eps_obs", "clip_reward", "eps_reward")]
+                + [(n, C.c_int32) for n in ("update_obs", "update_ret", "norm_reward", "deterministic")])
+
+
 class FwScenario(C.Structure):
     """``fw_scenario`` of include/fwsim.h: host arrays of a caller-supplied scenario (NULL = keep the env's own draw)."""
     _fields_ = [("targets", C.c_void_p), ("duck_pos", C.c_void_p), ("obstacles", C.c_void_p), ("num_obstacles", C.c_void_p),

@@ -15,6 +15,7 @@
 #include "fwsim_rollout.hpp"
 #include "fwsim_ppo.hpp"
 #include "fwsim_collect.hpp"
+#include "fwsim_fused.hpp"
 #include "fwsim_objlock.hpp"
 #include "fwsim_render.hpp"
 
@@ -67,12 +68,12 @@ __global__ void fw_warm_kernel(Params<T>* Pm) {
 }
 
 // action shown in the observation: src 0 = this step's input, 1 = stored (stale), 2 = zeros
-template <typename T>
+template <typename T, bool COH = false>
 __device__ __forceinline__ void load_action(const DevState<T>& D, const T* actions, int env, int src, T a[4]) {
   const T* ap = actions + (size_t)env * 4;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    T cur = ap[k], old = D.r[(size_t)(RF_ACTION + k) * D.npad + env];
+    T cur = COH ? ld_coherent(ap + k) : ap[k], old = D.r[(size_t)(RF_ACTION + k) * D.npad + env];
     a[k] = (src == 0) ? cur : (src == 1) ? old : (T)0;
   }
 }
@@ -254,12 +255,14 @@ enum Phase : int { PH_STEP = 0, PH_WARM = 1, PH_DONE = 2 };
 // WPE = waves per SIMD the instantiation is built for (G = 8 only): 1 = the whole register file (359 registers: shared tick
 // constants resident in VGPRs), 2 = capped at 256 registers so that two waves share a SIMD -- the constants then stay
 // wave-uniform (scalar loads); used between 8 192 and 65 536 envs, where the 1-wave build would run its waves in two rounds.
-template <typename T, bool GENERAL, int G, int TKIND, int WPE = 1>
+// COLLECT = the step waves of fw_collect_step (fwsim_fused.hpp): block indices are offset by the act waves in front, the
+// actions are waited for and read coherently, and the epilogue carries the statistics of VecNormalize.step_wait.
+template <typename T, bool GENERAL, int G, int TKIND, int WPE = 1, bool COLLECT = false>
 __device__ __forceinline__
 void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> Dg,
                const T* __restrict__ actions, T* __restrict__ obs, T* __restrict__ reward,
                uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated, T* __restrict__ terminal_obs,
-               int32_t* __restrict__ info) {
+               int32_t* __restrict__ info, const CollectArgs* __restrict__ CAp = nullptr) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
   const Params<T>& P = *Pp;
@@ -278,10 +281,11 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   // consecutive workgroups are dealt round-robin to the 8 XCDs, whose L2s are private -- with the identity map both
   // halves of every line are fetched by two different L2s (PMC: 2x the algorithmic read traffic).  Give each XCD a
   // contiguous range of env blocks instead.  (Speed only: nothing depends on where a block really lands.)
-  const int wg = (int)blockIdx.x % nblk;
+  const int bx = (int)blockIdx.x - (COLLECT ? CAp->n_act : 0);       // my index among the step (+ worker) workgroups
+  const int wg = bx % nblk;
   const int blk = (G == 8 && (nblk & 7) == 0) ? (wg & 7) * (nblk >> 3) + (wg >> 3) : wg;
   const DevState<T> D = tile_view<T, EPW>(Dg, blk);  // this wave's tile: row stride EPW (a compile-time constant), global env ids
-  if ((GENERAL || DEFER) && (int)blockIdx.x >= nblk) {
+  if ((GENERAL || DEFER) && bx >= nblk) {
     if (GENERAL) shadow_worker<T, G, TKIND>(Pp, OCp, D, blk); else scenario_worker<T, G>(Pp, D, blk);
     FWP(if (D.prof && threadIdx.x == 0) {
       long long* w = D.prof + ((size_t)(D.epoch % kProfSlots) * 2 * nblk + blockIdx.x) * kProfWords;
@@ -317,7 +321,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
 #pragma unroll
       for (int k = 0; k < 3; ++k) tmine[k] = D.r[(size_t)(RF_TARGETS + 3 * sub + k) * n + envc];
     }
-    a_keep = actions[(size_t)envc * 4 + (sub & 3)];
+    if (!COLLECT) a_keep = actions[(size_t)envc * 4 + (sub & 3)];
   }
   Rigid<T> S;
   load_rigid<T>(D, envc, S);
@@ -348,9 +352,18 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   // fixedwing_base_env.py:325-331
   T rew = (T)-0.1;
   T cmd[FW_NUM_ACTUATORS];
+  // COLLECT: the actions of this launch come from the act waves in front of the grid; everything above was loaded while they
+  // worked.  Coherent loads from here on: the rows were written (write-through) by a wave of another XCD in this same launch.
+  if (COLLECT) {
+    collect_wait_actions(*CAp, Dg.epoch, env0, min(EPW, Dg.n - env0));
+    if (LANE_T) a_keep = ld_coherent(actions + (size_t)envc * 4 + (sub & 3));
+  }
   {
     const T* ap = actions + (size_t)envc * 4;
-    const T sp[4] = { ap[0], ap[1], ap[2], ap[3] * (T)0.5 + (T)0.5 };
+    T a4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a4[k] = COLLECT ? ld_coherent(ap + k) : ap[k];
+    const T sp[4] = { a4[0], a4[1], a4[2], a4[3] * (T)0.5 + (T)0.5 };
 #pragma unroll
     for (int c = 0; c < FW_NUM_ACTUATORS; ++c)
       cmd[c] = P.mixer[c][0] * sp[0] + P.mixer[c][1] * sp[1] + P.mixer[c][2] * sp[2] + P.mixer[c][3] * sp[3];
@@ -393,6 +406,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   if (pre_noise && !done_at_entry) rng_normal2<T>(P, genv, (uint32_t)episode, astep0 + (uint32_t)sub, nz0, nz1);
 
   int phase = active ? PH_STEP : PH_DONE;
+  double* latch = COLLECT ? reinterpret_cast<double*>(smem_raw + CAp->latch_off) : nullptr;     // COLLECT: [EPW][2] reward, done of this step
   int it = 0, warm_left = 0;
   bool resetting = false;                            // DEFER: auto-reset pending for the epilogue
   bool step_over = active && done_at_entry;          // nothing to simulate: finalise immediately
@@ -406,6 +420,8 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       step_count += 1;
       ep_return += rew;
       phase = PH_DONE;
+      // for the statistics tail: parked in LDS (two words per env behind the tile), not in registers across the rest of the loop
+      if (COLLECT && leader) { latch[2 * row] = (double)rew; latch[2 * row + 1] = (flags & (FL_TERM | FL_TRUNC)) ? 1.0 : 0.0; }
       // the outputs of the step leave for memory here (nothing is kept live across the rest of the loop for them)
       if (leader) {
         reward[env] = rew;
@@ -429,7 +445,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
         if (terminal_obs && leader) {
           T* trow = terminal_obs + (size_t)env * Dobs;
           T act_t[4];
-          load_action<T>(D, actions, env, act_src, act_t);
+          load_action<T, COLLECT>(D, actions, env, act_src, act_t);
           if (OBJ) obj_write_obs<T>(P, O, S, act_t, [&](int k, T v) { trow[k] = v; });
           else if (COMB) comb_write_obs<T>(P, D, env, O, S, act_t, tgt_obs, [&](int k, T v) { trow[k] = v; });
           else write_obs<T>(P, D, env, S, act_t, tgt_obs, [&](int k, T v) { trow[k] = v; });
@@ -661,7 +677,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       o += 3;
     }
   } else if (active && leader) {
-    load_action<T>(D, actions, env, act_src, act_obs);
+    load_action<T, COLLECT>(D, actions, env, act_src, act_obs);
     if (OBJ) obj_write_obs<T>(P, O, S, act_obs, [&](int k, T v) { tile[row * ld + k] = v; });
     else if (COMB) comb_write_obs<T>(P, D, env, O, S, act_obs, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
     else write_obs<T>(P, D, env, S, act_obs, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
@@ -775,6 +791,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   }
   __syncthreads();
   flush_obs_tile<T>(tile, ld, obs, env0, EPW, D.n, Dobs);
+  if (COLLECT) collect_stats_tail<T>(*CAp, tile, ld, min(EPW, D.n - env0), wg, nblk, active && leader, row, latch[2 * row], latch[2 * row + 1] != 0.0, env);
   FWP(long long p_capmax = HASOBJ ? O.p_cap : 0; const int p_ncapw = HASOBJ ? __popcll(__ballot(leader && O.p_ncap > 0)) : 0;)
   FWP(if (D.prof) {
     for (int o = 32; o > 0; o >>= 1) p_capmax = max(p_capmax, (long long)__shfl_xor((long long)p_capmax, o, kWave));
@@ -819,6 +836,27 @@ template <typename T, int TKIND>
 __global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g8(FW_STEP_ARGS) { FW_STEP_RUN(T, true, 8, TKIND); }
 template <typename T, int TKIND>
 __global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g1(FW_STEP_ARGS) { FW_STEP_RUN(T, true, 1, TKIND); }
+
+// fw_collect_step (fwsim_fused.hpp): act waves in front, then the step waves of the same step kernels with COLLECT on.  The
+// 8-lane mapping at one wave per SIMD only (the collector's regime: thousands of envs per GPU).
+#define FW_COLLECT_RUN(...) do {                                                                                       \
+    if ((int)blockIdx.x < CA.n_act) {                                                                                  \
+      /* launch index = the word of a step workgroup of MY chunk: it cannot finish (and advance its word) before I publish */ \
+      const int nblk_ = (D.npad + 7) / 8, c_ = min((int)blockIdx.x >> 1, CA.n_chunks - 1);                              \
+      const int blk_ = min(c_ * kCRows / 8, nblk_ - 1);                                                                 \
+      const int wg_ = ((nblk_ & 7) == 0) ? (blk_ % (nblk_ >> 3)) * 8 + blk_ / (nblk_ >> 3) : blk_;   /* inverse of the XCD-aware map */ \
+      collect_act_wave(CA, 1u + D.lctr[wg_]);                                                                          \
+      return;                                                                                                           \
+    }                                                                                                                   \
+    const int bx_ = (int)blockIdx.x - CA.n_act;                                                                         \
+    D.epoch = 1u + D.lctr[bx_];                                                                                         \
+    step_body<__VA_ARGS__>(FW_STEP_PASS, &CA);                                                                          \
+    if (threadIdx.x == 0) D.lctr[bx_] = D.epoch;                                                                        \
+  } while (0)
+template <typename T, bool GENERAL>
+__global__ __launch_bounds__(kWave) void fw_collect_kernel_g8(FW_STEP_ARGS, const CollectArgs CA) { FW_COLLECT_RUN(T, GENERAL, 8, FW_TASK_WAYPOINTS, 1, true); }
+template <typename T, int TKIND>
+__global__ __launch_bounds__(kWave) void fw_collect_kernel_obj_g8(FW_STEP_ARGS, const CollectArgs CA) { FW_COLLECT_RUN(T, true, 8, TKIND, 1, true); }
 
 // Caller-supplied scenario of the episodes a fw_reset starts (fw_scenario, uploaded to device memory by the host side;
 // doubles indexed by the handle's local env, null = keep the env's own draw).
@@ -985,7 +1023,6 @@ void fw_reset_kernel(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict
 // ======================================================================
 namespace {
 
-constexpr int kG8OneWaveMaxEnvs = 8192;   // 1024 SIMDs x 8 envs per wave: above, the one-wave-per-SIMD build needs a second round
 constexpr int kG8MaxEnvs = 16384;   // measured crossover on MI355X: 8 lanes/env wins up to 2^14 envs (51 vs 70 us), loses at 2^15 (93 vs 76 us)
 thread_local std::string g_err;
 
@@ -1444,6 +1481,53 @@ int ensure_learner_lds(int dev, int which, size_t bytes) {
 }
 }  // namespace
 
+// ---- fw_collect_step: one launch per vec-step (fwsim_fused.hpp) ----
+namespace {
+struct CollectWs { size_t part1, part2, flag_p, flag_v, tk, status, total; };
+CollectWs collect_ws(const fw_env* h) {
+  const size_t PW = 2 * (size_t)obs_dim_of(&h->cfg) + 2, nblk = (size_t)h->npad / 8, nch = ((size_t)h->n + kCRows - 1) / kCRows;
+  CollectWs w; size_t o = 0;
+  w.part1 = o; o += sizeof(double) * nblk * PW;
+  w.part2 = o; o += sizeof(double) * kCGroups * PW;
+  w.flag_p = o; o += sizeof(unsigned int) * nch;
+  w.flag_v = o; o += sizeof(unsigned int) * nch;
+  w.tk = o; o += sizeof(unsigned int) * 16;
+  w.status = o; o += sizeof(unsigned int) * 16;
+  w.total = (o + 255) & ~(size_t)255;
+  return w;
+}
+template <typename T>
+int collect_step_T(fw_env* h, CollectArgs& CA, const void* actions, void* obs, void* reward, uint8_t* term, uint8_t* trunc, void* tobs,
+                   int32_t* info, hipStream_t st) {
+  const size_t latch_off = (tile_bytes<T>(h) + 15) & ~(size_t)15;
+  const size_t lds = std::max(latch_off + sizeof(double) * 2 * (kWave / 8), collect_act_lds_bytes(CA.A.D));
+  if (lds > 160 * 1024) { h->err = "fw_collect_step: the networks do not fit the LDS next to the step kernel's tile"; return FW_EINVAL; }
+  const void* fn = h->cfg.task == FW_TASK_OBJLOCK ? (const void*)fw_collect_kernel_obj_g8<T, FW_TASK_OBJLOCK>
+                 : h->cfg.task == FW_TASK_WAYPOINT_OBJLOCK ? (const void*)fw_collect_kernel_obj_g8<T, FW_TASK_WAYPOINT_OBJLOCK>
+                 : h->cfg.wind_mode != FW_WIND_OFF ? (const void*)fw_collect_kernel_g8<T, true> : (const void*)fw_collect_kernel_g8<T, false>;
+  if (lds > 48 * 1024) {                       // opt in once per (device, kernel, size class): only ever raised
+    static size_t have[64][8] = {};
+    const int which = (h->cfg.task == FW_TASK_OBJLOCK ? 0 : h->cfg.task == FW_TASK_WAYPOINT_OBJLOCK ? 1 : h->cfg.wind_mode != FW_WIND_OFF ? 2 : 3) + (sizeof(T) == 8 ? 0 : 4);
+    if (h->device < 64 && lds > have[h->device][which]) {
+      HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      have[h->device][which] = lds;
+    }
+  }
+  CA.latch_off = (int32_t)latch_off;
+  dim3 grid((unsigned)CA.n_act + grid_of(h).x * (h->shadow_on ? 2u : 1u));
+#define FW_LAUNCH_COLLECT(KERNEL)                                                                                  \
+  hipLaunchKernelGGL((KERNEL), grid, dim3(kWave), lds, st, (const Params<T>*)h->params_dev, (const ObjC<T>*)h->objc_dev, \
+                     dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term, trunc, (T*)tobs, info, CA)
+  if (h->cfg.task == FW_TASK_OBJLOCK) FW_LAUNCH_COLLECT((fw_collect_kernel_obj_g8<T, FW_TASK_OBJLOCK>));
+  else if (h->cfg.task == FW_TASK_WAYPOINT_OBJLOCK) FW_LAUNCH_COLLECT((fw_collect_kernel_obj_g8<T, FW_TASK_WAYPOINT_OBJLOCK>));
+  else if (h->cfg.wind_mode != FW_WIND_OFF) FW_LAUNCH_COLLECT((fw_collect_kernel_g8<T, true>));
+  else FW_LAUNCH_COLLECT((fw_collect_kernel_g8<T, false>));
+  HIP_TRY(h, hipGetLastError());
+  return FW_OK;
+}
+}  // namespace
+
+
 // ======================================================================
 // C ABI
 // ======================================================================
@@ -1473,25 +1557,34 @@ int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64
   if (!h) return FW_ENOMEM;
   h->cfg = *cfg; h->n = num_envs; h->npad = (num_envs + kWave - 1) / kWave * kWave;
   h->device = device; h->seed = seed; h->env_offset = global_env_offset;
-  // Lane mapping: below ~1 wave per SIMD of env-per-lane work, split each env over 8 lanes
-  // (512 waves for 4096 envs) -- latency-bound regime; above, one lane per env.
-  // FWSIM_LANES_PER_ENV=1|8 overrides (used by the benchmark sweep).
+  // Lane mapping, by measured crossover (tools/crossover.py, profiles/r03_crossover.txt; us per step, fp64):
+  //   wind-free waypoints   N:  8192  12288  16384  24576  32768  65536       waypoints + wind   N:  8192  16384  32768
+  //     8 lanes, 1 wave/SIMD    26.6   44.4   47.7   66.9   88.8  167.2                                50.1   74.9  137.5
+  //     8 lanes, 2 waves/SIMD   29.2   37.5   40.6   58.6   70.9   (*)                                 43.1   80.8  137.7
+  //     1 lane                  57.5   58.4   60.5   66.8   67.4   87.0                                64.8   67.8   80.7
+  //   8 lanes per env split an env's five lifting surfaces over lanes (latency mapping: 4096 envs are 512 waves instead of
+  //   64); its full-register-file build holds ONE wave per SIMD, so above 8192 envs (1024 waves) a second round starts -- there
+  //   the build capped at 256 registers (two waves per SIMD) takes over, and one lane per env above that.  The wind kernels
+  //   run as many worker waves again, which halves their thresholds.  (*) never: with > 8192 waves its scratch throttles the
+  //   dispatch (4 ms per launch measured).
+  // FWSIM_LANES_PER_ENV=1|8 and FWSIM_G8_WAVES=1|2 override (parity tests, the benchmark sweep).
   // Camera tasks with obstacles stay on the 8-lane mapping at every size: there the cylinders are drawn by the wave from LDS
   // work lists; one lane per env tests every pixel against every cylinder (combined, 20 cylinders: 330 us vs 7.8 ms per
-  // step at 32 768 envs, tools/crossover.py).
+  // step at 32 768 envs).
   const bool cyl_camera = cfg->task != FW_TASK_WAYPOINTS && cfg->num_obstacles > 0;
-  h->lanes_per_env = ((num_envs <= kG8MaxEnvs || cyl_camera) && cfg->num_targets <= 8 && cfg->n_collision_pts <= 8) ? 8 : 1;
+  const bool wp = cfg->task == FW_TASK_WAYPOINTS, windy = wp && cfg->wind_mode != FW_WIND_OFF;
+  const int one_wave_max = windy ? 4096 : 8192;                 // largest N the one-wave-per-SIMD build serves in a single round
+  const int g8_max = !wp ? kG8MaxEnvs : (windy ? 8192 : 24576);
+  const bool fits8 = cfg->num_targets <= 8 && cfg->n_collision_pts <= 8;
+  h->lanes_per_env = ((num_envs <= g8_max || cyl_camera) && fits8) ? 8 : 1;
   if (const char* ev = getenv("FWSIM_LANES_PER_ENV")) {
     int v = atoi(ev);
-    if (v == 1 || (v == 8 && cfg->num_targets <= 8 && cfg->n_collision_pts <= 8)) h->lanes_per_env = v;
+    if (v == 1 || (v == 8 && fits8)) h->lanes_per_env = v;
   }
-  // 8-lane mapping of the waypoints kernels above kG8OneWaveMaxEnvs envs: the build capped at 256 registers, two waves per
-  // SIMD (the full-file build holds one, so N = 16 384 ran as two rounds of 1024 waves: the 8 k -> 16 k cliff).
-  // FWSIM_G8_WAVES=1|2 overrides.
-  h->g8_waves = (h->lanes_per_env == 8 && cfg->task == FW_TASK_WAYPOINTS && num_envs > kG8OneWaveMaxEnvs) ? 2 : 1;
+  h->g8_waves = (h->lanes_per_env == 8 && wp && num_envs > one_wave_max && num_envs <= 32768) ? 2 : 1;
   if (const char* ev = getenv("FWSIM_G8_WAVES")) {
     int v = atoi(ev);
-    if ((v == 1 || v == 2) && h->lanes_per_env == 8 && cfg->task == FW_TASK_WAYPOINTS) h->g8_waves = v;
+    if ((v == 1 || (v == 2 && num_envs <= 32768)) && h->lanes_per_env == 8 && wp) h->g8_waves = v;
   }
   DeviceGuard g(device);
   rc = (cfg->dtype == FW_F64) ? create_T<double>(h) : create_T<float>(h);
@@ -1763,6 +1856,50 @@ int32_t fw_collect_act(const float* params, const void* raw_obs, int32_t obs_is_
   return FW_OK;
 }
 
+int64_t fw_collect_step_workspace_bytes(fw_handle h) { return h ? (int64_t)collect_ws(h).total : FW_EINVAL; }
+
+int32_t fw_collect_step(fw_handle h, const fw_collect_args* a, void* hip_stream) {
+  if (!h || !a) return FW_EINVAL;
+  if (h->lanes_per_env != 8 || h->g8_waves != 1) {
+    h->err = "fw_collect_step serves the 8-lanes-per-env mapping at one wave per SIMD (<= 8192 envs per GPU; <= 4096 with wind); use fw_collect_act / fw_step / fw_collect_stats";
+    return FW_EUNSUPPORTED;
+  }
+  const int D = obs_dim_of(&h->cfg), N = h->n;
+  if (D > 64) { h->err = "fw_collect_step: obs_dim must be <= 64"; return FW_EINVAL; }
+  if (!a->params || !a->obs_mean || !a->obs_var || !a->obs_count || !a->returns || !a->ret_mean || !a->ret_var || !a->ret_count ||
+      !a->act_raw || !a->act_env || !a->logp || !a->value || !a->obs || !a->reward || !a->terminated || !a->truncated || !a->terminal_obs ||
+      (!a->deterministic && !a->rng) || (!a->rew_out != !a->start_out)) { h->err = "fw_collect_step: missing buffers"; return FW_EINVAL; }
+  const CollectWs W = collect_ws(h);
+  if (!a->workspace || a->workspace_bytes < (int64_t)W.total) { h->err = "fw_collect_step: workspace smaller than fw_collect_step_workspace_bytes()"; return FW_EINVAL; }
+  DeviceGuard g(h->device);
+  const int f64 = h->cfg.dtype == FW_F64;
+  CollectArgs CA;
+  std::memset(&CA, 0, sizeof CA);
+  CA.n_chunks = (N + kCRows - 1) / kCRows;
+  CA.n_act = (2 * CA.n_chunks + 7) & ~7;
+  ActArgs& A = CA.A;
+  A.params = a->params; A.N = N; A.D = D; A.nets = 3; A.deterministic = a->deterministic; A.act_is_f64 = f64;
+  A.rng = a->rng; A.env_offset = h->env_offset; A.obs_copy = a->obs_copy; A.act_raw = a->act_raw; A.act_env = a->act_env; A.logp = a->logp; A.value = a->value;
+  A.raw = a->obs; A.raw_is_f64 = f64; A.mean = a->obs_mean; A.var = a->obs_var; A.clip = a->clip_obs; A.eps = a->eps_obs;
+  if (a->rew_out) {
+    A.prev_reward = a->reward; A.prev_term = a->terminated; A.prev_trunc = a->truncated; A.prev_tobs = a->terminal_obs;
+    A.rew_out = a->rew_out; A.start_out = a->start_out;
+  }
+  A.ret_var = a->ret_var; A.norm_reward = a->norm_reward; A.clip_reward = a->clip_reward; A.rew_eps = a->eps_reward; A.gamma = (float)a->gamma;
+  StatsArgs& S = CA.S;
+  S.obs = a->obs; S.obs_is_f64 = f64; S.N = N; S.D = D; S.mean = a->obs_mean; S.var = a->obs_var; S.count = a->obs_count; S.update_obs = a->update_obs;
+  S.reward = a->reward; S.rew_is_f64 = f64; S.terminated = a->terminated; S.truncated = a->truncated; S.returns = a->returns;
+  S.ret_mean = a->ret_mean; S.ret_var = a->ret_var; S.ret_count = a->ret_count; S.update_ret = a->update_ret; S.gamma = a->gamma; S.rng = a->rng;
+  S.obs_acc = a->obs_acc; S.ret_acc = a->ret_acc;
+  char* ws = (char*)a->workspace;
+  CA.part1 = (double*)(ws + W.part1); CA.part2 = (double*)(ws + W.part2);
+  CA.flag_p = (unsigned int*)(ws + W.flag_p); CA.flag_v = (unsigned int*)(ws + W.flag_v);
+  CA.tk = (unsigned int*)(ws + W.tk); CA.status = (unsigned int*)(ws + W.status);
+  hipStream_t st = (hipStream_t)hip_stream;
+  return f64 ? collect_step_T<double>(h, CA, a->act_env, a->obs, a->reward, a->terminated, a->truncated, a->terminal_obs, a->info_i32, st)
+             : collect_step_T<float>(h, CA, a->act_env, a->obs, a->reward, a->terminated, a->truncated, a->terminal_obs, a->info_i32, st);
+}
+
 static int collect_stats_blocks(int N) { return N >= 64 * 64 ? 64 : (N + 63) / 64; }
 int64_t fw_collect_stats_workspace_bytes(int32_t D) { return D > 0 ? (int64_t)(sizeof(double) * 64 * (2 * (size_t)D + 2) + 64) : FW_EINVAL; }
 
@@ -1824,7 +1961,7 @@ int32_t fw_rollout_post(const void* reward, int32_t rew_is_f64, const uint8_t* t
 }
 
 int32_t fw_num_envs(fw_handle h) { return h ? h->n : FW_EINVAL; }
-int32_t fw_lanes_per_env(fw_handle h) { return h ? h->lanes_per_env : FW_EINVAL; }
+int32_t fw_lanes_per_env(fw_handle h) { return h ? (h->lanes_per_env == 8 && h->g8_waves == 2 ? 16 : h->lanes_per_env) : FW_EINVAL; }
 
 const char* fw_last_error(fw_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
 

@@ -659,12 +659,18 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
     // capture step lasts as long as its longest set).  Count, sum x, sum y are sums of integers and half-integers -- exact in
     // floating point, so LDS atomic adds in any order give the same bits; the nearest fragment is a max.
     const bool listed = duck_ok && !straddle && y1 >= y0;
-    if (vsub == 0) {
+    {
+      // No `if (vsub == 0)` here.  Every lane of the set takes part: the position in the list is claimed by an atomic whose
+      // operand is the set's row count in its first lane and 0 in the others, the first lane's result is handed round, and all
+      // lanes store the same words.  (A leader-only branch made hipcc 7.2 save registers that are live across the row loop at
+      // the top of its join block -- ahead of the exec restore, i.e. for the leader only: the hazard tools/check_isa.py guards
+      // against showed up at this very join in three different builds.)
       T* sc = sconst_all + erow * kSetWords;
-      int base = 0;
-      if (listed) base = (int)__hip_atomic_fetch_add(lu + 2, (uint32_t)(y1 - y0 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t claim = (vsub == 0 && listed) ? (uint32_t)(y1 - y0 + 1) : 0u;
+      int base = (int)__hip_atomic_fetch_add(lu + 2, claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      base = __shfl(base, (int)(threadIdx.x & (kWave - 1)) - vsub, kWave);
       sc[10] = zc; sc[11] = xc; sc[12] = yc; sc[13] = k2; sc[14] = A; sc[15] = iA; sc[16] = (T)y0;
-      sc[17] = listed ? (T)(y1 - y0 + 1) : (T)0; sc[18] = (T)base;
+      sc[17] = listed ? (T)(y1 - y0 + 1) : (T)0; sc[18] = listed ? (T)base : (T)0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const int total_rows = (int)lu[2];

@@ -504,6 +504,7 @@ class PPOConfig:
     use_graphs: bool = True                # replay the rollout / minibatch update as hipGraphs (single-GPU, device envs)
     fused_update: bool = True              # run the whole minibatch sequence of train() in one HIP kernel (fw_ppo_update) when it applies
     fused_collect: bool = True             # policy forward / sampling / buffer writes and the reward path as fw_policy_act + fw_rollout_post
+    one_launch_collect: bool = True        # ... and, where the env's lane mapping has it, the whole vec-step as ONE launch (fw_collect_step)
     detector: str = "none"                 # "cnn": CnnDetectorPolicy over the FPV render (fw_render) of a camera task -- torch path, gradient all-reduce
     image_res: int = 32                    #        side of the rendered image
     cnn_features: int = 32                 #        width of the extractor's output
@@ -683,6 +684,11 @@ class PPO:
             self._rng = torch.tensor([cfg.seed * 7919 + 17, 0], dtype=torch.int64, device=self.device)      # seed, draw counter
             self._act_env = torch.zeros((env.num_envs, 4), dtype=env.venv.torch_dtype, device=self.device)
             self._tval = torch.zeros(env.num_envs, dtype=torch.float32, device=self.device)
+        # one launch per vec-step (fw_collect_step) where the handle's lane mapping has it: 8 lanes per env at one wave per SIMD
+        self._one_launch = (self._collect_fused and bool(cfg.one_launch_collect) and hasattr(env.venv, "_h")
+                            and getattr(env.venv, "lanes_per_env", 0) == 8 and getattr(env.venv, "g8_waves", 1) == 1
+                            and float(env.gamma) == float(cfg.gamma))
+        self._ws_collect = None
         self._warm_rollouts = 0
         self._gathered = None
         self.allgather_ms = self.allgather_bytes = 0.0
@@ -781,7 +787,36 @@ class PPO:
                                         int(getattr(venv, "global_env_offset", 0)), bo, ba, _p(self._act_env),
                                         int(self._act_env.dtype == torch.float64), bl, _p(value_out), *prev, st))
 
-        for t in range(T):
+        if self._one_launch:
+            # ONE launch per vec-step (fw_collect_step): act waves, the env's step waves and the statistics fold share a grid
+            from . import config as K
+            if self._ws_collect is None:
+                nb = int(L.fw_collect_step_workspace_bytes(venv._h))
+                self._ws_collect = torch.zeros((nb + 7) // 8, dtype=torch.float64, device=self.device)      # zeroed once, caller-owned
+            upd_obs = int(env.training and env.norm_obs)
+            for t in range(T):
+                a = K.FwCollectArgs()
+                a.params = self._fused.flat.data_ptr()
+                a.obs_mean, a.obs_var, a.obs_count = env.obs_rms.mean.data_ptr(), env.obs_rms.var.data_ptr(), env.obs_rms.count.data_ptr()
+                a.returns = env.returns.data_ptr()
+                a.ret_mean, a.ret_var, a.ret_count = env.ret_rms.mean.data_ptr(), env.ret_rms.var.data_ptr(), env.ret_rms.count.data_ptr()
+                a.obs_acc = env._obs_acc.data_ptr() if (upd_obs and env._obs_acc is not None) else None
+                a.ret_acc = env._ret_acc.data_ptr() if (track and env._ret_acc is not None) else None
+                a.rng = self._rng.data_ptr()
+                a.obs_copy, a.act_raw, a.logp, a.value = (self.buf_obs[t].data_ptr(), self.buf_act[t].data_ptr(), self.buf_logp[t].data_ptr(),
+                                                          self.buf_val[t].data_ptr())
+                a.act_env = self._act_env.data_ptr()
+                if t > 0:                                        # the value waves finalise step t - 1 while its outputs are still in the env's buffers
+                    a.rew_out, a.start_out = self.buf_rew[t - 1].data_ptr(), self.buf_start[t].data_ptr()
+                a.obs, a.reward = venv.obs.data_ptr(), venv.rewards.data_ptr()
+                a.terminated, a.truncated = venv.terminated.data_ptr(), venv.truncated.data_ptr()
+                a.terminal_obs, a.info_i32 = venv.terminal_obs.data_ptr(), venv.info.data_ptr()
+                a.workspace, a.workspace_bytes = self._ws_collect.data_ptr(), self._ws_collect.numel() * 8
+                a.gamma = float(cfg.gamma)
+                a.clip_obs, a.eps_obs, a.clip_reward, a.eps_reward = float(env.clip_obs), float(env.epsilon), float(env.clip_reward), float(env.epsilon)
+                a.update_obs, a.update_ret, a.norm_reward, a.deterministic = upd_obs, track, int(env.norm_reward), 0
+                _lib.check(L.fw_collect_step(venv._h, C.byref(a), st), venv._h)
+        for t in (range(T) if not self._one_launch else ()):
             act(t, 3, self.buf_val[t], t - 1 if t > 0 else None)
             venv.step_tensor(self._act_env)
             _lib.check(L.fw_collect_stats(_p(venv.obs), f64, N, D, _p(env.obs_rms.mean), _p(env.obs_rms.var), _p(env.obs_rms.count),

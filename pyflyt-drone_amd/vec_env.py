@@ -125,6 +125,9 @@ class FixedwingVecEnv(_VecEnvBase):
         _lib.check(rc, None)
         self._h = h
         self.lanes_per_env = int(_lib.lib().fw_lanes_per_env(h))    # which lane mapping fw_create picked (diagnostic)
+        self.g8_waves = 2 if self.lanes_per_env == 16 else 1
+        if self.lanes_per_env == 16:                                # (16 = the 8-lane mapping built for two waves per SIMD)
+            self.lanes_per_env = 8
         n, d = self.num_envs, self.obs_dim
         kw = dict(device=dev)
         self.obs = torch.zeros((n, d), dtype=self.torch_dtype, **kw)

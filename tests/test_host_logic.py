@@ -251,10 +251,12 @@ _Z4kernv:
 .Lfunc_end0:
 """
     good = bad.replace("\tv_accvgpr_write_b32 a16, v208\n\ts_or_b64 exec, exec, s[0:1]", "\ts_or_b64 exec, exec, s[0:1]\n\tv_accvgpr_write_b32 a16, v208")
-    mfma = bad.replace("\tds_read_b32", "\tv_mfma_f32_32x32x2_f32 a[0:15], v0, v1, a[0:15]\n\tds_read_b32")
+    mfma = bad.replace("\tds_read_b32", "\tv_mfma_f32_32x32x2_f32 a[16:31], v0, v1, a[16:31]\n\tds_read_b32")      # a16 is an accumulator there
+    mfma_elsewhere = bad.replace("\tds_read_b32", "\tv_mfma_f32_32x32x2_f32 a[32:47], v0, v1, a[32:47]\n\tds_read_b32")   # a16 is still a spill slot
     staged = bad.replace("\tv_accvgpr_write_b32 a16, v208\n", "\tv_accvgpr_write_b32 a16, v208\n\tglobal_store_dwordx4 v[82:83], a[16:19], off offset:48\n")
     assert [h[1] for h in m.scan(bad)] == [".LBB0_2"]
     assert m.scan(good) == [] and m.scan(mfma) == [] and m.scan(staged) == []
+    assert [h[1] for h in m.scan(mfma_elsewhere)] == [".LBB0_2"]      # an MFMA somewhere in the function does not switch the check off
 
 
 def test_isa_check_wants_a_vmcnt_wait_between_the_partial_stores_and_the_ticket():

@@ -649,5 +649,5 @@ def test_fw_create_picks_the_two_wave_build_between_8k_and_16k_envs(oracle, monk
     cfg = K.train_waypoints_v3_config()
     n = 16384
     hip, ora = P.FixedwingVecEnv(cfg, n, seed=42), oracle.OracleEnv(cfg, n, seed=42)
-    assert hip.lanes_per_env == 8
+    assert hip.lanes_per_env == 8 and hip.g8_waves == 2
     run_lockstep(hip, ora, 6, np.random.default_rng(0), kind="uniform", atol=1e-7, rtol=0)

@@ -1,6 +1,7 @@
 """GPU checks of the collector kernels (through the C ABI) and an end-to-end PPO run on the
 fused env -- configs[0]/[1] plumbing: the hyper-parameters of
 train/train_Fixedwing_Waypoints_v3.py:27-55 with n_steps scaled to the env count."""
+import ctypes as C
 import math
 
 import numpy as np
@@ -451,3 +452,50 @@ def test_fw_collect_act_normalises_on_load_and_finalises_the_previous_step():
     assert L.fw_collect_act(R._p(flat), R._p(raw), 1, n, d, R._p(mean), R._p(var), 10.0, 1e-8, 1, 0, R._p(rng), 512, R._p(oc1), R._p(ar1),
                             R._p(ae1), 1, R._p(lp1), None, R._p(rew), R._p(term), R._p(trunc), R._p(tobs), R._p(ret_var), 1, 10.0, 1e-8, 0.99,
                             R._p(rew1), R._p(st1), None) == K.FW_EINVAL           # finalisation needs the value block
+
+
+@pytest.mark.parametrize("task,n", [("waypoints", 4096), ("waypoints", 1000), ("objlock", 1024), ("combined", 520), ("waypoints_wind", 2048)])
+def test_one_launch_vec_step_equals_the_three_launch_collector(task, n):
+    """fw_collect_step (act waves + step waves + statistics fold in ONE grid) against fw_collect_act -> fw_step ->
+    fw_collect_stats on twin envs, through PPO.collect_rollouts (hipGraph replays included): the same actions, log-probs,
+    values, observations, rewards and episode starts in the rollout buffers, the same normaliser statistics (the fold order
+    differs: 1e-12), the env's hand-off counters agree, and no step wave ever gave up waiting for its actions."""
+    cfgs = {"waypoints": lambda: K.train_waypoints_v3_config(flight_dome_size=60.0, max_duration_seconds=6.0),
+            "waypoints_wind": lambda: K.train_waypoints_v3_config(wind_config=K.TRAIN_OBJLOCK_WIND, flight_dome_size=60.0, max_duration_seconds=6.0),
+            "objlock": lambda: K.train_objlock_config(max_duration_seconds=4.0), "combined": lambda: K.train_waypoint_objlock_config(max_duration_seconds=6.0)}
+    runs = {}
+    for one in (True, False):
+        env = P.FixedwingVecEnv(cfgs[task](), n, seed=21)
+        ppo = R.PPO(R.VecNormalizeDevice(env), R.PPOConfig(n_steps=8, batch_size=64, n_epochs=1, seed=3, one_launch_collect=one))
+        assert ppo._collect_fused and ppo._one_launch == one
+        bufs = []
+        for _ in range(5):                                     # eager, capture, three replays
+            ppo.collect_rollouts()
+            bufs.append([b.clone() for b in (ppo.buf_obs, ppo.buf_act, ppo.buf_logp, ppo.buf_val, ppo.buf_rew, ppo.buf_start, ppo.last_values, ppo.last_starts)])
+        torch.cuda.synchronize()
+        st = torch.cat([ppo.env.obs_rms.mean, ppo.env.obs_rms.var, ppo.env.obs_rms.count, ppo.env.ret_rms.mean.reshape(1), ppo.env.ret_rms.var.reshape(1),
+                        ppo.env.ret_rms.count, ppo.env.returns])
+        status = int(ppo._ws_collect.view(torch.int32)[-16:].abs().sum()) if one else 0
+        runs[one] = (bufs, st, env.get_counters(), env.get_state(), int(ppo._rng[1]), status)
+    (ba, sa, ca, xa, ra, status), (bb, sb, cb, xb, rb, _) = runs[True], runs[False]
+    assert status == 0, "a step wave's wait for its actions ran out"
+    assert ra == rb == 5 * 8
+    assert ca == cb and ca["resets"] > 0, (ca, cb)
+    torch.testing.assert_close(sa, sb, rtol=1e-11, atol=1e-11)
+    for it, (x, y) in enumerate(zip(ba, bb)):
+        for name, u, v in zip(("obs", "act", "logp", "val", "rew", "start", "last_values", "last_starts"), x, y):
+            torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-5, msg=lambda m: f"rollout {it} {name}: {m}")
+        assert torch.equal(x[5], y[5]) and torch.equal(x[7], y[7])
+    np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-9)      # the simulators end in the same state
+
+
+def test_fw_collect_step_refuses_the_mappings_it_does_not_serve(monkeypatch):
+    from pyflyt_drone_amd import _lib
+    monkeypatch.setenv("FWSIM_LANES_PER_ENV", "1")
+    env = P.FixedwingVecEnv(K.train_waypoints_v3_config(), 256, seed=1)
+    ppo = R.PPO(R.VecNormalizeDevice(env), R.PPOConfig(n_steps=4, batch_size=64, n_epochs=1))
+    assert ppo._collect_fused and not ppo._one_launch                  # falls back to the three-launch collector
+    a = K.FwCollectArgs()
+    assert _lib.lib().fw_collect_step(env._h, C.byref(a), None) == K.FW_EUNSUPPORTED
+    ppo.collect_rollouts()
+    assert float(ppo.env.obs_rms.count) == pytest.approx(1e-4 + 5 * 256)

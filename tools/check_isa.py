@@ -24,14 +24,23 @@ def scan(text):
         if not name.startswith("_Z"):
             continue
         lines = [l for l in fn.split("\n") if l.strip() and not re.match(r"\s*(\.loc|\.Ltmp|\.cfi|;|\.p2align)", l)]
-        # kernels with MFMA keep accumulators in AGPRs on purpose: a predicated v_accvgpr_write there is an assignment, not a spill
-        reloaded = set() if "v_mfma" in fn else set(re.findall(r"v_accvgpr_read_b32 v\d+, (a\d+)", fn))
+        # MFMA accumulators live in AGPRs on purpose: a predicated v_accvgpr_write to one of them is an assignment, not a spill.
+        # They are the AGPRs inside the operand ranges of the function's MFMAs; every other AGPR that is read back is a spill slot.
+        acc = set()
+        for ops in re.findall(r"v_mfma_\S+ ([^\n]*)", fn):
+            for lo, hi in re.findall(r"a\[(\d+):(\d+)\]", ops):
+                acc.update(f"a{i}" for i in range(int(lo), int(hi) + 1))
+        reloaded = set(re.findall(r"v_accvgpr_read_b32 v\d+, (a\d+)", fn)) - acc
         for n, l in enumerate(lines):
             if not re.match(r"\.LBB\d+_\d+:", l):
                 continue
             pre = []
             for x in lines[n + 1:n + 40]:
                 if re.match(r"\.LBB", x) or "s_cbranch" in x or "s_branch" in x or "s_endpgm" in x:
+                    break
+                # another exec change first (the else-half of an if / else, a nested region): what follows is a new divergent
+                # region whose stores are ordinary predicated assignments, not spills ahead of THIS block's restore
+                if re.search(r"saveexec|s_xor_b64 exec|s_andn2_b64 exec|s_mov_b64 exec", x):
                     break
                 if re.search(r"s_or_b64 exec, exec,", x):
                     spills = [p.strip() for p in pre
