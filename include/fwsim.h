@@ -463,14 +463,15 @@ int32_t fw_collect_stats(const void* obs, int32_t obs_is_f64, int32_t N, int32_t
 
 /* The same collection in ONE launch per vec-step: the policy / value forward of step t (fw_collect_act's work, by "act waves" at
  * the front of the grid), the env step (fw_step's waves, which wait for their actions inside the launch) and the statistics
- * of VecNormalize.step_wait (fw_collect_stats' work, folded by the last step waves).  Semantics and arithmetic are those of
- * fw_collect_act -> fw_step -> fw_collect_stats called with the same buffers: `obs`, `reward`, `terminated`, `truncated`,
- * `terminal_obs` hold the PREVIOUS step on entry (obs = the observation to act on) and this step on return; rew_out /
- * start_out (both or neither) receive the finalisation of the previous step; (obs_mean, obs_var, obs_count) and the
- * return statistics are read at entry and updated at the end.  Serves handles on the 8-lanes-per-env mapping at one wave per
- * SIMD (FW_EUNSUPPORTED otherwise: use the three calls).  workspace: caller-owned, fw_collect_step_workspace_bytes(h) bytes,
- * zero-initialised once; its last word block holds a status word that stays 0 (bit 0: a step wave gave up waiting for its
- * actions -- never expected). */
+ * of VecNormalize.step_wait.  Semantics and arithmetic are those of fw_collect_act -> fw_step -> fw_collect_stats called with the
+ * same buffers (statistics to ~1e-12: another summation order; normalised observations within an ulp of double before the
+ * float32 rounding): `obs`, `reward`, `terminated`, `truncated`, `terminal_obs` hold the PREVIOUS step on entry (obs = the
+ * observation to act on) and this step on return; rew_out / start_out (both or neither) receive the finalisation of the
+ * previous step.  The statistics of a step are folded by the NEXT fw_collect_step (which needs them first) -- or by
+ * fw_collect_finish: call it after the last step of a rollout, before anything else reads (obs_mean, obs_var, obs_count) /
+ * the return statistics.  Serves handles on the 8-lanes-per-env mapping at one wave per SIMD (FW_EUNSUPPORTED otherwise: use
+ * the three calls).  workspace: caller-owned, fw_collect_step_workspace_bytes(h) bytes, zero-initialised once; the uint32 at
+ * (workspace_bytes - 64 + 12) is a status word that stays 0 (a wave gave up waiting inside the launch -- never expected). */
 typedef struct fw_collect_args {
   const float* params;                     /* flat parameter image (fw_ppo_update layout) */
   double *obs_mean, *obs_var, *obs_count;  /* VecNormalize observation statistics (in/out) */
@@ -486,12 +487,14 @@ typedef struct fw_collect_args {
   void* terminal_obs;
   int32_t* info_i32;                       /* may be NULL */
   void* workspace; int64_t workspace_bytes;
+  void* trace;                             /* NULL, or device int64[(grid size) * 8]: per-workgroup wall-clock stamps (diagnostic, tools/trace_collect.py) */
   double gamma;
   float clip_obs, eps_obs, clip_reward, eps_reward;
   int32_t update_obs, update_ret, norm_reward, deterministic;
 } fw_collect_args;
 int64_t fw_collect_step_workspace_bytes(fw_handle h);
 int32_t fw_collect_step(fw_handle h, const fw_collect_args* a, void* hip_stream);
+int32_t fw_collect_finish(fw_handle h, const fw_collect_args* a, void* hip_stream);   /* statistics buffers, flags and workspace of `a` only */
 
 int32_t fw_num_envs(fw_handle h);
 /* Lane mapping of this handle's step kernels: 8 = eight lanes of a wavefront share one env (latency mapping, one wave per SIMD),

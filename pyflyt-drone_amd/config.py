@@ -250,7 +250,7 @@ class FwCollectArgs(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("params", "obs_mean", "obs_var", "obs_count", "returns", "ret_mean", "ret_var", "ret_count",
                                            "obs_acc", "ret_acc", "rng", "obs_copy", "act_raw", "logp", "value", "act_env", "rew_out",
                                            "start_out", "obs", "reward", "terminated", "truncated", "terminal_obs", "info_i32", "workspace")]
-                + [("workspace_bytes", C.c_int64), ("gamma", C.c_double)]
+                + [("workspace_bytes", C.c_int64), ("trace", C.c_void_p), ("gamma", C.c_double)]
                 + [(n, C.c_float) for n in ("clip_obs", "eps_obs", "clip_reward", "eps_reward")]
                 + [(n, C.c_int32) for n in ("update_obs", "update_ret", "norm_reward", "deterministic")])
 

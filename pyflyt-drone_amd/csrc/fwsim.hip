@@ -791,7 +791,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   }
   __syncthreads();
   flush_obs_tile<T>(tile, ld, obs, env0, EPW, D.n, Dobs);
-  if (COLLECT) collect_stats_tail<T>(*CAp, tile, ld, min(EPW, D.n - env0), wg, nblk, active && leader, row, latch[2 * row], latch[2 * row + 1] != 0.0, env);
+  if (COLLECT) collect_stats_tail<T>(*CAp, D.epoch, tile, ld, min(EPW, D.n - env0), wg, nblk, active && leader, latch[2 * row], latch[2 * row + 1] != 0.0, env);
   FWP(long long p_capmax = HASOBJ ? O.p_cap : 0; const int p_ncapw = HASOBJ ? __popcll(__ballot(leader && O.p_ncap > 0)) : 0;)
   FWP(if (D.prof) {
     for (int o = 32; o > 0; o >>= 1) p_capmax = max(p_capmax, (long long)__shfl_xor((long long)p_capmax, o, kWave));
@@ -848,10 +848,12 @@ __global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g1(FW_STEP_ARGS) { F
       collect_act_wave(CA, 1u + D.lctr[wg_]);                                                                          \
       return;                                                                                                           \
     }                                                                                                                   \
+    if (CA.trace && threadIdx.x == 0) CA.trace[(size_t)blockIdx.x * 8] = collect_now();                                 \
     const int bx_ = (int)blockIdx.x - CA.n_act;                                                                         \
     D.epoch = 1u + D.lctr[bx_];                                                                                         \
     step_body<__VA_ARGS__>(FW_STEP_PASS, &CA);                                                                          \
     if (threadIdx.x == 0) D.lctr[bx_] = D.epoch;                                                                        \
+    if (CA.trace && threadIdx.x == 0) CA.trace[(size_t)blockIdx.x * 8 + 7] = collect_now();                             \
   } while (0)
 template <typename T, bool GENERAL>
 __global__ __launch_bounds__(kWave) void fw_collect_kernel_g8(FW_STEP_ARGS, const CollectArgs CA) { FW_COLLECT_RUN(T, GENERAL, 8, FW_TASK_WAYPOINTS, 1, true); }
@@ -1483,17 +1485,17 @@ int ensure_learner_lds(int dev, int which, size_t bytes) {
 
 // ---- fw_collect_step: one launch per vec-step (fwsim_fused.hpp) ----
 namespace {
-struct CollectWs { size_t part1, part2, flag_p, flag_v, tk, status, total; };
+struct CollectWs { size_t part1, tot, flag_p, flag_v, sync, total; };
 CollectWs collect_ws(const fw_env* h) {
   const size_t PW = 2 * (size_t)obs_dim_of(&h->cfg) + 2, nblk = (size_t)h->npad / 8, nch = ((size_t)h->n + kCRows - 1) / kCRows;
   CollectWs w; size_t o = 0;
-  w.part1 = o; o += sizeof(double) * nblk * PW;
-  w.part2 = o; o += sizeof(double) * kCGroups * PW;
+  w.part1 = o; o += sizeof(double) * PW * kCGroups * ((nblk + kCGroups - 1) / kCGroups);
+  w.tot = o; o += sizeof(double) * 2 * PW;
   w.flag_p = o; o += sizeof(unsigned int) * nch;
   w.flag_v = o; o += sizeof(unsigned int) * nch;
-  w.tk = o; o += sizeof(unsigned int) * 16;
-  w.status = o; o += sizeof(unsigned int) * 16;
-  w.total = (o + 255) & ~(size_t)255;
+  o = (o + 63) & ~(size_t)63;
+  w.sync = o; o += sizeof(unsigned int) * 16;                 // the last 64 bytes of the workspace: CS_* words (status = word 3)
+  w.total = o;
   return w;
 }
 template <typename T>
@@ -1865,7 +1867,7 @@ int32_t fw_collect_step(fw_handle h, const fw_collect_args* a, void* hip_stream)
     return FW_EUNSUPPORTED;
   }
   const int D = obs_dim_of(&h->cfg), N = h->n;
-  if (D > 64) { h->err = "fw_collect_step: obs_dim must be <= 64"; return FW_EINVAL; }
+  if (D > 62) { h->err = "fw_collect_step: obs_dim must be <= 62"; return FW_EINVAL; }
   if (!a->params || !a->obs_mean || !a->obs_var || !a->obs_count || !a->returns || !a->ret_mean || !a->ret_var || !a->ret_count ||
       !a->act_raw || !a->act_env || !a->logp || !a->value || !a->obs || !a->reward || !a->terminated || !a->truncated || !a->terminal_obs ||
       (!a->deterministic && !a->rng) || (!a->rew_out != !a->start_out)) { h->err = "fw_collect_step: missing buffers"; return FW_EINVAL; }
@@ -1876,7 +1878,8 @@ int32_t fw_collect_step(fw_handle h, const fw_collect_args* a, void* hip_stream)
   CollectArgs CA;
   std::memset(&CA, 0, sizeof CA);
   CA.n_chunks = (N + kCRows - 1) / kCRows;
-  CA.n_act = (2 * CA.n_chunks + 7) & ~7;
+  CA.n_act = (2 * CA.n_chunks + 1 + 7) & ~7;                 // act waves + the merge wave, padded: the step waves keep their XCD alignment
+  CA.nblk = (int32_t)(h->npad / 8);
   ActArgs& A = CA.A;
   A.params = a->params; A.N = N; A.D = D; A.nets = 3; A.deterministic = a->deterministic; A.act_is_f64 = f64;
   A.rng = a->rng; A.env_offset = h->env_offset; A.obs_copy = a->obs_copy; A.act_raw = a->act_raw; A.act_env = a->act_env; A.logp = a->logp; A.value = a->value;
@@ -1892,12 +1895,33 @@ int32_t fw_collect_step(fw_handle h, const fw_collect_args* a, void* hip_stream)
   S.ret_mean = a->ret_mean; S.ret_var = a->ret_var; S.ret_count = a->ret_count; S.update_ret = a->update_ret; S.gamma = a->gamma; S.rng = a->rng;
   S.obs_acc = a->obs_acc; S.ret_acc = a->ret_acc;
   char* ws = (char*)a->workspace;
-  CA.part1 = (double*)(ws + W.part1); CA.part2 = (double*)(ws + W.part2);
+  CA.part1 = (double*)(ws + W.part1); CA.tot = (double*)(ws + W.tot);
   CA.flag_p = (unsigned int*)(ws + W.flag_p); CA.flag_v = (unsigned int*)(ws + W.flag_v);
-  CA.tk = (unsigned int*)(ws + W.tk); CA.status = (unsigned int*)(ws + W.status);
+  CA.sync = (unsigned int*)(ws + W.sync);
+  CA.trace = (long long*)a->trace;
   hipStream_t st = (hipStream_t)hip_stream;
   return f64 ? collect_step_T<double>(h, CA, a->act_env, a->obs, a->reward, a->terminated, a->truncated, a->terminal_obs, a->info_i32, st)
              : collect_step_T<float>(h, CA, a->act_env, a->obs, a->reward, a->terminated, a->truncated, a->terminal_obs, a->info_i32, st);
+}
+
+int32_t fw_collect_finish(fw_handle h, const fw_collect_args* a, void* hip_stream) {
+  if (!h || !a) return FW_EINVAL;
+  if (h->lanes_per_env != 8 || h->g8_waves != 1) { h->err = "fw_collect_finish: this handle's lane mapping has no fw_collect_step"; return FW_EUNSUPPORTED; }
+  if (!a->obs_mean || !a->obs_var || !a->obs_count || !a->ret_mean || !a->ret_var || !a->ret_count) { h->err = "fw_collect_finish: missing statistics buffers"; return FW_EINVAL; }
+  const CollectWs W = collect_ws(h);
+  if (!a->workspace || a->workspace_bytes < (int64_t)W.total) { h->err = "fw_collect_finish: workspace smaller than fw_collect_step_workspace_bytes()"; return FW_EINVAL; }
+  DeviceGuard g(h->device);
+  CollectArgs CA;
+  std::memset(&CA, 0, sizeof CA);
+  CA.n_chunks = (h->n + kCRows - 1) / kCRows; CA.nblk = (int32_t)(h->npad / 8);
+  StatsArgs& S = CA.S;
+  S.N = h->n; S.D = obs_dim_of(&h->cfg); S.mean = a->obs_mean; S.var = a->obs_var; S.count = a->obs_count; S.update_obs = a->update_obs;
+  S.ret_mean = a->ret_mean; S.ret_var = a->ret_var; S.ret_count = a->ret_count; S.update_ret = a->update_ret; S.obs_acc = a->obs_acc; S.ret_acc = a->ret_acc;
+  char* ws = (char*)a->workspace;
+  CA.part1 = (double*)(ws + W.part1); CA.tot = (double*)(ws + W.tot); CA.sync = (unsigned int*)(ws + W.sync);
+  hipLaunchKernelGGL(fw_collect_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, CA);
+  HIP_TRY(h, hipGetLastError());
+  return FW_OK;
 }
 
 static int collect_stats_blocks(int N) { return N >= 64 * 64 ? 64 : (N + 63) / 64; }

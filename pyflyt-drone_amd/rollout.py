@@ -504,7 +504,9 @@ class PPOConfig:
     use_graphs: bool = True                # replay the rollout / minibatch update as hipGraphs (single-GPU, device envs)
     fused_update: bool = True              # run the whole minibatch sequence of train() in one HIP kernel (fw_ppo_update) when it applies
     fused_collect: bool = True             # policy forward / sampling / buffer writes and the reward path as fw_policy_act + fw_rollout_post
-    one_launch_collect: bool = True        # ... and, where the env's lane mapping has it, the whole vec-step as ONE launch (fw_collect_step)
+    one_launch_collect: bool = False       # the whole vec-step as ONE launch (fw_collect_step) where the env's lane mapping has it.  Off by default:
+                                           # measured 49.1 vs 48.3 us per vec-step (waypoints, 4096 envs) -- the in-grid hand-offs between waves of
+                                           # different XCDs cost what the two launch boundaries they replace cost (tools/trace_collect.py)
     detector: str = "none"                 # "cnn": CnnDetectorPolicy over the FPV render (fw_render) of a camera task -- torch path, gradient all-reduce
     image_res: int = 32                    #        side of the rendered image
     cnn_features: int = 32                 #        width of the extractor's output
@@ -689,6 +691,7 @@ class PPO:
                             and getattr(env.venv, "lanes_per_env", 0) == 8 and getattr(env.venv, "g8_waves", 1) == 1
                             and float(env.gamma) == float(cfg.gamma))
         self._ws_collect = None
+        self._trace = None                 # optional int64 [grid, 8] device tensor: per-workgroup wall-clock stamps of the last fw_collect_step
         self._warm_rollouts = 0
         self._gathered = None
         self.allgather_ms = self.allgather_bytes = 0.0
@@ -812,10 +815,12 @@ class PPO:
                 a.terminated, a.truncated = venv.terminated.data_ptr(), venv.truncated.data_ptr()
                 a.terminal_obs, a.info_i32 = venv.terminal_obs.data_ptr(), venv.info.data_ptr()
                 a.workspace, a.workspace_bytes = self._ws_collect.data_ptr(), self._ws_collect.numel() * 8
+                a.trace = self._trace.data_ptr() if self._trace is not None else None      # (tools/trace_collect.py)
                 a.gamma = float(cfg.gamma)
                 a.clip_obs, a.eps_obs, a.clip_reward, a.eps_reward = float(env.clip_obs), float(env.epsilon), float(env.clip_reward), float(env.epsilon)
                 a.update_obs, a.update_ret, a.norm_reward, a.deterministic = upd_obs, track, int(env.norm_reward), 0
                 _lib.check(L.fw_collect_step(venv._h, C.byref(a), st), venv._h)
+            _lib.check(L.fw_collect_finish(venv._h, C.byref(a), st), venv._h)      # the last step's statistics (each step's are folded by the next launch)
         for t in (range(T) if not self._one_launch else ()):
             act(t, 3, self.buf_val[t], t - 1 if t > 0 else None)
             venv.step_tensor(self._act_env)
