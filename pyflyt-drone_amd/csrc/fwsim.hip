@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "fwsim_device.hpp"
@@ -328,8 +329,12 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   T new_dist = D.r[RF_NEW_DIST * n + envc];
   T ep_return = D.r[RF_EP_RETURN * n + envc];
   // tick constants + this lane's lifting surface (G = 8: resident in VGPRs for the whole launch)
-  TickC<T> C; SurfC<T> mine; T wmask;
-  load_tick_constants<T, G, DEFER && G == 8 && WPE == 1>(Pp, C, mine, wmask);
+  TickC<T> C; SurfC<T> mine_regs; T wmask;
+  load_tick_constants<T, G, DEFER && G == 8 && WPE == 1>(Pp, C, mine_regs, wmask);
+  // (Tried for WPE = 2: this lane's surface constants in LDS, read field by field through a volatile reference -- 54 registers
+  // fewer to hold, but the allocator spilled as much elsewhere and the ds_reads sit on the tick's critical path: 40.6 -> 50.9 us
+  // at 16 384 envs.  surface_wrench / physics_tick keep the template parameter that made the experiment a four-line change.)
+  SurfC<T>& mine = mine_regs;
 
   normalize_quat<T>(S.q);
   T R[9];
@@ -1559,34 +1564,33 @@ int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64
   if (!h) return FW_ENOMEM;
   h->cfg = *cfg; h->n = num_envs; h->npad = (num_envs + kWave - 1) / kWave * kWave;
   h->device = device; h->seed = seed; h->env_offset = global_env_offset;
-  // Lane mapping, by measured crossover (tools/crossover.py, profiles/r03_crossover.txt; us per step, fp64):
-  //   wind-free waypoints   N:  8192  12288  16384  24576  32768  65536       waypoints + wind   N:  8192  16384  32768
-  //     8 lanes, 1 wave/SIMD    26.6   44.4   47.7   66.9   88.8  167.2                                50.1   74.9  137.5
-  //     8 lanes, 2 waves/SIMD   29.2   37.5   40.6   58.6   70.9   (*)                                 43.1   80.8  137.7
-  //     1 lane                  57.5   58.4   60.5   66.8   67.4   87.0                                64.8   67.8   80.7
+  // Lane mapping, by measured crossover (tools/crossover.py, profiles/r03_crossover.txt; us per eager step, fp64, median of 7 x 20):
+  //   wind-free waypoints   N:  8192  12288  16384  24576  32768  65536     waypoints + wind   N:  4096  6144  8192  12288  16384
+  //     8 lanes, 1 wave/SIMD    25.6   42.3   46.8   64.2   83.5  150.4                              25.5  34.8  48.8   58.1   69.8
+  //     8 lanes, 2 waves/SIMD   28.0   36.8   39.1   54.0   68.1  149.6                              35.1  38.2  41.2   54.3   74.7
+  //     1 lane                  57.6   58.5   59.6   63.9   66.8   80.9                              62.3  63.1  63.1   66.0   67.0
   //   8 lanes per env split an env's five lifting surfaces over lanes (latency mapping: 4096 envs are 512 waves instead of
   //   64); its full-register-file build holds ONE wave per SIMD, so above 8192 envs (1024 waves) a second round starts -- there
   //   the build capped at 256 registers (two waves per SIMD) takes over, and one lane per env above that.  The wind kernels
-  //   run as many worker waves again, which halves their thresholds.  (*) never: with > 8192 waves its scratch throttles the
-  //   dispatch (4 ms per launch measured).
+  //   run as many worker waves again, which lowers their thresholds.
   // FWSIM_LANES_PER_ENV=1|8 and FWSIM_G8_WAVES=1|2 override (parity tests, the benchmark sweep).
   // Camera tasks with obstacles stay on the 8-lane mapping at every size: there the cylinders are drawn by the wave from LDS
   // work lists; one lane per env tests every pixel against every cylinder (combined, 20 cylinders: 330 us vs 7.8 ms per
   // step at 32 768 envs).
   const bool cyl_camera = cfg->task != FW_TASK_WAYPOINTS && cfg->num_obstacles > 0;
   const bool wp = cfg->task == FW_TASK_WAYPOINTS, windy = wp && cfg->wind_mode != FW_WIND_OFF;
-  const int one_wave_max = windy ? 4096 : 8192;                 // largest N the one-wave-per-SIMD build serves in a single round
-  const int g8_max = !wp ? kG8MaxEnvs : (windy ? 8192 : 24576);
+  const int one_wave_max = windy ? 6144 : 8192;                 // up to here the one-wave-per-SIMD build wins
+  const int g8_max = !wp ? kG8MaxEnvs : (windy ? 12288 : 24576);   // ... and up to here the 8-lane mapping
   const bool fits8 = cfg->num_targets <= 8 && cfg->n_collision_pts <= 8;
   h->lanes_per_env = ((num_envs <= g8_max || cyl_camera) && fits8) ? 8 : 1;
   if (const char* ev = getenv("FWSIM_LANES_PER_ENV")) {
     int v = atoi(ev);
     if (v == 1 || (v == 8 && fits8)) h->lanes_per_env = v;
   }
-  h->g8_waves = (h->lanes_per_env == 8 && wp && num_envs > one_wave_max && num_envs <= 32768) ? 2 : 1;
+  h->g8_waves = (h->lanes_per_env == 8 && wp && num_envs > one_wave_max) ? 2 : 1;
   if (const char* ev = getenv("FWSIM_G8_WAVES")) {
     int v = atoi(ev);
-    if ((v == 1 || (v == 2 && num_envs <= 32768)) && h->lanes_per_env == 8 && wp) h->g8_waves = v;
+    if ((v == 1 || v == 2) && h->lanes_per_env == 8 && wp) h->g8_waves = v;
   }
   DeviceGuard g(device);
   rc = (cfg->dtype == FW_F64) ? create_T<double>(h) : create_T<float>(h);

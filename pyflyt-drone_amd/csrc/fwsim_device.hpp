@@ -391,11 +391,14 @@ template <typename T> __device__ __forceinline__ T interp2(T x, T x0, T x1, T y0
 // evaluated on the same sincos, selected per lane => no wave divergence).
 // cos(alpha), sin(alpha) are never formed: V*cos = v_f, V*sin = -v_l.
 // Returns the surface's force f and its torque about the COM (r x f + pitching moment).
-template <typename T>
-__device__ __forceinline__ void surface_wrench(const SurfC<T>& S, T act, const T v_b[3], const T w_b[3],
+// SC = SurfC<T> (constants in registers / scalar loads) or volatile SurfC<T> (the 256-register build of the 8-lane mapping:
+// this lane's surface sits in LDS and every use is a fresh ds_read -- 54 registers the allocator otherwise spilled to scratch).
+template <typename T, typename SC>
+__device__ __forceinline__ void surface_wrench(SC& S, T act, const T v_b[3], const T w_b[3],
                                                const T wind_b[3], T f[3], T tq[3]) {
   T wxr[3];
-  cross(w_b, S.pos, wxr);
+  const T spos[3] = { S.pos[0], S.pos[1], S.pos[2] };
+  cross(w_b, spos, wxr);
   T vl0 = v_b[0] + wxr[0] - wind_b[0], vl1 = v_b[1] + wxr[1] - wind_b[1], vl2 = v_b[2] + wxr[2] - wind_b[2];
   T v_l = vl0 * S.lift[0] + vl1 * S.lift[1] + vl2 * S.lift[2];
   T v_f = vl0 * S.fwd[0] + vl1 * S.fwd[1] + vl2 * S.fwd[2];
@@ -454,7 +457,7 @@ __device__ __forceinline__ void surface_wrench(const SurfC<T>& S, T act, const T
   T Mq = S.hra * V2 * CM * S.chord;
   f[0] = S.lift[0] * Fn + S.fwd[0] * Fp; f[1] = S.lift[1] * Fn + S.fwd[1] * Fp; f[2] = S.lift[2] * Fn + S.fwd[2] * Fp;
   T rxf[3];
-  cross(S.pos, f, rxf);
+  cross(spos, f, rxf);
   tq[0] = rxf[0] + Mq * S.tq[0]; tq[1] = rxf[1] + Mq * S.tq[1]; tq[2] = rxf[2] + Mq * S.tq[2];
 }
 
@@ -638,10 +641,10 @@ __device__ __forceinline__ void quat_integrate(const TickC<T>& C, Rigid<T>& S) {
 // G = 1: rolled loop over the 5 surfaces (constants by scalar loads at a wave-uniform index
 //        -- unrolling makes hipcc hoist ~100 constants into SGPRs and spill).
 // G = 8: `mine` holds this lane's surface constants in VGPRs, `wmask` zeroes lanes 5-7.
-template <typename T, bool WIND, int G>
+template <typename T, bool WIND, int G, typename SC>
 __device__ __forceinline__ bool physics_tick(const Params<T>& P, const TickC<T>& C, Rigid<T>& S, T R[9],
                                              const T cmd[FW_NUM_ACTUATORS], T noise_z, const T wind[3],
-                                             const SurfC<T>& mine, T wmask, LaneAct<T>& LA) {
+                                             SC& mine, T wmask, LaneAct<T>& LA) {
   if (G == 8) {
     LA.a += mine.dt_tau * (LA.cmd - LA.a);                          // my surface
     T thr = S.act[FW_NUM_SURFACES];                                 // the motor, replicated
@@ -659,7 +662,7 @@ __device__ __forceinline__ bool physics_tick(const Params<T>& P, const TickC<T>&
   if (G == 8) {
     const T a_s = LA.a;
     T f[3], tq[3];
-    surface_wrench<T>(mine, a_s, v_b, w_b, wind_b, f, tq);
+    surface_wrench<T, SC>(mine, a_s, v_b, w_b, wind_b, f, tq);
 #pragma unroll
     for (int k = 0; k < 3; ++k) { F[k] = group_sum<8, T>(f[k] * wmask); Tq[k] = group_sum<8, T>(tq[k] * wmask); }
   } else {
@@ -667,7 +670,7 @@ __device__ __forceinline__ bool physics_tick(const Params<T>& P, const TickC<T>&
     for (int s = 0; s < FW_NUM_SURFACES; ++s) {
       T a_s = (s == 0) ? S.act[0] : (s == 1) ? S.act[1] : (s == 2) ? S.act[2] : (s == 3) ? S.act[3] : S.act[4];
       T f[3], tq[3];
-      surface_wrench<T>(P.s[s], a_s, v_b, w_b, wind_b, f, tq);
+      surface_wrench<T, const SurfC<T>>(P.s[s], a_s, v_b, w_b, wind_b, f, tq);
 #pragma unroll
       for (int k = 0; k < 3; ++k) { F[k] += f[k]; Tq[k] += tq[k]; }
     }

@@ -26,11 +26,21 @@
 // groups, then the last group): 36 us -- every hop between waves of different XCDs is a write-through store, its
 // acknowledgement, a ticket and a coherent load, ~3 us each, six of them in a row (tools/trace_collect.py).  Now a step wave
 // only leaves its 2 D + 2 partial sums with plain stores (they become visible at the kernel boundary, for free) and the NEXT
-// launch folds them while it waits for its weights anyway: act wave j sums word j over all step waves (one coalesced round
-// trip, fixed association), publishes the total; every act wave reads the 2 D + 2 totals and derives the updated statistics
-// itself (same arithmetic, same bits everywhere).  The merge wave does the same and writes them to the caller's buffers --
-// after every act wave has announced that it has read the old ones.  The last step of a rollout is folded by
+// launch folds them while its weights are in flight anyway: act wave j sums word j over all step waves (one coalesced round
+// trip, fixed association) and stores the total over a sentinel the merge wave of the launch before last left -- a total
+// announces itself, no flag and no store acknowledgement in between; every act wave reads the 2 D + 2 totals and derives the
+// updated statistics itself (same arithmetic, same bits everywhere).  The merge wave does the same and writes them to the
+// caller's buffers -- after every act wave has announced that it has read the old ones.  The last step of a rollout is folded by
 // fw_collect_finish (one small launch per rollout).
+// Measured (tools/trace_collect.py, profiles/r03_collect_step_trace.txt; waypoints, 4096 envs): statistics known 9.4 us into the
+// launch, inputs + weights in LDS +4.2, forward +7.7, actions published at 23-24 us, step waves done at 43, launch end 45 us --
+// 49.1 us per vec-step with the per-rollout launches, against 48.3 for fw_collect_act -> fw_step -> fw_collect_stats.  A bare
+// hand-off between two waves costs 0.36 us inside an XCD and 0.41 us across two (tools/microbench_xcd.hip); in the grid, with
+// hundreds of waves polling, each of the three dependent hops (partials -> totals -> inputs; actions -> step waves) measures
+// 2-3 us, and one wave per (chunk, network) runs its three GEMM phases in 7.7 us where the four waves of fw_collect_act's
+// workgroups need ~4.  (Tried: one completion counter instead of self-announcing totals and a 7 us nap before the step waves
+// start polling: 12.1 us to the statistics, 52 us per vec-step -- worse.)  The launch boundaries this design removes cost what
+// its in-grid hand-offs cost: it stays an option (PPOConfig.one_launch_collect), off by default.
 #pragma once
 #include "fwsim_collect.hpp"
 

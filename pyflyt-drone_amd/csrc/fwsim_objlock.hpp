@@ -1243,11 +1243,11 @@ __device__ __forceinline__ void obj_write_obs(const Params<T>& P, const ObjState
 // motor-noise normals (zero for warm-up lanes: their throttle is exactly 0).  OBJ adds the
 // duck / cylinder contacts per tick; the camera capture every physics_camera_ratio ticks
 // (envs/fixedwing_objlock_env.py:631-641) is the caller's next call: obj_capture_step, by the whole wave.
-template <typename T, bool WIND, int G, bool OBJ>
+template <typename T, bool WIND, int G, bool OBJ, typename SC>
 __device__ __forceinline__ bool aviary_step(const Params<T>& P, const TickC<T>& C, const ObjC<T>& OC, const DevState<T>& D,
                                             int env, ObjState<T>& O, Rigid<T>& S, T R[9], const T cmd[FW_NUM_ACTUATORS],
                                             int32_t& tick, T z0, T z1, const T wb[3], const T wa[3], T gust[2],
-                                            const SurfC<T>& mine, T wmask, LaneAct<T>& LA) {
+                                            SC& mine, T wmask, LaneAct<T>& LA) {
   bool contact = false;
 #pragma unroll 1
   for (int t = 0; t < P.ticks_per_aviary; ++t) {

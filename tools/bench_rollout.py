@@ -15,12 +15,13 @@ from pyflyt_drone_amd import config as K, rollout as R
 
 task = sys.argv[1] if len(sys.argv) > 1 else "waypoints"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096          # envs on this GPU (configs[4] of BASELINE.json: 2048 per GPU)
+one = len(sys.argv) > 3 and sys.argv[3] == "one_launch"      # PPOConfig.one_launch_collect (fw_collect_step)
 if task == "objlock":
-    cfg, ppo_cfg = K.train_objlock_config(), R.PPOConfig(n_steps=8, batch_size=64, n_epochs=10)        # 16 x 2048 = 32768 samples
+    cfg, ppo_cfg = K.train_objlock_config(), R.PPOConfig(n_steps=8, batch_size=64, n_epochs=10, one_launch_collect=one)        # 16 x 2048 = 32768 samples
 elif task == "combined":
-    cfg, ppo_cfg = K.train_waypoint_objlock_config(), R.PPOConfig(n_steps=8, batch_size=128, n_epochs=20)  # 32 x 1024 = 32768
+    cfg, ppo_cfg = K.train_waypoint_objlock_config(), R.PPOConfig(n_steps=8, batch_size=128, n_epochs=20, one_launch_collect=one)  # 32 x 1024 = 32768
 else:
-    cfg, ppo_cfg = K.train_waypoints_v3_config(), R.PPOConfig(n_steps=16, batch_size=128, n_epochs=20)     # 32 x 2048 = 65536
+    cfg, ppo_cfg = K.train_waypoints_v3_config(), R.PPOConfig(n_steps=16, batch_size=128, n_epochs=20, one_launch_collect=one)     # 32 x 2048 = 65536
 env = P.FixedwingVecEnv(cfg, n, seed=42)
 vn = R.VecNormalizeDevice(env)
 ppo = R.PPO(vn, ppo_cfg)
@@ -32,7 +33,7 @@ for _ in range(reps):
     ppo.collect_rollouts()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 T = ppo_cfg.n_steps
-out = {"task": task, "envs": n, "obs_dim": env.obs_dim, "rollout_env_steps_per_s": reps * T * n / dt,
+out = {"task": task, "envs": n, "one_launch_collect": bool(ppo._one_launch), "obs_dim": env.obs_dim, "rollout_env_steps_per_s": reps * T * n / dt,
        "rollout_us_per_vec_step": dt * 1e6 / (reps * T)}
 ppo.train(); torch.cuda.synchronize()
 t0 = time.perf_counter(); ppo.train(); torch.cuda.synchronize()

@@ -21,10 +21,13 @@ if [ -n "$LANES" ]; then export FWSIM_LANES_PER_ENV=$LANES; fi
 mkdir -p $OUT
 TASKS=${@:-waypoints waypoints_wind objlock combined}
 for t in $TASKS; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$t$SFX/stats -o p -- python3 bench.py --task $t --steps $STEPS --warmup 100 --no-cpu-baseline $EXTRA > $OUT/$t$SFX.bench.json 2> $OUT/$t$SFX.stats.err || echo "stats pass failed for $t"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$t$SFX/stats -o p -- python3 bench.py --task $t --steps $STEPS --warmup 100 --repeats 3 --no-cpu-baseline $EXTRA > $OUT/$t$SFX.bench.json 2> $OUT/$t$SFX.stats.err || echo "stats pass failed for $t"
   rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/$t$SFX/fetch -o p -- python3 bench.py --task $t --steps $CSTEPS --warmup $CWARM --repeats 1 --no-cpu-baseline --no-graph $EXTRA > /dev/null 2> $OUT/$t$SFX.fetch.err || echo "fetch pass failed for $t"
   rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/$t$SFX/write -o p -- python3 bench.py --task $t --steps $CSTEPS --warmup $CWARM --repeats 1 --no-cpu-baseline --no-graph $EXTRA > /dev/null 2> $OUT/$t$SFX.write.err || echo "write pass failed for $t"
   rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $OUT/$t$SFX/sq -o p -- python3 bench.py --task $t --steps $CSTEPS --warmup $CWARM --repeats 1 --no-cpu-baseline --no-graph $EXTRA > /dev/null 2> $OUT/$t$SFX.sq.err || echo "sq pass failed for $t"
   echo "collected $t"
 done
 python3 tools/summarize_profiles.py $OUT $ROUND
+# the GPU box returns gpurun_out/ only: leave a copy of the summaries there (the raw counter dumps are trimmed to the csv files)
+mkdir -p gpurun_out/${ROUND}_profiles && cp profiles/${ROUND}_* gpurun_out/${ROUND}_profiles/ 2>/dev/null
+find $OUT -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' ! -name '*.json' ! -name '*.err' -delete 2>/dev/null || true

@@ -18,9 +18,12 @@ for n in map(int, sys.argv[2:]):
         acts = [(torch.rand((n, 4), generator=g, dtype=torch.float64) * 2 - 1).cuda() for _ in range(4)]
         for i in range(40): e.step_tensor(acts[i % 4])          # into steady state (captures, resets)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(20): e.step_tensor(acts[i % 4])
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 20
+        reps = []
+        for _ in range(7):                                       # median of 7 x 20 steps (a single timed window once caught an 80 ms hiccup)
+            t0 = time.perf_counter()
+            for i in range(20): e.step_tensor(acts[i % 4])
+            torch.cuda.synchronize()
+            reps.append((time.perf_counter() - t0) / 20)
+        dt = sorted(reps)[len(reps) // 2]
         print(f"{which} N={n} lanes={lanes} waves/SIMD={waves if lanes == 8 else 2}: {dt*1e6:.1f} us/step  {n/dt/1e6:.1f} M env-steps/s", flush=True)
         e.close(); del e

@@ -13,7 +13,7 @@ task = sys.argv[1] if len(sys.argv) > 1 else "waypoints"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 cfg = {"waypoints": K.train_waypoints_v3_config, "objlock": K.train_objlock_config, "combined": K.train_waypoint_objlock_config}[task]()
 env = P.FixedwingVecEnv(cfg, n, seed=42)
-ppo = R.PPO(R.VecNormalizeDevice(env), R.PPOConfig(n_steps=8, batch_size=64, n_epochs=1, use_graphs=False))
+ppo = R.PPO(R.VecNormalizeDevice(env), R.PPOConfig(n_steps=8, batch_size=64, n_epochs=1, use_graphs=False, one_launch_collect=True))
 assert ppo._one_launch
 for _ in range(3):
     ppo.collect_rollouts()
