@@ -515,7 +515,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
         contact = aviary_step<T, false, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd, tick, z0, z1, wb, wa, gust, mine, wmask, LA);    // :339
       }
     }
-    if (HASOBJ) obj_capture_step<T, G>(OC, D, stepped, envc, O, S, R, tick);     // the camera, by the whole wave
+    if (HASOBJ) obj_capture_step<T, G, COLLECT>(OC, D, stepped, envc, O, S, R, tick);     // the camera, by the whole wave
     FWP(const long long p_c = FWP_NOW(); p_avi += p_c - p_b;)
     if (stepped) {
       if (stepping && OBJ) {

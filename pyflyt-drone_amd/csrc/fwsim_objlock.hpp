@@ -456,7 +456,7 @@ __device__ __forceinline__ int cyl_columns(float ox, float oy, float r2, float p
 // the duck mask, cylinders and pixels of row h//2 are dealt out modulo VG; partial statistics are combined inside the set (DPP
 // inside 8 lanes, xor-butterflies above), after which every lane of the set holds the same `frame`.  `work` = false: a lane set
 // without an env this time (it only takes part in the cross-lane steps).
-template <typename T, int G>
+template <typename T, int G, bool NOLEAD = false>
 __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T>& D, int env, const T duck[3], int nob_in,
                                              const T Sp[3], const T R[9], int vsub, int VG, int erow, bool work, T frame[8],
                                              long long* ph = nullptr, bool ph_on = false /* dev-only: cycles per phase (FW_PROFILE) */) {
@@ -659,12 +659,21 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
     // capture step lasts as long as its longest set).  Count, sum x, sum y are sums of integers and half-integers -- exact in
     // floating point, so LDS atomic adds in any order give the same bits; the nearest fragment is a max.
     const bool listed = duck_ok && !straddle && y1 >= y0;
-    {
-      // No `if (vsub == 0)` here.  Every lane of the set takes part: the position in the list is claimed by an atomic whose
-      // operand is the set's row count in its first lane and 0 in the others, the first lane's result is handed round, and all
-      // lanes store the same words.  (A leader-only branch made hipcc 7.2 save registers that are live across the row loop at
-      // the top of its join block -- ahead of the exec restore, i.e. for the leader only: the hazard tools/check_isa.py guards
-      // against showed up at this very join in three different builds.)
+    if (!NOLEAD) {
+      if (vsub == 0) {
+        T* sc = sconst_all + erow * kSetWords;
+        int base = 0;
+        if (listed) base = (int)__hip_atomic_fetch_add(lu + 2, (uint32_t)(y1 - y0 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        sc[10] = zc; sc[11] = xc; sc[12] = yc; sc[13] = k2; sc[14] = A; sc[15] = iA; sc[16] = (T)y0;
+        sc[17] = listed ? (T)(y1 - y0 + 1) : (T)0; sc[18] = (T)base;
+      }
+    } else {
+      // NOLEAD (the fw_collect_step instantiations): no `if (vsub == 0)` here.  Every lane of the set takes part: the position in
+      // the list is claimed by an atomic whose operand is the set's row count in its first lane and 0 in the others, the first
+      // lane's result is handed round, and all lanes store the same words.  In those builds the leader-only branch made hipcc 7.2
+      // save registers that are live across the row loop at the top of its join block -- ahead of the exec restore, i.e. for the
+      // leader only: the hazard tools/check_isa.py guards against (it showed up at this very join in three different builds).
+      // The all-lane form costs 2.9 us (ObjLock) / 4.5 us (combined) per step, so the plain step kernels keep the branch.
       T* sc = sconst_all + erow * kSetWords;
       const uint32_t claim = (vsub == 0 && listed) ? (uint32_t)(y1 - y0 + 1) : 0u;
       int base = (int)__hip_atomic_fetch_add(lu + 2, claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -997,13 +1006,13 @@ __device__ __forceinline__ void capture_body(const ObjC<T>& OC, const DevState<T
 // for 1 / 2 / 3 / 4 / 5+ envs due (only a few of the wave's 8 envs capture at the same sub-step, and the launch lasts as long as
 // its slowest wave): set j = lanes [j VG, (j + 1) VG) works for the j-th due env, whichever env's state those lanes hold
 // themselves; the frame travels back by shuffle.  Must be called by all 64 lanes (wave-uniform control flow).
-template <typename T, int G>
+template <typename T, int G, bool NOLEAD = false>
 __device__ __forceinline__ void obj_capture_wave(const ObjC<T>& OC, const DevState<T>& D, bool due, int env, ObjState<T>& O,
                                                  const Rigid<T>& S, const T R[9]) {
   T fr[8];
   if (G != 8) {
     if (due) {
-      capture_body<T, G>(OC, D, env, O.duck, O.nob, S.p, R, 0, 1, 0, true, fr);
+      capture_body<T, G, NOLEAD>(OC, D, env, O.duck, O.nob, S.p, R, 0, 1, 0, true, fr);
 #pragma unroll
       for (int i = 0; i < 8; ++i) O.frame[i] = fr[i];
       O.frame_has = (T)1;
@@ -1036,10 +1045,10 @@ __device__ __forceinline__ void obj_capture_wave(const ObjC<T>& OC, const DevSta
   for (int i = 0; i < 9; ++i) oR[i] = __shfl(R[i], src, kWave);
   const int onob = __shfl(O.nob, src, kWave), oenv = __shfl(env, src, kWave);
 #ifdef FW_PROFILE
-  capture_body<T, G>(OC, D, oenv, oduck, onob, oSp, oR, lane & (VG - 1), VG, j, work, fr, O.p_ph, m >= 5);   // (always the array itself: a pointer that may be null keeps it from living in registers)
+  capture_body<T, G, NOLEAD>(OC, D, oenv, oduck, onob, oSp, oR, lane & (VG - 1), VG, j, work, fr, O.p_ph, m >= 5);   // (always the array itself: a pointer that may be null keeps it from living in registers)
   if (m >= 5) O.p_ph[5] += 1;
 #else
-  capture_body<T, G>(OC, D, oenv, oduck, onob, oSp, oR, lane & (VG - 1), VG, j, work, fr);
+  capture_body<T, G, NOLEAD>(OC, D, oenv, oduck, onob, oSp, oR, lane & (VG - 1), VG, j, work, fr);
 #endif
   const int back = __popc(dmask & ((1u << grp) - 1u)) * VG + sub;      // a lane of the set that worked for my env
 #pragma unroll
@@ -1262,14 +1271,14 @@ __device__ __forceinline__ bool aviary_step(const Params<T>& P, const TickC<T>& 
 }
 
 // the capture that follows an Aviary step (`stepped`: this lane's env ran one); all lanes of the wave call it
-template <typename T, int G>
+template <typename T, int G, bool NOLEAD = false>
 __device__ __forceinline__ void obj_capture_step(const ObjC<T>& OC, const DevState<T>& D, bool stepped, int env, ObjState<T>& O,
                                                  const Rigid<T>& S, const T R[9], int32_t tick) {
   const bool due = stepped && OC.camera_ratio_ticks > 0 && (tick % OC.camera_ratio_ticks) == 0;
 #ifdef FW_PROFILE
   const long long c0 = (long long)__builtin_readcyclecounter();
 #endif
-  obj_capture_wave<T, G>(OC, D, due, env, O, S, R);
+  obj_capture_wave<T, G, NOLEAD>(OC, D, due, env, O, S, R);
 #ifdef FW_PROFILE
   const long long c1 = (long long)__builtin_readcyclecounter();
   if (due) { O.p_cap += c1 - c0; O.p_ncap += 1; }
