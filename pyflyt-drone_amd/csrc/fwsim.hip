@@ -68,6 +68,12 @@ __global__ void fw_warm_kernel(Params<T>* Pm) {
   for (int k = 0; k < 9; ++k) Pm->warm_R[k] = Rw[k];
 }
 
+// (The prefetches of the reset epilogue are plain loads.  tools/wave_profile.py still shows ~2.3 k cycles between the
+// terminal-observation copy and the new row in the waves that reset, whatever is requested ahead of the observation pass;
+// volatile loads -- to keep the compiler from sinking them to their only use inside the divergent reset block -- make it far
+// worse: the backend waits for every volatile access at once, 20.1 -> 24.5 us per step.)
+template <typename T> __device__ __forceinline__ T vload(const T* p) { return *p; }
+
 // action shown in the observation: src 0 = this step's input, 1 = stored (stale), 2 = zeros
 template <typename T, bool COH = false>
 __device__ __forceinline__ void load_action(const DevState<T>& D, const T* actions, int env, int src, T a[4]) {
@@ -216,8 +222,33 @@ __device__ __forceinline__ void scenario_worker(const Params<T>* __restrict__ Pp
   const bool begin = fresh && (uint32_t)(dn >> 32) != target;
   if (__ballot(begin) == 0ull) return;
   if (begin) {
+    const Params<T>& P = *Pp;
     Scenario<T> sc;
     sample_scenario_inl<T, G>(Pp, D.rs, (size_t)D.npad, env, target, &sc);
+    // ... and the observation the new episode starts with (cached attitude block ++ deltas of the fresh waypoints, zero padded)
+    // plus its first distance: the reset that takes this hand-off is then a copy (state = the cached warm state)
+    T* orow = D.sobs + (size_t)env * P.obs_dim;
+    for (int k = sub; k < P.att_dim; k += G) orow[k] = Pp->warm_obs[k];
+    if (G > 1) {
+      if (sub < P.ctx) {
+        T d[3] = {(T)0, (T)0, (T)0}, b[3] = {(T)0, (T)0, (T)0};
+        if (sub < P.num_targets) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) d[k] = sc.t_mine[k] - P.warm[k];
+          mtv(P.warm_R, d, b);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) orow[P.att_dim + 3 * sub + k] = b[k];
+      }
+      if (sub == 0) {
+        T nd = (T)0;
+        if (P.num_targets > 0) {
+          const T dx = sc.t_mine[0] - P.warm[0], dy = sc.t_mine[1] - P.warm[1], dz = sc.t_mine[2] - P.warm[2];
+          nd = M<T>::sqrt_(dx * dx + dy * dy + dz * dz);
+        }
+        D.rs[(size_t)RF_NEW_DIST * D.npad + env] = nd;
+      }
+    }
     if (sub == 0) D.sdone[env] = pack_done(target, D.epoch, 1);
   }
 }
@@ -626,7 +657,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
                    (uint32_t)((sh_done >> 8) & 0xFFFFFFu) != (D.epoch & 0xFFFFFFu);
   if (pre && sub < P.num_targets) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) tpre[k] = D.rs[(size_t)(RF_TARGETS + 3 * sub + k) * n + env];
+    for (int k = 0; k < 3; ++k) tpre[k] = vload(&D.rs[(size_t)(RF_TARGETS + 3 * sub + k) * n + env]);
   }
   // ... and so is the cached attitude block of the observation a reset returns (lane `sub` holds its words sub, sub + G, ...)
   constexpr bool WO = DEFER && G == 8;               // (one lane per env: the block is copied straight from memory below)
@@ -634,7 +665,29 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   T wo[kWO];
   if (WO && resetting) {
 #pragma unroll
-    for (int j = 0; j < kWO; ++j) { const int k = sub + j * G; wo[j] = (k < P.att_dim) ? Pp->warm_obs[k] : (T)0; }
+    for (int j = 0; j < kWO; ++j) { const int k = sub + j * G; wo[j] = (k < P.att_dim) ? vload(&Pp->warm_obs[k]) : (T)0; }
+  }
+
+  // DEFER: ... and so is the cached warm state itself (19 words + the rotation its target deltas use).  Read where it is used --
+  // inside the divergent reset block -- it arrives by scalar loads issued one batch at a time, each a scalar-cache round trip
+  // that only the waves with a reset pay: the slowest wave of nearly every launch (epilogue 9.4 k cycles against 5.2 k).  Here
+  // every lane of such a wave requests the 28 words as vector loads through a per-lane address, before the observation pass.
+  // (pre: the worker also left the first observation row and the first distance: requested here as well)
+  constexpr int kDOW = WO ? (kMaxObs + G - 1) / G : 1;
+  T dow[kDOW], dnd = (T)0;
+  if (WO && pre) {
+#pragma unroll
+    for (int j = 0; j < kDOW; ++j) { const int k = sub + j * G; dow[j] = (k < Dobs) ? vload(&Dg.sobs[(size_t)env * Dobs + k]) : (T)0; }
+    dnd = vload(&D.rs[(size_t)RF_NEW_DIST * n + env]);
+  }
+  constexpr int kWarmW = DEFER ? 19 : 1, kWarmR = DEFER ? 9 : 1;
+  T warm_v[kWarmW], warmR_v[kWarmR];
+  if (DEFER && __ballot(resetting) != 0ull) {
+    const Params<T>* Q = Pp + opaque_zero();
+#pragma unroll
+    for (int k = 0; k < kWarmW; ++k) warm_v[k] = vload(&Q->warm[k]);
+#pragma unroll
+    for (int k = 0; k < kWarmR; ++k) warmR_v[k] = vload(&Q->warm_R[k]);
   }
 
   // GENERAL: the rows of a shadow that is being taken, fetched by the env's G lanes before the observation pass (their round
@@ -687,6 +740,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     else if (COMB) comb_write_obs<T>(P, D, env, O, S, act_obs, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
     else write_obs<T>(P, D, env, S, act_obs, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
   }
+  FWP(const long long p_e0 = FWP_NOW();)
   if (DEFER && resetting) {                          // group-uniform: all G lanes of the env take part
     // the row just written is the terminal observation: move it out before the new episode's row replaces it
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -695,6 +749,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       for (int k = sub; k < Dobs; k += G) trow[k] = tile[row * ld + k];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    FWP(const long long p_e1 = FWP_NOW(); p_r1 = p_e1 - p_e0;)      // obs pass end -> terminal observation copied out
     episode += 1;
     if (leader) { stat_add(D.stats, FW_CTR_RESETS); stat_add(D.stats, pre ? FW_CTR_SCENARIO_HITS : FW_CTR_FALLBACKS); }
     Scenario<T> sc;
@@ -711,8 +766,13 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     }
     const int nt = min(P.ctx, P.num_targets);
     T t0[3] = {(T)0, (T)0, (T)0};
+    const bool copied = WO && pre;                    // the worker left the whole first observation row: nothing to compute
+    if (copied) {
+#pragma unroll
+      for (int j = 0; j < kDOW; ++j) { const int k = sub + j * G; if (k < Dobs) tile[row * ld + k] = dow[j]; }
+    }
 #pragma unroll 1
-    for (int i = 0; i < P.ctx; ++i) {
+    for (int i = 0; i < (copied ? 0 : P.ctx); ++i) {
       T tw[3] = {(T)0, (T)0, (T)0};
       if (G > 1) {
 #pragma unroll
@@ -724,27 +784,28 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       T d[3] = {(T)0, (T)0, (T)0}, b[3] = {(T)0, (T)0, (T)0};
       if (i < nt) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) d[k] = tw[k] - P.warm[k];
-        mtv(P.warm_R, d, b);
+        for (int k = 0; k < 3; ++k) d[k] = tw[k] - warm_v[k];
+        mtv(warmR_v, d, b);
         if (i == 0) { t0[0] = tw[0]; t0[1] = tw[1]; t0[2] = tw[2]; }
       }
       if (leader) { tile[row * ld + P.att_dim + 3 * i] = b[0]; tile[row * ld + P.att_dim + 3 * i + 1] = b[1]; tile[row * ld + P.att_dim + 3 * i + 2] = b[2]; }
     }
-    if (WO) {
+    FWP(const long long p_e2 = FWP_NOW(); p_r2 = p_e2 - p_e1;)      // new waypoints stored, their deltas in the tile
+    if (WO && !copied) {
 #pragma unroll
       for (int j = 0; j < kWO; ++j) { const int k = sub + j * G; if (k < P.att_dim) tile[row * ld + k] = wo[j]; }   // the env's lanes share the cached attitude block
     }
-    for (int k = sub + (WO ? kWO * G : 0); k < P.att_dim; k += G) tile[row * ld + k] = Pp->warm_obs[k];
+    if (!copied) for (int k = sub + (WO ? kWO * G : 0); k < P.att_dim; k += G) tile[row * ld + k] = Pp->warm_obs[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { S.p[k] = P.warm[k]; S.v[k] = P.warm[7 + k]; S.w[k] = P.warm[10 + k]; }
+    for (int k = 0; k < 3; ++k) { S.p[k] = warm_v[k]; S.v[k] = warm_v[7 + k]; S.w[k] = warm_v[10 + k]; }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) S.q[k] = P.warm[3 + k];
+    for (int k = 0; k < 4; ++k) S.q[k] = warm_v[3 + k];
 #pragma unroll
-    for (int k = 0; k < FW_NUM_ACTUATORS; ++k) S.act[k] = P.warm[13 + k];
+    for (int k = 0; k < FW_NUM_ACTUATORS; ++k) S.act[k] = warm_v[13 + k];
     tick = P.warm_ticks;
     step_count = 0; flags = 0; ep_return = (T)0; tgt_obs = 0; num_reached = 0;
-    new_dist = (T)0;
-    if (P.num_targets > 0) {
+    new_dist = copied ? dnd : (T)0;
+    if (P.num_targets > 0 && !copied) {
       if (G == 1 && nt == 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) t0[k] = D.r[(size_t)(RF_TARGETS + k) * n + env];
@@ -757,6 +818,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) act_obs[k] = (T)0;
+    FWP(p_r3 = FWP_NOW() - p_e2;)                                   // cached block + warm state + first distance
   }
   if (GENERAL && resetting) {                        // group-uniform: all G lanes of the env take part
     // the row just written is the terminal observation: move it out, then the new episode's row and state replace the old
