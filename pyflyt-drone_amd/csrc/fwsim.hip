@@ -68,10 +68,17 @@ __global__ void fw_warm_kernel(Params<T>* Pm) {
   for (int k = 0; k < 9; ++k) Pm->warm_R[k] = Rw[k];
 }
 
-// (The prefetches of the reset epilogue are plain loads.  tools/wave_profile.py still shows ~2.3 k cycles between the
-// terminal-observation copy and the new row in the waves that reset, whatever is requested ahead of the observation pass;
-// volatile loads -- to keep the compiler from sinking them to their only use inside the divergent reset block -- make it far
-// worse: the backend waits for every volatile access at once, 20.1 -> 24.5 us per step.)
+// Prefetch that stays where it is written.  What a resetting env copies in the epilogue is only USED inside the divergent reset
+// block, and LLVM sinks a plain load down to its only use: the round trip the prefetch was meant to hide then sits inside that
+// block (tools/wave_profile.py: ~2.3 k cycles in the waves that reset -- the slowest waves of nearly every launch -- whatever was
+// "requested" ahead of the observation pass).  Volatile loads are no way out (the backend waits for each at once: 20.1 -> 24.5 us
+// per step).  So the load is issued by hand: `pf_issue` emits it here, `pf_wait` (one s_waitcnt for the lot, tied to the values
+// through "+v") comes right before the first use.  The compiler's own vmcnt bookkeeping stays conservative-correct: loads return
+// in order, extra outstanding loads only make its waits longer.
+__device__ __forceinline__ void pf_issue(double& dst, const double* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
+__device__ __forceinline__ void pf_issue(float& dst, const float* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
+template <typename T> __device__ __forceinline__ void pf_wait(T& a, T& b, T& c, T& d) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory"); }
+template <typename T> __device__ __forceinline__ void pf_tie(T& a, T& b, T& c, T& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 template <typename T> __device__ __forceinline__ T vload(const T* p) { return *p; }
 
 // action shown in the observation: src 0 = this step's input, 1 = stored (stale), 2 = zeros
@@ -655,9 +662,9 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   T tpre[3] = {(T)0, (T)0, (T)0};
   const bool pre = DEFER && resetting && D.shadow_on && (int)(sh_done & 0xFF) == 1 && (uint32_t)(sh_done >> 32) == (uint32_t)(episode + 1) &&
                    (uint32_t)((sh_done >> 8) & 0xFFFFFFu) != (D.epoch & 0xFFFFFFu);
-  if (pre && sub < P.num_targets) {
+  if (pre) {      // (every lane issues: rows >= num_targets of the shadow are zero and are not stored back)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) tpre[k] = vload(&D.rs[(size_t)(RF_TARGETS + 3 * sub + k) * n + env]);
+    for (int k = 0; k < 3; ++k) pf_issue(tpre[k], &D.rs[(size_t)(RF_TARGETS + 3 * sub + k) * n + env]);
   }
   // ... and so is the cached attitude block of the observation a reset returns (lane `sub` holds its words sub, sub + G, ...)
   constexpr bool WO = DEFER && G == 8;               // (one lane per env: the block is copied straight from memory below)
@@ -668,26 +675,13 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     for (int j = 0; j < kWO; ++j) { const int k = sub + j * G; wo[j] = (k < P.att_dim) ? vload(&Pp->warm_obs[k]) : (T)0; }
   }
 
-  // DEFER: ... and so is the cached warm state itself (19 words + the rotation its target deltas use).  Read where it is used --
-  // inside the divergent reset block -- it arrives by scalar loads issued one batch at a time, each a scalar-cache round trip
-  // that only the waves with a reset pay: the slowest wave of nearly every launch (epilogue 9.4 k cycles against 5.2 k).  Here
-  // every lane of such a wave requests the 28 words as vector loads through a per-lane address, before the observation pass.
   // (pre: the worker also left the first observation row and the first distance: requested here as well)
-  constexpr int kDOW = WO ? (kMaxObs + G - 1) / G : 1;
+  constexpr int kDOW = 4;                            // words per lane of the first observation row (obs_dim <= 32: every waypoints config up to ctx 3)
   T dow[kDOW], dnd = (T)0;
-  if (WO && pre) {
+  if (WO && pre && Dobs <= kDOW * G) {
 #pragma unroll
-    for (int j = 0; j < kDOW; ++j) { const int k = sub + j * G; dow[j] = (k < Dobs) ? vload(&Dg.sobs[(size_t)env * Dobs + k]) : (T)0; }
-    dnd = vload(&D.rs[(size_t)RF_NEW_DIST * n + env]);
-  }
-  constexpr int kWarmW = DEFER ? 19 : 1, kWarmR = DEFER ? 9 : 1;
-  T warm_v[kWarmW], warmR_v[kWarmR];
-  if (DEFER && __ballot(resetting) != 0ull) {
-    const Params<T>* Q = Pp + opaque_zero();
-#pragma unroll
-    for (int k = 0; k < kWarmW; ++k) warm_v[k] = vload(&Q->warm[k]);
-#pragma unroll
-    for (int k = 0; k < kWarmR; ++k) warmR_v[k] = vload(&Q->warm_R[k]);
+    for (int j = 0; j < kDOW; ++j) { const int k = sub + j * G; dow[j] = (T)0; if (k < Dobs) pf_issue(dow[j], &Dg.sobs[(size_t)env * Dobs + k]); }
+    pf_issue(dnd, &D.rs[(size_t)RF_NEW_DIST * n + env]);
   }
 
   // GENERAL: the rows of a shadow that is being taken, fetched by the env's G lanes before the observation pass (their round
@@ -697,12 +691,22 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   constexpr bool SWAP_REGS = GENERAL && G == 8;       // G = 1: one lane would hold all 171 words; it copies through memory below
   T cw[kCW], ow[kOW];
   int32_t tick_new = 0;
+  // PF_GEN (the wind kernel on the 8-lane mapping): requested by hand, like the headline's reset (pf_issue above) -- 15 words a
+  // lane.  The camera kernels keep plain loads: 30 more values live across the observation pass cost their loop more than the
+  // reset gains (they sit at the edge of the register file).
+  constexpr bool PF_GEN = SWAP_REGS && !HASOBJ;
   if (GENERAL && resetting) {
     if (SWAP_REGS) {
 #pragma unroll
-      for (int j = 0; j < kCW; ++j) { const int w = sub + j * G; cw[j] = (w < kRows) ? D.rs[(size_t)w * n + env] : (T)0; }
+      for (int j = 0; j < kCW; ++j) {
+        const int w = sub + j * G; cw[j] = (T)0;
+        if (w < kRows) { if (PF_GEN) pf_issue(cw[j], &D.rs[(size_t)w * n + env]); else cw[j] = D.rs[(size_t)w * n + env]; }
+      }
 #pragma unroll
-      for (int j = 0; j < kOW; ++j) { const int k = sub + j * G; ow[j] = (k < Dobs) ? Dg.sobs[(size_t)env * Dobs + k] : (T)0; }
+      for (int j = 0; j < kOW; ++j) {
+        const int k = sub + j * G; ow[j] = (T)0;
+        if (k < Dobs) { if (PF_GEN) pf_issue(ow[j], &Dg.sobs[(size_t)env * Dobs + k]); else ow[j] = Dg.sobs[(size_t)env * Dobs + k]; }
+      }
     }
     tick_new = D.is[env];
   }
@@ -741,6 +745,12 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     else write_obs<T>(P, D, env, S, act_obs, tgt_obs, [&](int k, T v) { tile[row * ld + k] = v; });
   }
   FWP(const long long p_e0 = FWP_NOW();)
+  if (DEFER && pre) {
+    // the hand-issued prefetches: ONE wait, here -- behind the observation pass and AHEAD of the terminal-observation stores below
+    // (vmcnt counts stores too: a wait placed after them pays their acknowledgement, ~2 k cycles) -- tied to every value
+    pf_wait(tpre[0], tpre[1], tpre[2], dnd);
+    if (WO) pf_tie(dow[0], dow[1], dow[2], dow[3]);
+  }
   if (DEFER && resetting) {                          // group-uniform: all G lanes of the env take part
     // the row just written is the terminal observation: move it out before the new episode's row replaces it
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -766,7 +776,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     }
     const int nt = min(P.ctx, P.num_targets);
     T t0[3] = {(T)0, (T)0, (T)0};
-    const bool copied = WO && pre;                    // the worker left the whole first observation row: nothing to compute
+    const bool copied = WO && pre && Dobs <= kDOW * G;    // the worker left the whole first observation row: nothing to compute
     if (copied) {
 #pragma unroll
       for (int j = 0; j < kDOW; ++j) { const int k = sub + j * G; if (k < Dobs) tile[row * ld + k] = dow[j]; }
@@ -784,8 +794,8 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       T d[3] = {(T)0, (T)0, (T)0}, b[3] = {(T)0, (T)0, (T)0};
       if (i < nt) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) d[k] = tw[k] - warm_v[k];
-        mtv(warmR_v, d, b);
+        for (int k = 0; k < 3; ++k) d[k] = tw[k] - P.warm[k];
+        mtv(P.warm_R, d, b);
         if (i == 0) { t0[0] = tw[0]; t0[1] = tw[1]; t0[2] = tw[2]; }
       }
       if (leader) { tile[row * ld + P.att_dim + 3 * i] = b[0]; tile[row * ld + P.att_dim + 3 * i + 1] = b[1]; tile[row * ld + P.att_dim + 3 * i + 2] = b[2]; }
@@ -797,11 +807,11 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     }
     if (!copied) for (int k = sub + (WO ? kWO * G : 0); k < P.att_dim; k += G) tile[row * ld + k] = Pp->warm_obs[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { S.p[k] = warm_v[k]; S.v[k] = warm_v[7 + k]; S.w[k] = warm_v[10 + k]; }
+    for (int k = 0; k < 3; ++k) { S.p[k] = P.warm[k]; S.v[k] = P.warm[7 + k]; S.w[k] = P.warm[10 + k]; }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) S.q[k] = warm_v[3 + k];
+    for (int k = 0; k < 4; ++k) S.q[k] = P.warm[3 + k];
 #pragma unroll
-    for (int k = 0; k < FW_NUM_ACTUATORS; ++k) S.act[k] = warm_v[13 + k];
+    for (int k = 0; k < FW_NUM_ACTUATORS; ++k) S.act[k] = P.warm[13 + k];
     tick = P.warm_ticks;
     step_count = 0; flags = 0; ep_return = (T)0; tgt_obs = 0; num_reached = 0;
     new_dist = copied ? dnd : (T)0;
@@ -819,6 +829,13 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
 #pragma unroll
     for (int k = 0; k < 4; ++k) act_obs[k] = (T)0;
     FWP(p_r3 = FWP_NOW() - p_e2;)                                   // cached block + warm state + first distance
+  }
+  if (PF_GEN && resetting) {                         // ONE wait for the hand-issued loads, ahead of the terminal-observation stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < kCW; ++j) asm volatile("" : "+v"(cw[j]));
+#pragma unroll
+    for (int j = 0; j < kOW; ++j) asm volatile("" : "+v"(ow[j]));
   }
   if (GENERAL && resetting) {                        // group-uniform: all G lanes of the env take part
     // the row just written is the terminal observation: move it out, then the new episode's row and state replace the old
