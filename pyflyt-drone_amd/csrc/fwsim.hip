@@ -691,10 +691,10 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   constexpr bool SWAP_REGS = GENERAL && G == 8;       // G = 1: one lane would hold all 171 words; it copies through memory below
   T cw[kCW], ow[kOW];
   int32_t tick_new = 0;
-  // PF_GEN (the wind kernel on the 8-lane mapping): requested by hand, like the headline's reset (pf_issue above) -- 15 words a
-  // lane.  The camera kernels keep plain loads: 30 more values live across the observation pass cost their loop more than the
-  // reset gains (they sit at the edge of the register file).
-  constexpr bool PF_GEN = SWAP_REGS && !HASOBJ;
+  // PF_GEN: the same hand-issued form for the shadow take-over of the wind / camera kernels.  Measured on the wind kernel: 23.35 ->
+  // 23.49 us (15 more values live across the observation pass cost as much as the sunk loads), so it stays off; the camera
+  // kernels sit at the edge of the register file and were not tried.
+  constexpr bool PF_GEN = false;
   if (GENERAL && resetting) {
     if (SWAP_REGS) {
 #pragma unroll
