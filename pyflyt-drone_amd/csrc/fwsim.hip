@@ -449,7 +449,15 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   if (pre_noise && !done_at_entry) rng_normal2<T>(P, genv, (uint32_t)episode, astep0 + (uint32_t)sub, nz0, nz1);
 
   int phase = active ? PH_STEP : PH_DONE;
-  double* latch = COLLECT ? reinterpret_cast<double*>(smem_raw + CAp->latch_off) : nullptr;     // COLLECT: [EPW][2] reward, done of this step
+  // STASH: the outputs of the step (reward, flags, info) wait in LDS -- four words per env behind the tile / the camera's map --
+  // from the latch point to the END of the epilogue.  Stored at the latch point (round 2: to keep them out of registers) they
+  // sat in front of the epilogue's loads (stored action, waypoints of the observation): vector memory operations retire in order
+  // on gfx9, so those loads paid the stores' acknowledgement, ~2 k cycles in every wave.  The wind-free headline kernel has no such
+  // loads (actions and waypoints ride in registers) and keeps storing at the latch point.
+  // (The camera kernels would gain the same way -- but with the stash their plain builds trip the compiler hazard of section 3
+  // of DESIGN.md at the mask-row join, and the hazard-free form of that join costs 3-4 us; they keep the latch-point stores.)
+  constexpr bool STASH = (!DEFER && !HASOBJ) || COLLECT;
+  double* latch = STASH ? reinterpret_cast<double*>(smem_raw + Dg.stash_off) : nullptr;        // [EPW][4]: reward, done, (num_reached, flags), (strike, step_count)
   int it = 0, warm_left = 0;
   bool resetting = false;                            // DEFER: auto-reset pending for the epilogue
   bool step_over = active && done_at_entry;          // nothing to simulate: finalise immediately
@@ -463,10 +471,12 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       step_count += 1;
       ep_return += rew;
       phase = PH_DONE;
-      // for the statistics tail: parked in LDS (two words per env behind the tile), not in registers across the rest of the loop
-      if (COLLECT && leader) { latch[2 * row] = (double)rew; latch[2 * row + 1] = (flags & (FL_TERM | FL_TRUNC)) ? 1.0 : 0.0; }
-      // the outputs of the step leave for memory here (nothing is kept live across the rest of the loop for them)
-      if (leader) {
+      if (STASH && leader) {
+        latch[4 * row] = (double)rew; latch[4 * row + 1] = (flags & (FL_TERM | FL_TRUNC)) ? 1.0 : 0.0;
+        latch[4 * row + 2] = __hiloint2double(num_reached, flags); latch[4 * row + 3] = __hiloint2double(out_strike, step_count);
+      }
+      // DEFER: the outputs of the step leave for memory here (nothing is kept live across the rest of the loop for them)
+      if (!(STASH && !DEFER) && leader) {     // (COLLECT && DEFER stashes for the statistics tail and stores here as well)
         reward[env] = rew;
         terminated[env] = (uint8_t)((flags & FL_TERM) ? 1 : 0);
         truncated[env] = (uint8_t)((flags & FL_TRUNC) ? 1 : 0);
@@ -873,9 +883,21 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     D.i[IF_FLAGS * n + env] = flags | (tgt_obs << FL_TGT_SHIFT);
     D.i[IF_NUM_REACHED * n + env] = num_reached;
   }
+  if (STASH && !DEFER && active && leader) {         // the outputs parked at the latch point: behind every load of the epilogue
+    const double w2 = latch[4 * row + 2], w3 = latch[4 * row + 3];
+    const int o_nr = __double2hiint(w2), o_fl = __double2loint(w2), o_st = __double2hiint(w3), o_sc = __double2loint(w3);
+    reward[env] = (T)latch[4 * row];
+    terminated[env] = (uint8_t)((o_fl & FL_TERM) ? 1 : 0);
+    truncated[env] = (uint8_t)((o_fl & FL_TRUNC) ? 1 : 0);
+    if (info) {
+      int4* ip = reinterpret_cast<int4*>(info + (size_t)env * FW_INFO_DIM);
+      ip[0] = make_int4(o_nr, (o_fl & FL_COLLISION) ? 1 : 0, (o_fl & FL_OOB) ? 1 : 0, (o_fl & FL_COMPLETE) ? 1 : 0);
+      ip[1] = make_int4(o_st, OBJ ? o_st : 0, o_sc, 0);
+    }
+  }
   __syncthreads();
   flush_obs_tile<T>(tile, ld, obs, env0, EPW, D.n, Dobs);
-  if (COLLECT) collect_stats_tail<T>(*CAp, D.epoch, tile, ld, min(EPW, D.n - env0), wg, nblk, active && leader, latch[2 * row], latch[2 * row + 1] != 0.0, env);
+  if (COLLECT) collect_stats_tail<T>(*CAp, D.epoch, tile, ld, min(EPW, D.n - env0), wg, nblk, active && leader, latch[4 * row], latch[4 * row + 1] != 0.0, env);
   FWP(long long p_capmax = HASOBJ ? O.p_cap : 0; const int p_ncapw = HASOBJ ? __popcll(__ballot(leader && O.p_ncap > 0)) : 0;)
   FWP(if (D.prof) {
     for (int o = 32; o > 0; o >>= 1) p_capmax = max(p_capmax, (long long)__shfl_xor((long long)p_capmax, o, kWave));
@@ -1315,10 +1337,12 @@ int device_of(const void* p) {
 // before (i.e. on the first call per observation width), never again on the launch path.
 int ensure_learner_lds(int dev, int which /*0: fw_ppo_update, 1: fw_policy_act*/, size_t bytes);
 
+template <typename T> size_t tile_bytes(const fw_env* h);
 template <typename T> DevState<T> dev_state(fw_env* h) {
   DevState<T> D; D.r = (T*)h->r_dev; D.i = h->i_dev; D.n = h->n; D.npad = h->npad;
   D.rs = (T*)h->rs_dev; D.is = h->is_dev; D.sobs = (T*)h->sobs_dev; D.sreq = h->sreq_dev; D.sdone = h->sdone_dev; D.epoch = 0; D.shadow_on = h->shadow_on;
   D.lctr = h->lctr_dev; D.stats = h->stats_dev;
+  D.stash_off = (int32_t)((tile_bytes<T>(h) + 15) & ~(size_t)15);
   FWP(D.prof = h->prof_dev;)
   return D;
 }
@@ -1352,6 +1376,8 @@ template <typename T> size_t tile_bytes(const fw_env* h) {
   }
   return b;
 }
+// dynamic LDS of a step launch: the tile (or the camera's map) + the output stash of the envs of a wave
+template <typename T> size_t step_lds_bytes(const fw_env* h) { return ((tile_bytes<T>(h) + 15) & ~(size_t)15) + sizeof(double) * 4 * (size_t)(kWave / h->lanes_per_env); }
 inline dim3 grid_of(const fw_env* h) { return dim3((unsigned)(h->npad / (kWave / h->lanes_per_env))); }
 
 // ObjLock task constants (analytic camera axes, shaping coefficients of envs/fixedwing_objlock_env.py:54-80)
@@ -1438,7 +1464,7 @@ int create_T(fw_env* h) {
   // the camera's LDS map outgrows what a workgroup gets without asking from ~700 columns on.  The attribute belongs to the
   // (device, kernel) pair, not to the handle: keep the maximum ever asked for and only ever raise it, so a later, smaller
   // handle cannot lower the cap under an earlier one
-  if (const size_t lds = tile_bytes<T>(h); lds > 48 * 1024) {
+  if (const size_t lds = step_lds_bytes<T>(h); lds > 48 * 1024) {
     if (lds > 160 * 1024) { h->err = "camera_resolution x num_obstacles needs more LDS than a CU has"; return FW_EINVAL; }
     const int which = (h->cfg.task == FW_TASK_OBJLOCK ? 0 : 1) + (sizeof(T) == 8 ? 0 : 2);
     static size_t have[64][4] = {};
@@ -1460,7 +1486,7 @@ int create_T(fw_env* h) {
 }
 
 #define FW_LAUNCH_STEP(KERNEL)                                                                                   \
-  hipLaunchKernelGGL((KERNEL), step_grid, dim3(kWave), tile_bytes<T>(h), st, (const Params<T>*)h->params_dev,    \
+  hipLaunchKernelGGL((KERNEL), step_grid, dim3(kWave), step_lds_bytes<T>(h), st, (const Params<T>*)h->params_dev,    \
                      (const ObjC<T>*)h->objc_dev, dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term,  \
                      trunc, (T*)tobs, info)
 
@@ -1585,8 +1611,7 @@ CollectWs collect_ws(const fw_env* h) {
 template <typename T>
 int collect_step_T(fw_env* h, CollectArgs& CA, const void* actions, void* obs, void* reward, uint8_t* term, uint8_t* trunc, void* tobs,
                    int32_t* info, hipStream_t st) {
-  const size_t latch_off = (tile_bytes<T>(h) + 15) & ~(size_t)15;
-  const size_t lds = std::max(latch_off + sizeof(double) * 2 * (kWave / 8), collect_act_lds_bytes(CA.A.D));
+  const size_t lds = std::max(step_lds_bytes<T>(h), collect_act_lds_bytes(CA.A.D));
   if (lds > 160 * 1024) { h->err = "fw_collect_step: the networks do not fit the LDS next to the step kernel's tile"; return FW_EINVAL; }
   const void* fn = h->cfg.task == FW_TASK_OBJLOCK ? (const void*)fw_collect_kernel_obj_g8<T, FW_TASK_OBJLOCK>
                  : h->cfg.task == FW_TASK_WAYPOINT_OBJLOCK ? (const void*)fw_collect_kernel_obj_g8<T, FW_TASK_WAYPOINT_OBJLOCK>
@@ -1599,7 +1624,6 @@ int collect_step_T(fw_env* h, CollectArgs& CA, const void* actions, void* obs, v
       have[h->device][which] = lds;
     }
   }
-  CA.latch_off = (int32_t)latch_off;
   dim3 grid((unsigned)CA.n_act + grid_of(h).x * (h->shadow_on ? 2u : 1u));
 #define FW_LAUNCH_COLLECT(KERNEL)                                                                                  \
   hipLaunchKernelGGL((KERNEL), grid, dim3(kWave), lds, st, (const Params<T>*)h->params_dev, (const ObjC<T>*)h->objc_dev, \

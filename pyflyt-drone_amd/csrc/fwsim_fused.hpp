@@ -56,7 +56,6 @@ __device__ __forceinline__ bool collect_is_sentinel(double v) { return __double_
 struct CollectArgs {
   int32_t n_act;                      // workgroups in front of the step waves: 2 per chunk + the merge wave, padded to a multiple of 8
   int32_t n_chunks;                   // ceil(N / 32)
-  int32_t latch_off;                  // byte offset in dynamic LDS of the step waves' [envs per wave][2] (reward, done) words
   int32_t nblk;                       // step workgroups
   ActArgs A;                          // as fw_collect_act
   StatsArgs S;                        // as fw_collect_stats (S.obs / S.part / S.ticket unused)
