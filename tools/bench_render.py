@@ -24,7 +24,10 @@ us = e0.elapsed_time(e1) * 1e3 / 50
 line = {"task": "combined", "envs": n, "res": res, "fw_render_us": us, "pixels_per_s": n * res * res / us * 1e6,
         "image_bytes": out.numel() * 4, "write_GBps": out.numel() * 4 / us / 1e3}
 T = max(32 * 1024 // n, 1)
-ppo = R.PPO(R.VecNormalizeDevice(venv), R.PPOConfig(n_steps=T, batch_size=1024, n_epochs=20, detector="cnn", image_res=res))
+graphs = not (len(sys.argv) > 3 and sys.argv[3] == "eager")
+if os.environ.get("CNN_BENCHMARK"): torch.backends.cudnn.benchmark = True      # MIOpen: search for the fastest algorithm per shape
+ppo = R.PPO(R.VecNormalizeDevice(venv), R.PPOConfig(n_steps=T, batch_size=1024, n_epochs=20, detector="cnn", image_res=res, cnn_graphs=graphs))
+line["cnn_graphs"] = bool(ppo._graphs)
 for _ in range(2):
     ppo.collect_rollouts()
 torch.cuda.synchronize(); t0 = time.perf_counter(); reps = 5
