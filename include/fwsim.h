@@ -467,11 +467,12 @@ int32_t fw_collect_stats(const void* obs, int32_t obs_is_f64, int32_t N, int32_t
  * same buffers (statistics to ~1e-12: another summation order; normalised observations within an ulp of double before the
  * float32 rounding): `obs`, `reward`, `terminated`, `truncated`, `terminal_obs` hold the PREVIOUS step on entry (obs = the
  * observation to act on) and this step on return; rew_out / start_out (both or neither) receive the finalisation of the
- * previous step.  The statistics of a step are folded by the NEXT fw_collect_step (which needs them first) -- or by
- * fw_collect_finish: call it after the last step of a rollout, before anything else reads (obs_mean, obs_var, obs_count) /
- * the return statistics.  Serves handles on the 8-lanes-per-env mapping at one wave per SIMD (FW_EUNSUPPORTED otherwise: use
- * the three calls).  workspace: caller-owned, fw_collect_step_workspace_bytes(h) bytes, zero-initialised once; the uint32 at
- * (workspace_bytes - 64 + 12) is a status word that stays 0 (a wave gave up waiting inside the launch -- never expected). */
+ * previous step.  The batch sums of a step are folded by "fold waves" at the end of its own launch and merged into the
+ * statistics buffers by the NEXT fw_collect_step (which needs them first) -- or by fw_collect_finish: call it after the last
+ * step of a rollout, before anything else reads (obs_mean, obs_var, obs_count) / the return statistics.  Serves handles on the 8-lanes-per-env mapping at one wave per SIMD (FW_EUNSUPPORTED otherwise: use
+ * the three calls).  workspace: caller-owned, fw_collect_step_workspace_bytes(h) bytes, one per handle, prepared ONCE with
+ * fw_collect_workspace_init (stream-ordered; not inside a graph that is replayed); the uint32 at (workspace_bytes - 64 + 12) is
+ * a status word that stays 0 (1 | 2 | 4: a wave gave up waiting inside the launch -- never expected; 8: workspace not initialised). */
 typedef struct fw_collect_args {
   const float* params;                     /* flat parameter image (fw_ppo_update layout) */
   double *obs_mean, *obs_var, *obs_count;  /* VecNormalize observation statistics (in/out) */
@@ -493,6 +494,7 @@ typedef struct fw_collect_args {
   int32_t update_obs, update_ret, norm_reward, deterministic;
 } fw_collect_args;
 int64_t fw_collect_step_workspace_bytes(fw_handle h);
+int32_t fw_collect_workspace_init(fw_handle h, void* workspace, int64_t workspace_bytes, void* hip_stream);
 int32_t fw_collect_step(fw_handle h, const fw_collect_args* a, void* hip_stream);
 int32_t fw_collect_finish(fw_handle h, const fw_collect_args* a, void* hip_stream);   /* statistics buffers, flags and workspace of `a` only */
 

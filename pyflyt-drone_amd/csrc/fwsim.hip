@@ -397,7 +397,9 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   T cmd[FW_NUM_ACTUATORS];
   // COLLECT: the actions of this launch come from the act waves in front of the grid; everything above was loaded while they
   // worked.  Coherent loads from here on: the rows were written (write-through) by a wave of another XCD in this same launch.
+  double c_ret = 0.0;                                // COLLECT: my env's discounted-return tracker, fetched while the wave waits anyway
   if (COLLECT) {
+    if (active && leader) c_ret = ld_sc1(CAp->S.returns + env);
     collect_wait_actions(*CAp, Dg.epoch, env0, min(EPW, Dg.n - env0));
     if (LANE_T) a_keep = ld_coherent(actions + (size_t)envc * 4 + (sub & 3));
   }
@@ -897,7 +899,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   }
   __syncthreads();
   flush_obs_tile<T>(tile, ld, obs, env0, EPW, D.n, Dobs);
-  if (COLLECT) collect_stats_tail<T>(*CAp, D.epoch, tile, ld, min(EPW, D.n - env0), wg, nblk, active && leader, latch[4 * row], latch[4 * row + 1] != 0.0, env);
+  if (COLLECT) collect_stats_tail<T>(*CAp, D.epoch, tile, ld, min(EPW, D.n - env0), wg, nblk, active && leader, latch[4 * row], latch[4 * row + 1] != 0.0, env, c_ret);
   FWP(long long p_capmax = HASOBJ ? O.p_cap : 0; const int p_ncapw = HASOBJ ? __popcll(__ballot(leader && O.p_ncap > 0)) : 0;)
   FWP(if (D.prof) {
     for (int o = 32; o > 0; o >>= 1) p_capmax = max(p_capmax, (long long)__shfl_xor((long long)p_capmax, o, kWave));
@@ -956,6 +958,11 @@ __global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g1(FW_STEP_ARGS) { F
     }                                                                                                                   \
     if (CA.trace && threadIdx.x == 0) CA.trace[(size_t)blockIdx.x * 8] = collect_now();                                 \
     const int bx_ = (int)blockIdx.x - CA.n_act;                                                                         \
+    if (bx_ >= CA.n_workers) {                                                                                          \
+      collect_fold_wave(CA, bx_ - CA.n_workers);                                                                        \
+      if (CA.trace && threadIdx.x == 0) CA.trace[(size_t)blockIdx.x * 8 + 7] = collect_now();                           \
+      return;                                                                                                           \
+    }                                                                                                                   \
     D.epoch = 1u + D.lctr[bx_];                                                                                         \
     step_body<__VA_ARGS__>(FW_STEP_PASS, &CA);                                                                          \
     if (threadIdx.x == 0) D.lctr[bx_] = D.epoch;                                                                        \
@@ -1600,7 +1607,7 @@ CollectWs collect_ws(const fw_env* h) {
   const size_t PW = 2 * (size_t)obs_dim_of(&h->cfg) + 2, nblk = (size_t)h->npad / 8, nch = ((size_t)h->n + kCRows - 1) / kCRows;
   CollectWs w; size_t o = 0;
   w.part1 = o; o += sizeof(double) * PW * kCGroups * ((nblk + kCGroups - 1) / kCGroups);
-  w.tot = o; o += sizeof(double) * 2 * PW;
+  w.tot = o; o += sizeof(double) * PW;
   w.flag_p = o; o += sizeof(unsigned int) * nch;
   w.flag_v = o; o += sizeof(unsigned int) * nch;
   o = (o + 63) & ~(size_t)63;
@@ -1624,7 +1631,8 @@ int collect_step_T(fw_env* h, CollectArgs& CA, const void* actions, void* obs, v
       have[h->device][which] = lds;
     }
   }
-  dim3 grid((unsigned)CA.n_act + grid_of(h).x * (h->shadow_on ? 2u : 1u));
+  CA.n_workers = (int32_t)(grid_of(h).x * (h->shadow_on ? 2u : 1u));
+  dim3 grid((unsigned)(CA.n_act + CA.n_workers + 2 * CA.A.D + 2));          // + one fold wave per partial-sum word
 #define FW_LAUNCH_COLLECT(KERNEL)                                                                                  \
   hipLaunchKernelGGL((KERNEL), grid, dim3(kWave), lds, st, (const Params<T>*)h->params_dev, (const ObjC<T>*)h->objc_dev, \
                      dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term, trunc, (T*)tobs, info, CA)
@@ -2011,6 +2019,21 @@ int32_t fw_collect_step(fw_handle h, const fw_collect_args* a, void* hip_stream)
              : collect_step_T<float>(h, CA, a->act_env, a->obs, a->reward, a->terminated, a->truncated, a->terminal_obs, a->info_i32, st);
 }
 
+int32_t fw_collect_workspace_init(fw_handle h, void* workspace, int64_t workspace_bytes, void* hip_stream) {
+  if (!h) return FW_EINVAL;
+  if (h->lanes_per_env != 8 || h->g8_waves != 1) { h->err = "fw_collect_workspace_init: this handle's lane mapping has no fw_collect_step"; return FW_EUNSUPPORTED; }
+  const CollectWs W = collect_ws(h);
+  if (!workspace || workspace_bytes < (int64_t)W.total) { h->err = "fw_collect_workspace_init: workspace smaller than fw_collect_step_workspace_bytes()"; return FW_EINVAL; }
+  DeviceGuard g(h->device);
+  hipStream_t st = (hipStream_t)hip_stream;
+  char* ws = (char*)workspace;
+  HIP_TRY(h, hipMemsetAsync(ws, 0, W.total, st));
+  const size_t n = (W.tot - W.part1) / sizeof(double);
+  hipLaunchKernelGGL(fw_collect_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (double*)(ws + W.part1), n, (unsigned int*)(ws + W.sync));
+  HIP_TRY(h, hipGetLastError());
+  return FW_OK;
+}
+
 int32_t fw_collect_finish(fw_handle h, const fw_collect_args* a, void* hip_stream) {
   if (!h || !a) return FW_EINVAL;
   if (h->lanes_per_env != 8 || h->g8_waves != 1) { h->err = "fw_collect_finish: this handle's lane mapping has no fw_collect_step"; return FW_EUNSUPPORTED; }
@@ -2026,7 +2049,7 @@ int32_t fw_collect_finish(fw_handle h, const fw_collect_args* a, void* hip_strea
   S.ret_mean = a->ret_mean; S.ret_var = a->ret_var; S.ret_count = a->ret_count; S.update_ret = a->update_ret; S.obs_acc = a->obs_acc; S.ret_acc = a->ret_acc;
   char* ws = (char*)a->workspace;
   CA.part1 = (double*)(ws + W.part1); CA.tot = (double*)(ws + W.tot); CA.sync = (unsigned int*)(ws + W.sync);
-  hipLaunchKernelGGL(fw_collect_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, CA);
+  hipLaunchKernelGGL(fw_collect_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, CA);
   HIP_TRY(h, hipGetLastError());
   return FW_OK;
 }

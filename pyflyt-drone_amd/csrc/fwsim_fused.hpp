@@ -46,9 +46,10 @@
 
 namespace fwsim {
 
-constexpr int kCRows = 32;            // rows (envs) per act wave
+constexpr int kCRows = 16;            // rows (envs) per act wave
 constexpr int kCGroups = 8;           // partial-sum rows are grouped by workgroup index mod 8 (the XCD a step wave runs on)
-enum { CS_PART_EPOCH = 0, CS_FOLDED_EPOCH = 1, CS_READERS = 2, CS_STATUS = 3, CS_CEPOCH = 4 };
+enum { CS_PART_EPOCH = 0, CS_FOLDED_EPOCH = 1, CS_READERS = 2, CS_STATUS = 3, CS_INIT = 4 };
+constexpr unsigned int kCollectInitMagic = 0xF01DC0DEu;  // left in sync[CS_INIT] by fw_collect_workspace_init
 // a total that has not been published yet: a quiet NaN no sum can produce
 __device__ __forceinline__ double collect_sentinel() { return __longlong_as_double(0x7FF8C0DEC0DE0001ll); }
 __device__ __forceinline__ bool collect_is_sentinel(double v) { return __double_as_longlong(v) == 0x7FF8C0DEC0DE0001ll; }
@@ -57,12 +58,13 @@ struct CollectArgs {
   int32_t n_act;                      // workgroups in front of the step waves: 2 per chunk + the merge wave, padded to a multiple of 8
   int32_t n_chunks;                   // ceil(N / 32)
   int32_t nblk;                       // step workgroups
+  int32_t n_workers;                  // step + shadow / scenario workgroups; the fold waves follow them
   ActArgs A;                          // as fw_collect_act
   StatsArgs S;                        // as fw_collect_stats (S.obs / S.part / S.ticket unused)
   unsigned int* flag_p;               // [n_chunks] policy wave: actions of launch `epoch` are in act_env
   unsigned int* flag_v;               // [n_chunks] value wave: inputs of launch `epoch` have been read
-  double* part1;                      // [2 D + 2][8][ceil(nblk / 8)] partial sums of the step waves: word-major, a group's members consecutive
-  double* tot;                        // [2][2 D + 2] totals of the pending step, double-buffered by collect-launch parity; unpublished = sentinel
+  double* part1;                      // [2 D + 2][8][ceil(nblk / 8)] partial sums of the step waves: word-major; a slot nobody has written since the last fold holds a sentinel
+  double* tot;                        // [2 D + 2] totals of the pending step (written by the fold waves of the launch that produced it)
   unsigned int* sync;                 // [8] CS_*: launch index of the partials in part1 / of the last fold, readers counter, status bits, collect-launch counter
   long long* trace;                   // null, or [grid][8] wall-clock stamps (10 ns ticks) per workgroup: tools/trace_collect.py
 };
@@ -74,84 +76,88 @@ template <typename T> __device__ __forceinline__ T ld_coherent(const T* p) { ret
 template <typename T> __device__ __forceinline__ void st_coherent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 inline size_t collect_act_lds_bytes(int D) {
-  const int Dp = (D + 1) & ~1, ldx = Dp + 1;
-  return sizeof(float) * ((size_t)Dp * kPH + kPH + kPH * kPLdh + kPH + kPH * 4 + 4 + 4 + 2 * (size_t)kCRows * ldx + 2 * (size_t)kCRows * kPLdh + kCRows * 4);
+  const int Dk = (D + 3) & ~3, ldx = Dk + 1;
+  return sizeof(float) * ((size_t)Dk * kPH + kPH + kPH * kPLdh + kPH + kPH * 4 + 4 + 4 + 2 * (size_t)kCRows * ldx + 2 * (size_t)kCRows * kPLdh + kCRows * 4);
 }
 
-// C0 / C1 (32 x 32 each) += A(32 x K) * B(K x 64): both column tiles of one layer in ONE pass over K -- the A operand is read
-// once for the two MFMAs of a k-step and the two accumulators interleave, so one tile's LDS latency hides behind the other's
-// MFMA.  Per tile the k order and the operands are those of ppo_mfma_tile: the same bits.
-template <int STEPS>
-__device__ __forceinline__ void act_mfma2_batch(const float* a, int sak, const float* b, int sbk, int step0, f32x16& c0, f32x16& c1) {
-  float av[STEPS], b0[STEPS], b1[STEPS];
-#pragma unroll
-  for (int i = 0; i < STEPS; ++i) { const int k0 = 2 * (step0 + i); av[i] = a[k0 * sak]; b0[i] = b[k0 * sbk]; b1[i] = b[k0 * sbk + 32]; }
+// One act wave carries 16 rows: v_mfma_f32_16x16x4_f32 tiles (lane l holds A[l % 16][l / 16], B[l / 16][l % 16] and the four
+// results D[4 (l / 16) + v][l % 16]).  Half the rows of a 32x32x2 tile per wave means half the MFMA passes, half the tanh and half
+// the input normalisation on the path to the published actions, for twice the act waves -- they are the critical path of the
+// launch, and there are SIMDs to spare while the step waves wait.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+// C_t (16 x 16, t < NT) += A(16 x 4 STEPS, from k-step step0) * B(.. x 16 NT): operands of STEPS k-steps fetched together, the
+// NT accumulators interleaved so that one tile's MFMA latency hides behind the others'.
+template <int NT, int STEPS>
+__device__ __forceinline__ void act_mfma16_batch(const float* a, const float* b, int sbk, int step0, f32x4 (&c)[NT]) {
+  float av[STEPS], bv[STEPS][NT];
 #pragma unroll
   for (int i = 0; i < STEPS; ++i) {
-    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b0[i], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1[i], c1, 0, 0, 0);
+    const int k0 = 4 * (step0 + i);
+    av[i] = a[k0];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[i][t] = b[k0 * sbk + 16 * t];
+  }
+#pragma unroll
+  for (int i = 0; i < STEPS; ++i) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i][t], c[t], 0, 0, 0);
   }
 }
-__device__ __forceinline__ void act_mfma2(const float* A, int sam, const float* B, int sbk, int K, f32x16& c0, f32x16& c1) {
-  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const float* a = A + r * sam + h;            // A(m, k) = A[m * sam + k]
-  const float* b = B + h * sbk + r;            // B(k, n) = B[k * sbk + n]
-  const int steps = K >> 1;
+template <int NT>
+__device__ __forceinline__ void act_mfma16(const float* A, int sam, const float* B, int sbk, int K, f32x4 (&c)[NT]) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const float* a = A + r * sam + q;            // A(m, k) = A[m * sam + k]
+  const float* b = B + q * sbk + r;            // B(k, n) = B[k * sbk + n]
+  const int steps = K >> 2;
   int s = 0;
-  for (; s + 8 <= steps; s += 8) act_mfma2_batch<8>(a, 1, b, sbk, s, c0, c1);
-  if (s + 4 <= steps) { act_mfma2_batch<4>(a, 1, b, sbk, s, c0, c1); s += 4; }
-  if (s + 2 <= steps) { act_mfma2_batch<2>(a, 1, b, sbk, s, c0, c1); s += 2; }
-  if (s < steps) act_mfma2_batch<1>(a, 1, b, sbk, s, c0, c1);
+  for (; s + 4 <= steps; s += 4) act_mfma16_batch<NT, 4>(a, b, sbk, s, c);
+  if (s + 2 <= steps) { act_mfma16_batch<NT, 2>(a, b, sbk, s, c); s += 2; }
+  if (s < steps) act_mfma16_batch<NT, 1>(a, b, sbk, s, c);
 }
 
-// 32 rows through one network, one wave: X[32, Dp] -> tanh -> H1 -> tanh -> H2 -> head: out[32, 4] (KO columns used).
-__device__ __forceinline__ void act_forward_wave(const PpoNetLds& W, const float* X, float* H1, float* H2, float* out, int KO, int Dp, int ldx) {
-  const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+// 16 rows through one network, one wave: X[16, Dk] -> tanh -> H1 -> tanh -> H2 -> head: out[16, 4] (KO columns used).
+// Dk = the input width padded to a multiple of 4 (zero columns of X against zero rows of W1).
+__device__ __forceinline__ void act_forward_wave(const PpoNetLds& W, const float* X, float* H1, float* H2, float* out, int KO, int Dk, int ldx) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
   {
-    f32x16 c0, c1;
-    const float bias0 = W.b1[r], bias1 = W.b1[32 + r];
+    f32x4 c[4];
 #pragma unroll
-    for (int v = 0; v < 16; ++v) { c0[v] = bias0; c1[v] = bias1; }
-    act_mfma2(X, ldx, W.W1, kPH, Dp, c0, c1);
+    for (int t = 0; t < 4; ++t) { const float bias = W.b1[16 * t + r]; c[t] = f32x4{bias, bias, bias, bias}; }
+    act_mfma16<4>(X, ldx, W.W1, kPH, Dk, c);
 #pragma unroll
-    for (int v = 0; v < 16; ++v) { H1[ppo_acc_row(v) * kPLdh + r] = ppo_tanh(c0[v]); H1[ppo_acc_row(v) * kPLdh + 32 + r] = ppo_tanh(c1[v]); }
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) H1[(4 * q + v) * kPLdh + 16 * t + r] = ppo_tanh(c[t][v]);
   }
   __syncthreads();
   {
-    f32x16 c0, c1;
-    const float bias0 = W.b2[r], bias1 = W.b2[32 + r];
+    f32x4 c[4];
 #pragma unroll
-    for (int v = 0; v < 16; ++v) { c0[v] = bias0; c1[v] = bias1; }
-    act_mfma2(H1, kPLdh, W.W2, kPLdh, kPH, c0, c1);
+    for (int t = 0; t < 4; ++t) { const float bias = W.b2[16 * t + r]; c[t] = f32x4{bias, bias, bias, bias}; }
+    act_mfma16<4>(H1, kPLdh, W.W2, kPLdh, kPH, c);
 #pragma unroll
-    for (int v = 0; v < 16; ++v) { H2[ppo_acc_row(v) * kPLdh + r] = ppo_tanh(c0[v]); H2[ppo_acc_row(v) * kPLdh + 32 + r] = ppo_tanh(c1[v]); }
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) H2[(4 * q + v) * kPLdh + 16 * t + r] = ppo_tanh(c[t][v]);
   }
   __syncthreads();
   {
-    f32x16 c;
-    const float bias = r < KO ? W.Wo[kPH * KO + (r < KO ? r : 0)] : 0.f;       // bo follows Wo
+    const int rc = r < KO ? r : 0;
+    const float bias = r < KO ? W.Wo[kPH * KO + rc] : 0.f;             // bo follows Wo
+    f32x4 c = {bias, bias, bias, bias};
+    const float* a = H2 + r * kPLdh + q;
+    const float* wo = W.Wo + q * KO + rc;
+    float av[16], bv[16];
 #pragma unroll
-    for (int v = 0; v < 16; ++v) c[v] = bias;
-    const float* a = H2 + r * kPLdh + hh;
-    const float* wo = W.Wo + hh * KO + (r < KO ? r : 0);
-    c = ppo_mfma_k([&](int k0) { return a[k0]; }, [&](int k0) { return r < KO ? wo[k0 * KO] : 0.f; }, kPH, c);
+    for (int i = 0; i < 16; ++i) { av[i] = a[4 * i]; bv[i] = r < KO ? wo[4 * i * KO] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], c, 0, 0, 0);
     if (r < KO) {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) out[ppo_acc_row(v) * 4 + r] = c[v];
+      for (int v = 0; v < 4; ++v) out[(4 * q + v) * 4 + r] = c[v];
     }
   }
   __syncthreads();
-}
-
-// Sum of word w over the step waves' partial rows, by one wave, in a fixed association: lane l adds its slots l, l + 64, ... in
-// ascending order, then an xor-butterfly over the lanes.  (Slots of members a group does not have stay at their initial zero.)
-__device__ __forceinline__ double collect_fold_word(const double* part1, int w, int slots) {
-  const int lane = threadIdx.x & 63;
-  const double* row = part1 + (size_t)w * slots;
-  double v = 0.0;
-  for (int i = lane; i < slots; i += 64) v += row[i];
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
 }
 
 // Running statistics after the pending step: (old statistics) (+) (batch sums), SB3's RunningMeanStd.update_from_moments.
@@ -166,51 +172,33 @@ __device__ __forceinline__ CollectMerged collect_chan(double om, double ov, doub
   return r;
 }
 
-// What every wave in front of the step waves does first: read the statistics the previous launches left, take its share of
-// the pending fold, wait for the totals and derive the statistics THIS step is normalised with.  Lane d < D ends with column d's
-// (mean, var); `ret_var` is wave-uniform.  Returns false if a wait ran out.
-struct CollectStats { double mean, var, cnt, ret_mean, ret_var, ret_cnt; double cs, cs2, r1, r2; bool pend_obs, pend_ret; unsigned int cepoch; };
-__device__ __forceinline__ bool collect_front_stats(const CollectArgs& CA, int aw, bool count_me, CollectStats& Q) {
+// What every wave in front of the step waves does first: read the statistics the previous launches left and the totals of the
+// pending step, and derive the statistics THIS step is normalised with.  Lane d < D ends with column d's (mean, var);
+// `ret_var` is wave-uniform.
+struct CollectStats { double mean, var, cnt, ret_mean, ret_var, ret_cnt; double cs, cs2, r1, r2; bool pend_obs, pend_ret; unsigned int part_ep; };
+// (in two halves, so that a caller can put other loads between the statistics' loads and their first use)
+__device__ __forceinline__ void collect_front_load(const CollectArgs& CA, CollectStats& Q) {
   const StatsArgs& S = CA.S;
-  const int lane = threadIdx.x & 63, D = S.D, PW = 2 * D + 2, n_real = 2 * CA.n_chunks;
+  const int lane = threadIdx.x & 63, D = S.D;
   const unsigned int part_ep = CA.sync[CS_PART_EPOCH], folded_ep = CA.sync[CS_FOLDED_EPOCH];
-  Q.cepoch = CA.sync[CS_CEPOCH];
-  // my share of the fold is read whether or not a step is pending (the loads leave with the first round trip of the wave; a
-  // wave-uniform branch on `pend` would put them behind the scalar loads above)
-  const int slots = kCGroups * ((CA.nblk + kCGroups - 1) / kCGroups);
-  const int nf = min(n_real, 64);                                      // fold waves: the first act waves; word w belongs to wave w mod nf
-  double fw0 = 0.0, fw1 = 0.0;                                         // (2 D + 2 <= 126 words over up to 64 waves: at most two each)
-  if (aw < nf) {
-    if (aw < PW) fw0 = collect_fold_word(CA.part1, aw, slots);
-    if (aw + nf < PW) fw1 = collect_fold_word(CA.part1, aw + nf, slots);
-  }
   Q.mean = 0.0; Q.var = 1.0;
   if (lane < D) { Q.mean = S.mean[lane]; Q.var = S.var[lane]; }
   Q.cnt = S.count[0]; Q.ret_mean = S.ret_mean[0]; Q.ret_var = S.ret_var[0]; Q.ret_cnt = S.ret_count[0];
-  Q.cs = Q.cs2 = Q.r1 = Q.r2 = 0.0;
-  const bool pend = part_ep != folded_ep;
-  Q.pend_obs = pend && S.update_obs; Q.pend_ret = pend && S.update_ret;
-  double* tot = CA.tot + (size_t)(Q.cepoch & 1u) * PW;
-  if (pend && aw < nf && lane == 0) {
-    if (aw < PW) st_sc1(tot + aw, fw0);
-    if (aw + nf < PW) st_sc1(tot + aw + nf, fw1);
-  }
-  // the old statistics are in registers: tell the merge wave (it overwrites them only after every wave in front has said so)
-  asm volatile("" :: "v"(Q.mean), "v"(Q.var), "v"(Q.cnt), "v"(Q.ret_mean), "v"(Q.ret_var), "v"(Q.ret_cnt), "s"(part_ep), "s"(folded_ep), "s"(Q.cepoch) : "memory");
-  if (count_me && lane == 0) (void)__hip_atomic_fetch_add(CA.sync + CS_READERS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (!(Q.pend_obs || Q.pend_ret)) return true;
-  // the totals announce themselves: a word is there as soon as it is not the sentinel the merge wave of the launch before
-  // last left (no flag, no store acknowledgement in between)
+  // the totals of the pending step: folded by the fold waves at the END of the launch that produced them (collect_fold_wave),
+  // i.e. plain memory by now
   const int dcol = lane < D ? lane : 0;
-  const double* pa = tot + (lane == 63 ? 2 * D : dcol);
-  const double* pb = tot + (lane == 63 ? 2 * D + 1 : D + dcol);
-  bool ok = false;
-  for (int it = 0; it < (1 << 21); ++it) {
-    Q.cs = ld_sc1(pa); Q.cs2 = ld_sc1(pb);
-    const bool mine = !collect_is_sentinel(Q.cs) && !collect_is_sentinel(Q.cs2);
-    if (__ballot(!mine) == 0ull) { ok = true; break; }
-    __builtin_amdgcn_s_sleep(1);
-  }
+  Q.cs = CA.tot[lane == 63 ? 2 * D : dcol];
+  Q.cs2 = CA.tot[lane == 63 ? 2 * D + 1 : D + dcol];
+  const bool pend = part_ep != folded_ep;
+  Q.part_ep = part_ep;
+  Q.pend_obs = pend && S.update_obs; Q.pend_ret = pend && S.update_ret;
+}
+__device__ __forceinline__ void collect_front_merge(const CollectArgs& CA, bool count_me, CollectStats& Q) {
+  const StatsArgs& S = CA.S;
+  const int lane = threadIdx.x & 63, D = S.D;
+  // the old statistics are in registers: tell the merge wave (it overwrites them only after every wave in front has said so)
+  asm volatile("" :: "v"(Q.mean), "v"(Q.var), "v"(Q.cnt), "v"(Q.ret_mean), "v"(Q.ret_var), "v"(Q.ret_cnt), "v"(Q.cs), "v"(Q.cs2), "s"(Q.part_ep), "s"((int)Q.pend_obs), "s"((int)Q.pend_ret) : "memory");
+  if (count_me && lane == 0) (void)__hip_atomic_fetch_add(CA.sync + CS_READERS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   Q.r1 = __shfl(Q.cs, 63, 64); Q.r2 = __shfl(Q.cs2, 63, 64);
   const double n = (double)S.N;
   if (Q.pend_obs) {
@@ -222,8 +210,54 @@ __device__ __forceinline__ bool collect_front_stats(const CollectArgs& CA, int a
     const CollectMerged m = collect_chan(Q.ret_mean, Q.ret_var, Q.ret_cnt, Q.r1, Q.r2, n);
     Q.ret_mean = m.mean; Q.ret_var = m.var; Q.ret_cnt += n;
   }
+}
+__device__ __forceinline__ void collect_front_stats(const CollectArgs& CA, bool count_me, CollectStats& Q) {
+  collect_front_load(CA, Q);
+  collect_front_merge(CA, count_me, Q);
+}
+
+// A fold wave (one of the 2 D + 2 workgroups at the very END of the grid): waits until every step wave has left its partial of
+// word w -- a slot is there as soon as it is not the sentinel this wave itself put back after the previous fold -- sums the slots in
+// a fixed association (lane l adds its slots l, l + 64, ... in ascending order, then an xor-butterfly over the lanes), stores the total (plain: the next launch reads it) and restores the sentinels.
+// It waits only for workgroups in front of it (dispatch is in block order): no residency can deadlock it.
+__device__ __forceinline__ void collect_fold_wave(const CollectArgs& CA, int w) {
+  const int lane = threadIdx.x & 63, PW = 2 * CA.S.D + 2;
+  if (w >= PW) return;
+  const int mstride = (CA.nblk + kCGroups - 1) / kCGroups, slots = kCGroups * mstride;
+  double* row = CA.part1 + (size_t)w * slots;
+  // slot i belongs to step workgroup (i / mstride) + 8 (i % mstride); groups with fewer members leave their last slot unused
+  auto used = [&](int i) { const int g = i / mstride, m = i - g * mstride; return g + kCGroups * m < CA.nblk; };
+  // a slot that has arrived stays in its register: the pass that sees the last partial reads only what was still missing
+  constexpr int kS = 16;                             // slots per lane: 1024 step workgroups = 8192 envs, the mapping's limit
+  double x[kS];
+  unsigned int missing = 0;
+#pragma unroll
+  for (int k = 0; k < kS; ++k) { x[k] = 0.0; const int i = lane + 64 * k; if (i < slots && used(i)) missing |= 1u << k; }
+  bool ok = false;
+  for (int it = 0; it < (1 << 20); ++it) {
+#pragma unroll
+    for (int k = 0; k < kS; ++k) if ((missing >> k) & 1u) x[k] = ld_sc1(row + lane + 64 * k);
+#pragma unroll
+    for (int k = 0; k < kS; ++k) if (((missing >> k) & 1u) && !collect_is_sentinel(x[k])) missing &= ~(1u << k);
+    if (__ballot(missing != 0u) == 0ull) { ok = true; break; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  double v = 0.0;
+#pragma unroll
+  for (int k = 0; k < kS; ++k) v += ((missing >> k) & 1u) ? 0.0 : x[k];     // ascending slot order
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  // every act wave has read the totals of the step before (its step waves have finished), the merge wave maybe not yet: it
+  // puts the readers counter back to 0 when it has
+  if (ok) {
+    ok = false;
+    for (int it = 0; it < (1 << 20); ++it) {
+      if (ld_flag(CA.sync + CS_READERS) == 0u) { ok = true; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  if (lane == 0) CA.tot[w] = v;
+  for (int i = lane; i < slots; i += 64) row[i] = collect_sentinel();
   if (!ok && lane == 0) atomicOr(CA.sync + CS_STATUS, 2u);
-  return ok;
 }
 
 // writes the statistics of `Q` (already merged) to the caller's buffers and closes the pending fold
@@ -242,28 +276,25 @@ __device__ __forceinline__ void collect_commit_stats(const CollectArgs& CA, cons
     S.ret_mean[0] = Q.ret_mean; S.ret_var[0] = Q.ret_var; S.ret_count[0] = Q.ret_cnt;
     if (S.ret_acc) { S.ret_acc[0] += Q.r1; S.ret_acc[1] += Q.r2; S.ret_acc[2] += n; }
   }
-  if (lane == 0) CA.sync[CS_FOLDED_EPOCH] = CA.sync[CS_PART_EPOCH];
+  if (lane == 0) CA.sync[CS_FOLDED_EPOCH] = Q.part_ep;
 }
 
 // The merge wave (block 2 n_chunks): same statistics as everybody, written back once every act wave has read the old ones; the
 // action sampler's draw counter advances here too (the policy waves read it at their start).
 __device__ __forceinline__ void collect_merge_wave(const CollectArgs& CA) {
-  const int lane = threadIdx.x & 63, n_real = 2 * CA.n_chunks, PW = 2 * CA.S.D + 2;
+  const int lane = threadIdx.x & 63, n_real = 2 * CA.n_chunks;
   CollectStats Q;
-  (void)collect_front_stats(CA, n_real, false, Q);
+  collect_front_stats(CA, false, Q);
   bool ok = false;
   for (int it = 0; it < (1 << 21); ++it) {
     if (ld_flag(CA.sync + CS_READERS) >= (unsigned int)n_real) { ok = true; break; }
     __builtin_amdgcn_s_sleep(8);
   }
   if (!ok && lane == 0) atomicOr(CA.sync + CS_STATUS, 4u);
+  if (lane == 0 && CA.sync[CS_INIT] != kCollectInitMagic) atomicOr(CA.sync + CS_STATUS, 8u);   // workspace never initialised
   collect_commit_stats(CA, Q);
-  // the totals buffer of the NEXT collect launch back to "unpublished" (its last readers finished a launch ago)
-  double* other = CA.tot + (size_t)((Q.cepoch + 1u) & 1u) * PW;
-  for (int w = lane; w < PW; w += 64) other[w] = collect_sentinel();
   if (lane == 0) {
     if (CA.S.rng) CA.S.rng[1] += 1;
-    CA.sync[CS_CEPOCH] = Q.cepoch + 1u;
     st_flag(CA.sync + CS_READERS, 0u);
   }
 }
@@ -280,14 +311,14 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   if (chunk >= CA.n_chunks) return;                                  // padding waves
   const int KO = net == 0 ? 4 : 1;
   const int lane = threadIdx.x;
-  const int D = A.D, Dp = (D + 1) & ~1, ldx = Dp + 1;
+  const int D = A.D, Dp = (D + 1) & ~1, Dk = (D + 3) & ~3, ldx = Dk + 1;      // Dp: rows of W1 in the parameter image, Dk: in LDS
   const int row0 = chunk * kCRows;
 
   long long* tr = CA.trace ? CA.trace + (size_t)blockIdx.x * 8 : nullptr;
   if (tr && lane == 0) tr[0] = collect_now();
   float* p = lds;
   PpoNetLds W;
-  W.W1 = p; p += Dp * kPH; W.b1 = p; p += kPH; W.W2 = p; p += kPH * kPLdh; W.b2 = p; p += kPH; W.Wo = p; p += kPH * 4; W.bo = p; p += 4;
+  W.W1 = p; p += Dk * kPH; W.b1 = p; p += kPH; W.W2 = p; p += kPH * kPLdh; W.b2 = p; p += kPH; W.Wo = p; p += kPH * 4; W.bo = p; p += 4;
   float* log_std = p; p += 4;
   float* X = p;  p += kCRows * ldx;
   float* X2 = p; p += kCRows * ldx;                                  // value wave: terminal observations of the previous step
@@ -295,8 +326,11 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   float* H2 = p; p += kCRows * kPLdh;
   float* out = p; p += kCRows * 4;
 
-  // ---- everything whose address is known at entry leaves first ----
-  const int frow = row0 + (lane & 31);
+  // ---- everything whose address is known at entry leaves first; the statistics lead: the memory counter retires in order,
+  // and the inputs are normalised (the statistics' first use) while the 33 KB of weights are still arriving ----
+  CollectStats Q;
+  collect_front_load(CA, Q);
+  const int frow = row0 + (lane & (kCRows - 1));
   const bool fmine = net == 1 && A.prev_reward && lane < kCRows && frow < A.N;
   uint8_t f_term = 0, f_trunc = 0; double f_rew = 0.0;
   if (fmine) {
@@ -311,12 +345,24 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
     return A.raw_is_f64 ? reinterpret_cast<const double*>(base)[(size_t)row * D + d] : (double)reinterpret_cast<const float*>(base)[(size_t)row * D + d];
   };
   double rawv[kXB];
-  auto load_batch = [&](const void* base, int e0) {
+  // element e = e0 + 64 u of the [kCRows][ldx] tile -> (row, column): one division per batch, the rest by stepping
+  const int q64 = kWave / ldx, r64 = kWave - q64 * ldx;
+  auto split = [&](int e0, int (&es)[kXB], int (&ed)[kXB]) {
+    int s_ = e0 / ldx, d = e0 - s_ * ldx;
 #pragma unroll
     for (int u = 0; u < kXB; ++u) {
-      const int e = e0 + u * kWave;
-      const int s_ = e / ldx, d = e - s_ * ldx, row = row0 + s_;
-      rawv[u] = (e < nel && d < D && row < A.N) ? raw_at(base, row, d) : 0.0;
+      es[u] = s_; ed[u] = d;
+      s_ += q64; d += r64;
+      if (d >= ldx) { d -= ldx; ++s_; }
+    }
+  };
+  auto load_batch = [&](const void* base, int e0) {
+    int es[kXB], ed[kXB];
+    split(e0, es, ed);
+#pragma unroll
+    for (int u = 0; u < kXB; ++u) {
+      const int e = e0 + u * kWave, row = row0 + es[u];
+      rawv[u] = (e < nel && ed[u] < D && row < A.N) ? raw_at(base, row, ed[u]) : 0.0;
     }
   };
   load_batch(A.raw, lane);
@@ -338,9 +384,8 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
 #pragma unroll
   for (int j = 0; j < 5; ++j) { const int i = lane + j * kWave; wov[j] = i < kPH * KO + KO ? params[oWo + i] : 0.f; }
   const float wls = lane < 4 ? params[oLs + lane] : 0.f;
-  // ---- statistics: old ones, my share of the pending fold, the totals ----
-  CollectStats Q;
-  (void)collect_front_stats(CA, aw, true, Q);
+  // ---- statistics of THIS step: the old ones (+) the totals of the pending step ----
+  collect_front_merge(CA, true, Q);
   const bool timeout = fmine && f_trunc && !f_term;
   const bool any_timeout = __ballot(timeout) != 0ull;                // wave-uniform: some episode of my rows was truncated
   if (tr && lane == 0) tr[1] = collect_now();                          // statistics of this step known
@@ -354,11 +399,13 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   auto build = [&](const void* base, float* dstX, bool copy) {
     for (int e0 = lane; e0 < nel; e0 += kXB * kWave) {
       if (!(base == A.raw && e0 == lane)) load_batch(base, e0);      // (the first batch of the observations is already in flight)
+      int es[kXB], ed[kXB];
+      split(e0, es, ed);
 #pragma unroll
       for (int u = 0; u < kXB; ++u) {
         const int e = e0 + u * kWave;
         if (e >= nel) continue;
-        const int s_ = e / ldx, d = e - s_ * ldx, row = row0 + s_;
+        const int d = ed[u], row = row0 + es[u];
         float x = 0.f;
         if (d < D && row < A.N) {
           x = fminf(fmaxf((float)((rawv[u] - cmean[d]) * cstd[d]), -A.clip), A.clip);
@@ -368,7 +415,9 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
       }
     }
   };
+  if (tr && lane == 0) tr[6] = collect_now();                          // statistics merged, reciprocal deviations in LDS
   build(A.raw, X, net == 0);
+  if (tr && lane == 0) tr[5] = collect_now();                          // observations normalised
   if (net == 1) {
     if (any_timeout) build(A.prev_tobs, X2, false);
     // everything the env step of THIS launch overwrites has been read: let the step waves of my chunk go
@@ -379,7 +428,7 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   {
     float4* dst = reinterpret_cast<float4*>(W.W1);
 #pragma unroll
-    for (int j = 0; j < kW1V; ++j) { const int i = lane + j * kWave; if (i < Dp * kPH / 4) dst[i] = w1v[j]; }
+    for (int j = 0; j < kW1V; ++j) { const int i = lane + j * kWave; if (i < Dk * kPH / 4) dst[i] = w1v[j]; }      // (rows Dp .. Dk - 1: the zeros loaded above)
 #pragma unroll
     for (int j = 0; j < kW2V; ++j) {
       const int i = lane + j * kWave;
@@ -394,7 +443,7 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   __syncthreads();
   if (tr && lane == 0) tr[2] = collect_now();                          // inputs and weights in LDS (value wave: flag_v published)
 
-  act_forward_wave(W, X, H1, H2, out, KO, Dp, ldx);
+  act_forward_wave(W, X, H1, H2, out, KO, Dk, ldx);
   if (tr && lane == 0) tr[3] = collect_now();                          // forward done
   if (lane < kCRows) {
     const int row = row0 + lane;
@@ -438,7 +487,7 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   if (A.prev_reward) {
     if (any_timeout) {
       __syncthreads();
-      act_forward_wave(W, X2, H1, H2, out, 1, Dp, ldx);
+      act_forward_wave(W, X2, H1, H2, out, 1, Dk, ldx);
     }
     if (fmine) {
       double rn = f_rew;
@@ -478,7 +527,7 @@ __device__ __forceinline__ void collect_wait_actions(const CollectArgs& CA, uint
 // lanes only), wg = workgroup index among the nblk step workgroups.
 template <typename T>
 __device__ __forceinline__ void collect_stats_tail(const CollectArgs& CA, uint32_t epoch, const T* tile, int ld, int rows, int wg, int nblk,
-                                                   bool is_leader, double rew, bool done, int env) {
+                                                   bool is_leader, double rew, bool done, int env, double ret_prev) {
   const StatsArgs& S = CA.S;
   const int lane = threadIdx.x & 63, D = S.D;
   long long* tr = CA.trace ? CA.trace + (size_t)blockIdx.x * 8 : nullptr;
@@ -489,60 +538,43 @@ __device__ __forceinline__ void collect_stats_tail(const CollectArgs& CA, uint32
   }
   double rt = 0.0;
   if (is_leader) {
-    if (S.update_ret) { rt = S.returns[env] * S.gamma + rew; S.returns[env] = done ? 0.0 : rt; }
+    if (S.update_ret) { rt = ret_prev * S.gamma + rew; S.returns[env] = done ? 0.0 : rt; }
     else if (done) S.returns[env] = 0.0;
   }
   // leaders' tracker values summed in row order (a fixed order)
   double r1 = 0.0, r2 = 0.0;
   {
-    const unsigned long long lead = __ballot(is_leader);
-    for (int l = 0; l < 64; ++l) {
-      if (!((lead >> l) & 1ull)) continue;
+    unsigned long long lead = __ballot(is_leader);
+    while (lead) {                                   // (ascending lanes)
+      const int l = __builtin_ctzll(lead);
+      lead &= lead - 1;
       const double v = __shfl(rt, l, 64);
       r1 += v; r2 += v * v;
     }
   }
   const int grp = wg & (kCGroups - 1), mem = wg >> 3, mstride = (nblk + kCGroups - 1) / kCGroups;
   auto p1 = [&](int w) { return CA.part1 + ((size_t)w * kCGroups + grp) * mstride + mem; };
-  if (lane < D) { *p1(lane) = s; *p1(D + lane) = s2; }
-  if (lane == 0) { *p1(2 * D) = r1; *p1(2 * D + 1) = r2; if (wg == 0) CA.sync[CS_PART_EPOCH] = epoch; }
+  // write-through: the fold waves at the end of THIS launch read them (and a slot announces itself: it replaces a sentinel)
+  if (lane < D) { st_sc1(p1(lane), s); st_sc1(p1(D + lane), s2); }
+  if (lane == 0) { st_sc1(p1(2 * D), r1); st_sc1(p1(2 * D + 1), r2); if (wg == 0) CA.sync[CS_PART_EPOCH] = epoch; }
   if (tr && lane == 0) tr[4] = collect_now();
 }
 
-// fw_collect_finish: folds the partial sums the last fw_collect_step left and merges them into the caller's statistics (once
-// per rollout).  One workgroup of 1024 lanes: wave k folds words k, k + 16, ... with collect_fold_word (the association of the
-// in-grid fold), wave 0 merges.
-__global__ __launch_bounds__(1024) void fw_collect_finish_kernel(CollectArgs CA) {
-  __shared__ double s_tot[2 * kMaxObs + 2];
-  const StatsArgs& S = CA.S;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, D = S.D, PW = 2 * D + 2;
+// fw_collect_finish: merges the totals the last fw_collect_step left into the caller's statistics (once per rollout; the
+// fold itself was done by that launch's fold waves).  One wave.
+__global__ __launch_bounds__(64) void fw_collect_finish_kernel(CollectArgs CA) {
   const bool pend = CA.sync[CS_PART_EPOCH] != CA.sync[CS_FOLDED_EPOCH];
   if (!pend) return;
-  const int slots = kCGroups * ((CA.nblk + kCGroups - 1) / kCGroups);
-  for (int w = wave; w < PW; w += 16) {
-    const double v = collect_fold_word(CA.part1, w, slots);
-    if (lane == 0) s_tot[w] = v;
-  }
-  __syncthreads();
-  if (wave != 0) return;
   CollectStats Q;
-  Q.pend_obs = S.update_obs != 0; Q.pend_ret = S.update_ret != 0;
-  Q.mean = 0.0; Q.var = 1.0;
-  if (lane < D) { Q.mean = S.mean[lane]; Q.var = S.var[lane]; }
-  Q.cnt = S.count[0]; Q.ret_mean = S.ret_mean[0]; Q.ret_var = S.ret_var[0]; Q.ret_cnt = S.ret_count[0];
-  const int dcol = lane < D ? lane : 0;
-  Q.cs = s_tot[dcol]; Q.cs2 = s_tot[D + dcol]; Q.r1 = s_tot[2 * D]; Q.r2 = s_tot[2 * D + 1];
-  const double n = (double)S.N;
-  if (Q.pend_obs) {
-    const CollectMerged m = collect_chan(Q.mean, Q.var, Q.cnt, Q.cs, Q.cs2, n);
-    if (lane < D) { Q.mean = m.mean; Q.var = m.var; }
-    Q.cnt += n;
-  }
-  if (Q.pend_ret) {
-    const CollectMerged m = collect_chan(Q.ret_mean, Q.ret_var, Q.ret_cnt, Q.r1, Q.r2, n);
-    Q.ret_mean = m.mean; Q.ret_var = m.var; Q.ret_cnt += n;
-  }
+  collect_front_stats(CA, false, Q);
   collect_commit_stats(CA, Q);
+}
+
+// fw_collect_workspace_init (after a memset to zero): every partial-sum slot "not there yet", and the mark that says so
+__global__ void fw_collect_init_kernel(double* part1, size_t n, unsigned int* sync) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) part1[i] = collect_sentinel();
+  if (i == 0) sync[CS_INIT] = kCollectInitMagic;
 }
 
 }  // namespace fwsim

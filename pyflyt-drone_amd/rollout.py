@@ -805,7 +805,8 @@ class PPO:
             from . import config as K
             if self._ws_collect is None:
                 nb = int(L.fw_collect_step_workspace_bytes(venv._h))
-                self._ws_collect = torch.zeros((nb + 7) // 8, dtype=torch.float64, device=self.device)      # zeroed once, caller-owned
+                self._ws_collect = torch.empty((nb + 7) // 8, dtype=torch.float64, device=self.device)      # caller-owned, initialised once
+                _lib.check(L.fw_collect_workspace_init(venv._h, self._ws_collect.data_ptr(), self._ws_collect.numel() * 8, st), venv._h)
             upd_obs = int(env.training and env.norm_obs)
             for t in range(T):
                 a = K.FwCollectArgs()
@@ -830,7 +831,7 @@ class PPO:
                 a.clip_obs, a.eps_obs, a.clip_reward, a.eps_reward = float(env.clip_obs), float(env.epsilon), float(env.clip_reward), float(env.epsilon)
                 a.update_obs, a.update_ret, a.norm_reward, a.deterministic = upd_obs, track, int(env.norm_reward), 0
                 _lib.check(L.fw_collect_step(venv._h, C.byref(a), st), venv._h)
-            _lib.check(L.fw_collect_finish(venv._h, C.byref(a), st), venv._h)      # the last step's statistics (each step's are folded by the next launch)
+            _lib.check(L.fw_collect_finish(venv._h, C.byref(a), st), venv._h)      # the last step's statistics (each step's are merged by the next launch)
         for t in (range(T) if not self._one_launch else ()):
             act(t, 3, self.buf_val[t], t - 1 if t > 0 else None)
             venv.step_tensor(self._act_env)

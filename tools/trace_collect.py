@@ -17,10 +17,11 @@ ppo = R.PPO(R.VecNormalizeDevice(env), R.PPOConfig(n_steps=8, batch_size=64, n_e
 assert ppo._one_launch
 for _ in range(3):
     ppo.collect_rollouts()
-n_chunks = (n + 31) // 32
+n_chunks = (n + 15) // 16
 n_act = (2 * n_chunks + 1 + 7) & ~7
 nblk = (n + 63) // 64 * 64 // 8
-grid = n_act + 2 * nblk
+pw = 2 * int(env.observation_space.shape[0]) + 2
+grid = n_act + 2 * nblk + pw
 ppo._trace = torch.zeros((grid, 8), dtype=torch.int64, device=env.device)
 rows = []
 for rep in range(5):
@@ -33,14 +34,14 @@ for rep in range(5):
     pol, val = act[0::2], act[1::2]
     rel = lambda x: x - t0
     rows.append(dict(
-        act_start_max=rel(act[:, 0]).max(), act_stats_known=np.mean(act[:, 1] - act[:, 0]), act_inputs_weights=np.mean(act[:, 2] - act[:, 1]),
+        act_start_max=rel(act[:, 0]).max(), act_stats_known=np.mean(act[:, 1] - act[:, 0]), act_rstd=np.mean(act[:, 6] - act[:, 1]), act_normalised=np.mean(act[:, 5] - act[:, 6]), act_weights_lds=np.mean(act[:, 2] - act[:, 5]),
         act_forward=np.mean(act[:, 3] - act[:, 2]), pol_publish_mean=rel(pol[:, 4]).mean(), pol_publish_max=rel(pol[:, 4]).max(),
         val_inputs_max=rel(val[:, 2]).max(), val_done_max=rel(val[:, 4]).max(),
         step_start_mean=rel(step[:, 0]).mean(), step_start_max=rel(step[:, 0]).max(), wait_begin_mean=rel(step[:, 1]).mean(),
         wait_end_mean=rel(step[:, 2]).mean(), wait_end_max=rel(step[:, 2]).max(), wait_us_mean=np.mean(step[:, 2] - step[:, 1]),
         step_body_mean=np.mean(step[:, 3] - step[:, 2]), step_over_max=rel(step[:, 3]).max(), partials_max=rel(step[:, 4]).max(),
-        launch_end=rel(t[:, 7].max())))
+        fold_start_max=rel(t[n_act + 2 * nblk:, 0]).max(), launch_end=rel(t[:, 7].max())))
 keys = rows[0].keys()
-print(f"{task} {n} envs: grid {grid} = {n_act} act + {nblk} step + {nblk} worker workgroups; us from the launch's first stamp, median of 5 launches")
+print(f"{task} {n} envs: grid {grid} = {n_act} act + {nblk} step + {nblk} worker + {pw} fold workgroups; us from the launch's first stamp, median of 5 launches")
 for k in keys:
     print(f"  {k:18s} {np.median([r[k] for r in rows]):8.2f}")
