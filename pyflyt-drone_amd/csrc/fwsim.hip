@@ -947,13 +947,13 @@ __global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g1(FW_STEP_ARGS) { F
 
 // fw_collect_step (fwsim_fused.hpp): act waves in front, then the step waves of the same step kernels with COLLECT on.  The
 // 8-lane mapping at one wave per SIMD only (the collector's regime: thousands of envs per GPU).
-#define FW_COLLECT_RUN(...) do {                                                                                       \
+#define FW_COLLECT_RUN(T_, ...) do {                                                                                       \
     if ((int)blockIdx.x < CA.n_act) {                                                                                  \
       /* launch index = the word of a step workgroup of MY chunk: it cannot finish (and advance its word) before I publish */ \
       const int nblk_ = (D.npad + 7) / 8, c_ = min((int)blockIdx.x >> 1, CA.n_chunks - 1);                              \
       const int blk_ = min(c_ * kCRows / 8, nblk_ - 1);                                                                 \
       const int wg_ = ((nblk_ & 7) == 0) ? (blk_ % (nblk_ >> 3)) * 8 + blk_ / (nblk_ >> 3) : blk_;   /* inverse of the XCD-aware map */ \
-      collect_act_wave(CA, 1u + D.lctr[wg_]);                                                                          \
+      collect_act_wave<T_>(CA, 1u + D.lctr[wg_]);                                                                          \
       return;                                                                                                           \
     }                                                                                                                   \
     if (CA.trace && threadIdx.x == 0) CA.trace[(size_t)blockIdx.x * 8] = collect_now();                                 \
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g1(FW_STEP_ARGS) { F
       return;                                                                                                           \
     }                                                                                                                   \
     D.epoch = 1u + D.lctr[bx_];                                                                                         \
-    step_body<__VA_ARGS__>(FW_STEP_PASS, &CA);                                                                          \
+    step_body<T_, __VA_ARGS__>(FW_STEP_PASS, &CA);                                                                     \
     if (threadIdx.x == 0) D.lctr[bx_] = D.epoch;                                                                        \
     if (CA.trace && threadIdx.x == 0) CA.trace[(size_t)blockIdx.x * 8 + 7] = collect_now();                             \
   } while (0)

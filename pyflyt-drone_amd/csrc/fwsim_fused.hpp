@@ -302,6 +302,8 @@ __device__ __forceinline__ void collect_merge_wave(const CollectArgs& CA) {
 // One act wave (workgroup of 64 lanes).  Inlined into the collect kernels: CollectArgs is a by-value kernel argument, and
 // handing its address to an out-of-line function made the compiler copy the whole struct to scratch in every wave (544 B).
 // (tools/check_isa.py therefore tells MFMA accumulator registers from spill slots by the operand ranges of the MFMAs.)
+// T = the env's real type: the type of its observation / reward / action buffers.
+template <typename T>
 __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t epoch) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   float* lds = reinterpret_cast<float*>(smem_raw);
@@ -335,14 +337,15 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   uint8_t f_term = 0, f_trunc = 0; double f_rew = 0.0;
   if (fmine) {
     f_term = A.prev_term[frow]; f_trunc = A.prev_trunc[frow];
-    f_rew = A.raw_is_f64 ? reinterpret_cast<const double*>(A.prev_reward)[frow] : (double)reinterpret_cast<const float*>(A.prev_reward)[frow];
+    f_rew = (double)reinterpret_cast<const T*>(A.prev_reward)[frow];
   }
   uint64_t rng_key = 0, rng_ctr = 0;
   if (net == 0 && !A.deterministic && lane < kCRows) { rng_key = A.rng[0]; rng_ctr = A.rng[1]; }
   constexpr int kXB = 8;
   const int nel = kCRows * ldx;
   auto raw_at = [&](const void* base, int row, int d) {
-    return A.raw_is_f64 ? reinterpret_cast<const double*>(base)[(size_t)row * D + d] : (double)reinterpret_cast<const float*>(base)[(size_t)row * D + d];
+    // (uniform base + 32-bit byte offset: one address register per load instead of 64-bit arithmetic per lane)
+    return (double)*reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (unsigned int)((row * D + d) * (int)sizeof(T)));
   };
   double rawv[kXB];
   // element e = e0 + 64 u of the [kCRows][ldx] tile -> (row, column): one division per batch, the rest by stepping
@@ -465,15 +468,9 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] = fminf(fmaxf(a[k], -1.0f), 1.0f);
         // the env's action row: write-through, the step waves of other XCDs read it in this same launch
-        if (A.act_is_f64) {
-          double* o = reinterpret_cast<double*>(A.act_env) + (size_t)row * 4;
+        T* o = reinterpret_cast<T*>(A.act_env) + (size_t)row * 4;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) st_coherent(o + k, (double)a[k]);
-        } else {
-          float* o = reinterpret_cast<float*>(A.act_env) + (size_t)row * 4;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) st_coherent(o + k, a[k]);
-        }
+        for (int k = 0; k < 4; ++k) st_coherent(o + k, (T)a[k]);
       }
     }
   }

@@ -15,7 +15,7 @@ from pyflyt_drone_amd import config as K, rollout as R
 
 task = sys.argv[1] if len(sys.argv) > 1 else "waypoints"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096          # envs on this GPU (configs[4] of BASELINE.json: 2048 per GPU)
-one = len(sys.argv) > 3 and sys.argv[3] == "one_launch"      # PPOConfig.one_launch_collect (fw_collect_step)
+one = not (len(sys.argv) > 3 and sys.argv[3] == "three")     # PPOConfig.one_launch_collect (fw_collect_step, the default) | "three": the three-launch collector
 if task == "objlock":
     cfg, ppo_cfg = K.train_objlock_config(), R.PPOConfig(n_steps=8, batch_size=64, n_epochs=10, one_launch_collect=one)        # 16 x 2048 = 32768 samples
 elif task == "combined":

@@ -40,7 +40,7 @@ for rep in range(5):
         step_start_mean=rel(step[:, 0]).mean(), step_start_max=rel(step[:, 0]).max(), wait_begin_mean=rel(step[:, 1]).mean(),
         wait_end_mean=rel(step[:, 2]).mean(), wait_end_max=rel(step[:, 2]).max(), wait_us_mean=np.mean(step[:, 2] - step[:, 1]),
         step_body_mean=np.mean(step[:, 3] - step[:, 2]), step_over_max=rel(step[:, 3]).max(), partials_max=rel(step[:, 4]).max(),
-        fold_start_max=rel(t[n_act + 2 * nblk:, 0]).max(), launch_end=rel(t[:, 7].max())))
+        fold_start_max=rel(t[n_act + 2 * nblk:, 0]).max(), launch_end=rel(t[n_act:, 7].max())))
 keys = rows[0].keys()
 print(f"{task} {n} envs: grid {grid} = {n_act} act + {nblk} step + {nblk} worker + {pw} fold workgroups; us from the launch's first stamp, median of 5 launches")
 for k in keys:
