@@ -101,10 +101,11 @@ __device__ __forceinline__ float ppo_wave_sum(float x) {
 }
 
 // Adam moments are kept in "slot" order: slot = ((net * 3 + kind) * 4 + wave) * 1024 + lane * 16 + v for the
-// accumulator tiles (kind 0 = W2, 1 = W1, 2 = Wo), then kPTileSlots + q * 256 + thread for the scalars
-// (q = 3 net + {0: b1, 1: b2, 2: bo}, q = 6: log_std).  Slots nobody owns are padding.
+// accumulator tiles (kind 0 = W2, 1 = W1; kind 2 is unused since round 3), then kPTileSlots + q * 256 + thread for the
+// per-thread elements (q = 3 net + {0: b1, 1: b2, 2: bo}, q = 6: log_std, q = 7 + net: Wo[thread / 4][thread % 4]).
+// Slots nobody owns are padding.
 constexpr int kPTileSlots = 2 * 3 * 4 * 64 * 16;
-constexpr int kPMomentSlots = kPTileSlots + 7 * kPThreads;
+constexpr int kPMomentSlots = kPTileSlots + 9 * kPThreads;
 __host__ __device__ inline int ppo_tile_slot(int net, int kind, int wave, int lane) { return (((net * 3 + kind) * 4 + wave) * 64 + lane) * 16; }
 
 // flat parameter index of every moment slot (-1 = padding); host side of the layout above
@@ -125,10 +126,10 @@ inline void ppo_moment_map(int D, int32_t* flat_of_slot) {
           const int i = mt * 32 + row, j = nt * 32 + r;
           flat_of_slot[ppo_tile_slot(n, 0, wave, lane) + v] = oW2 + i * kPH + j;
           if (wave < tilesW1 && i < D) flat_of_slot[ppo_tile_slot(n, 1, wave, lane) + v] = oW1 + i * kPH + j;
-          if (wave < 2 && r < KO) flat_of_slot[ppo_tile_slot(n, 2, wave, lane) + v] = oWo + (wave * 32 + row) * KO + r;
         }
     for (int t = 0; t < kPH; ++t) { flat_of_slot[kPTileSlots + (n * 3 + 0) * kPThreads + t] = ob1 + t; flat_of_slot[kPTileSlots + (n * 3 + 1) * kPThreads + t] = ob2 + t; }
     for (int t = 0; t < KO; ++t) flat_of_slot[kPTileSlots + (n * 3 + 2) * kPThreads + t] = obo + t;
+    for (int t = 0; t < kPThreads; ++t) if ((t & 3) < KO) flat_of_slot[kPTileSlots + (7 + n) * kPThreads + t] = oWo + (t >> 2) * KO + (t & 3);
     oLs = off;
   }
   for (int t = 0; t < 4; ++t) flat_of_slot[kPTileSlots + 6 * kPThreads + t] = oLs + t;
@@ -201,6 +202,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   float* sS = p; p += kPChunk * 4;                // per-sample scalars: old_logp, adv (normalised), ret, -
   float* bred = p; p += 2 * 4 * kPH;              // bias-gradient partials [b1 | b2][wave][64]
   float* red = p; p += 8;
+  float* sred = p; p += 32;                       // per wave: the four components of dbo and of dlog_std over its samples
 
   // flat offsets of this net
   const int nP0 = ppo_net_params(Dp, 4);
@@ -218,7 +220,8 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 
   const int mt = wave >> 1, nt = wave & 1;
   const int tilesW1 = ((Dp + 31) / 32) * 2;       // 2 or 4 tiles of dW1
-  const bool hasW1 = wave < tilesW1, hasWo = wave < 2;
+  const bool hasW1 = wave < tilesW1;
+  const int hq = t & 3, hs = t >> 2;              // head work: thread (sample or hidden unit hs, quarter / component hq)
 
   float bc1 = powf(H.beta1, (float)H.step0), bc2 = powf(H.beta2, (float)H.step0);     // beta^t
   float acc_l = 0.f;                              // loss sum (wave 0 lanes, reduced at the end)
@@ -260,7 +263,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   if (half == 1) {
     // private working copy of the Adam moments for the second chunk-half block (same lanes own the same slots)
 #pragma unroll
-    for (int kind = 0; kind < 3; ++kind) {
+    for (int kind = 0; kind < 2; ++kind) {
       const int s0 = ppo_tile_slot(n, kind, wave, lane);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -268,7 +271,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         reinterpret_cast<float4*>(mom_v + s0)[q] = reinterpret_cast<const float4*>(A.mom_v + s0)[q];
       }
     }
-    for (int q = 0; q < 7; ++q) { mom_m[kPTileSlots + q * kPThreads + t] = A.mom_m[kPTileSlots + q * kPThreads + t]; mom_v[kPTileSlots + q * kPThreads + t] = A.mom_v[kPTileSlots + q * kPThreads + t]; }
+    for (int q = 0; q < 9; ++q) { mom_m[kPTileSlots + q * kPThreads + t] = A.mom_m[kPTileSlots + q * kPThreads + t]; mom_v[kPTileSlots + q * kPThreads + t] = A.mom_v[kPTileSlots + q * kPThreads + t]; }
   }
   prefetch(pmb * cpm + pci);
   pci += nhalf; if (pci >= cpm) { pmb += 1; pci = half; }
@@ -282,11 +285,14 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     pf_stats += PPO_T() - pf0;
 #endif
     // gradient accumulators of this minibatch (registers)
-    f32x16 gW2, gW1, gWo;
+    f32x16 gW2, gW1;
     float gb1p = 0.f, gb2p = 0.f;                                     // column-sum partials of this thread's 16 rows
-    float gbo[4] = {0.f, 0.f, 0.f, 0.f}, gls[4] = {0.f, 0.f, 0.f, 0.f};   // wave 0: per-lane (= per-sample) partials
+    float gWoq[KO];                                                   // dWo[hidden unit hs][0 .. KO) over the samples 16 hq .. 16 hq + 15 of every chunk
+    float gbo_p = 0.f, gls_p = 0.f;                                   // component hq of dbo / dlog_std over this thread's samples
 #pragma unroll
-    for (int v = 0; v < 16; ++v) { gW2[v] = 0.f; gW1[v] = 0.f; gWo[v] = 0.f; }
+    for (int v = 0; v < 16; ++v) { gW2[v] = 0.f; gW1[v] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < KO; ++k) gWoq[k] = 0.f;
 
 #pragma unroll 1
     for (int c0 = half * kPChunk; c0 < B; c0 += nhalf * kPChunk) {
@@ -325,24 +331,28 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         for (int v = 0; v < 16; ++v) H2[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
       }
       __syncthreads();
-      // ---- head: out = H2 Wo + bo (rows 32 w .. on waves 0-1, columns masked to KO) ----
-      if (hasWo) {
-        f32x16 c;
-        const float bias = r < KO ? W.bo[r < KO ? r : 0] : 0.f;
+      // ---- head and loss gradient, on the vector ALU by all four waves (the 64 x KO head is 6 % of a 32 x 32 MFMA tile):
+      // thread (sample hs, quarter hq) sums hidden units 16 hq .. 16 hq + 15 for all KO outputs, the four quarters are
+      // combined by a butterfly inside the quad, and every lane of the quad then holds the sample's head output ----
+      {
+        float o[KO];
 #pragma unroll
-        for (int v = 0; v < 16; ++v) c[v] = bias;
-        const float* a = H2 + (wave * 32 + r) * kPLdh + hh;
-        const float* wo = W.Wo + hh * KO + (r < KO ? r : 0);
-        c = ppo_mfma_k([&](int k0) { return a[k0]; }, [&](int k0) { return r < KO ? wo[k0 * KO] : 0.f; }, kPH, c);
-        if (r < KO) {
+        for (int k = 0; k < KO; ++k) o[k] = 0.f;
+        const float* h2 = H2 + hs * kPLdh + 16 * hq;
+        const float* wo = W.Wo + 16 * hq * KO;
 #pragma unroll
-          for (int v = 0; v < 16; ++v) gout[(wave * 32 + ppo_acc_row(v)) * 4 + r] = c[v];
+        for (int j = 0; j < 16; ++j) {
+          const float h = h2[j];
+          if (KO == 4) {
+            const float4 w4 = reinterpret_cast<const float4*>(wo)[j];
+            o[0] += h * w4.x; o[KO > 1 ? 1 : 0] += h * w4.y; o[KO > 2 ? 2 : 0] += h * w4.z; o[KO > 3 ? 3 : 0] += h * w4.w;
+          } else {
+            o[0] += h * wo[j];
+          }
         }
-      }
-      __syncthreads();
-      // ---- loss gradient wrt the head output: one sample per lane of wave 0 ----
-      if (wave == 0) {
-        const int s = lane;
+#pragma unroll
+        for (int k = 0; k < KO; ++k) { o[k] += __shfl_xor(o[k], 1, 64); o[k] += __shfl_xor(o[k], 2, 64); o[k] += W.bo[k]; }
+        const int s = hs;
         float go[4] = {0.f, 0.f, 0.f, 0.f};
         if (NET == 0) {
           // log pi(a|s), ratio, clipped surrogate (SB3 PPO.train)
@@ -351,14 +361,14 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
           for (int k = 0; k < 4; ++k) {
             const float ls = log_std[k];
             iv[k] = expf(-2.0f * ls);                         // 1 / sigma^2
-            z[k] = sA[s * 4 + k] - gout[s * 4 + k];
+            z[k] = sA[s * 4 + k] - o[KO == 4 ? k : 0];
             logp += -0.5f * z[k] * z[k] * iv[k] - ls - 0.9189385332046727f;
           }
           const float a = sS[s * 4 + 1];
           const float ratio = expf(logp - sS[s * 4 + 0]);
           const float rc = fminf(fmaxf(ratio, 1.0f - H.clip_range), 1.0f + H.clip_range);
           const float l1 = a * ratio, l2 = a * rc;
-          acc_l += -fminf(l1, l2);
+          if (hq == 0) acc_l += -fminf(l1, l2);
           // d(-min(l1, l2))/dlogp: through l1 when it is the smaller; on a tie (ratio inside the range: rc == ratio)
           // torch.min halves the gradient between the two branches and the clamp passes its half
           const bool inside = ratio >= 1.0f - H.clip_range && ratio <= 1.0f + H.clip_range;
@@ -366,22 +376,31 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             go[k] = coef * z[k] * iv[k];                                  // dL/dmu_k = dL/dlogp * (a_k - mu_k) / sigma_k^2
-            gls[k] += coef * (z[k] * z[k] * iv[k] - 1.0f);                // dL/dlog_std_k of this lane's samples
+            if (k == hq) gls_p += coef * (z[k] * z[k] * iv[k] - 1.0f);    // dL/dlog_std_k, component hq of this thread's samples
           }
         } else {
-          const float dv = gout[s * 4] - sS[s * 4 + 2];
-          acc_l += dv * dv;
+          const float dv = o[0] - sS[s * 4 + 2];
+          if (hq == 0) acc_l += dv * dv;
           go[0] = H.vf_coef * 2.0f * dv * invB;
         }
 #pragma unroll
-        for (int k = 0; k < KO; ++k) { gout[s * 4 + k] = go[k]; gbo[k] += go[k]; }
+        for (int k = 0; k < KO; ++k) if (k == hq) { gout[s * 4 + k] = go[k]; gbo_p += go[k]; }
       }
       __syncthreads();
-      // ---- dWo += H2^T gout (before H2 is overwritten) ----
-      if (hasWo) {
-        const float* a = H2 + wave * 32 + r + hh * kPLdh;                 // A(m = hidden unit, k = sample)
-        const float* go = gout + hh * 4 + (r < KO ? r : 0);
-        gWo = ppo_mfma_k([&](int k0) { return a[k0 * kPLdh]; }, [&](int k0) { return r < KO ? go[k0 * 4] : 0.f; }, kPChunk, gWo);
+      // ---- dWo += H2^T gout (before H2 is overwritten): thread (hidden unit hs, quarter hq) over samples 16 hq .. 16 hq + 15 ----
+      {
+        const float* h2 = H2 + 16 * hq * kPLdh + hs;
+        const float* go = gout + 16 * hq * 4;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float h = h2[j * kPLdh];
+          if (KO == 4) {
+            const float4 g4 = reinterpret_cast<const float4*>(go)[j];
+            gWoq[0] += h * g4.x; gWoq[KO > 1 ? 1 : 0] += h * g4.y; gWoq[KO > 2 ? 2 : 0] += h * g4.z; gWoq[KO > 3 ? 3 : 0] += h * g4.w;
+          } else {
+            gWoq[0] += h * go[j * 4];
+          }
+        }
       }
       __syncthreads();
       // ---- G2 = (gout Wo^T) * (1 - H2^2), in place over H2 (K = KO <= 4) ----
@@ -443,21 +462,39 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #ifdef FW_PPO_PROF
     const long long pf3 = PPO_T();
 #endif
-    // Adam moments of the tiles this wave owns: requested now, consumed after the norm exchange (their L2 latency
-    // hides behind the reductions and the partner's answer)
-    float4 pm[3][4], pv[3][4];
+    // Adam moments of the tiles this wave owns and of this thread's own elements: requested now, consumed after the norm
+    // exchange (their L2 latency hides behind the reductions and the partner's answer)
+    float4 pm[2][4], pv[2][4];
     {
-      const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane), s2 = ppo_tile_slot(n, 2, wave, lane);
+      const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         pm[0][q] = reinterpret_cast<const float4*>(mom_m + s0)[q]; pv[0][q] = reinterpret_cast<const float4*>(mom_v + s0)[q];
         if (hasW1) { pm[1][q] = reinterpret_cast<const float4*>(mom_m + s1)[q]; pv[1][q] = reinterpret_cast<const float4*>(mom_v + s1)[q]; }
-        if (hasWo) { pm[2][q] = reinterpret_cast<const float4*>(mom_m + s2)[q]; pv[2][q] = reinterpret_cast<const float4*>(mom_v + s2)[q]; }
       }
     }
-    // ---- finish the bias gradients: sum the four row-block partials; reduce the per-sample partials of wave 0 ----
+    // per-thread elements: b1[t], b2[t] (t < 64), bo[t] (t < KO), Wo[t / 4][t % 4] (t % 4 < KO), log_std[t] (t < 4, pi block)
+    constexpr int NQ = NET == 0 ? 5 : 4;
+    int sl[NQ];
+    float smm[NQ], svv[NQ];
+    sl[0] = kPTileSlots + (n * 3 + 0) * kPThreads + t; sl[1] = kPTileSlots + (n * 3 + 1) * kPThreads + t;
+    sl[2] = kPTileSlots + (n * 3 + 2) * kPThreads + t; sl[3] = kPTileSlots + (7 + n) * kPThreads + t;
+    if (NET == 0) sl[NQ - 1] = kPTileSlots + 6 * kPThreads + t;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { smm[q] = mom_m[sl[q]]; svv[q] = mom_v[sl[q]]; }
+    // ---- finish the per-thread gradients: the four row-block partials of the biases; dWo over the quad's sample quarters;
+    // dbo / dlog_std component hq over all samples ----
+    float my_gwo = 0.f;
+#pragma unroll
+    for (int k = 0; k < KO; ++k) {
+      float g = gWoq[k];
+      g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64);
+      if (hq == k) my_gwo = g;
+    }
+    for (int o = 4; o < 64; o <<= 1) { gbo_p += __shfl_xor(gbo_p, o, 64); if (NET == 0) gls_p += __shfl_xor(gls_p, o, 64); }
     __syncthreads();
     bred[wave * kPH + lane] = gb1p; bred[(4 + wave) * kPH + lane] = gb2p;
+    if (lane < 4) { sred[wave * 8 + lane] = gbo_p; sred[wave * 8 + 4 + lane] = gls_p; }
     __syncthreads();
     float gb1 = 0.f, gb2 = 0.f;
     if (t < kPH) {
@@ -465,12 +502,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       for (int q = 0; q < 4; ++q) { gb1 += bred[q * kPH + t]; gb2 += bred[(4 + q) * kPH + t]; }
     }
     float my_gbo = 0.f, my_gls = 0.f;
-    if (wave == 0) {
-#pragma unroll
-      for (int k = 0; k < KO; ++k) { const float sfull = ppo_wave_sum(gbo[k]); if (lane == k) my_gbo = sfull; }
+    if (t < 4) {
+      if (t < KO) my_gbo = sred[t] + sred[8 + t] + sred[16 + t] + sred[24 + t];
       if (NET == 0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const float sfull = ppo_wave_sum(gls[k]); if (lane == k) my_gls = sfull; }
+        my_gls = sred[4 + t] + sred[12 + t] + sred[20 + t] + sred[28 + t];
         if (half == 0) my_gls -= H.ent_coef;   // entropy bonus: entropy_loss = -mean(sum_k (c + log_std_k)) -> d/dlog_std_k = -ent_coef (once)
       }
     }
@@ -481,7 +516,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       const float* theirs = A.gx + (size_t)((mb & 1) * 4 + NET * 2 + (1 - half)) * kPMomentSlots;
       unsigned long long* fmine = A.xch + 8 + (mb & 1) * 4 + NET * 2 + half;
       unsigned long long* ftheirs = A.xch + 8 + (mb & 1) * 4 + NET * 2 + (1 - half);
-      const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane), s2 = ppo_tile_slot(n, 2, wave, lane);
+      const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane);
       // Plain vector stores / loads bracketed by a device-scope release (every storing wave, before the barrier and the
       // flag) and acquire (after the flag).  (Tried instead of the fences: per-word sc1 atomics -- 27.4 vs 23.9 us; sc1 dwordx4
       // stores / loads by inline asm -- hand-off 12 k -> 9 k cycles but the chunk passes slow down by as much: no gain.)
@@ -490,9 +525,8 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       for (int q = 0; q < 4; ++q) {
         reinterpret_cast<float4*>(mine + s0)[q] = make_float4(gW2[4 * q], gW2[4 * q + 1], gW2[4 * q + 2], gW2[4 * q + 3]);
         if (hasW1) reinterpret_cast<float4*>(mine + s1)[q] = make_float4(gW1[4 * q], gW1[4 * q + 1], gW1[4 * q + 2], gW1[4 * q + 3]);
-        if (hasWo) reinterpret_cast<float4*>(mine + s2)[q] = make_float4(gWo[4 * q], gWo[4 * q + 1], gWo[4 * q + 2], gWo[4 * q + 3]);
       }
-      mine[sq] = gb1; mine[sq + kPThreads] = gb2; mine[sq + 2 * kPThreads] = my_gbo; mine[sq + 3 * kPThreads] = my_gls;
+      mine[sq] = gb1; mine[sq + kPThreads] = gb2; mine[sq + 2 * kPThreads] = my_gbo; mine[sq + 3 * kPThreads] = my_gls; mine[sq + 4 * kPThreads] = my_gwo;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");              // every storing wave: write back to where the partner can see it
       __syncthreads();
       if (t == 0) {
@@ -508,9 +542,8 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         const float4 a = reinterpret_cast<const float4*>(theirs + s0)[q];
         gW2[4 * q] += a.x; gW2[4 * q + 1] += a.y; gW2[4 * q + 2] += a.z; gW2[4 * q + 3] += a.w;
         if (hasW1) { const float4 b = reinterpret_cast<const float4*>(theirs + s1)[q]; gW1[4 * q] += b.x; gW1[4 * q + 1] += b.y; gW1[4 * q + 2] += b.z; gW1[4 * q + 3] += b.w; }
-        if (hasWo) { const float4 c = reinterpret_cast<const float4*>(theirs + s2)[q]; gWo[4 * q] += c.x; gWo[4 * q + 1] += c.y; gWo[4 * q + 2] += c.z; gWo[4 * q + 3] += c.w; }
       }
-      gb1 += theirs[sq]; gb2 += theirs[sq + kPThreads]; my_gbo += theirs[sq + 2 * kPThreads]; my_gls += theirs[sq + 3 * kPThreads];
+      gb1 += theirs[sq]; gb2 += theirs[sq + kPThreads]; my_gbo += theirs[sq + 2 * kPThreads]; my_gls += theirs[sq + 3 * kPThreads]; my_gwo += theirs[sq + 4 * kPThreads];
     }
 
     // ---- global gradient norm: own elements, then the other network's partial ----
@@ -519,10 +552,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     for (int v = 0; v < 16; ++v) {
       ss += gW2[v] * gW2[v];
       if (hasW1 && mt * 32 + ppo_acc_row(v) < D) ss += gW1[v] * gW1[v];
-      if (hasWo && r < KO) ss += gWo[v] * gWo[v];
     }
     if (t < kPH) ss += gb1 * gb1 + gb2 * gb2;
     if (t < KO) ss += my_gbo * my_gbo;
+    if (hq < KO) ss += my_gwo * my_gwo;
     if (NET == 0 && t < 4) ss += my_gls * my_gls;
     const float ss_mine = ppo_block_sum(ss, red);
     float ss_other = 0.f;
@@ -582,28 +615,23 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     adam_tile(gW2, ppo_tile_slot(n, 0, wave, lane), pm[0], pv[0], [&](int v) { return W.W2 + (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r; });
     if (hasW1) adam_tile(gW1, ppo_tile_slot(n, 1, wave, lane), pm[1], pv[1],
                          [&](int v) { const int i = mt * 32 + ppo_acc_row(v); return i < D ? W.W1 + i * kPH + nt * 32 + r : (float*)nullptr; });
-    if (hasWo) adam_tile(gWo, ppo_tile_slot(n, 2, wave, lane), pm[2], pv[2],
-                         [&](int v) { return r < KO ? W.Wo + (wave * 32 + ppo_acc_row(v)) * KO + r : (float*)nullptr; });
     {
-      // scalars: slot q * 256 + t for q = 3 net + {b1, b2, bo} and q = 6 (log_std, pi block); the owner test only gates the LDS write
-      constexpr int NQ = NET == 0 ? 4 : 3;
-      float gs[NQ], *ws[NQ], mm[NQ], vv[NQ];
-      int sl[NQ];
-      gs[0] = gb1; ws[0] = t < kPH ? W.b1 + t : nullptr; sl[0] = kPTileSlots + (n * 3 + 0) * kPThreads + t;
-      gs[1] = gb2; ws[1] = t < kPH ? W.b2 + t : nullptr; sl[1] = kPTileSlots + (n * 3 + 1) * kPThreads + t;
-      gs[2] = my_gbo; ws[2] = t < KO ? W.bo + t : nullptr; sl[2] = kPTileSlots + (n * 3 + 2) * kPThreads + t;
-      if (NET == 0) { gs[NQ - 1] = my_gls; ws[NQ - 1] = t < 4 ? log_std + t : nullptr; sl[NQ - 1] = kPTileSlots + 6 * kPThreads + t; }
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) { mm[q] = mom_m[sl[q]]; vv[q] = mom_v[sl[q]]; }
+      // per-thread elements (moments fetched above); the owner test only gates the LDS write
+      float gs[NQ], *ws[NQ];
+      gs[0] = gb1; ws[0] = t < kPH ? W.b1 + t : nullptr;
+      gs[1] = gb2; ws[1] = t < kPH ? W.b2 + t : nullptr;
+      gs[2] = my_gbo; ws[2] = t < KO ? W.bo + t : nullptr;
+      gs[3] = my_gwo; ws[3] = hq < KO ? W.Wo + hs * KO + hq : nullptr;
+      if (NET == 0) { gs[NQ - 1] = my_gls; ws[NQ - 1] = t < 4 ? log_std + t : nullptr; }
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const float gg = gs[q] * clipc;
-        mm[q] = H.beta1 * mm[q] + (1.0f - H.beta1) * gg; vv[q] = H.beta2 * vv[q] + (1.0f - H.beta2) * gg * gg;
+        smm[q] = H.beta1 * smm[q] + (1.0f - H.beta1) * gg; svv[q] = H.beta2 * svv[q] + (1.0f - H.beta2) * gg * gg;
       }
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) { mom_m[sl[q]] = mm[q]; mom_v[sl[q]] = vv[q]; }
+      for (int q = 0; q < NQ; ++q) { mom_m[sl[q]] = smm[q]; mom_v[sl[q]] = svv[q]; }
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) if (ws[q]) *ws[q] -= c1 * mm[q] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv[q]) * sc2 + H.eps);
+      for (int q = 0; q < NQ; ++q) if (ws[q]) *ws[q] -= c1 * smm[q] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(svv[q]) * sc2 + H.eps);
     }
     __syncthreads();
 #ifdef FW_PPO_PROF
@@ -646,7 +674,7 @@ __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(PpoArgs A) {
 inline size_t ppo_lds_bytes(int D) {
   const int Dp = (D + 1) & ~1, ldx = Dp + 1;
   size_t f = (size_t)ppo_net_lds_floats(Dp, 4) + 4 + (size_t)kPChunk * ldx + 64 + 2 * (size_t)kPChunk * kPLdh +
-             3 * (size_t)kPChunk * 4 + 8 * kPH + 8;
+             3 * (size_t)kPChunk * 4 + 8 * kPH + 8 + 32;
   return f * sizeof(float);
 }
 
