@@ -1878,8 +1878,8 @@ int32_t fw_ppo_moment_map(int32_t obs_dim, int32_t* flat_index_of_slot) {
   return FW_OK;
 }
 
-// workspace layout of fw_ppo_update: [0,128) exchange words | gradient hand-off buffer | per-minibatch advantage statistics
-static constexpr size_t kPpoWsXch = 16 * sizeof(unsigned long long);
+// workspace layout of fw_ppo_update: [0,192) exchange words | gradient hand-off buffer | per-minibatch advantage statistics
+static constexpr size_t kPpoWsXch = 24 * sizeof(unsigned long long);
 static constexpr size_t kPpoWsGx = sizeof(float) * 8 * (size_t)kPMomentSlots;
 int64_t fw_ppo_update_workspace_bytes(int32_t n_minibatches) {
   return n_minibatches > 0 ? (int64_t)(kPpoWsXch + kPpoWsGx + sizeof(float) * 2 * (size_t)n_minibatches) : FW_EINVAL;
@@ -1919,7 +1919,7 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   std::memcpy(&A.H, hyper, sizeof A.H);
   if (batch_size <= 1 && A.H.norm_adv == 1) A.H.norm_adv = 0;      // SB3 skips the normalisation of single-sample minibatches
   const int nhalf = batch_size >= 2 * kPChunk ? 2 : 1;            // two chunk-half blocks per network from 128 samples on
-  hipLaunchKernelGGL(fw_ppo_update_kernel, dim3(2 * nhalf), dim3(kPThreads), lds, st, A);
+  hipLaunchKernelGGL(fw_ppo_update_kernel, dim3(nhalf == 2 ? 16 : 2), dim3(kPThreads), lds, st, A);      // (16: blocks 0, 1, 8, 9 work -- see the kernel)
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;
 }

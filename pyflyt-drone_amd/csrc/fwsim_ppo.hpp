@@ -171,7 +171,7 @@ struct PpoArgs {
   int32_t n_mb, B, D;
   PpoHyper H;
   float* loss_acc;                   // [3] += policy, value, entropy loss
-  unsigned long long* xch;           // [16] exchange words (norm partials [parity][net][half], gradient flags + 8), zeroed by the host
+  unsigned long long* xch;           // [24] exchange words (norm partials [parity][net][half], gradient flags + 8, XCD ids of the chunk-half blocks + 16), zeroed by the host
   float* gx;                         // [2 parities][2 nets][2 halves][kPMomentSlots] gradient partials of the chunk halves
   const float* adv_stats;            // [n_mb][2] mean, std of each minibatch's advantages (fw_ppo_adv_stats_kernel)
 };
@@ -218,6 +218,30 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   for (int i = t; i < kPChunk * ldx + 64; i += kPThreads) X[i] = 0.f;                           // incl. the pad the dW1 tiles read
   __syncthreads();
 
+  // The two chunk-half blocks of a network swap their gradient partials once per minibatch.  If both run on the same XCD
+  // they share an L2: the swap then needs no device-scope release / acquire (a write-back and an invalidate of the WHOLE L2,
+  // ~12 k cycles per minibatch with the misses that follow) -- the vector L1 writes through, so the producer only waits for
+  // its stores and the consumer only drops its own L1.  The launch puts them there (blocks b and b + 8), but nothing
+  // promises that mapping: each block reads the XCD it really runs on and the pair compares notes once per call; a pair that
+  // was split keeps the device-scope fences.
+  bool same_xcd = false;
+  if (nhalf == 2) {
+    if (t == 0) {
+      const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));      // HW_REG_XCC_ID[3:0]
+      unsigned long long* mine = A.xch + 16 + NET * 2 + half;
+      unsigned long long* theirs = A.xch + 16 + NET * 2 + (1 - half);
+      __hip_atomic_store(mine, (unsigned long long)(my_xcc + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long w = 0;
+      long long spins = 0;
+      do {
+        w = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > (1ll << 26)) __builtin_trap();      // the partner block is gone: fail loudly instead of hanging
+      } while (w == 0ull);
+      red[5] = (unsigned)w == my_xcc + 1u ? 1.f : 0.f;
+    }
+    __syncthreads();
+    same_xcd = red[5] != 0.f;
+  }
   const int mt = wave >> 1, nt = wave & 1;
   const int tilesW1 = ((Dp + 31) / 32) * 2;       // 2 or 4 tiles of dW1
   const bool hasW1 = wave < tilesW1;
@@ -236,9 +260,17 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   const int gs = t >> 2, gk = t & 3;
   const int per = (Dp + 3) >> 2, gd0 = gk * per;                          // per <= 16
   const int cpm = B / kPChunk;
-  float pre_x[16], pre_a = 0.f, pre_s = 0.f;
+  float pre_x[16], pre_a = 0.f, pre_s = 0.f, pre_mu = 0.f, pre_sd = 1.f;
+  // the sample index of a chunk is fetched one chunk ahead of its rows (a dependent load: fetched in place it stalls the wave
+  // for a full memory latency before the row loads can even be issued); nothing in `prefetch` waits for a load
+  int pre_si = 0, imb = 0, ici = half;              // index fetched for the next `prefetch`; the chunk after that one
+  auto fetch_index = [&]() {
+    if (imb < n_mb) pre_si = perm[(size_t)(imb * cpm + ici) * kPChunk + gs];
+    ici += nhalf; if (ici >= cpm) { imb += 1; ici = half; }
+  };
+  fetch_index();
   auto prefetch = [&](int g) {
-    const int si = perm[(size_t)g * kPChunk + gs];
+    const int si = pre_si;
     const float* orow = obs + (size_t)si * D;
 #pragma unroll
     for (int j = 0; j < 16; ++j) { const int d = gd0 + j; pre_x[j] = (j < per && d < D) ? orow[d] : 0.f; }
@@ -248,12 +280,14 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       if (gk == 0) pre_s = old_logp[si];
       else if (gk == 1) {
         pre_s = adv[si];
-        if (H.norm_adv == 1) { const int m = g / cpm; pre_s = (pre_s - A.adv_stats[2 * m]) / (A.adv_stats[2 * m + 1] + 1e-8f); }
-        else if (H.norm_adv == 2) pre_s = (pre_s - H.adv_mean) / (H.adv_std + 1e-8f);
+        if (H.norm_adv == 1) { const int m = g / cpm; pre_mu = A.adv_stats[2 * m]; pre_sd = A.adv_stats[2 * m + 1]; }
+        else if (H.norm_adv == 2) { pre_mu = H.adv_mean; pre_sd = H.adv_std; }
       }
     } else if (gk == 2) pre_s = ret[si];
+    fetch_index();
   };
   auto commit = [&]() {
+    if (NET == 0 && gk == 1 && H.norm_adv != 0) pre_s = (pre_s - pre_mu) / (pre_sd + 1e-8f);
 #pragma unroll
     for (int j = 0; j < 16; ++j) { const int d = gd0 + j; if (j < per && d < Dp) X[gs * ldx + d] = pre_x[j]; }
     if (NET == 0) sA[t] = pre_a;
@@ -353,17 +387,14 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #pragma unroll
         for (int k = 0; k < KO; ++k) { o[k] += __shfl_xor(o[k], 1, 64); o[k] += __shfl_xor(o[k], 2, 64); o[k] += W.bo[k]; }
         const int s = hs;
-        float go[4] = {0.f, 0.f, 0.f, 0.f};
         if (NET == 0) {
-          // log pi(a|s), ratio, clipped surrogate (SB3 PPO.train)
-          float logp = 0.f, z[4], iv[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float ls = log_std[k];
-            iv[k] = expf(-2.0f * ls);                         // 1 / sigma^2
-            z[k] = sA[s * 4 + k] - o[KO == 4 ? k : 0];
-            logp += -0.5f * z[k] * z[k] * iv[k] - ls - 0.9189385332046727f;
-          }
+          // log pi(a|s), ratio, clipped surrogate (SB3 PPO.train): lane hq of the quad takes action component hq
+          const float mu = hq == 0 ? o[0] : hq == 1 ? o[KO > 1 ? 1 : 0] : hq == 2 ? o[KO > 2 ? 2 : 0] : o[KO > 3 ? 3 : 0];
+          const float ls = log_std[hq];
+          const float iv = expf(-2.0f * ls);                  // 1 / sigma^2
+          const float z = sA[s * 4 + hq] - mu;
+          float logp = -0.5f * z * z * iv - ls - 0.9189385332046727f;
+          logp += __shfl_xor(logp, 1, 64); logp += __shfl_xor(logp, 2, 64);
           const float a = sS[s * 4 + 1];
           const float ratio = expf(logp - sS[s * 4 + 0]);
           const float rc = fminf(fmaxf(ratio, 1.0f - H.clip_range), 1.0f + H.clip_range);
@@ -373,18 +404,15 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
           // torch.min halves the gradient between the two branches and the clamp passes its half
           const bool inside = ratio >= 1.0f - H.clip_range && ratio <= 1.0f + H.clip_range;
           const float coef = (l1 < l2 || (l1 == l2 && inside)) ? -a * ratio * invB : (l1 == l2 ? -0.5f * a * ratio * invB : 0.f);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            go[k] = coef * z[k] * iv[k];                                  // dL/dmu_k = dL/dlogp * (a_k - mu_k) / sigma_k^2
-            if (k == hq) gls_p += coef * (z[k] * z[k] * iv[k] - 1.0f);    // dL/dlog_std_k, component hq of this thread's samples
-          }
+          const float g = coef * z * iv;                                  // dL/dmu_k = dL/dlogp * (a_k - mu_k) / sigma_k^2
+          gls_p += coef * (z * z * iv - 1.0f);                            // dL/dlog_std_k of this thread's samples
+          gout[s * 4 + hq] = g; gbo_p += g;
         } else {
           const float dv = o[0] - sS[s * 4 + 2];
           if (hq == 0) acc_l += dv * dv;
-          go[0] = H.vf_coef * 2.0f * dv * invB;
+          const float g = H.vf_coef * 2.0f * dv * invB;
+          if (hq == 0) { gout[s * 4] = g; gbo_p += g; }
         }
-#pragma unroll
-        for (int k = 0; k < KO; ++k) if (k == hq) { gout[s * 4 + k] = go[k]; gbo_p += go[k]; }
       }
       __syncthreads();
       // ---- dWo += H2^T gout (before H2 is overwritten): thread (hidden unit hs, quarter hq) over samples 16 hq .. 16 hq + 15 ----
@@ -519,7 +547,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane);
       // Plain vector stores / loads bracketed by a device-scope release (every storing wave, before the barrier and the
       // flag) and acquire (after the flag).  (Tried instead of the fences: per-word sc1 atomics -- 27.4 vs 23.9 us; sc1 dwordx4
-      // stores / loads by inline asm -- hand-off 12 k -> 9 k cycles but the chunk passes slow down by as much: no gain.)
+      // stores / loads by inline asm -- hand-off 12 k -> 9 k cycles but the chunk passes slow down by as much: no gain; round 3:
+      // thread-to-thread self-announcing 8-byte write-through words polled by the receiver, no barrier / flag / fence --
+      // 14.5 k cycles: the memory system serves small device-scope accesses slowly.)
       const int sq = kPTileSlots + t;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -527,16 +557,19 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         if (hasW1) reinterpret_cast<float4*>(mine + s1)[q] = make_float4(gW1[4 * q], gW1[4 * q + 1], gW1[4 * q + 2], gW1[4 * q + 3]);
       }
       mine[sq] = gb1; mine[sq + kPThreads] = gb2; mine[sq + 2 * kPThreads] = my_gbo; mine[sq + 3 * kPThreads] = my_gls; mine[sq + 4 * kPThreads] = my_gwo;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");              // every storing wave: write back to where the partner can see it
+      if (same_xcd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my stores are in the L2 the partner reads from
+      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // every storing wave: write back to where the partner can see it
       __syncthreads();
       if (t == 0) {
-        __hip_atomic_store(fmine, (unsigned long long)(unsigned)(mb + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // (relaxed: the ordering is the waves' release / acquire -- or, on a shared L2, their store wait / L1 drop -- around the barriers)
+        __hip_atomic_store(fmine, (unsigned long long)(unsigned)(mb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         long long spins = 0;
-        while ((unsigned)__hip_atomic_load(ftheirs, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(mb + 1))
+        while ((unsigned)__hip_atomic_load(ftheirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(mb + 1))
           if (++spins > (1ll << 26)) __builtin_trap();                // the partner block is gone: fail loudly instead of hanging
       }
       __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (same_xcd) asm volatile("buffer_inv sc0" ::: "memory");      // drop this CU's L1: the partner's rows come from the shared L2
+      else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 a = reinterpret_cast<const float4*>(theirs + s0)[q];
@@ -664,11 +697,16 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   }
 }
 
-// grid = 2 or 4 blocks x 256 threads: block b runs network b & 1 (0: policy, 1: value) on chunk half b >> 1; dynamic LDS = ppo_lds_bytes().
+// 256 threads per block, dynamic LDS = ppo_lds_bytes().  grid = 2: block b runs network b (0: policy, 1: value).  grid = 16 (two
+// chunk halves per network): blocks 0, 1 and 8, 9 work -- network b & 1, chunk half b >> 3, so that the two halves of a network
+// land on the same XCD where workgroups are dealt round-robin to the 8 XCDs (checked at run time, see ppo_net_body) -- the
+// others leave at once.
 __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(PpoArgs A) {
   extern __shared__ __align__(16) float lds[];
-  const int half = blockIdx.x >> 1, nhalf = gridDim.x >> 1;
-  if ((blockIdx.x & 1) == 0) ppo_net_body<0>(A, lds, half, nhalf); else ppo_net_body<1>(A, lds, half, nhalf);
+  const int b = (int)blockIdx.x;
+  if ((b & 7) >= 2) return;
+  const int half = b >> 3, nhalf = gridDim.x > 2 ? 2 : 1;
+  if ((b & 1) == 0) ppo_net_body<0>(A, lds, half, nhalf); else ppo_net_body<1>(A, lds, half, nhalf);
 }
 
 inline size_t ppo_lds_bytes(int D) {
