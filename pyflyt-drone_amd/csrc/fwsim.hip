@@ -1919,7 +1919,7 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   std::memcpy(&A.H, hyper, sizeof A.H);
   if (batch_size <= 1 && A.H.norm_adv == 1) A.H.norm_adv = 0;      // SB3 skips the normalisation of single-sample minibatches
   const int nhalf = batch_size >= 2 * kPChunk ? 2 : 1;            // two chunk-half blocks per network from 128 samples on
-  hipLaunchKernelGGL(fw_ppo_update_kernel, dim3(nhalf == 2 ? 16 : 2), dim3(kPThreads), lds, st, A);      // (16: blocks 0, 1, 8, 9 work -- see the kernel)
+  hipLaunchKernelGGL(fw_ppo_update_kernel, dim3(nhalf == 2 ? 32 : 16), dim3(kPThreads), lds, st, A);      // (every 8th block works -- see the kernel)
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;
 }

@@ -164,6 +164,22 @@ __global__ __launch_bounds__(64) void fw_ppo_adv_stats_kernel(const float* __res
 //   * the per-sample loss runs one sample per lane on wave 0.
 // Each lane applies clipping + Adam to the accumulator elements it holds (their moments stay in global memory / L2,
 // in slot order; held in registers for the whole call they push the kernel past the 512-register budget).
+// Exchange words between two blocks.  `l2` = both run on one XCD: the word is written through this CU's L1 into the shared L2 and
+// read by an atomic OR of zero -- atomics execute in the L2 -- instead of device-scope accesses that travel to memory.
+__device__ __forceinline__ void ppo_word_store(unsigned long long* p, unsigned long long v, bool l2) {
+  if (l2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ppo_word_load(unsigned long long* p, bool l2) {
+  if (l2) {
+    unsigned long long r;
+    const unsigned long long zero = 0ull;
+    asm volatile("global_atomic_or_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p), "v"(zero) : "memory");
+    return r;
+  }
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct PpoArgs {
   float *params, *mom_m, *mom_v;
   const float *obs, *act, *old_logp, *adv, *ret;
@@ -224,23 +240,25 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   // its stores and the consumer only drops its own L1.  The launch puts them there (blocks b and b + 8), but nothing
   // promises that mapping: each block reads the XCD it really runs on and the pair compares notes once per call; a pair that
   // was split keeps the device-scope fences.
-  bool same_xcd = false;
-  if (nhalf == 2) {
+  bool same_xcd = false, same_xcd_net = false;      // ... as my chunk-half partner; as the other network's block of my half
+  {
     if (t == 0) {
       const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));      // HW_REG_XCC_ID[3:0]
-      unsigned long long* mine = A.xch + 16 + NET * 2 + half;
-      unsigned long long* theirs = A.xch + 16 + NET * 2 + (1 - half);
-      __hip_atomic_store(mine, (unsigned long long)(my_xcc + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned long long w = 0;
-      long long spins = 0;
-      do {
-        w = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (++spins > (1ll << 26)) __builtin_trap();      // the partner block is gone: fail loudly instead of hanging
-      } while (w == 0ull);
-      red[5] = (unsigned)w == my_xcc + 1u ? 1.f : 0.f;
+      __hip_atomic_store(A.xch + 16 + NET * 2 + half, (unsigned long long)(my_xcc + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      auto wait_id = [&](unsigned long long* p_) {
+        unsigned long long w = 0;
+        long long spins = 0;
+        do {
+          w = __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (++spins > (1ll << 26)) __builtin_trap();      // the other block is gone: fail loudly instead of hanging
+        } while (w == 0ull);
+        return (unsigned)w;
+      };
+      red[5] = (nhalf == 2 && wait_id(A.xch + 16 + NET * 2 + (1 - half)) == my_xcc + 1u) ? 1.f : 0.f;
+      red[6] = wait_id(A.xch + 16 + (1 - NET) * 2 + half) == my_xcc + 1u ? 1.f : 0.f;
     }
     __syncthreads();
-    same_xcd = red[5] != 0.f;
+    same_xcd = red[5] != 0.f; same_xcd_net = red[6] != 0.f;
   }
   const int mt = wave >> 1, nt = wave & 1;
   const int tilesW1 = ((Dp + 31) / 32) * 2;       // 2 or 4 tiles of dW1
@@ -562,9 +580,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       __syncthreads();
       if (t == 0) {
         // (relaxed: the ordering is the waves' release / acquire -- or, on a shared L2, their store wait / L1 drop -- around the barriers)
-        __hip_atomic_store(fmine, (unsigned long long)(unsigned)(mb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ppo_word_store(fmine, (unsigned long long)(unsigned)(mb + 1), same_xcd);
         long long spins = 0;
-        while ((unsigned)__hip_atomic_load(ftheirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(mb + 1))
+        while ((unsigned)ppo_word_load(ftheirs, same_xcd) != (unsigned)(mb + 1))
           if (++spins > (1ll << 26)) __builtin_trap();                // the partner block is gone: fail loudly instead of hanging
       }
       __syncthreads();
@@ -600,12 +618,11 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       unsigned long long* mine = A.xch + (mb & 1) * 4 + NET * 2 + half;
       unsigned long long* other = A.xch + (mb & 1) * 4 + (1 - NET) * 2 + half;
       if (t == 0) {
-        __hip_atomic_store(mine, ((unsigned long long)(unsigned)(mb + 1) << 32) | (unsigned long long)__float_as_uint(ss_mine),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ppo_word_store(mine, ((unsigned long long)(unsigned)(mb + 1) << 32) | (unsigned long long)__float_as_uint(ss_mine), same_xcd_net);
         unsigned long long w = 0;
         long long spins = 0;
         do {
-          w = __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w = ppo_word_load(other, same_xcd_net);
           if (++spins > (1ll << 26)) __builtin_trap();      // the partner block is gone: fail loudly instead of hanging
         } while ((unsigned)(w >> 32) != (unsigned)(mb + 1));
         red[4] = __uint_as_float((unsigned)w);
@@ -697,16 +714,16 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   }
 }
 
-// 256 threads per block, dynamic LDS = ppo_lds_bytes().  grid = 2: block b runs network b (0: policy, 1: value).  grid = 16 (two
-// chunk halves per network): blocks 0, 1 and 8, 9 work -- network b & 1, chunk half b >> 3, so that the two halves of a network
-// land on the same XCD where workgroups are dealt round-robin to the 8 XCDs (checked at run time, see ppo_net_body) -- the
-// others leave at once.
+// 256 threads per block, dynamic LDS = ppo_lds_bytes().  Every 8th block of the grid works (the others leave at once): where
+// workgroups are dealt round-robin to the 8 XCDs that puts all working blocks on ONE XCD, whose L2 then carries their
+// exchanges (checked at run time, see ppo_net_body).  Working block i = blockIdx / 8 runs network i & 1 (0: policy, 1: value)
+// on chunk half i >> 1; grid = 16 (one block per network) or 32 (two chunk halves per network).
 __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(PpoArgs A) {
   extern __shared__ __align__(16) float lds[];
-  const int b = (int)blockIdx.x;
-  if ((b & 7) >= 2) return;
-  const int half = b >> 3, nhalf = gridDim.x > 2 ? 2 : 1;
-  if ((b & 1) == 0) ppo_net_body<0>(A, lds, half, nhalf); else ppo_net_body<1>(A, lds, half, nhalf);
+  if (blockIdx.x & 7) return;
+  const int i = (int)blockIdx.x >> 3;
+  const int half = i >> 1, nhalf = gridDim.x > 16 ? 2 : 1;
+  if ((i & 1) == 0) ppo_net_body<0>(A, lds, half, nhalf); else ppo_net_body<1>(A, lds, half, nhalf);
 }
 
 inline size_t ppo_lds_bytes(int D) {
