@@ -76,82 +76,100 @@ template <typename T> __device__ __forceinline__ T ld_coherent(const T* p) { ret
 template <typename T> __device__ __forceinline__ void st_coherent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 inline size_t collect_act_lds_bytes(int D) {
-  const int Dk = (D + 3) & ~3, ldx = Dk + 1;
-  return sizeof(float) * ((size_t)Dk * kPH + kPH + kPH * kPLdh + kPH + kPH * 4 + 4 + 4 + 2 * (size_t)kCRows * ldx + 2 * (size_t)kCRows * kPLdh + kCRows * 4);
+  const int Dk = (D + 15) & ~15, ldx = Dk + 1;
+  return sizeof(float) * (2 * (size_t)kCRows * ldx + 2 * (size_t)kCRows * kPLdh + kCRows * 4 + 4);
 }
 
-// One act wave carries 16 rows: v_mfma_f32_16x16x4_f32 tiles (lane l holds A[l % 16][l / 16], B[l / 16][l % 16] and the four
-// results D[4 (l / 16) + v][l % 16]).  Half the rows of a 32x32x2 tile per wave means half the MFMA passes, half the tanh and half
-// the input normalisation on the path to the published actions, for twice the act waves -- they are the critical path of the
-// launch, and there are SIMDs to spare while the step waves wait.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-// C_t (16 x 16, t < NT) += A(16 x 4 STEPS, from k-step step0) * B(.. x 16 NT): operands of STEPS k-steps fetched together, the
-// NT accumulators interleaved so that one tile's MFMA latency hides behind the others'.
-template <int NT, int STEPS>
-__device__ __forceinline__ void act_mfma16_batch(const float* a, const float* b, int sbk, int step0, f32x4 (&c)[NT]) {
-  float av[STEPS], bv[STEPS][NT];
-#pragma unroll
-  for (int i = 0; i < STEPS; ++i) {
-    const int k0 = 4 * (step0 + i);
-    av[i] = a[k0];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bv[i][t] = b[k0 * sbk + 16 * t];
-  }
-#pragma unroll
-  for (int i = 0; i < STEPS; ++i) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i][t], c[t], 0, 0, 0);
-  }
-}
-template <int NT>
-__device__ __forceinline__ void act_mfma16(const float* A, int sam, const float* B, int sbk, int K, f32x4 (&c)[NT]) {
+
+// The weights of one network as this lane's B operands, fetched from global memory straight into registers in the operand
+// layout (the parameter image is L2-resident and every act wave reads all of it exactly once: staging it in LDS first cost a
+// 33 KB LDS write, its barrier and a second read).  Column tile t of a layer is the columns 4 r + t, r = 0 .. 15 (any partition
+// of the 64 columns into four tiles of 16 serves the MFMA as long as operands, biases and results agree on it): a lane's four
+// tiles are four CONSECUTIVE floats of a weight row -- one dwordx4 load.  w1[s][t] = W1[4 s + q][4 r + t] (zero beyond the
+// image's rows), w2[s][t] = W2[4 s + q][4 r + t], wo[s] = Wo[4 s + q][r] (zero for r >= KO), biases of the lane's columns.
+struct ActWeights { float w1[16][4], w2[16][4], wo[16], b1[4], b2[4], bo; };
+__device__ __forceinline__ void act_load_weights(ActWeights& Wt, const float* __restrict__ params, int oW1, int Dp, int Dk, int KO) {
   const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-  const float* a = A + r * sam + q;            // A(m, k) = A[m * sam + k]
-  const float* b = B + q * sbk + r;            // B(k, n) = B[k * sbk + n]
-  const int steps = K >> 2;
-  int s = 0;
-  for (; s + 4 <= steps; s += 4) act_mfma16_batch<NT, 4>(a, b, sbk, s, c);
-  if (s + 2 <= steps) { act_mfma16_batch<NT, 2>(a, b, sbk, s, c); s += 2; }
-  if (s < steps) act_mfma16_batch<NT, 1>(a, b, sbk, s, c);
+  const int ob1 = oW1 + Dp * kPH, oW2 = ob1 + kPH, ob2 = oW2 + kPH * kPH, oWo = ob2 + kPH, obo = oWo + kPH * KO;
+  const float4* p1 = reinterpret_cast<const float4*>(params + oW1 + q * kPH + 4 * r);
+  const float4* p2 = reinterpret_cast<const float4*>(params + oW2 + q * kPH + 4 * r);
+  const float* po = params + oWo + q * KO + (r < KO ? r : 0);
+#pragma unroll
+  for (int s_ = 0; s_ < 16; ++s_) {
+    const float4 a = (4 * s_ < Dk && 4 * s_ + q < Dp) ? p1[s_ * kPH] : make_float4(0.f, 0.f, 0.f, 0.f);      // (rows 4 s_ + q: kPH floats = kPH / 4 float4 apart, x 4 rows)
+    const float4 b = p2[s_ * kPH];
+    Wt.w1[s_][0] = a.x; Wt.w1[s_][1] = a.y; Wt.w1[s_][2] = a.z; Wt.w1[s_][3] = a.w;
+    Wt.w2[s_][0] = b.x; Wt.w2[s_][1] = b.y; Wt.w2[s_][2] = b.z; Wt.w2[s_][3] = b.w;
+    Wt.wo[s_] = r < KO ? po[s_ * 4 * KO] : 0.f;
+  }
+  {
+    const float4 a = *reinterpret_cast<const float4*>(params + ob1 + 4 * r), b = *reinterpret_cast<const float4*>(params + ob2 + 4 * r);
+    Wt.b1[0] = a.x; Wt.b1[1] = a.y; Wt.b1[2] = a.z; Wt.b1[3] = a.w;
+    Wt.b2[0] = b.x; Wt.b2[1] = b.y; Wt.b2[2] = b.z; Wt.b2[3] = b.w;
+  }
+  Wt.bo = r < KO ? params[obo + (r < KO ? r : 0)] : 0.f;
 }
 
-// 16 rows through one network, one wave: X[16, Dk] -> tanh -> H1 -> tanh -> H2 -> head: out[16, 4] (KO columns used).
-// Dk = the input width padded to a multiple of 4 (zero columns of X against zero rows of W1).
-__device__ __forceinline__ void act_forward_wave(const PpoNetLds& W, const float* X, float* H1, float* H2, float* out, int KO, int Dk, int ldx) {
+// 16 rows through one network, one wave, on v_mfma_f32_16x16x4_f32 (lane l holds A[l % 16][l / 16], B[l / 16][l % 16] and the
+// four results D[4 (l / 16) + v][l % 16]): X[16, Dk] -> tanh -> H1 -> tanh -> H2 -> head: out[16, 4] (KO columns used).  Dk =
+// the input width padded to a multiple of 16 (zero columns of X against zero operands).  Half the rows of a 32x32x2 tile per
+// wave means half the MFMA passes, half the tanh and half the input normalisation on the path to the published actions, for
+// twice the act waves -- they are the critical path of the launch, and there are SIMDs to spare while the step waves wait.
+// The A operands of four k-steps are fetched from LDS together and the four column tiles' accumulators interleave.
+__device__ __forceinline__ void act_forward_wave(const ActWeights& Wt, const float* X, float* H1, float* H2, float* out, int KO, int Dk, int ldx) {
   const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
   {
     f32x4 c[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { const float bias = W.b1[16 * t + r]; c[t] = f32x4{bias, bias, bias, bias}; }
-    act_mfma16<4>(X, ldx, W.W1, kPH, Dk, c);
+    for (int t = 0; t < 4; ++t) c[t] = f32x4{Wt.b1[t], Wt.b1[t], Wt.b1[t], Wt.b1[t]};
+    const float* a = X + r * ldx + q;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (16 * g >= Dk) break;
+      float av[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = a[16 * g + 4 * i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], Wt.w1[4 * g + i][t], c[t], 0, 0, 0);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) H1[(4 * q + v) * kPLdh + 16 * t + r] = ppo_tanh(c[t][v]);
+      for (int v = 0; v < 4; ++v) H1[(4 * q + v) * kPLdh + 4 * r + t] = ppo_tanh(c[t][v]);
   }
   __syncthreads();
   {
     f32x4 c[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { const float bias = W.b2[16 * t + r]; c[t] = f32x4{bias, bias, bias, bias}; }
-    act_mfma16<4>(H1, kPLdh, W.W2, kPLdh, kPH, c);
+    for (int t = 0; t < 4; ++t) c[t] = f32x4{Wt.b2[t], Wt.b2[t], Wt.b2[t], Wt.b2[t]};
+    const float* a = H1 + r * kPLdh + q;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float av[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = a[16 * g + 4 * i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], Wt.w2[4 * g + i][t], c[t], 0, 0, 0);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) H2[(4 * q + v) * kPLdh + 16 * t + r] = ppo_tanh(c[t][v]);
+      for (int v = 0; v < 4; ++v) H2[(4 * q + v) * kPLdh + 4 * r + t] = ppo_tanh(c[t][v]);
   }
   __syncthreads();
   {
-    const int rc = r < KO ? r : 0;
-    const float bias = r < KO ? W.Wo[kPH * KO + rc] : 0.f;             // bo follows Wo
-    f32x4 c = {bias, bias, bias, bias};
+    f32x4 c = {Wt.bo, Wt.bo, Wt.bo, Wt.bo};
     const float* a = H2 + r * kPLdh + q;
-    const float* wo = W.Wo + q * KO + rc;
-    float av[16], bv[16];
+    float av[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { av[i] = a[4 * i]; bv[i] = r < KO ? wo[4 * i * KO] : 0.f; }
+    for (int i = 0; i < 16; ++i) av[i] = a[4 * i];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], c, 0, 0, 0);
+    for (int i = 0; i < 16; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], Wt.wo[i], c, 0, 0, 0);
     if (r < KO) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) out[(4 * q + v) * 4 + r] = c[v];
@@ -313,15 +331,12 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   if (chunk >= CA.n_chunks) return;                                  // padding waves
   const int KO = net == 0 ? 4 : 1;
   const int lane = threadIdx.x;
-  const int D = A.D, Dp = (D + 1) & ~1, Dk = (D + 3) & ~3, ldx = Dk + 1;      // Dp: rows of W1 in the parameter image, Dk: in LDS
+  const int D = A.D, Dp = (D + 1) & ~1, Dk = (D + 15) & ~15, ldx = Dk + 1;    // Dp: rows of W1 in the parameter image, Dk: columns of the input tile
   const int row0 = chunk * kCRows;
 
   long long* tr = CA.trace ? CA.trace + (size_t)blockIdx.x * 8 : nullptr;
   if (tr && lane == 0) tr[0] = collect_now();
   float* p = lds;
-  PpoNetLds W;
-  W.W1 = p; p += Dk * kPH; W.b1 = p; p += kPH; W.W2 = p; p += kPH * kPLdh; W.b2 = p; p += kPH; W.Wo = p; p += kPH * 4; W.bo = p; p += 4;
-  float* log_std = p; p += 4;
   float* X = p;  p += kCRows * ldx;
   float* X2 = p; p += kCRows * ldx;                                  // value wave: terminal observations of the previous step
   float* H1 = p; p += kCRows * kPLdh;
@@ -341,7 +356,7 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   }
   uint64_t rng_key = 0, rng_ctr = 0;
   if (net == 0 && !A.deterministic && lane < kCRows) { rng_key = A.rng[0]; rng_ctr = A.rng[1]; }
-  constexpr int kXB = 8;
+  constexpr int kXB = 9;                                             // 9 x 64 >= 16 x 33: one batch of loads covers the tile of a <= 32-wide observation
   const int nel = kCRows * ldx;
   auto raw_at = [&](const void* base, int row, int d) {
     // (uniform base + 32-bit byte offset: one address register per load instead of 64-bit arithmetic per lane)
@@ -369,24 +384,16 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
     }
   };
   load_batch(A.raw, lane);
-  // ---- weights of my network: all loads in flight together (registers), LDS writes after the inputs are built ----
+  // ---- weights of my network: this lane's MFMA operands, all loads in flight together ----
   const int nP0 = ppo_net_params(Dp, 4);
-  const int oW1 = net == 0 ? 0 : nP0, ob1 = oW1 + Dp * kPH, oW2 = ob1 + kPH, ob2 = oW2 + kPH * kPH, oWo = ob2 + kPH;
+  const int oW1 = net == 0 ? 0 : nP0;
   const int oLs = nP0 + ppo_net_params(Dp, 1);
   const float* __restrict__ params = A.params;
-  constexpr int kW1V = (64 * kPH / 4 + kWave - 1) / kWave, kW2V = kPH * kPH / 4 / kWave;       // float4 per lane: W1 (<= 16), W2 (16)
-  float4 w1v[kW1V], w2v[kW2V];
-  const float4* src1 = reinterpret_cast<const float4*>(params + oW1);
-  const float4* src2 = reinterpret_cast<const float4*>(params + oW2);
+  ActWeights Wt;
+  act_load_weights(Wt, params, oW1, Dp, Dk, KO);
+  float log_std[4];                                                  // (uniform addresses: scalar loads)
 #pragma unroll
-  for (int j = 0; j < kW1V; ++j) { const int i = lane + j * kWave; w1v[j] = i < Dp * kPH / 4 ? src1[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-  for (int j = 0; j < kW2V; ++j) w2v[j] = src2[lane + j * kWave];
-  const float wb1 = params[ob1 + lane], wb2 = params[ob2 + lane];
-  float wov[5];
-#pragma unroll
-  for (int j = 0; j < 5; ++j) { const int i = lane + j * kWave; wov[j] = i < kPH * KO + KO ? params[oWo + i] : 0.f; }
-  const float wls = lane < 4 ? params[oLs + lane] : 0.f;
+  for (int k = 0; k < 4; ++k) log_std[k] = params[oLs + k];
   // ---- statistics of THIS step: the old ones (+) the totals of the pending step ----
   collect_front_merge(CA, true, Q);
   const bool timeout = fmine && f_trunc && !f_term;
@@ -427,26 +434,10 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) st_flag(CA.flag_v + chunk, epoch);
   }
-  // weights -> LDS
-  {
-    float4* dst = reinterpret_cast<float4*>(W.W1);
-#pragma unroll
-    for (int j = 0; j < kW1V; ++j) { const int i = lane + j * kWave; if (i < Dk * kPH / 4) dst[i] = w1v[j]; }      // (rows Dp .. Dk - 1: the zeros loaded above)
-#pragma unroll
-    for (int j = 0; j < kW2V; ++j) {
-      const int i = lane + j * kWave;
-      float* q = W.W2 + ((4 * i) >> 6) * kPLdh + ((4 * i) & 63);
-      q[0] = w2v[j].x; q[1] = w2v[j].y; q[2] = w2v[j].z; q[3] = w2v[j].w;
-    }
-    W.b1[lane] = wb1; W.b2[lane] = wb2;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) { const int i = lane + j * kWave; if (i < kPH * KO + KO) W.Wo[i] = wov[j]; }
-    if (lane < 4) log_std[lane] = wls;
-  }
   __syncthreads();
-  if (tr && lane == 0) tr[2] = collect_now();                          // inputs and weights in LDS (value wave: flag_v published)
+  if (tr && lane == 0) tr[2] = collect_now();                          // inputs in LDS (value wave: flag_v published)
 
-  act_forward_wave(W, X, H1, H2, out, KO, Dk, ldx);
+  act_forward_wave(Wt, X, H1, H2, out, KO, Dk, ldx);
   if (tr && lane == 0) tr[3] = collect_now();                          // forward done
   if (lane < kCRows) {
     const int row = row0 + lane;
@@ -484,7 +475,7 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   if (A.prev_reward) {
     if (any_timeout) {
       __syncthreads();
-      act_forward_wave(W, X2, H1, H2, out, 1, Dk, ldx);
+      act_forward_wave(Wt, X2, H1, H2, out, 1, Dk, ldx);
     }
     if (fmine) {
       double rn = f_rew;
