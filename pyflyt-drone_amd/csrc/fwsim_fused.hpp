@@ -1,46 +1,51 @@
 // fw_collect_step: ONE launch per vec-step of the rollout collector (SB3 OnPolicyAlgorithm.collect_rollouts +
 // VecNormalize.step_wait around Env.step, train/train_Fixedwing_Waypoints_v3.py:260,293-310).
 //
-// Round 2 ran a vec-step as three dependent launches, fw_collect_act -> fw_step -> fw_collect_stats: 48.3 us of which 20.5 are
+// Round 2 ran a vec-step as three dependent launches, fw_collect_act -> fw_step -> fw_collect_stats: 48.0 us of which 20 are
 // physics -- each of the two small kernels pays ~8 us of dependent-launch latency (barrier packet, the producer's L2
 // write-back, cold L2s on the XCDs that did not write the data) for < 1 us of work.  Here the three are one grid:
 //
-//   blocks [0, 2 n_chunks)      "act waves": one wave per (32-row chunk, network).  Same arithmetic as fw_collect_act (raw
-//                               observation normalised on load, 64-64 tanh MLP on v_mfma_f32_32x32x2_f32, Philox / Box-Muller
-//                               sampling, log-prob, the rollout-buffer rows; the value wave also finalises the PREVIOUS step:
-//                               reward normalisation, truncation bootstrap, episode starts).  The policy wave publishes its 32
-//                               clipped actions with write-through stores and then a generation word flag_p[chunk] = launch
-//                               index; the value wave publishes flag_v[chunk] as soon as it has READ everything the env step
-//                               is about to overwrite (observations, rewards, flags, terminal observations).
+//   blocks [0, 2 n_chunks)      "act waves": one wave per (16-row chunk, network).  The arithmetic of fw_collect_act (raw
+//                               observation normalised on load, 64-64 tanh MLP, Philox / Box-Muller sampling, log-prob, the
+//                               rollout-buffer rows; the value wave also finalises the PREVIOUS step: reward normalisation,
+//                               truncation bootstrap, episode starts) on v_mfma_f32_16x16x4_f32 tiles whose weight operands
+//                               come from global memory straight into registers.  The policy wave publishes its 16 clipped
+//                               actions with write-through stores and then a generation word flag_p[chunk] = launch index;
+//                               the value wave publishes flag_v[chunk] as soon as it has READ everything the env step is
+//                               about to overwrite (observations, rewards, flags, terminal observations).
 //   block 2 n_chunks            the "merge wave": writes the updated statistics back for the caller (see below).
 //   blocks [n_act, n_act+nblk)  the env step waves of fw_step (step_body<..., COLLECT = true>): they load their state, then
-//                               wait -- bounded -- for the two words of the chunks their envs sit in, read the actions with
-//                               coherent loads, and run the step.  Workgroups are dispatched in block order and an act wave
-//                               waits only for act waves in front of it, so every word a wave waits for belongs to a wave that
-//                               is already running or done: no deadlock whatever the residency.  A wait that runs out (it
-//                               never should) raises status and the wave goes on with what it finds; tests assert it stays 0.
-//   blocks beyond               the shadow / scenario workers of fw_step, unchanged.
+//                               wait -- bounded -- for the two words of the chunk their envs sit in, read the actions with
+//                               coherent loads, and run the step; in their tail they leave 2 D + 2 partial sums.
+//   blocks beyond               the shadow / scenario workers of fw_step, unchanged;
+//   the last 2 D + 2 blocks     "fold waves", one per partial-sum word (collect_fold_wave).
+// Workgroups are dispatched in block order and every wave waits only for waves in front of it (act waves for nobody, step
+// waves for act waves, fold waves for step waves and the merge wave), so every word a wave waits for belongs to a wave that
+// is already running or done: no deadlock whatever the residency.  A wait that runs out (it never should) raises a status
+// bit and the wave goes on with what it finds; tests assert the word stays 0.
 //
 // The statistics of VecNormalize.step_wait (observation moments, discounted-return tracker) need a reduction over ALL envs
-// between the env step and the next policy forward.  A first version folded them in the step waves' tail (last wave of 8
-// groups, then the last group): 36 us -- every hop between waves of different XCDs is a write-through store, its
-// acknowledgement, a ticket and a coherent load, ~3 us each, six of them in a row (tools/trace_collect.py).  Now a step wave
-// only leaves its 2 D + 2 partial sums with plain stores (they become visible at the kernel boundary, for free) and the NEXT
-// launch folds them while its weights are in flight anyway: act wave j sums word j over all step waves (one coalesced round
-// trip, fixed association) and stores the total over a sentinel the merge wave of the launch before last left -- a total
-// announces itself, no flag and no store acknowledgement in between; every act wave reads the 2 D + 2 totals and derives the
-// updated statistics itself (same arithmetic, same bits everywhere).  The merge wave does the same and writes them to the
-// caller's buffers -- after every act wave has announced that it has read the old ones.  The last step of a rollout is folded by
-// fw_collect_finish (one small launch per rollout).
-// Measured (tools/trace_collect.py, profiles/r03_collect_step_trace.txt; waypoints, 4096 envs): statistics known 9.4 us into the
-// launch, inputs + weights in LDS +4.2, forward +7.7, actions published at 23-24 us, step waves done at 43, launch end 45 us --
-// 49.1 us per vec-step with the per-rollout launches, against 48.3 for fw_collect_act -> fw_step -> fw_collect_stats.  A bare
-// hand-off between two waves costs 0.36 us inside an XCD and 0.41 us across two (tools/microbench_xcd.hip); in the grid, with
-// hundreds of waves polling, each of the three dependent hops (partials -> totals -> inputs; actions -> step waves) measures
-// 2-3 us, and one wave per (chunk, network) runs its three GEMM phases in 7.7 us where the four waves of fw_collect_act's
-// workgroups need ~4.  (Tried: one completion counter instead of self-announcing totals and a 7 us nap before the step waves
-// start polling: 12.1 us to the statistics, 52 us per vec-step -- worse.)  The launch boundaries this design removes cost what
-// its in-grid hand-offs cost: it stays an option (PPOConfig.one_launch_collect), off by default.
+// between the env step and the next policy forward.  Versions of this round, in order (waypoints, 4096 envs, us per
+// vec-step with the per-rollout launches; three launches: 48.0):
+//   * fold in the step waves' tail (last wave of 8 groups, then the last group): +36 us -- every hop between waves of
+//     different XCDs is a write-through store, its acknowledgement, a ticket and a coherent load, ~3 us each, six in a row;
+//   * plain partial stores, folded by the act waves of the NEXT launch in front of their own work (self-announcing totals):
+//     49.1 -- the fold sat on the critical path of every act wave (statistics known 9.4 us into the launch);
+//   * fold waves at the END of the launch that produced the partials (now): a step wave writes its partials through, a
+//     slot announces itself by no longer holding the sentinel the fold wave put back after the previous fold, fold wave w sums
+//     word w over all step waves in a fixed association (a slot that has arrived stays in its register: the pass that sees the
+//     last partial reads only what was still missing) and stores the total with a plain store -- the next launch's act waves
+//     and merge wave read 2 D + 2 plain words and derive the statistics THIS step is normalised with, each for itself (same
+//     arithmetic, same bits everywhere); the merge wave writes them to the caller's buffers after every act wave has announced
+//     that it has read the old ones.  fw_collect_finish merges the last step of a rollout.  46.3;
+//   * 16-row act waves on 16x16x4 tiles instead of 32-row ones on 32x32x2 (half the MFMA passes, tanh and normalisation on
+//     the path to the published actions, twice the waves -- there are SIMDs to spare while the step waves wait): 40.3;
+//   * weight operands from global memory into registers, column tiles = columns 4 r + t (one dwordx4 per weight row): 39.1.
+// Timeline of a launch (tools/trace_collect.py, profiles/r03_collect_step_trace.txt): statistics known 4.6 us after an act
+// wave starts (half of it the issue of ~70 loads and their addresses on a SIMD the wave has to itself), inputs normalised
+// +2.3, forward +4.1, actions published at 13.6 (mean) / 15.6 us (last), step waves done at 33.0, partials 34.1, totals and
+// launch end 36.2 us.  A bare hand-off between two waves costs 0.36 us inside an XCD and 0.41 us across two
+// (tools/microbench_xcd.hip); in the grid, with hundreds of waves polling, each dependent hop measures ~1 us.
 #pragma once
 #include "fwsim_collect.hpp"
 

@@ -10,4 +10,5 @@ for spec in "waypoints 4096" "waypoints 2048" "waypoints 8192" "objlock 4096" "c
   timeout -k 10 300 python tools/bench_rollout.py $spec three >> "$OUT/${ROUND}_rollout_bench_three_launch.jsonl" 2>> "$OUT/rollout_bench.err" || exit 1
 done
 timeout -k 10 200 python tools/trace_collect.py waypoints 4096 > "$OUT/${ROUND}_collect_step_trace.txt" 2>> "$OUT/rollout_bench.err" || exit 1
+if [ -f tools/_build/libfwsim_ppoprof.so ]; then timeout -k 10 300 python tools/prof_ppo.py > "$OUT/${ROUND}_ppo_update_cycles.txt" 2>> "$OUT/rollout_bench.err" || exit 1; cat "$OUT/${ROUND}_ppo_update_cycles.txt"; fi
 cut -c1-170 "$OUT/${ROUND}_rollout_bench.jsonl" "$OUT/${ROUND}_rollout_bench_three_launch.jsonl"; cat "$OUT/${ROUND}_collect_step_trace.txt"
