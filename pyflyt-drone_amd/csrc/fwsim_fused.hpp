@@ -185,13 +185,15 @@ __device__ __forceinline__ void act_forward_wave(const ActWeights& Wt, const flo
 
 // Running statistics after the pending step: (old statistics) (+) (batch sums), SB3's RunningMeanStd.update_from_moments.
 struct CollectMerged { double mean, var; };
-__device__ __forceinline__ CollectMerged collect_chan(double om, double ov, double cnt, double cs, double cs2, double n) {
-  const double bm = cs / n;
-  double bv = cs2 / n - bm * bm;                                     // population variance, as np.var
+// (one division: 1 / (cnt + n); the batch moments use inv_n = 1 / n computed once per wave -- within an ulp or two of double of the
+// quotients update_from_moments writes, ~1e-16 of a statistic; eight divisions on the critical path of every act wave otherwise)
+__device__ __forceinline__ CollectMerged collect_chan(double om, double ov, double cnt, double cs, double cs2, double n, double inv_n) {
+  const double bm = cs * inv_n;
+  double bv = cs2 * inv_n - bm * bm;                                 // population variance, as np.var
   bv = bv < 0 ? 0 : bv;
-  const double delta = bm - om, tot = cnt + n;
-  const double m2 = ov * cnt + bv * n + delta * delta * cnt * n / tot;
-  CollectMerged r; r.mean = om + delta * n / tot; r.var = m2 / tot;
+  const double delta = bm - om, tot = cnt + n, inv_tot = 1.0 / tot;
+  const double m2 = ov * cnt + bv * n + delta * delta * cnt * n * inv_tot;
+  CollectMerged r; r.mean = om + delta * n * inv_tot; r.var = m2 * inv_tot;
   return r;
 }
 
@@ -223,14 +225,14 @@ __device__ __forceinline__ void collect_front_merge(const CollectArgs& CA, bool 
   asm volatile("" :: "v"(Q.mean), "v"(Q.var), "v"(Q.cnt), "v"(Q.ret_mean), "v"(Q.ret_var), "v"(Q.ret_cnt), "v"(Q.cs), "v"(Q.cs2), "s"(Q.part_ep), "s"((int)Q.pend_obs), "s"((int)Q.pend_ret) : "memory");
   if (count_me && lane == 0) (void)__hip_atomic_fetch_add(CA.sync + CS_READERS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   Q.r1 = __shfl(Q.cs, 63, 64); Q.r2 = __shfl(Q.cs2, 63, 64);
-  const double n = (double)S.N;
+  const double n = (double)S.N, inv_n = 1.0 / n;
   if (Q.pend_obs) {
-    const CollectMerged m = collect_chan(Q.mean, Q.var, Q.cnt, Q.cs, Q.cs2, n);
+    const CollectMerged m = collect_chan(Q.mean, Q.var, Q.cnt, Q.cs, Q.cs2, n, inv_n);
     if (lane < D) { Q.mean = m.mean; Q.var = m.var; }
     Q.cnt += n;
   }
   if (Q.pend_ret) {
-    const CollectMerged m = collect_chan(Q.ret_mean, Q.ret_var, Q.ret_cnt, Q.r1, Q.r2, n);
+    const CollectMerged m = collect_chan(Q.ret_mean, Q.ret_var, Q.ret_cnt, Q.r1, Q.r2, n, inv_n);
     Q.ret_mean = m.mean; Q.ret_var = m.var; Q.ret_cnt += n;
   }
 }
@@ -361,34 +363,26 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   }
   uint64_t rng_key = 0, rng_ctr = 0;
   if (net == 0 && !A.deterministic && lane < kCRows) { rng_key = A.rng[0]; rng_ctr = A.rng[1]; }
-  constexpr int kXB = 9;                                             // 9 x 64 >= 16 x 33: one batch of loads covers the tile of a <= 32-wide observation
-  const int nel = kCRows * ldx;
+  // The [kCRows][ldx] input tile: a lane keeps ONE column (lane % CW, CW = 32 or 64 columns per pass) and takes every
+  // (64 / CW)-th row of it -- its column's mean and reciprocal deviation stay in two registers, a wave-level load is CW
+  // consecutive elements of a row, and no index needs a division.
+  const int CW = D <= 32 ? 32 : 64, rpp = kWave / CW;                // columns per pass, rows per pass
+  const int xcol = lane & (CW - 1), xrow0 = lane / CW;
+  constexpr int kXB = 16;                                            // rows a lane takes: kCRows / rpp <= 16 (8 for <= 32 columns)
+  const int nxb = kCRows / rpp;
   auto raw_at = [&](const void* base, int row, int d) {
     // (uniform base + 32-bit byte offset: one address register per load instead of 64-bit arithmetic per lane)
     return (double)*reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (unsigned int)((row * D + d) * (int)sizeof(T)));
   };
   double rawv[kXB];
-  // element e = e0 + 64 u of the [kCRows][ldx] tile -> (row, column): one division per batch, the rest by stepping
-  const int q64 = kWave / ldx, r64 = kWave - q64 * ldx;
-  auto split = [&](int e0, int (&es)[kXB], int (&ed)[kXB]) {
-    int s_ = e0 / ldx, d = e0 - s_ * ldx;
+  auto load_batch = [&](const void* base) {
 #pragma unroll
     for (int u = 0; u < kXB; ++u) {
-      es[u] = s_; ed[u] = d;
-      s_ += q64; d += r64;
-      if (d >= ldx) { d -= ldx; ++s_; }
+      const int row = row0 + xrow0 + u * rpp;
+      rawv[u] = (u < nxb && xcol < D && row < A.N) ? raw_at(base, row, xcol) : 0.0;
     }
   };
-  auto load_batch = [&](const void* base, int e0) {
-    int es[kXB], ed[kXB];
-    split(e0, es, ed);
-#pragma unroll
-    for (int u = 0; u < kXB; ++u) {
-      const int e = e0 + u * kWave, row = row0 + es[u];
-      rawv[u] = (e < nel && ed[u] < D && row < A.N) ? raw_at(base, row, ed[u]) : 0.0;
-    }
-  };
-  load_batch(A.raw, lane);
+  load_batch(A.raw);
   // ---- weights of my network: this lane's MFMA operands, all loads in flight together ----
   const int nP0 = ppo_net_params(Dp, 4);
   const int oW1 = net == 0 ? 0 : nP0;
@@ -407,30 +401,25 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   // ---- inputs: normalise on load with the statistics of THIS step ----
   // (x - mean) * (1 / sqrt(var + eps)): one division per column and wave instead of one per element -- within an ulp of
   // double of VecNormalize's (x - mean) / sqrt(var + eps), i.e. the same float32 except once in ~1e9 elements
-  double* cstd = reinterpret_cast<double*>(H2);                       // per-column 1 / sqrt(var + eps) and mean (H2 is written after X is built)
-  double* cmean = cstd + 64;
-  if (lane < D) { cstd[lane] = 1.0 / sqrt(Q.var + (double)A.eps); cmean[lane] = Q.mean; }
-  __syncthreads();
+  const int scol = xcol < D ? xcol : 0;                              // (lane d < D holds column d's statistics)
+  const double cmean = __shfl(Q.mean, scol, 64), crstd = 1.0 / sqrt(__shfl(Q.var, scol, 64) + (double)A.eps);
   auto build = [&](const void* base, float* dstX, bool copy) {
-    for (int e0 = lane; e0 < nel; e0 += kXB * kWave) {
-      if (!(base == A.raw && e0 == lane)) load_batch(base, e0);      // (the first batch of the observations is already in flight)
-      int es[kXB], ed[kXB];
-      split(e0, es, ed);
+    if (base != A.raw) load_batch(base);                             // (the observations are already in flight)
 #pragma unroll
-      for (int u = 0; u < kXB; ++u) {
-        const int e = e0 + u * kWave;
-        if (e >= nel) continue;
-        const int d = ed[u], row = row0 + es[u];
-        float x = 0.f;
-        if (d < D && row < A.N) {
-          x = fminf(fmaxf((float)((rawv[u] - cmean[d]) * cstd[d]), -A.clip), A.clip);
-          if (copy && A.obs_copy) A.obs_copy[(size_t)row * D + d] = x;
-        }
-        dstX[e] = x;
+    for (int u = 0; u < kXB; ++u) {
+      if (u >= nxb) break;
+      const int s_ = xrow0 + u * rpp, row = row0 + s_;
+      float x = 0.f;
+      if (xcol < D && row < A.N) {
+        x = fminf(fmaxf((float)((rawv[u] - cmean) * crstd), -A.clip), A.clip);
+        if (copy && A.obs_copy) *reinterpret_cast<float*>(reinterpret_cast<char*>(A.obs_copy) + (unsigned int)((row * D + xcol) * 4)) = x;
       }
+      if (xcol < ldx) dstX[s_ * ldx + xcol] = x;
     }
+    // columns CW .. ldx - 1 of the tile (padding when the pass is narrower than the padded width): zero
+    for (int e = lane; e < kCRows * (ldx - CW); e += kWave) { const int s_ = e / (ldx - CW), d = CW + e - s_ * (ldx - CW); dstX[s_ * ldx + d] = 0.f; }
   };
-  if (tr && lane == 0) tr[6] = collect_now();                          // statistics merged, reciprocal deviations in LDS
+  if (tr && lane == 0) tr[6] = collect_now();                          // statistics merged, this lane's column constants known
   build(A.raw, X, net == 0);
   if (tr && lane == 0) tr[5] = collect_now();                          // observations normalised
   if (net == 1) {
