@@ -454,7 +454,7 @@ def test_fw_collect_act_normalises_on_load_and_finalises_the_previous_step():
                             R._p(rew1), R._p(st1), None) == K.FW_EINVAL           # finalisation needs the value block
 
 
-@pytest.mark.parametrize("task,n", [("waypoints", 4096), ("waypoints", 1000), ("objlock", 1024), ("combined", 520), ("waypoints_wind", 2048)])
+@pytest.mark.parametrize("task,n", [("waypoints", 4096), ("waypoints", 1000), ("waypoints", 24), ("waypoints", 8192), ("objlock", 1024), ("combined", 520), ("waypoints_wind", 2048)])
 def test_one_launch_vec_step_equals_the_three_launch_collector(task, n):
     """fw_collect_step (act waves + step waves + statistics fold in ONE grid) against fw_collect_act -> fw_step ->
     fw_collect_stats on twin envs, through PPO.collect_rollouts (hipGraph replays included): the same actions, log-probs,
@@ -480,7 +480,7 @@ def test_one_launch_vec_step_equals_the_three_launch_collector(task, n):
     (ba, sa, ca, xa, ra, status), (bb, sb, cb, xb, rb, _) = runs[True], runs[False]
     assert status == 0, "a step wave's wait for its actions ran out"
     assert ra == rb == 5 * 8
-    assert ca == cb and ca["resets"] > 0, (ca, cb)
+    assert ca == cb and (ca["resets"] > 0 or n < 100), (ca, cb)
     torch.testing.assert_close(sa, sb, rtol=1e-9, atol=1e-9)           # (another fold order: 1e-12 of a column's scale)
     for it, (x, y) in enumerate(zip(ba, bb)):
         for name, u, v in zip(("obs", "act", "logp", "val", "rew", "start", "last_values", "last_starts"), x, y):
