@@ -81,7 +81,7 @@ template <typename T> __device__ __forceinline__ T ld_coherent(const T* p) { ret
 template <typename T> __device__ __forceinline__ void st_coherent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 inline size_t collect_act_lds_bytes(int D) {
-  const int Dk = (D + 15) & ~15, ldx = Dk + 1;
+  const int Dk = D <= 32 ? 32 : 64, ldx = Dk + 1;
   return sizeof(float) * (2 * (size_t)kCRows * ldx + 2 * (size_t)kCRows * kPLdh + kCRows * 4 + 4);
 }
 
@@ -118,54 +118,43 @@ __device__ __forceinline__ void act_load_weights(ActWeights& Wt, const float* __
 
 // 16 rows through one network, one wave, on v_mfma_f32_16x16x4_f32 (lane l holds A[l % 16][l / 16], B[l / 16][l % 16] and the
 // four results D[4 (l / 16) + v][l % 16]): X[16, Dk] -> tanh -> H1 -> tanh -> H2 -> head: out[16, 4] (KO columns used).  Dk =
-// the input width padded to a multiple of 16 (zero columns of X against zero operands).  Half the rows of a 32x32x2 tile per
+// the input width padded to 32 or 64 (zero columns of X against zero operands).  Half the rows of a 32x32x2 tile per
 // wave means half the MFMA passes, half the tanh and half the input normalisation on the path to the published actions, for
 // twice the act waves -- they are the critical path of the launch, and there are SIMDs to spare while the step waves wait.
 // The A operands of four k-steps are fetched from LDS together and the four column tiles' accumulators interleave.
+// One hidden layer, Hout = tanh(A W + b): the four column tiles in two pairs -- the two accumulators of a pair alternate, so a
+// tile's next MFMA never waits for its previous one -- with the tanh epilogue of the FIRST pair written between the MFMAs of
+// the second: vector instructions issue in the shadow of a running MFMA, so half of the epilogue costs nothing.
+template <int S>
+__device__ __forceinline__ void act_layer(const float* a, const float (&w)[16][4], const float (&b)[4], float* Hout) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  float av[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) av[i] = a[4 * i];
+  float* h = Hout + 4 * q * kPLdh + 4 * r;
+  f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    f32x4 c0 = {b[2 * pr], b[2 * pr], b[2 * pr], b[2 * pr]}, c1 = {b[2 * pr + 1], b[2 * pr + 1], b[2 * pr + 1], b[2 * pr + 1]};
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], w[i][2 * pr], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], w[i][2 * pr + 1], c1, 0, 0, 0);
+      if (pr == 1 && (i + 1) % (S / 8) == 0) {                          // eight elements of the first pair over the S steps
+        const int e = (i + 1) / (S / 8) - 1, v = e & 3;
+        h[v * kPLdh + (e >> 2)] = ppo_tanh(e < 4 ? p0[v] : p1[v]);
+      }
+    }
+    p0 = c0; p1 = c1;
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) { h[v * kPLdh + 2] = ppo_tanh(p0[v]); h[v * kPLdh + 3] = ppo_tanh(p1[v]); }
+}
 __device__ __forceinline__ void act_forward_wave(const ActWeights& Wt, const float* X, float* H1, float* H2, float* out, int KO, int Dk, int ldx) {
   const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-  {
-    f32x4 c[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) c[t] = f32x4{Wt.b1[t], Wt.b1[t], Wt.b1[t], Wt.b1[t]};
-    const float* a = X + r * ldx + q;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (16 * g >= Dk) break;
-      float av[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) av[i] = a[16 * g + 4 * i];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], Wt.w1[4 * g + i][t], c[t], 0, 0, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) H1[(4 * q + v) * kPLdh + 4 * r + t] = ppo_tanh(c[t][v]);
-  }
+  if (Dk == 32) act_layer<8>(X + r * ldx + q, Wt.w1, Wt.b1, H1); else act_layer<16>(X + r * ldx + q, Wt.w1, Wt.b1, H1);
   __syncthreads();
-  {
-    f32x4 c[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) c[t] = f32x4{Wt.b2[t], Wt.b2[t], Wt.b2[t], Wt.b2[t]};
-    const float* a = H1 + r * kPLdh + q;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float av[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) av[i] = a[16 * g + 4 * i];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], Wt.w2[4 * g + i][t], c[t], 0, 0, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) H2[(4 * q + v) * kPLdh + 4 * r + t] = ppo_tanh(c[t][v]);
-  }
+  act_layer<16>(H1 + r * kPLdh + q, Wt.w2, Wt.b2, H2);
   __syncthreads();
   {
     f32x4 c = {Wt.bo, Wt.bo, Wt.bo, Wt.bo};
@@ -338,7 +327,7 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   if (chunk >= CA.n_chunks) return;                                  // padding waves
   const int KO = net == 0 ? 4 : 1;
   const int lane = threadIdx.x;
-  const int D = A.D, Dp = (D + 1) & ~1, Dk = (D + 15) & ~15, ldx = Dk + 1;    // Dp: rows of W1 in the parameter image, Dk: columns of the input tile
+  const int D = A.D, Dp = (D + 1) & ~1, Dk = D <= 32 ? 32 : 64, ldx = Dk + 1;  // Dp: rows of W1 in the parameter image, Dk: columns of the input tile
   const int row0 = chunk * kCRows;
 
   long long* tr = CA.trace ? CA.trace + (size_t)blockIdx.x * 8 : nullptr;
