@@ -269,7 +269,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   float acc_l = 0.f;                              // loss sum (wave 0 lanes, reduced at the end)
   const float invB = 1.0f / (float)B;
 #ifdef FW_PPO_PROF
-  long long pf_stats = 0, pf_gather = 0, pf_net = 0, pf_adam = 0, pf_xch = 0;
+  long long pf_stats = 0, pf_gather = 0, pf_net = 0, pf_adam = 0, pf_xch = 0, pf_red = 0, pf_ho = 0, pf_norm = 0, pf_tile = 0, pf_scal = 0;
 #define PPO_T() ((long long)__builtin_readcyclecounter())
 #endif
 
@@ -556,6 +556,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       }
     }
 
+#ifdef FW_PPO_PROF
+    const long long pfa = PPO_T(); pf_red += pfa - pf3;
+#endif
     // ---- chunk halves: swap gradient partials with the partner block of this network, keep the sum ----
     if (nhalf == 2) {
       float* mine = A.gx + (size_t)((mb & 1) * 4 + NET * 2 + half) * kPMomentSlots;
@@ -567,7 +570,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       // flag) and acquire (after the flag).  (Tried instead of the fences: per-word sc1 atomics -- 27.4 vs 23.9 us; sc1 dwordx4
       // stores / loads by inline asm -- hand-off 12 k -> 9 k cycles but the chunk passes slow down by as much: no gain; round 3:
       // thread-to-thread self-announcing 8-byte write-through words polled by the receiver, no barrier / flag / fence --
-      // 14.5 k cycles: the memory system serves small device-scope accesses slowly.)
+      // 14.5 k cycles: the memory system serves small device-scope accesses slowly.  Also measured, no gain: the tile partials
+      // stored before the bias reductions (the wait moves, 8.7 k -> 7.9 k for the pair of sections), a register copy of the
+      // lane's own weights so that Adam needs no LDS read (tile Adam 5.5 k -> 5.1 k, the chunk pass +1 k: 32 more live registers).)
       const int sq = kPTileSlots + t;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -597,6 +602,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       gb1 += theirs[sq]; gb2 += theirs[sq + kPThreads]; my_gbo += theirs[sq + 2 * kPThreads]; my_gls += theirs[sq + 3 * kPThreads]; my_gwo += theirs[sq + 4 * kPThreads];
     }
 
+#ifdef FW_PPO_PROF
+    const long long pfb = PPO_T(); pf_ho += pfb - pfa;
+#endif
     // ---- global gradient norm: own elements, then the other network's partial ----
     float ss = 0.f;
 #pragma unroll
@@ -611,7 +619,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     const float ss_mine = ppo_block_sum(ss, red);
     float ss_other = 0.f;
 #ifdef FW_PPO_PROF
-    const long long pfx = PPO_T();
+    const long long pfx = PPO_T(); pf_norm += pfx - pfb;
 #endif
     {
       // one 64-bit word per block and minibatch parity: (minibatch + 1) << 32 | float bits
@@ -631,7 +639,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       ss_other = red[4];
     }
 #ifdef FW_PPO_PROF
-    pf_xch += PPO_T() - pfx;
+    const long long pfc = PPO_T(); pf_xch += pfc - pfx;
 #endif
     const float total_norm = sqrtf(ss_mine + ss_other);
     const float clipc = fminf(H.max_grad_norm / (total_norm + 1e-6f), 1.0f);
@@ -665,6 +673,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     adam_tile(gW2, ppo_tile_slot(n, 0, wave, lane), pm[0], pv[0], [&](int v) { return W.W2 + (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r; });
     if (hasW1) adam_tile(gW1, ppo_tile_slot(n, 1, wave, lane), pm[1], pv[1],
                          [&](int v) { const int i = mt * 32 + ppo_acc_row(v); return i < D ? W.W1 + i * kPH + nt * 32 + r : (float*)nullptr; });
+#ifdef FW_PPO_PROF
+    const long long pfd = PPO_T(); pf_tile += pfd - pfc;
+#endif
     {
       // per-thread elements (moments fetched above); the owner test only gates the LDS write
       float gs[NQ], *ws[NQ];
@@ -685,7 +696,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     }
     __syncthreads();
 #ifdef FW_PPO_PROF
-    pf_adam += PPO_T() - pf3;
+    { const long long pfe = PPO_T(); pf_adam += pfe - pf3; pf_scal += pfe - pfd; }
 #endif
   }
 
@@ -710,6 +721,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #ifdef FW_PPO_PROF
     float* pr = A.loss_acc + 3 + NET * 4;
     pr[0] = (float)pf_xch / n_mb; pr[1] = (float)pf_gather / n_mb; pr[2] = (float)pf_net / n_mb; pr[3] = (float)pf_adam / n_mb;
+    if (NET == 0 && half == 0) {      // the finish section of the policy block, piece by piece
+      float* px = A.loss_acc + 11;
+      px[0] = (float)pf_red / n_mb; px[1] = (float)pf_ho / n_mb; px[2] = (float)pf_norm / n_mb; px[3] = (float)pf_tile / n_mb; px[4] = (float)pf_scal / n_mb;
+    }
 #endif
   }
 }

@@ -25,4 +25,4 @@ for D, B in ((28, 128), (28, 64), (56, 64), (28, 256)):
     run(); torch.cuda.synchronize()
     t0 = time.perf_counter(); run(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     l = loss.tolist()
-    print(f"D={D} B={B}: {dt / n_mb * 1e6:.1f} us/minibatch; cycles/minibatch pi: exchange {l[3]:.0f} gather {l[4]:.0f} net {l[5]:.0f} norm+adam {l[6]:.0f} | V: exchange {l[7]:.0f} gather {l[8]:.0f} net {l[9]:.0f} norm+adam {l[10]:.0f}", flush=True)
+    print(f"D={D} B={B}: {dt / n_mb * 1e6:.1f} us/minibatch; cycles/minibatch pi: exchange {l[3]:.0f} gather {l[4]:.0f} net {l[5]:.0f} norm+adam {l[6]:.0f} | V: exchange {l[7]:.0f} gather {l[8]:.0f} net {l[9]:.0f} norm+adam {l[10]:.0f} || pi finish: reductions {l[11]:.0f} hand-off {l[12]:.0f} norm {l[13]:.0f} tile Adam {l[14]:.0f} thread Adam + barrier {l[15]:.0f}", flush=True)
