@@ -498,6 +498,20 @@ int64_t fw_collect_step_workspace_bytes(fw_handle h);
 int32_t fw_collect_workspace_init(fw_handle h, void* workspace, int64_t workspace_bytes, void* hip_stream);
 int32_t fw_collect_step(fw_handle h, const fw_collect_args* a, void* hip_stream);
 int32_t fw_collect_finish(fw_handle h, const fw_collect_args* a, void* hip_stream);   /* statistics buffers, flags and workspace of `a` only */
+/* The end of a rollout of T fw_collect_step launches in ONE more launch instead of fw_collect_finish + a value forward + a
+ * normalisation + fw_gae: merges the last step's statistics; V(final observation) -> a->value [N] (SB3's last values); the
+ * normalised final observation -> a->obs_copy (may be NULL); finalises step T - 1 (a->rew_out = row T - 1 of `rewards`,
+ * a->start_out = the episode starts after the last step: fw_gae's last_dones); then SB3's
+ * RolloutBuffer.compute_returns_and_advantage over the [T, N] float32 buffers (fw_gae's arithmetic, each value wave for its
+ * own rows).  `a` as for fw_collect_step (obs / reward / terminated / truncated / terminal_obs = the outputs of the last
+ * step; the policy-side buffers are not used). */
+typedef struct fw_collect_close_args {
+  const float *rewards, *values, *episode_starts;   /* [T, N] rollout buffers */
+  float *adv, *ret;                                  /* [T, N] out */
+  int32_t T;
+  float gae_gamma, gae_lambda;
+} fw_collect_close_args;
+int32_t fw_collect_close(fw_handle h, const fw_collect_args* a, const fw_collect_close_args* c, void* hip_stream);
 
 int32_t fw_num_envs(fw_handle h);
 /* Lane mapping of this handle's step kernels: 8 = eight lanes of a wavefront share one env (latency mapping, one wave per SIMD),

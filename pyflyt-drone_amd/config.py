@@ -255,6 +255,12 @@ class FwCollectArgs(C.Structure):
                 + [(n, C.c_int32) for n in ("update_obs", "update_ret", "norm_reward", "deterministic")])
 
 
+class FwCollectCloseArgs(C.Structure):
+    """``fw_collect_close_args`` of include/fwsim.h (GAE buffers of the rollout-closing launch)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("rewards", "values", "episode_starts", "adv", "ret")]
+                + [("T", C.c_int32), ("gae_gamma", C.c_float), ("gae_lambda", C.c_float)])
+
+
 class FwScenario(C.Structure):
     """``fw_scenario`` of include/fwsim.h: host arrays of a caller-supplied scenario (NULL = keep the env's own draw)."""
     _fields_ = [("targets", C.c_void_p), ("duck_pos", C.c_void_p), ("obstacles", C.c_void_p), ("num_obstacles", C.c_void_p),

@@ -1975,28 +1975,27 @@ int32_t fw_collect_act(const float* params, const void* raw_obs, int32_t obs_is_
 
 int64_t fw_collect_step_workspace_bytes(fw_handle h) { return h ? (int64_t)collect_ws(h).total : FW_EINVAL; }
 
-int32_t fw_collect_step(fw_handle h, const fw_collect_args* a, void* hip_stream) {
-  if (!h || !a) return FW_EINVAL;
+// checks and argument block shared by fw_collect_step and fw_collect_close
+static int32_t collect_fill(fw_handle h, const fw_collect_args* a, const char* who, bool close, CollectArgs& CA) {
   if (h->lanes_per_env != 8 || h->g8_waves != 1) {
-    h->err = "fw_collect_step serves the 8-lanes-per-env mapping at one wave per SIMD (<= 8192 envs per GPU; <= 4096 with wind); use fw_collect_act / fw_step / fw_collect_stats";
+    h->err = std::string(who) + " serves the 8-lanes-per-env mapping at one wave per SIMD (<= 8192 envs per GPU; <= 4096 with wind); use fw_collect_act / fw_step / fw_collect_stats";
     return FW_EUNSUPPORTED;
   }
   const int D = obs_dim_of(&h->cfg), N = h->n;
-  if (D > 62) { h->err = "fw_collect_step: obs_dim must be <= 62"; return FW_EINVAL; }
+  if (D > 62) { h->err = std::string(who) + ": obs_dim must be <= 62"; return FW_EINVAL; }
+  const bool pol = close || (a->act_raw && a->act_env && a->logp && (a->deterministic || a->rng));
   if (!a->params || !a->obs_mean || !a->obs_var || !a->obs_count || !a->returns || !a->ret_mean || !a->ret_var || !a->ret_count ||
-      !a->act_raw || !a->act_env || !a->logp || !a->value || !a->obs || !a->reward || !a->terminated || !a->truncated || !a->terminal_obs ||
-      (!a->deterministic && !a->rng) || (!a->rew_out != !a->start_out)) { h->err = "fw_collect_step: missing buffers"; return FW_EINVAL; }
+      !pol || !a->value || !a->obs || !a->reward || !a->terminated || !a->truncated || !a->terminal_obs ||
+      (!a->rew_out != !a->start_out) || (close && !a->rew_out)) { h->err = std::string(who) + ": missing buffers"; return FW_EINVAL; }
   const CollectWs W = collect_ws(h);
-  if (!a->workspace || a->workspace_bytes < (int64_t)W.total) { h->err = "fw_collect_step: workspace smaller than fw_collect_step_workspace_bytes()"; return FW_EINVAL; }
-  DeviceGuard g(h->device);
+  if (!a->workspace || a->workspace_bytes < (int64_t)W.total) { h->err = std::string(who) + ": workspace smaller than fw_collect_step_workspace_bytes()"; return FW_EINVAL; }
   const int f64 = h->cfg.dtype == FW_F64;
-  CollectArgs CA;
   std::memset(&CA, 0, sizeof CA);
   CA.n_chunks = (N + kCRows - 1) / kCRows;
   CA.n_act = (2 * CA.n_chunks + 1 + 7) & ~7;                 // act waves + the merge wave, padded: the step waves keep their XCD alignment
   CA.nblk = (int32_t)(h->npad / 8);
   ActArgs& A = CA.A;
-  A.params = a->params; A.N = N; A.D = D; A.nets = 3; A.deterministic = a->deterministic; A.act_is_f64 = f64;
+  A.params = a->params; A.N = N; A.D = D; A.nets = close ? 2 : 3; A.deterministic = a->deterministic; A.act_is_f64 = f64;
   A.rng = a->rng; A.env_offset = h->env_offset; A.obs_copy = a->obs_copy; A.act_raw = a->act_raw; A.act_env = a->act_env; A.logp = a->logp; A.value = a->value;
   A.raw = a->obs; A.raw_is_f64 = f64; A.mean = a->obs_mean; A.var = a->obs_var; A.clip = a->clip_obs; A.eps = a->eps_obs;
   if (a->rew_out) {
@@ -2013,10 +2012,36 @@ int32_t fw_collect_step(fw_handle h, const fw_collect_args* a, void* hip_stream)
   CA.part1 = (double*)(ws + W.part1); CA.tot = (double*)(ws + W.tot);
   CA.flag_p = (unsigned int*)(ws + W.flag_p); CA.flag_v = (unsigned int*)(ws + W.flag_v);
   CA.sync = (unsigned int*)(ws + W.sync);
-  CA.trace = (long long*)a->trace;
+  CA.trace = close ? nullptr : (long long*)a->trace;
+  return FW_OK;
+}
+
+int32_t fw_collect_step(fw_handle h, const fw_collect_args* a, void* hip_stream) {
+  if (!h || !a) return FW_EINVAL;
+  CollectArgs CA;
+  if (int32_t rc = collect_fill(h, a, "fw_collect_step", false, CA)) return rc;
+  DeviceGuard g(h->device);
   hipStream_t st = (hipStream_t)hip_stream;
-  return f64 ? collect_step_T<double>(h, CA, a->act_env, a->obs, a->reward, a->terminated, a->truncated, a->terminal_obs, a->info_i32, st)
-             : collect_step_T<float>(h, CA, a->act_env, a->obs, a->reward, a->terminated, a->truncated, a->terminal_obs, a->info_i32, st);
+  return h->cfg.dtype == FW_F64 ? collect_step_T<double>(h, CA, a->act_env, a->obs, a->reward, a->terminated, a->truncated, a->terminal_obs, a->info_i32, st)
+                                : collect_step_T<float>(h, CA, a->act_env, a->obs, a->reward, a->terminated, a->truncated, a->terminal_obs, a->info_i32, st);
+}
+
+int32_t fw_collect_close(fw_handle h, const fw_collect_args* a, const fw_collect_close_args* c, void* hip_stream) {
+  if (!h || !a || !c) return FW_EINVAL;
+  CollectArgs CA;
+  if (int32_t rc = collect_fill(h, a, "fw_collect_close", true, CA)) return rc;
+  if (!c->rewards || !c->values || !c->episode_starts || !c->adv || !c->ret || c->T <= 0) { h->err = "fw_collect_close: missing GAE buffers"; return FW_EINVAL; }
+  if (a->rew_out != c->rewards + (size_t)(c->T - 1) * h->n) { h->err = "fw_collect_close: rew_out must be row T - 1 of the rewards buffer"; return FW_EINVAL; }
+  DeviceGuard g(h->device);
+  CloseArgs GA;
+  GA.rewards = c->rewards; GA.values = c->values; GA.episode_starts = c->episode_starts; GA.adv = c->adv; GA.ret = c->ret;
+  GA.T = c->T; GA.gamma = c->gae_gamma; GA.lam = c->gae_lambda;
+  const size_t lds = collect_act_lds_bytes(CA.A.D);
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (h->cfg.dtype == FW_F64) hipLaunchKernelGGL(fw_collect_close_kernel<double>, dim3((unsigned)CA.n_chunks + 1), dim3(64), lds, st, CA, GA);
+  else hipLaunchKernelGGL(fw_collect_close_kernel<float>, dim3((unsigned)CA.n_chunks + 1), dim3(64), lds, st, CA, GA);
+  HIP_TRY(h, hipGetLastError());
+  return FW_OK;
 }
 
 int32_t fw_collect_workspace_init(fw_handle h, void* workspace, int64_t workspace_bytes, void* hip_stream) {

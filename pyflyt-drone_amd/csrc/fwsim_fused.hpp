@@ -74,6 +74,14 @@ struct CollectArgs {
   long long* trace;                   // null, or [grid][8] wall-clock stamps (10 ns ticks) per workgroup: tools/trace_collect.py
 };
 
+// fw_collect_close: the GAE scan the value waves run for their own rows once the last values are known
+struct CloseArgs {
+  const float *rewards, *values, *episode_starts;   // [T, N] rollout buffers (row T - 1 of `rewards` is finalised by this launch)
+  float *adv, *ret;                                  // [T, N]
+  int32_t T;
+  float gamma, lam;
+};
+
 __device__ __forceinline__ unsigned int ld_flag(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_flag(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ long long collect_now() { return (long long)__builtin_amdgcn_s_memrealtime(); }
@@ -295,8 +303,8 @@ __device__ __forceinline__ void collect_commit_stats(const CollectArgs& CA, cons
 
 // The merge wave (block 2 n_chunks): same statistics as everybody, written back once every act wave has read the old ones; the
 // action sampler's draw counter advances here too (the policy waves read it at their start).
-__device__ __forceinline__ void collect_merge_wave(const CollectArgs& CA) {
-  const int lane = threadIdx.x & 63, n_real = 2 * CA.n_chunks;
+__device__ __forceinline__ void collect_merge_wave(const CollectArgs& CA, int n_real, bool advance_rng) {
+  const int lane = threadIdx.x & 63;
   CollectStats Q;
   collect_front_stats(CA, false, Q);
   bool ok = false;
@@ -308,7 +316,7 @@ __device__ __forceinline__ void collect_merge_wave(const CollectArgs& CA) {
   if (lane == 0 && CA.sync[CS_INIT] != kCollectInitMagic) atomicOr(CA.sync + CS_STATUS, 8u);   // workspace never initialised
   collect_commit_stats(CA, Q);
   if (lane == 0) {
-    if (CA.S.rng) CA.S.rng[1] += 1;
+    if (advance_rng && CA.S.rng) CA.S.rng[1] += 1;
     st_flag(CA.sync + CS_READERS, 0u);
   }
 }
@@ -317,13 +325,15 @@ __device__ __forceinline__ void collect_merge_wave(const CollectArgs& CA) {
 // handing its address to an out-of-line function made the compiler copy the whole struct to scratch in every wave (544 B).
 // (tools/check_isa.py therefore tells MFMA accumulator registers from spill slots by the operand ranges of the MFMAs.)
 // T = the env's real type: the type of its observation / reward / action buffers.
-template <typename T>
-__device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t epoch) {
+// CLOSE = the waves of fw_collect_close (one per chunk, value network only): the last observation of a rollout -> last
+// values, the finalisation of its last step, and the GAE scan of the wave's own rows -- nobody to hand anything to.
+template <typename T, bool CLOSE = false>
+__device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t epoch, const CloseArgs* GA = nullptr) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   float* lds = reinterpret_cast<float*>(smem_raw);
   const ActArgs& A = CA.A;
-  const int aw = (int)blockIdx.x, chunk = aw >> 1, net = aw & 1;
-  if (aw == 2 * CA.n_chunks) { collect_merge_wave(CA); return; }
+  const int aw = (int)blockIdx.x, chunk = CLOSE ? aw : aw >> 1, net = CLOSE ? 1 : aw & 1;
+  if (aw == (CLOSE ? 1 : 2) * CA.n_chunks) { collect_merge_wave(CA, (CLOSE ? 1 : 2) * CA.n_chunks, !CLOSE); return; }
   if (chunk >= CA.n_chunks) return;                                  // padding waves
   const int KO = net == 0 ? 4 : 1;
   const int lane = threadIdx.x;
@@ -409,24 +419,28 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
     for (int e = lane; e < kCRows * (ldx - CW); e += kWave) { const int s_ = e / (ldx - CW), d = CW + e - s_ * (ldx - CW); dstX[s_ * ldx + d] = 0.f; }
   };
   if (tr && lane == 0) tr[6] = collect_now();                          // statistics merged, this lane's column constants known
-  build(A.raw, X, net == 0);
+  build(A.raw, X, net == 0 || CLOSE);
   if (tr && lane == 0) tr[5] = collect_now();                          // observations normalised
   if (net == 1) {
     if (any_timeout) build(A.prev_tobs, X2, false);
     // everything the env step of THIS launch overwrites has been read: let the step waves of my chunk go
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) st_flag(CA.flag_v + chunk, epoch);
+    if (!CLOSE) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) st_flag(CA.flag_v + chunk, epoch);
+    }
   }
   __syncthreads();
   if (tr && lane == 0) tr[2] = collect_now();                          // inputs in LDS (value wave: flag_v published)
 
   act_forward_wave(Wt, X, H1, H2, out, KO, Dk, ldx);
   if (tr && lane == 0) tr[3] = collect_now();                          // forward done
+  float v_mine = 0.f;                                                // value wave: V(row0 + lane)
   if (lane < kCRows) {
     const int row = row0 + lane;
     if (row < A.N) {
       if (net == 1) {
-        A.value[row] = out[lane * 4];
+        v_mine = out[lane * 4];
+        A.value[row] = v_mine;
       } else {
         float z[4] = {0.f, 0.f, 0.f, 0.f};
         if (!A.deterministic) act_normal4(rng_key, rng_ctr, (uint64_t)(A.env_offset + row), z);
@@ -470,6 +484,23 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
       if (timeout) o += A.gamma * out[lane * 4];                        // SB3: bootstrap truncated episodes with V(terminal_observation)
       A.rew_out[frow] = o;
       A.start_out[frow] = (f_term || f_trunc) ? 1.0f : 0.0f;
+      if (CLOSE) {
+        // SB3 RolloutBuffer.compute_returns_and_advantage for env frow (fw_gae's arithmetic): the time loop runs backwards in
+        // registers; the last row of the rewards is the one just finalised
+        const int N = A.N, Tn = GA->T;
+        float next_value = v_mine, next_non_terminal = (f_term || f_trunc) ? 0.0f : 1.0f, last_gae = 0.0f;
+        for (int t_ = Tn - 1; t_ >= 0; --t_) {
+          const size_t i = (size_t)t_ * N + frow;
+          const float v = GA->values[i];
+          const float rw = t_ == Tn - 1 ? o : GA->rewards[i];
+          const float delta = rw + GA->gamma * next_value * next_non_terminal - v;
+          last_gae = delta + GA->gamma * GA->lam * next_non_terminal * last_gae;
+          GA->adv[i] = last_gae;
+          GA->ret[i] = last_gae + v;
+          next_value = v;
+          next_non_terminal = 1.0f - GA->episode_starts[i];
+        }
+      }
     }
   }
   if (tr && lane == 0) tr[4] = collect_now();
@@ -539,6 +570,12 @@ __global__ __launch_bounds__(64) void fw_collect_finish_kernel(CollectArgs CA) {
   CollectStats Q;
   collect_front_stats(CA, false, Q);
   collect_commit_stats(CA, Q);
+}
+
+// fw_collect_close: grid = n_chunks value waves + the merge wave, 64 lanes, dynamic LDS = collect_act_lds_bytes(D).
+template <typename T>
+__global__ __launch_bounds__(64) void fw_collect_close_kernel(CollectArgs CA, CloseArgs GA) {
+  collect_act_wave<T, true>(CA, 0u, &GA);
 }
 
 // fw_collect_workspace_init (after a memset to zero): every partial-sum slot "not there yet", and the mark that says so

@@ -700,6 +700,9 @@ class PPO:
                             and getattr(env.venv, "lanes_per_env", 0) == 8 and getattr(env.venv, "g8_waves", 1) == 1
                             and float(env.gamma) == float(cfg.gamma))
         self._ws_collect = None
+        # ... and then the rollout ends in one launch too (fw_collect_close), unless the caller brought its own GAE
+        self._close_gae = bool(self._one_launch and gae_fn is gae_device)
+        self._adv_buf = self._ret_buf = None
         self._trace = None                 # optional int64 [grid, 8] device tensor: per-workgroup wall-clock stamps of the last fw_collect_step
         self._warm_rollouts = 0
         self._gathered = None
@@ -720,6 +723,8 @@ class PPO:
         self.buf_start = torch.zeros((T, N), **f32)
         self.buf_val = torch.zeros((T, N), **f32)
         self.buf_logp = torch.zeros((T, N), **f32)
+        if self._close_gae:
+            self._adv_buf, self._ret_buf = torch.zeros((T, N), **f32), torch.zeros((T, N), **f32)
         self.buf_img = self.last_img = None
         if self._img:
             r = int(self.policy.image_res)
@@ -831,6 +836,18 @@ class PPO:
                 a.clip_obs, a.eps_obs, a.clip_reward, a.eps_reward = float(env.clip_obs), float(env.epsilon), float(env.clip_reward), float(env.epsilon)
                 a.update_obs, a.update_ret, a.norm_reward, a.deterministic = upd_obs, track, int(env.norm_reward), 0
                 _lib.check(L.fw_collect_step(venv._h, C.byref(a), st), venv._h)
+            if self._close_gae:
+                # ... and the end of the rollout in one more: the last step's statistics, V(last observation), the finalisation of
+                # step T - 1, the normalised last observation and the GAE scan (fw_collect_close)
+                a.obs_copy, a.value = self.last_obs.data_ptr(), self.last_values.data_ptr()
+                a.act_raw = a.logp = a.act_env = None
+                a.rew_out, a.start_out = self.buf_rew[T - 1].data_ptr(), self.last_starts.data_ptr()
+                c = K.FwCollectCloseArgs()
+                c.rewards, c.values, c.episode_starts = self.buf_rew.data_ptr(), self.buf_val.data_ptr(), self.buf_start.data_ptr()
+                c.adv, c.ret, c.T = self._adv_buf.data_ptr(), self._ret_buf.data_ptr(), T
+                c.gae_gamma, c.gae_lambda = float(cfg.gamma), float(cfg.gae_lambda)
+                _lib.check(L.fw_collect_close(venv._h, C.byref(a), C.byref(c), st), venv._h)
+                return
             _lib.check(L.fw_collect_finish(venv._h, C.byref(a), st), venv._h)      # the last step's statistics (each step's are merged by the next launch)
         for t in (range(T) if not self._one_launch else ()):
             act(t, 3, self.buf_val[t], t - 1 if t > 0 else None)
@@ -887,8 +904,11 @@ class PPO:
         self._warm_rollouts += 1
         if hasattr(env, "sync_statistics"):
             env.sync_statistics()              # sharded job: one small all-reduce per rollout (no-op on one GPU)
-        self.adv, self.ret = self._gae(self.buf_rew, self.buf_val, self.buf_start, self.last_values, self.last_starts,
-                                       cfg.gamma, cfg.gae_lambda)
+        if self._collect_fused and self._close_gae:
+            self.adv, self.ret = self._adv_buf, self._ret_buf      # written by fw_collect_close inside the rollout
+        else:
+            self.adv, self.ret = self._gae(self.buf_rew, self.buf_val, self.buf_start, self.last_values, self.last_starts,
+                                           cfg.gamma, cfg.gae_lambda)
         td = _dist()
         self.num_timesteps += cfg.n_steps * env.num_envs * (td.get_world_size() if td is not None else 1)
 

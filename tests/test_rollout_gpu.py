@@ -471,7 +471,8 @@ def test_one_launch_vec_step_equals_the_three_launch_collector(task, n):
         bufs = []
         for _ in range(5):                                     # eager, capture, three replays
             ppo.collect_rollouts()
-            bufs.append([b.clone() for b in (ppo.buf_obs, ppo.buf_act, ppo.buf_logp, ppo.buf_val, ppo.buf_rew, ppo.buf_start, ppo.last_values, ppo.last_starts)])
+            bufs.append([b.clone() for b in (ppo.buf_obs, ppo.buf_act, ppo.buf_logp, ppo.buf_val, ppo.buf_rew, ppo.buf_start, ppo.last_values, ppo.last_starts,
+                                             ppo.adv, ppo.ret, ppo.last_obs)])      # (one launch: adv / ret / last_obs come from fw_collect_close)
         torch.cuda.synchronize()
         st = torch.cat([ppo.env.obs_rms.mean, ppo.env.obs_rms.var, ppo.env.obs_rms.count, ppo.env.ret_rms.mean.reshape(1), ppo.env.ret_rms.var.reshape(1),
                         ppo.env.ret_rms.count, ppo.env.returns])
@@ -483,7 +484,7 @@ def test_one_launch_vec_step_equals_the_three_launch_collector(task, n):
     assert ca == cb and (ca["resets"] > 0 or n < 100), (ca, cb)
     torch.testing.assert_close(sa, sb, rtol=1e-9, atol=1e-9)           # (another fold order: 1e-12 of a column's scale)
     for it, (x, y) in enumerate(zip(ba, bb)):
-        for name, u, v in zip(("obs", "act", "logp", "val", "rew", "start", "last_values", "last_starts"), x, y):
+        for name, u, v in zip(("obs", "act", "logp", "val", "rew", "start", "last_values", "last_starts", "adv", "ret", "last_obs"), x, y):
             torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-5, msg=lambda m: f"rollout {it} {name}: {m}")
         assert torch.equal(x[5], y[5]) and torch.equal(x[7], y[7])
     np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-5)      # the simulators end in the same state (1e-12 in the statistics -> an ulp of a float32 observation -> 1e-7 after 40 steps)
