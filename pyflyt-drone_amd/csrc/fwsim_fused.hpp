@@ -40,12 +40,17 @@
 //     that it has read the old ones.  fw_collect_finish merges the last step of a rollout.  46.3;
 //   * 16-row act waves on 16x16x4 tiles instead of 32-row ones on 32x32x2 (half the MFMA passes, tanh and normalisation on
 //     the path to the published actions, twice the waves -- there are SIMDs to spare while the step waves wait): 40.3;
-//   * weight operands from global memory into registers, column tiles = columns 4 r + t (one dwordx4 per weight row): 39.1.
-// Timeline of a launch (tools/trace_collect.py, profiles/r03_collect_step_trace.txt): statistics known 4.6 us after an act
-// wave starts (half of it the issue of ~70 loads and their addresses on a SIMD the wave has to itself), inputs normalised
-// +2.3, forward +4.1, actions published at 13.6 (mean) / 15.6 us (last), step waves done at 33.0, partials 34.1, totals and
-// launch end 36.2 us.  A bare hand-off between two waves costs 0.36 us inside an XCD and 0.41 us across two
-// (tools/microbench_xcd.hip); in the grid, with hundreds of waves polling, each dependent hop measures ~1 us.
+//   * weight operands from global memory into registers, column tiles = columns 4 r + t (one dwordx4 per weight row): 39.1;
+//   * a lane keeps one column of the input tile (statistics in two registers, no index division, no LDS staging), the
+//     statistics merge with one reciprocal per channel instead of four divisions: 38.4;
+//   * hidden layers as tile pairs, half of the tanh epilogue between the second pair's MFMAs: 37.9;
+//   * fw_collect_close instead of four launches at the end of a rollout (value waves: last values, finalisation, GAE): 37.6.
+// Timeline of a launch (tools/trace_collect.py, profiles/r03_collect_step_trace.txt): statistics known 3.8 us after an act
+// wave starts (half of it the issue of ~60 loads and their addresses on a SIMD the wave has to itself), inputs normalised and
+// in LDS +1.9, forward +4.9, actions published at 12.2 (mean) / 14.9 us (last), step waves done at 32.2, partials 33.3,
+// totals and launch end 35.7 us (rocprofv3: 36.0 us per launch).  A bare hand-off between two waves costs 0.36 us inside an
+// XCD and 0.41 us across two (tools/microbench_xcd.hip); in the grid, with hundreds of waves polling, each dependent hop
+// measures ~1 us.
 #pragma once
 #include "fwsim_collect.hpp"
 

@@ -34,7 +34,7 @@ for rep in range(5):
     pol, val = act[0::2], act[1::2]
     rel = lambda x: x - t0
     rows.append(dict(
-        act_start_max=rel(act[:, 0]).max(), act_stats_known=np.mean(act[:, 1] - act[:, 0]), act_rstd=np.mean(act[:, 6] - act[:, 1]), act_normalised=np.mean(act[:, 5] - act[:, 6]), act_weights_lds=np.mean(act[:, 2] - act[:, 5]),
+        act_start_max=rel(act[:, 0]).max(), act_stats_known=np.mean(act[:, 1] - act[:, 0]), act_column_consts=np.mean(act[:, 6] - act[:, 1]), act_normalised=np.mean(act[:, 5] - act[:, 6]), act_tile_in_lds=np.mean(act[:, 2] - act[:, 5]),
         act_forward=np.mean(act[:, 3] - act[:, 2]), pol_publish_mean=rel(pol[:, 4]).mean(), pol_publish_max=rel(pol[:, 4]).max(),
         val_inputs_max=rel(val[:, 2]).max(), val_done_max=rel(val[:, 4]).max(),
         step_start_mean=rel(step[:, 0]).mean(), step_start_max=rel(step[:, 0]).max(), wait_begin_mean=rel(step[:, 1]).mean(),
