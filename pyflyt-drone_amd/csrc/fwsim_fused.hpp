@@ -44,13 +44,15 @@
 //   * a lane keeps one column of the input tile (statistics in two registers, no index division, no LDS staging), the
 //     statistics merge with one reciprocal per channel instead of four divisions: 38.4;
 //   * hidden layers as tile pairs, half of the tanh epilogue between the second pair's MFMAs: 37.9;
-//   * fw_collect_close instead of four launches at the end of a rollout (value waves: last values, finalisation, GAE): 37.6.
-// Timeline of a launch (tools/trace_collect.py, profiles/r03_collect_step_trace.txt): statistics known 3.8 us after an act
-// wave starts (half of it the issue of ~60 loads and their addresses on a SIMD the wave has to itself), inputs normalised and
-// in LDS +1.9, forward +4.9, actions published at 12.2 (mean) / 14.9 us (last), step waves done at 32.2, partials 33.3,
-// totals and launch end 35.7 us (rocprofv3: 36.0 us per launch).  A bare hand-off between two waves costs 0.36 us inside an
-// XCD and 0.41 us across two (tools/microbench_xcd.hip); in the grid, with hundreds of waves polling, each dependent hop
-// measures ~1 us.
+//   * fw_collect_close instead of four launches at the end of a rollout (value waves: last values, finalisation, GAE): 37.6;
+//   * the weight operands fetched at once only by the first two waves per XCD and network, by the others when they are about
+//     to need them (lines the L2 holds by then): 37.1.
+// Timeline of a launch (tools/trace_collect.py, profiles/r03_collect_step_trace.txt): statistics known 2.8 us after an act
+// wave starts, inputs normalised and in LDS +3.2 (on the slowest XCD of a launch -- a different one each time -- the
+// observation rows arrive 2.5 us later than on the fastest), weight operands +0.1-0.5, forward 3.4, sampling and publishing
+// 1.4: actions published at 11.4 (mean) / 15.0 us (last), step waves done at 31.8, partials 32.8, totals and launch end
+// 35.0 us (rocprofv3: 35.8 us per launch).  A bare hand-off between two waves costs 0.36 us inside an XCD and 0.41 us across
+// two (tools/microbench_xcd.hip); in the grid, with hundreds of waves polling, each dependent hop measures ~1 us.
 #pragma once
 #include "fwsim_collect.hpp"
 
@@ -392,8 +394,13 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   const int oW1 = net == 0 ? 0 : nP0;
   const int oLs = nP0 + ppo_net_params(Dp, 1);
   const float* __restrict__ params = A.params;
+  // Every act wave of an XCD reads the same 33 KB, and the XCD's L2 is cold at the start of a launch: requested by all 65 waves
+  // at once the image arrives up to 4 us late on some XCDs (tools/trace_collect.py: the forward pass itself takes 3.4 us
+  // everywhere) -- misses to a line that is already on its way are not merged for free.  So the first waves of each XCD fetch
+  // it now and the others ask when they are about to need it, for lines the L2 holds by then.
   ActWeights Wt;
-  act_load_weights(Wt, params, oW1, Dp, Dk, KO);
+  const bool primer = aw < 2 * kCGroups;                             // (workgroups are dealt round-robin to the 8 XCDs: two waves per XCD and network)
+  if (primer) act_load_weights(Wt, params, oW1, Dp, Dk, KO);
   float log_std[4];                                                  // (uniform addresses: scalar loads)
 #pragma unroll
   for (int k = 0; k < 4; ++k) log_std[k] = params[oLs + k];
@@ -425,6 +432,7 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   };
   if (tr && lane == 0) tr[6] = collect_now();                          // statistics merged, this lane's column constants known
   build(A.raw, X, net == 0 || CLOSE);
+  if (!primer) act_load_weights(Wt, params, oW1, Dp, Dk, KO);
   if (tr && lane == 0) tr[5] = collect_now();                          // observations normalised
   if (net == 1) {
     if (any_timeout) build(A.prev_tobs, X2, false);
@@ -437,6 +445,7 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   __syncthreads();
   if (tr && lane == 0) tr[2] = collect_now();                          // inputs in LDS (value wave: flag_v published)
 
+  if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) tr[7] = collect_now(); }      // (tracing: the weight operands have arrived)
   act_forward_wave(Wt, X, H1, H2, out, KO, Dk, ldx);
   if (tr && lane == 0) tr[3] = collect_now();                          // forward done
   float v_mine = 0.f;                                                // value wave: V(row0 + lane)

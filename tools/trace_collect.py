@@ -45,3 +45,25 @@ keys = rows[0].keys()
 print(f"{task} {n} envs: grid {grid} = {n_act} act + {nblk} step + {nblk} worker + {pw} fold workgroups; us from the launch's first stamp, median of 5 launches")
 for k in keys:
     print(f"  {k:18s} {np.median([r[k] for r in rows]):8.2f}")
+# where the slowest act waves lose their time: phase means of the policy waves by decile of their publishing time (last launch)
+pol = t[:2 * n_chunks][0::2]
+order = np.argsort(pol[:, 4])
+k = max(1, len(order) // 10)
+for name, idx in (("fastest 10 %", order[:k]), ("median 10 %", order[len(order) // 2 - k // 2:len(order) // 2 + k // 2 + 1]), ("slowest 10 %", order[-k:])):
+    w = pol[idx]
+    print(f"  policy waves, {name}: start {np.mean(w[:, 0] - t0):5.2f}  statistics {np.mean(w[:, 1] - w[:, 0]):5.2f}  tile {np.mean(w[:, 2] - w[:, 1]):5.2f}  "
+          f"weights arrive +{np.mean(w[:, 7] - w[:, 2]):5.2f}  forward {np.mean(w[:, 3] - w[:, 7]):5.2f}  sample+publish {np.mean(w[:, 4] - w[:, 3]):5.2f}  published {np.mean(w[:, 4] - t0):5.2f}  "
+          f"XCDs {np.bincount((2 * idx) % 8, minlength=8).tolist()}")
+act = t[:2 * n_chunks]
+xcd = np.arange(2 * n_chunks) % 8
+print("  per XCD (act waves; even XCDs carry policy waves, odd ones value waves): us from a wave's start to its statistics / from there to its operands")
+for x in range(8):
+    w = act[xcd == x]
+    print(f"    XCD {x}: statistics {np.mean(w[:, 1] - w[:, 0]):5.2f}  operands {np.mean(w[:, 7] - w[:, 1]):5.2f}  forward {np.mean(w[:, 3] - w[:, 7]):5.2f}  done {np.mean(w[:, 4] - t0):5.2f}")
+step = t[n_act:n_act + nblk]
+sx = np.arange(nblk) % 8
+print("  per XCD (step waves): state loaded after / step body")
+for x in range(8):
+    w = step[sx == x]
+    print(f"    XCD {x}: load {np.mean(w[:, 1] - w[:, 0]):5.2f}  body {np.mean(w[:, 3] - w[:, 2]):5.2f}")
+
