@@ -60,7 +60,7 @@ namespace fwsim {
 
 constexpr int kCRows = 16;            // rows (envs) per act wave
 constexpr int kCGroups = 8;           // partial-sum rows are grouped by workgroup index mod 8 (the XCD a step wave runs on)
-enum { CS_PART_EPOCH = 0, CS_FOLDED_EPOCH = 1, CS_READERS = 2, CS_STATUS = 3, CS_INIT = 4 };
+enum { CS_PART_EPOCH = 0, CS_FOLDED_EPOCH = 1, CS_READERS = 2, CS_STATUS = 3, CS_INIT = 4, CS_MERGED = 5 };
 constexpr unsigned int kCollectInitMagic = 0xF01DC0DEu;  // left in sync[CS_INIT] by fw_collect_workspace_init
 // a total that has not been published yet: a quiet NaN no sum can produce
 __device__ __forceinline__ double collect_sentinel() { return __longlong_as_double(0x7FF8C0DEC0DE0001ll); }
@@ -276,11 +276,12 @@ __device__ __forceinline__ void collect_fold_wave(const CollectArgs& CA, int w) 
   for (int k = 0; k < kS; ++k) v += ((missing >> k) & 1u) ? 0.0 : x[k];     // ascending slot order
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   // every act wave has read the totals of the step before (its step waves have finished), the merge wave maybe not yet: it
-  // puts the readers counter back to 0 when it has
+  // leaves the launch's index in CS_MERGED when it has (the index itself: any chunk's word, all published by now)
   if (ok) {
     ok = false;
+    const unsigned int e = ld_flag(CA.flag_p);
     for (int it = 0; it < (1 << 20); ++it) {
-      if (ld_flag(CA.sync + CS_READERS) == 0u) { ok = true; break; }
+      if (ld_flag(CA.sync + CS_MERGED) == e) { ok = true; break; }
       __builtin_amdgcn_s_sleep(8);
     }
   }
@@ -309,15 +310,25 @@ __device__ __forceinline__ void collect_commit_stats(const CollectArgs& CA, cons
 }
 
 // The merge wave (block 2 n_chunks): same statistics as everybody, written back once every act wave has read the old ones; the
-// action sampler's draw counter advances here too (the policy waves read it at their start).
-__device__ __forceinline__ void collect_merge_wave(const CollectArgs& CA, int n_real, bool advance_rng) {
+// action sampler's draw counter advances here too (the policy waves read it at their start).  "Has read": in a step launch
+// every act wave publishes a word after it did (flag_p / flag_v = the launch's index) -- the merge wave watches those, no
+// counter (520 atomics on one word, fired while the step waves poll their flags next to it, cost the hand-off 1.5-4 us);
+// fw_collect_close has no such words and few waves: there they count themselves.
+__device__ __forceinline__ void collect_merge_wave(const CollectArgs& CA, int n_real, bool advance_rng, uint32_t epoch, bool by_flags) {
   const int lane = threadIdx.x & 63;
   CollectStats Q;
   collect_front_stats(CA, false, Q);
   bool ok = false;
   for (int it = 0; it < (1 << 21); ++it) {
-    if (ld_flag(CA.sync + CS_READERS) >= (unsigned int)n_real) { ok = true; break; }
-    __builtin_amdgcn_s_sleep(8);
+    if (by_flags) {
+      bool all = true;
+      for (int i = lane; i < 2 * CA.n_chunks; i += 64) all = all && ld_flag(i < CA.n_chunks ? CA.flag_p + i : CA.flag_v + (i - CA.n_chunks)) == epoch;
+      if (__ballot(!all) == 0ull) { ok = true; break; }
+      __builtin_amdgcn_s_sleep(32);
+    } else {
+      if (ld_flag(CA.sync + CS_READERS) >= (unsigned int)n_real) { ok = true; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
   }
   if (!ok && lane == 0) atomicOr(CA.sync + CS_STATUS, 4u);
   if (lane == 0 && CA.sync[CS_INIT] != kCollectInitMagic) atomicOr(CA.sync + CS_STATUS, 8u);   // workspace never initialised
@@ -325,6 +336,7 @@ __device__ __forceinline__ void collect_merge_wave(const CollectArgs& CA, int n_
   if (lane == 0) {
     if (advance_rng && CA.S.rng) CA.S.rng[1] += 1;
     st_flag(CA.sync + CS_READERS, 0u);
+    if (by_flags) st_flag(CA.sync + CS_MERGED, epoch);
   }
 }
 
@@ -340,7 +352,7 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   float* lds = reinterpret_cast<float*>(smem_raw);
   const ActArgs& A = CA.A;
   const int aw = (int)blockIdx.x, chunk = CLOSE ? aw : aw >> 1, net = CLOSE ? 1 : aw & 1;
-  if (aw == (CLOSE ? 1 : 2) * CA.n_chunks) { collect_merge_wave(CA, (CLOSE ? 1 : 2) * CA.n_chunks, !CLOSE); return; }
+  if (aw == (CLOSE ? 1 : 2) * CA.n_chunks) { collect_merge_wave(CA, (CLOSE ? 1 : 2) * CA.n_chunks, !CLOSE, epoch, !CLOSE); return; }
   if (chunk >= CA.n_chunks) return;                                  // padding waves
   const int KO = net == 0 ? 4 : 1;
   const int lane = threadIdx.x;
@@ -405,7 +417,11 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
 #pragma unroll
   for (int k = 0; k < 4; ++k) log_std[k] = params[oLs + k];
   // ---- statistics of THIS step: the old ones (+) the totals of the pending step ----
-  collect_front_merge(CA, true, Q);
+  collect_front_merge(CA, false, Q);
+  // ("I have read the old statistics": in a step launch my publishing word says so, the merge wave watches those; in the closing
+  // launch a counter at the END of the wave -- in front, every later wait on the memory counter also waited for that atomic's
+  // turn at a word 520 waves share: up to 4 us on the XCDs that came last)
+  auto announce_read = [&]() { if (CLOSE && lane == 0) (void)__hip_atomic_fetch_add(CA.sync + CS_READERS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   const bool timeout = fmine && f_trunc && !f_term;
   const bool any_timeout = __ballot(timeout) != 0ull;                // wave-uniform: some episode of my rows was truncated
   if (tr && lane == 0) tr[1] = collect_now();                          // statistics of this step known
@@ -480,6 +496,7 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the wave's action stores have left ...
     if (lane == 0) st_flag(CA.flag_p + chunk, epoch);                 // ... before the word that announces them
     if (tr && lane == 0) tr[4] = collect_now();
+    announce_read();
     return;
   }
   // ---- value wave: finalisation of the previous vec-step ----
@@ -518,6 +535,7 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
     }
   }
   if (tr && lane == 0) tr[4] = collect_now();
+  announce_read();
 }
 
 // Step wave: wait (bounded) until the act waves of the chunks covering rows [env0, env0 + rows) have published for `epoch`.
