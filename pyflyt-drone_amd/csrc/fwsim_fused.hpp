@@ -46,13 +46,15 @@
 //   * hidden layers as tile pairs, half of the tanh epilogue between the second pair's MFMAs: 37.9;
 //   * fw_collect_close instead of four launches at the end of a rollout (value waves: last values, finalisation, GAE): 37.6;
 //   * the weight operands fetched at once only by the first two waves per XCD and network, by the others when they are about
-//     to need them (lines the L2 holds by then): 37.1.
-// Timeline of a launch (tools/trace_collect.py, profiles/r03_collect_step_trace.txt): statistics known 2.8 us after an act
-// wave starts, inputs normalised and in LDS +3.2 (on the slowest XCD of a launch -- a different one each time -- the
-// observation rows arrive 2.5 us later than on the fastest), weight operands +0.1-0.5, forward 3.4, sampling and publishing
-// 1.4: actions published at 11.4 (mean) / 15.0 us (last), step waves done at 31.8, partials 32.8, totals and launch end
-// 35.0 us (rocprofv3: 35.8 us per launch).  A bare hand-off between two waves costs 0.36 us inside an XCD and 0.41 us across
-// two (tools/microbench_xcd.hip); in the grid, with hundreds of waves polling, each dependent hop measures ~1 us.
+//     to need them (lines the L2 holds by then): 37.1;
+//   * no shared readers counter: the merge wave watches the act waves' publishing words.  One atomic per act wave on one word
+//     cost every later wait on the wave's memory counter its turn at that word (2.5 us on the XCDs served last), and, moved
+//     to the end of the waves, 1.5-4 us per hand-off to the step waves polling next to it: 36.05 (113.6 M env-steps/s).
+// Timeline of a launch (tools/trace_collect.py, profiles/r03_collect_step_trace.txt): statistics known 2.5 us after an act
+// wave starts, inputs normalised and in LDS +2.2, weight operands +0.15, forward 3.3, sampling and publishing 1.3: actions
+// published at 10.0 (mean) / 12.3 us (last), step waves done at 30.1, partials 31.0, totals and launch end 33.2 us
+// (rocprofv3: 34.3 us per launch).  A bare hand-off between two waves costs 0.36 us inside an XCD and 0.41 us across two
+// (tools/microbench_xcd.hip); in the grid each dependent hop measures ~1 us.
 #pragma once
 #include "fwsim_collect.hpp"
 
@@ -269,7 +271,7 @@ __device__ __forceinline__ void collect_fold_wave(const CollectArgs& CA, int w) 
 #pragma unroll
     for (int k = 0; k < kS; ++k) if (((missing >> k) & 1u) && !collect_is_sentinel(x[k])) missing &= ~(1u << k);
     if (__ballot(missing != 0u) == 0ull) { ok = true; break; }
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(8);                     // (~0.2 us: 58 waves polling 512 slots each are traffic the step waves share the fabric with)
   }
   double v = 0.0;
 #pragma unroll
@@ -550,7 +552,7 @@ __device__ __forceinline__ void collect_wait_actions(const CollectArgs& CA, uint
   for (int it = 0; it < (1 << 21); ++it) {                             // ~ seconds: far beyond any healthy launch
     const bool mine = (c > c1) || ld_flag(w) == epoch;
     if (__ballot(!mine) == 0ull) { ok = true; break; }
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(4);
   }
   if (!ok && lane == 0) atomicOr(CA.sync + CS_STATUS, 1u);
   if (tr && lane == 0) tr[2] = collect_now();                          // actions there
