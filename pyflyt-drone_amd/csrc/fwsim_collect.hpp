@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kPThreads) void fw_policy_act_kernel(ActArgs A) {
   const int net = blockIdx.y;
   if (!((A.nets >> net) & 1)) return;
   const int KO = net == 0 ? 4 : 1;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, hh = lane >> 5;
+  const int t = threadIdx.x;
   const int D = A.D, Dp = (D + 1) & ~1, ldx = Dp + 1;
   const int row0 = blockIdx.x * kPChunk;
   if (!A.obs && A.truncated) {

@@ -79,7 +79,7 @@ struct CollectArgs {
   unsigned int* flag_v;               // [n_chunks] value wave: inputs of launch `epoch` have been read
   double* part1;                      // [2 D + 2][8][ceil(nblk / 8)] partial sums of the step waves: word-major; a slot nobody has written since the last fold holds a sentinel
   double* tot;                        // [2 D + 2] totals of the pending step (written by the fold waves of the launch that produced it)
-  unsigned int* sync;                 // [8] CS_*: launch index of the partials in part1 / of the last fold, readers counter, status bits, collect-launch counter
+  unsigned int* sync;                 // [16] CS_*: launch index of the partials in part1 / of the last merge, readers counter (closing launch), status bits, init mark, launch index of the last merge wave
   long long* trace;                   // null, or [grid][8] wall-clock stamps (10 ns ticks) per workgroup: tools/trace_collect.py
 };
 

@@ -222,7 +222,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 
   // flat offsets of this net
   const int nP0 = ppo_net_params(Dp, 4);
-  const int oW1 = n == 0 ? 0 : nP0, ob1 = oW1 + Dp * kPH, oW2 = ob1 + kPH, ob2 = oW2 + kPH * kPH, oWo = ob2 + kPH, obo = oWo + kPH * KO;
+  const int oW1 = n == 0 ? 0 : nP0, ob1 = oW1 + Dp * kPH, oW2 = ob1 + kPH, ob2 = oW2 + kPH * kPH, oWo = ob2 + kPH;
   const int oLs = nP0 + ppo_net_params(Dp, 1);
 
   // ---- load the weights once ----
