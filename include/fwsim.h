@@ -482,7 +482,8 @@ typedef struct fw_collect_args {
   double *obs_acc, *ret_acc;               /* sharded jobs: batch-sum accumulators (may be NULL) */
   uint64_t* rng;                           /* [2] seed, draw counter (advanced by one) */
   float *obs_copy, *act_raw, *logp, *value;/* rollout-buffer rows of the step being acted (obs_copy may be NULL) */
-  void* act_env;                           /* T[N,4] the clipped actions the envs step with (scratch owned by the caller) */
+  void* act_env;                           /* T[N,4] the clipped actions the envs step with (scratch owned by the caller, one per handle;
+                                            * between launches every word is NaN = "not there yet": the library fills a new buffer itself) */
   float *rew_out, *start_out;              /* finalisation of the previous step: both or neither */
   void *obs, *reward;                      /* env buffers, as fw_step (in: previous step, out: this step) */
   uint8_t *terminated, *truncated;

@@ -401,13 +401,16 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   if (COLLECT) {
     if (active && leader) c_ret = ld_sc1(CAp->S.returns + env);
     collect_wait_actions(*CAp, Dg.epoch, env0, min(EPW, Dg.n - env0));
-    if (LANE_T) a_keep = ld_coherent(actions + (size_t)envc * 4 + (sub & 3));
   }
   {
     const T* ap = actions + (size_t)envc * 4;
     T a4[4];
+    if (COLLECT) collect_load_actions<T>(*CAp, ap, a4);
+    else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a4[k] = COLLECT ? ld_coherent(ap + k) : ap[k];
+      for (int k = 0; k < 4; ++k) a4[k] = ap[k];
+    }
+    if (COLLECT && LANE_T) a_keep = (sub & 3) == 0 ? a4[0] : (sub & 3) == 1 ? a4[1] : (sub & 3) == 2 ? a4[2] : a4[3];
     const T sp[4] = { a4[0], a4[1], a4[2], a4[3] * (T)0.5 + (T)0.5 };
 #pragma unroll
     for (int c = 0; c < FW_NUM_ACTUATORS; ++c)
@@ -899,6 +902,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   }
   __syncthreads();
   flush_obs_tile<T>(tile, ld, obs, env0, EPW, D.n, Dobs);
+  if (COLLECT && active && leader) collect_clear_actions<T>(const_cast<T*>(actions) + (size_t)env * 4);      // "not there yet" for the next launch
   if (COLLECT) collect_stats_tail<T>(*CAp, D.epoch, tile, ld, min(EPW, D.n - env0), wg, nblk, active && leader, latch[4 * row], latch[4 * row + 1] != 0.0, env, c_ret);
   FWP(long long p_capmax = HASOBJ ? O.p_cap : 0; const int p_ncapw = HASOBJ ? __popcll(__ballot(leader && O.p_ncap > 0)) : 0;)
   FWP(if (D.prof) {
@@ -1308,6 +1312,7 @@ struct fw_env {
   double* scen_dev = nullptr;               // staging of a caller-supplied fw_scenario (allocated on first use)
   long long* prof_dev = nullptr; // FW_PROFILE builds only
   int32_t shadow_on = 0;        // background warm-up of the next episode (see shadow_* kernels)
+  const void* collect_act_seen = nullptr;   // the action buffer fw_collect_step last filled with "not there yet"
   std::string err;
 };
 
@@ -2022,6 +2027,13 @@ int32_t fw_collect_step(fw_handle h, const fw_collect_args* a, void* hip_stream)
   if (int32_t rc = collect_fill(h, a, "fw_collect_step", false, CA)) return rc;
   DeviceGuard g(h->device);
   hipStream_t st = (hipStream_t)hip_stream;
+  if (h->collect_act_seen != a->act_env) {
+    // a new action buffer: every word "not there yet" (NaN) -- the step waves see their actions replace it and put it back at the
+    // end of a launch.  (Stream-ordered; harmless if a captured graph replays it: between launches the words are NaN anyway.)
+    const size_t bytes = (size_t)h->n * 4 * (h->cfg.dtype == FW_F64 ? 8 : 4);
+    HIP_TRY(h, hipMemsetAsync(a->act_env, 0xFF, bytes, st));      // all-ones words: a NaN in float32 and in float64
+    h->collect_act_seen = a->act_env;
+  }
   return h->cfg.dtype == FW_F64 ? collect_step_T<double>(h, CA, a->act_env, a->obs, a->reward, a->terminated, a->truncated, a->terminal_obs, a->info_i32, st)
                                 : collect_step_T<float>(h, CA, a->act_env, a->obs, a->reward, a->terminated, a->truncated, a->terminal_obs, a->info_i32, st);
 }

@@ -420,6 +420,9 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   for (int k = 0; k < 4; ++k) log_std[k] = params[oLs + k];
   // ---- statistics of THIS step: the old ones (+) the totals of the pending step ----
   collect_front_merge(CA, false, Q);
+  // the policy wave's word says "I have read the old statistics" (the merge wave watches it; the fold waves take the launch's
+  // index from it) -- the actions themselves need no flag: a step wave sees them replace the NaN it left in their place
+  if (!CLOSE && net == 0 && lane == 0) st_flag(CA.flag_p + chunk, epoch);
   // ("I have read the old statistics": in a step launch my publishing word says so, the merge wave watches those; in the closing
   // launch a counter at the END of the wave -- in front, every later wait on the memory counter also waited for that atomic's
   // turn at a word 520 waves share: up to 4 us on the XCDs that came last)
@@ -495,8 +498,6 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
     }
   }
   if (net == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the wave's action stores have left ...
-    if (lane == 0) st_flag(CA.flag_p + chunk, epoch);                 // ... before the word that announces them
     if (tr && lane == 0) tr[4] = collect_now();
     announce_read();
     return;
@@ -540,22 +541,48 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   announce_read();
 }
 
-// Step wave: wait (bounded) until the act waves of the chunks covering rows [env0, env0 + rows) have published for `epoch`.
+// Step wave: wait (bounded) until the value waves of the chunks covering rows [env0, env0 + rows) have read what this step
+// overwrites (their word = `epoch`) ...
 __device__ __forceinline__ void collect_wait_actions(const CollectArgs& CA, uint32_t epoch, int env0, int rows) {
   long long* tr = CA.trace ? CA.trace + (size_t)blockIdx.x * 8 : nullptr;
   if (tr && (threadIdx.x & 63) == 0) tr[1] = collect_now();              // state loaded, wait begins
   const int c0 = env0 / kCRows, c1 = min((env0 + rows - 1) / kCRows, CA.n_chunks - 1);
   const int lane = threadIdx.x & 63;
-  const int c = c0 + (lane >> 1);
-  const unsigned int* w = ((lane & 1) ? CA.flag_v : CA.flag_p) + (c <= c1 ? c : c1);
+  const unsigned int* w = CA.flag_v + min(c0 + lane, c1);
   bool ok = false;
   for (int it = 0; it < (1 << 21); ++it) {                             // ~ seconds: far beyond any healthy launch
-    const bool mine = (c > c1) || ld_flag(w) == epoch;
-    if (__ballot(!mine) == 0ull) { ok = true; break; }
+    if (__ballot(ld_flag(w) != epoch) == 0ull) { ok = true; break; }
     __builtin_amdgcn_s_sleep(4);
   }
   if (!ok && lane == 0) atomicOr(CA.sync + CS_STATUS, 1u);
+}
+// ... and until this lane's env has its actions: the policy wave writes them through over the NaN the env's step wave of the
+// previous launch left there (a clipped action is never NaN), so the four words announce themselves -- no store wait and no
+// flag hop between the policy wave's last store and the step wave's first use.
+template <typename T>
+__device__ __forceinline__ void collect_load_actions(const CollectArgs& CA, const T* ap, T (&a4)[4]) {
+  long long* tr = CA.trace ? CA.trace + (size_t)blockIdx.x * 8 : nullptr;
+  const int lane = threadIdx.x & 63;
+  bool ok = false;
+  for (int it = 0; it < (1 << 21); ++it) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a4[k] = ld_coherent(ap + k);
+    const bool mine = a4[0] == a4[0] && a4[1] == a4[1] && a4[2] == a4[2] && a4[3] == a4[3];
+    if (__ballot(!mine) == 0ull) { ok = true; break; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  if (!ok) {                                                           // (never expected: go on with zeros rather than NaN)
+    if (lane == 0) atomicOr(CA.sync + CS_STATUS, 1u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a4[k] = a4[k] == a4[k] ? a4[k] : (T)0;
+  }
   if (tr && lane == 0) tr[2] = collect_now();                          // actions there
+}
+template <typename T>
+__device__ __forceinline__ void collect_clear_actions(T* ap) {
+  const T nan = (T)__builtin_nanf("");
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ap[k] = nan;
 }
 
 // Statistics tail of a step wave: its partial sums, left with plain stores for the next launch (or fw_collect_finish) to fold.

@@ -693,7 +693,8 @@ class PPO:
         if self._collect_fused:
             self._fused = FusedPpoUpdate(self.policy, self.optimizer, env.obs_dim)
             self._rng = torch.tensor([cfg.seed * 7919 + 17, 0], dtype=torch.int64, device=self.device)      # seed, draw counter
-            self._act_env = torch.zeros((env.num_envs, 4), dtype=env.venv.torch_dtype, device=self.device)
+            # (NaN = "not there yet": fw_collect_step's step waves see their actions replace it and put it back)
+            self._act_env = torch.full((env.num_envs, 4), float("nan"), dtype=env.venv.torch_dtype, device=self.device)
             self._tval = torch.zeros(env.num_envs, dtype=torch.float32, device=self.device)
         # one launch per vec-step (fw_collect_step) where the handle's lane mapping has it: 8 lanes per env at one wave per SIMD
         self._one_launch = (self._collect_fused and bool(cfg.one_launch_collect) and hasattr(env.venv, "_h")
