@@ -901,9 +901,10 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
     }
   }
   __syncthreads();
+  // (COLLECT: the partial sums first -- the fold waves at the end of the launch are waiting for them, nobody for the observation rows)
+  if (COLLECT) collect_stats_tail<T>(*CAp, D.epoch, tile, ld, min(EPW, D.n - env0), wg, nblk, active && leader, latch[4 * row], latch[4 * row + 1] != 0.0, env, c_ret);
   flush_obs_tile<T>(tile, ld, obs, env0, EPW, D.n, Dobs);
   if (COLLECT && active && leader) collect_clear_actions<T>(const_cast<T*>(actions) + (size_t)env * 4);      // "not there yet" for the next launch
-  if (COLLECT) collect_stats_tail<T>(*CAp, D.epoch, tile, ld, min(EPW, D.n - env0), wg, nblk, active && leader, latch[4 * row], latch[4 * row + 1] != 0.0, env, c_ret);
   FWP(long long p_capmax = HASOBJ ? O.p_cap : 0; const int p_ncapw = HASOBJ ? __popcll(__ballot(leader && O.p_ncap > 0)) : 0;)
   FWP(if (D.prof) {
     for (int o = 32; o > 0; o >>= 1) p_capmax = max(p_capmax, (long long)__shfl_xor((long long)p_capmax, o, kWave));
