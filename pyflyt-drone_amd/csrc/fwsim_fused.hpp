@@ -9,14 +9,16 @@
 //                               observation normalised on load, 64-64 tanh MLP, Philox / Box-Muller sampling, log-prob, the
 //                               rollout-buffer rows; the value wave also finalises the PREVIOUS step: reward normalisation,
 //                               truncation bootstrap, episode starts) on v_mfma_f32_16x16x4_f32 tiles whose weight operands
-//                               come from global memory straight into registers.  The policy wave publishes its 16 clipped
-//                               actions with write-through stores and then a generation word flag_p[chunk] = launch index;
-//                               the value wave publishes flag_v[chunk] as soon as it has READ everything the env step is
-//                               about to overwrite (observations, rewards, flags, terminal observations).
+//                               come from global memory straight into registers.  The policy wave writes its 16 clipped
+//                               actions through over the NaN the step waves left there (they announce themselves); its word
+//                               flag_p[chunk] = launch index, raised early, says "old statistics read".  The value wave
+//                               publishes flag_v[chunk] as soon as it has READ everything the env step is about to overwrite
+//                               (observations, rewards, flags, terminal observations).
 //   block 2 n_chunks            the "merge wave": writes the updated statistics back for the caller (see below).
 //   blocks [n_act, n_act+nblk)  the env step waves of fw_step (step_body<..., COLLECT = true>): they load their state, then
-//                               wait -- bounded -- for the two words of the chunk their envs sit in, read the actions with
-//                               coherent loads, and run the step; in their tail they leave 2 D + 2 partial sums.
+//                               wait -- bounded -- for the value wave's word of their chunk and for their actions (coherent
+//                               loads until no word is NaN), and run the step; in their tail they leave 2 D + 2 partial sums
+//                               and put the NaN back.
 //   blocks beyond               the shadow / scenario workers of fw_step, unchanged;
 //   the last 2 D + 2 blocks     "fold waves", one per partial-sum word (collect_fold_wave).
 // Workgroups are dispatched in block order and every wave waits only for waves in front of it (act waves for nobody, step
@@ -49,12 +51,15 @@
 //     to need them (lines the L2 holds by then): 37.1;
 //   * no shared readers counter: the merge wave watches the act waves' publishing words.  One atomic per act wave on one word
 //     cost every later wait on the wave's memory counter its turn at that word (2.5 us on the XCDs served last), and, moved
-//     to the end of the waves, 1.5-4 us per hand-off to the step waves polling next to it: 36.05 (113.6 M env-steps/s).
-// Timeline of a launch (tools/trace_collect.py, profiles/r03_collect_step_trace.txt): statistics known 2.5 us after an act
-// wave starts, inputs normalised and in LDS +2.2, weight operands +0.15, forward 3.3, sampling and publishing 1.3: actions
-// published at 10.0 (mean) / 12.3 us (last), step waves done at 30.1, partials 31.0, totals and launch end 33.2 us
-// (rocprofv3: 34.3 us per launch).  A bare hand-off between two waves costs 0.36 us inside an XCD and 0.41 us across two
-// (tools/microbench_xcd.hip); in the grid each dependent hop measures ~1 us.
+//     to the end of the waves, 1.5-4 us per hand-off to the step waves polling next to it: 36.05 (113.6 M env-steps/s);
+//   * actions that announce themselves (a step wave leaves NaN in its env's action row at the end of a launch; a clipped action
+//     is never NaN) instead of a store wait and a flag the step waves poll before loading them: 34.85;
+//   * the step waves' partial sums before their observation rows: 34.7 (118.2 M env-steps/s).
+// Timeline of a launch (tools/trace_collect.py, profiles/r03_collect_step_trace.txt): statistics known 2.6 us after an act
+// wave starts, inputs normalised and in LDS +2.2, weight operands +0.15, forward 3.3, sampling and the action stores 1.0:
+// actions out at 9.7 (mean) / 10.8 us (last), in the step waves' registers at 10.5 / 12.0, step waves done at 28.6, partials
+// 29.5, totals and launch end 31.9 us (rocprofv3: 33.0 us per launch).  A bare hand-off between two waves costs 0.36 us inside
+// an XCD and 0.41 us across two (tools/microbench_xcd.hip); in the grid each dependent hop measures ~1 us.
 #pragma once
 #include "fwsim_collect.hpp"
 
