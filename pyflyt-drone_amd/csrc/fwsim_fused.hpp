@@ -528,16 +528,29 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
         // registers; the last row of the rewards is the one just finalised
         const int N = A.N, Tn = GA->T;
         float next_value = v_mine, next_non_terminal = (f_term || f_trunc) ? 0.0f : 1.0f, last_gae = 0.0f;
-        for (int t_ = Tn - 1; t_ >= 0; --t_) {
-          const size_t i = (size_t)t_ * N + frow;
-          const float v = GA->values[i];
-          const float rw = t_ == Tn - 1 ? o : GA->rewards[i];
-          const float delta = rw + GA->gamma * next_value * next_non_terminal - v;
-          last_gae = delta + GA->gamma * GA->lam * next_non_terminal * last_gae;
-          GA->adv[i] = last_gae;
-          GA->ret[i] = last_gae + v;
-          next_value = v;
-          next_non_terminal = 1.0f - GA->episode_starts[i];
+        constexpr int kGB = 8;                                            // rows fetched together: the recurrence is a few FMAs per row,
+        for (int t1 = Tn - 1; t1 >= 0; t1 -= kGB) {                       // a row's three loads one memory round trip
+          float vv[kGB], rr[kGB], ss[kGB];
+#pragma unroll
+          for (int u = 0; u < kGB; ++u) {
+            const int t_ = t1 - u;
+            const size_t i = (size_t)(t_ >= 0 ? t_ : 0) * N + frow;
+            vv[u] = GA->values[i]; rr[u] = GA->rewards[i]; ss[u] = GA->episode_starts[i];
+          }
+#pragma unroll
+          for (int u = 0; u < kGB; ++u) {
+            const int t_ = t1 - u;
+            if (t_ < 0) break;
+            const size_t i = (size_t)t_ * N + frow;
+            const float v = vv[u];
+            const float rw = t_ == Tn - 1 ? o : rr[u];
+            const float delta = rw + GA->gamma * next_value * next_non_terminal - v;
+            last_gae = delta + GA->gamma * GA->lam * next_non_terminal * last_gae;
+            GA->adv[i] = last_gae;
+            GA->ret[i] = last_gae + v;
+            next_value = v;
+            next_non_terminal = 1.0f - ss[u];
+          }
         }
       }
     }
