@@ -54,7 +54,8 @@
 //     to the end of the waves, 1.5-4 us per hand-off to the step waves polling next to it: 36.05 (113.6 M env-steps/s);
 //   * actions that announce themselves (a step wave leaves NaN in its env's action row at the end of a launch; a clipped action
 //     is never NaN) instead of a store wait and a flag the step waves poll before loading them: 34.85;
-//   * the step waves' partial sums before their observation rows: 34.7 (118.2 M env-steps/s).
+//   * the step waves' partial sums before their observation rows: 34.7; the closing launch's GAE rows fetched eight at a time:
+//     34.3 (119.3 M env-steps/s).
 // Timeline of a launch (tools/trace_collect.py, profiles/r03_collect_step_trace.txt): statistics known 2.6 us after an act
 // wave starts, inputs normalised and in LDS +2.2, weight operands +0.15, forward 3.3, sampling and the action stores 1.0:
 // actions out at 9.7 (mean) / 10.8 us (last), in the step waves' registers at 10.5 / 12.0, step waves done at 28.6, partials
