@@ -500,3 +500,37 @@ def test_fw_collect_step_refuses_the_mappings_it_does_not_serve(monkeypatch):
     assert _lib.lib().fw_collect_step(env._h, C.byref(a), None) == K.FW_EUNSUPPORTED
     ppo.collect_rollouts()
     assert float(ppo.env.obs_rms.count) == pytest.approx(1e-4 + 5 * 256)
+
+
+def test_fw_collect_close_checks_its_arguments():
+    """fw_collect_close refuses what it cannot run: the mapping without a one-launch form (FW_EUNSUPPORTED, like fw_collect_step),
+    missing buffers, GAE buffers that do not match (rew_out must be row T - 1 of the rewards) -- FW_EINVAL, nothing launched."""
+    from pyflyt_drone_amd import _lib
+    L = _lib.lib()
+    env = P.FixedwingVecEnv(K.train_waypoints_v3_config(), 256, seed=1)
+    ppo = R.PPO(R.VecNormalizeDevice(env), R.PPOConfig(n_steps=4, batch_size=64, n_epochs=1))
+    assert ppo._one_launch and ppo._close_gae
+    ppo.collect_rollouts()                                              # allocates and initialises the workspace
+    a, c = K.FwCollectArgs(), K.FwCollectCloseArgs()
+    assert L.fw_collect_close(env._h, C.byref(a), C.byref(c), None) == K.FW_EINVAL          # nothing filled in
+    vn, venv, T = ppo.env, ppo.env.venv, 4
+    a.params = ppo._fused.flat.data_ptr()
+    a.obs_mean, a.obs_var, a.obs_count = vn.obs_rms.mean.data_ptr(), vn.obs_rms.var.data_ptr(), vn.obs_rms.count.data_ptr()
+    a.returns = vn.returns.data_ptr()
+    a.ret_mean, a.ret_var, a.ret_count = vn.ret_rms.mean.data_ptr(), vn.ret_rms.var.data_ptr(), vn.ret_rms.count.data_ptr()
+    a.value, a.obs_copy = ppo.last_values.data_ptr(), ppo.last_obs.data_ptr()
+    a.obs, a.reward = venv.obs.data_ptr(), venv.rewards.data_ptr()
+    a.terminated, a.truncated, a.terminal_obs = venv.terminated.data_ptr(), venv.truncated.data_ptr(), venv.terminal_obs.data_ptr()
+    a.workspace, a.workspace_bytes = ppo._ws_collect.data_ptr(), ppo._ws_collect.numel() * 8
+    a.gamma, a.clip_obs, a.eps_obs, a.clip_reward, a.eps_reward = 0.99, 10.0, 1e-8, 10.0, 1e-8
+    a.rew_out, a.start_out = ppo.buf_rew[T - 1].data_ptr(), ppo.last_starts.data_ptr()
+    assert L.fw_collect_close(env._h, C.byref(a), C.byref(c), None) == K.FW_EINVAL          # no GAE buffers
+    c.rewards, c.values, c.episode_starts = ppo.buf_rew.data_ptr(), ppo.buf_val.data_ptr(), ppo.buf_start.data_ptr()
+    c.adv, c.ret, c.T, c.gae_gamma, c.gae_lambda = ppo._adv_buf.data_ptr(), ppo._ret_buf.data_ptr(), T, 0.99, 0.95
+    a.rew_out = ppo.buf_rew[T - 2].data_ptr()
+    assert L.fw_collect_close(env._h, C.byref(a), C.byref(c), None) == K.FW_EINVAL          # rew_out is not row T - 1
+    a.rew_out = ppo.buf_rew[T - 1].data_ptr()
+    assert L.fw_collect_close(env._h, C.byref(a), C.byref(c), None) == K.FW_OK              # complete: runs
+    torch.cuda.synchronize()
+    assert torch.isfinite(ppo._adv_buf).all() and torch.isfinite(ppo._ret_buf).all() and torch.isfinite(ppo.last_values).all()
+    assert int(ppo._ws_collect.view(torch.int32)[-16 + 3]) == 0
