@@ -237,7 +237,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   // The two chunk-half blocks of a network swap their gradient partials once per minibatch.  If both run on the same XCD
   // they share an L2: the swap then needs no device-scope release / acquire (a write-back and an invalidate of the WHOLE L2,
   // ~12 k cycles per minibatch with the misses that follow) -- the vector L1 writes through, so the producer only waits for
-  // its stores and the consumer only drops its own L1.  The launch puts them there (blocks b and b + 8), but nothing
+  // its stores and the consumer only reads past its own L1.  The launch puts them there (blocks b and b + 8), but nothing
   // promises that mapping: each block reads the XCD it really runs on and the pair compares notes once per call; a pair that
   // was split keeps the device-scope fences.
   bool same_xcd = false, same_xcd_net = false;      // ... as my chunk-half partner; as the other network's block of my half
@@ -591,15 +591,41 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
           if (++spins > (1ll << 26)) __builtin_trap();                // the partner block is gone: fail loudly instead of hanging
       }
       __syncthreads();
-      if (same_xcd) asm volatile("buffer_inv sc0" ::: "memory");      // drop this CU's L1: the partner's rows come from the shared L2
-      else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // The partner's rows: on a shared L2 they are read with device-scope loads -- past this CU's L1, which may still hold the
+      // lines from two minibatches ago (`buffer_inv sc0` does not drop them outside tg-split mode: a loop of it and plain loads
+      // never saw a word change), served by the L2 the partner's stores sit in.  Otherwise: a device-scope acquire, plain loads.
+      typedef float ppo_f4 __attribute__((ext_vector_type(4)));
+      ppo_f4 ta[4], tb[4];
+      float tsc[5];
+      if (same_xcd) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(ta[q]) : "v"(theirs + s0 + 4 * q) : "memory");
+          if (hasW1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(tb[q]) : "v"(theirs + s1 + 4 * q) : "memory");
+          else tb[q] = ppo_f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(tsc[q]) : "v"(theirs + sq + q * kPThreads) : "memory");
+        // (one wait for the lot, tied to every value so that no use is scheduled ahead of it)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ta[0]), "+v"(ta[1]), "+v"(ta[2]), "+v"(ta[3]), "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3]),
+                     "+v"(tsc[0]), "+v"(tsc[1]), "+v"(tsc[2]), "+v"(tsc[3]), "+v"(tsc[4]) :: "memory");
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 a = reinterpret_cast<const float4*>(theirs + s0)[q];
+          ta[q] = ppo_f4{a.x, a.y, a.z, a.w};
+          if (hasW1) { const float4 b = reinterpret_cast<const float4*>(theirs + s1)[q]; tb[q] = ppo_f4{b.x, b.y, b.z, b.w}; } else tb[q] = ppo_f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) tsc[q] = theirs[sq + q * kPThreads];
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 a = reinterpret_cast<const float4*>(theirs + s0)[q];
-        gW2[4 * q] += a.x; gW2[4 * q + 1] += a.y; gW2[4 * q + 2] += a.z; gW2[4 * q + 3] += a.w;
-        if (hasW1) { const float4 b = reinterpret_cast<const float4*>(theirs + s1)[q]; gW1[4 * q] += b.x; gW1[4 * q + 1] += b.y; gW1[4 * q + 2] += b.z; gW1[4 * q + 3] += b.w; }
+        gW2[4 * q] += ta[q][0]; gW2[4 * q + 1] += ta[q][1]; gW2[4 * q + 2] += ta[q][2]; gW2[4 * q + 3] += ta[q][3];
+        if (hasW1) { gW1[4 * q] += tb[q][0]; gW1[4 * q + 1] += tb[q][1]; gW1[4 * q + 2] += tb[q][2]; gW1[4 * q + 3] += tb[q][3]; }
       }
-      gb1 += theirs[sq]; gb2 += theirs[sq + kPThreads]; my_gbo += theirs[sq + 2 * kPThreads]; my_gls += theirs[sq + 3 * kPThreads]; my_gwo += theirs[sq + 4 * kPThreads];
+      gb1 += tsc[0]; gb2 += tsc[1]; my_gbo += tsc[2]; my_gls += tsc[3]; my_gwo += tsc[4];
     }
 
 #ifdef FW_PPO_PROF

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <string>
 
 __device__ __forceinline__ unsigned xcc_id() {
   // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, width 4)
@@ -75,7 +76,46 @@ __global__ void handoff(unsigned long long* flag, unsigned long long* back, unsi
   if (me == peer && t == 0) out[2] = (long long)acc;          // 0 if every payload word arrived intact
 }
 
-int main() {
+// 3. A reader that HAS a line in its vector L1 and a writer on another CU of the same XCD (workgroups 0 and 8) that changes it
+//    with a PLAIN store (then s_waitcnt vmcnt(0)): which kind of re-read sees the change?
+//      mode 0: plain loads                       (expected: never -- the L1 copy is served)
+//      mode 1: `buffer_inv sc0` + plain loads    (the workgroup-scope invalidate)
+//      mode 2: `buffer_inv sc1` + plain loads    (the agent-scope invalidate)
+//      mode 3: loads with sc1 (device scope)     (past the L1, served by the shared L2)
+//    The reader first reads the word (old value, now in its L1), raises a flag (agent scope); the writer then stores the new
+//    value; the reader re-reads in the chosen way for a bounded number of rounds.
+__global__ void visible(unsigned* data, unsigned* flag, int mode, int peer, long long* out) {
+  if (threadIdx.x != 0) return;
+  const int me = blockIdx.x;
+  if (me != 0 && me != peer) return;
+  if (me == 0) {                                    // reader
+    unsigned v;                                     // a plain load: the line is in my L1 now
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(data) : "memory");
+    __hip_atomic_store(flag, 1u + v * 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    long long seen = -1;
+    for (int it = 0; it < 200000; ++it) {
+      unsigned x;
+      if (mode == 0) { asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(data) : "memory"); }
+      else if (mode == 1) { asm volatile("buffer_inv sc0\n\tglobal_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(data) : "memory"); }
+      else if (mode == 2) { asm volatile("buffer_inv sc1\n\tglobal_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(data) : "memory"); }
+      else { asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(data) : "memory"); }
+      if (x == 0xABCDu) { seen = (long long)__builtin_amdgcn_s_memrealtime() - t0; break; }
+    }
+    out[0] = seen;
+  } else {                                          // writer
+    long long spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) if (++spins > 2000000) break;
+    *data = 0xABCDu;                                // plain store: through my L1 into the XCD's L2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
+  const bool only_visible = argc > 1 && std::string(argv[1]) == "visible";      // section 3 alone (the others take minutes)
+  long long* out; hipMalloc(&out, 64);
+  if (!only_visible) {
   unsigned* dx; hipMalloc(&dx, 64 * sizeof(unsigned));
   hipLaunchKernelGGL(where, dim3(32), dim3(64), 0, 0, dx); hipDeviceSynchronize();
   std::vector<unsigned> hx(32); hipMemcpy(hx.data(), dx, 32 * sizeof(unsigned), hipMemcpyDeviceToHost);
@@ -84,7 +124,6 @@ int main() {
   for (int b = 0; b < 32; ++b) { printf(" %u", hx[b]); rr = rr && (hx[b] == hx[b % 8]); }
   printf("\n  -> workgroup b and b + 8 share an XCD: %s\n", rr ? "yes" : "NO");
   unsigned long long* w; hipMalloc(&w, 4096 * 8);
-  long long* out; hipMalloc(&out, 64);
   unsigned* xc; hipMalloc(&xc, 16);
   const int iters = 2000;
   for (int peer : {8, 1}) {
@@ -111,6 +150,21 @@ int main() {
         long long h[3]; hipMemcpy(h, out, 24, hipMemcpyDeviceToHost);
         printf("payload hand-off 0 -> %d, %s scope, %4d x 8 B: %.0f ns per round (store, drain, flag, load, ack)%s\n", peer, scope == 0 ? "agent" : "workgroup",
                words, h[0] * 10.0 / 500, h[2] == 0 ? "" : "  PAYLOAD MISMATCH");
+      }
+    }
+  }
+  }
+  {
+    unsigned* d; hipMalloc(&d, 4096);
+    const char* names[4] = {"plain loads", "buffer_inv sc0 + plain loads", "buffer_inv sc1 + plain loads", "sc1 loads"};
+    for (int peer : {8, 1}) {
+      for (int mode = 0; mode < 4; ++mode) {
+        hipMemset(d, 0, 4096); hipMemset(out, 0, 64);
+        hipLaunchKernelGGL(visible, dim3(16), dim3(64), 0, 0, d, d + 64, mode, peer, out);
+        hipDeviceSynchronize();
+        long long h; hipMemcpy(&h, out, 8, hipMemcpyDeviceToHost);
+        printf("plain store by workgroup %d, reader workgroup 0 with the line in its L1, %s: ", peer, names[mode]);
+        if (h >= 0) printf("seen after %.0f ns\n", h * 10.0); else printf("NEVER seen (200000 rounds)\n");
       }
     }
   }
