@@ -82,6 +82,7 @@ def parse():
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-collector", action="store_true", help="skip the informational `collector` object (rollout collector + PPO update rates)")
     ap.add_argument("--sweep", action="store_true", help="also print an N-sweep (stderr) 2^10..2^22")
     ap.add_argument("--task", default="waypoints", choices=sorted(TASKS),
                     help="step kernel to time (default: the headline FixedwingWaypoints workload of BASELINE.json)")
@@ -201,6 +202,40 @@ def cpu_baseline(cfg, n, seconds_target=20.0):
                       f"C restatement built -O3 -march=native (not PyBullet: PyFlyt/pybullet are not installable here)",
             "single_thread_value": single, "nproc": nproc, "affinity": avail, "cgroup_cpu_quota": quota,
             "cpu_model": O._cpu_model(), "repeats": [v for v, _ in reps]}
+
+
+def collector_rates(task, n):
+    """Informational, NOT the metric: the other half of north_star on the same GPU -- the rollout collector (policy / value forward,
+    env step and VecNormalize statistics of a vec-step in one launch: fw_collect_step; fw_collect_close per rollout) and the fused
+    PPO update (fw_ppo_update), with the reference's hyper-parameters for this task (tools/bench_rollout.py is the full tool)."""
+    import torch
+    from pyflyt_drone_amd import rollout as R
+    try:
+        from pyflyt_drone_amd import config as K
+        cfg = TASKS[task][1](K, "float64")
+        hp = dict(n_steps=16, batch_size=128, n_epochs=20) if task in ("waypoints", "waypoints_wind") else \
+             dict(n_steps=8, batch_size=64, n_epochs=10) if task == "objlock" else dict(n_steps=8, batch_size=128, n_epochs=20)
+        import pyflyt_drone_amd as P
+        ppo = R.PPO(R.VecNormalizeDevice(P.FixedwingVecEnv(cfg, n, seed=42)), R.PPOConfig(**hp))
+        for _ in range(3):
+            ppo.collect_rollouts()
+        torch.cuda.synchronize()
+        reps, t0 = 20, time.perf_counter()
+        for _ in range(reps):
+            ppo.collect_rollouts()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        T = hp["n_steps"]
+        ppo.train(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); ppo.train(); torch.cuda.synchronize()
+        upd = time.perf_counter() - t0
+        roll = dt / reps
+        return {"note": "informational: rollout collector + PPO update on the same GPU (north_star's other half); `value` above is the physics-only metric",
+                "envs": n, "one_launch_collect": bool(ppo._one_launch), "us_per_vec_step": dt * 1e6 / (reps * T),
+                "collected_env_steps_per_s": reps * T * n / dt, "update_s": upd, "update_minibatches": hp["n_epochs"] * (T * n // hp["batch_size"]),
+                "end_to_end_env_steps_per_s": T * n / (roll + upd), "ppo": hp}
+    except Exception as e:          # never let the informational part take the metric down
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def self_launch(args):
@@ -448,6 +483,8 @@ def main():
             out["update_allgather"] = allgather
         if not args.no_cpu_baseline and world == 1:          # timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, n)
+        if world == 1 and not args.no_collector and not args.no_cpu_baseline and n <= 8192:
+            out["collector"] = collector_rates(args.task, n)
         print(json.dumps(out), flush=True)
     if dist:
         td.barrier()
