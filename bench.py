@@ -226,6 +226,7 @@ def collector_rates(task, n):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         T = hp["n_steps"]
+        ppo.check_collect_status()                 # raises if a wait inside a fw_collect_step launch ran out (the rate would be void)
         ppo.train(); torch.cuda.synchronize()
         t0 = time.perf_counter(); ppo.train(); torch.cuda.synchronize()
         upd = time.perf_counter() - t0
@@ -318,16 +319,38 @@ def main():
             td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             td.init_process_group(backend)
+    def count_ranks(device):
+        """How many ranks really take part: an all-reduce(SUM) of ones over the job's backend -- on the GPUs when it is RCCL
+        (the driver's scaling run is the only place N > 1 ranks ever meet over xGMI; this is the collective it can check)."""
+        ones = torch.ones(1, dtype=torch.float64, device=device)
+        if dist:
+            td.all_reduce(ones, op=td.ReduceOp.SUM)
+        return int(round(float(ones.item())))
+
+    backend_name = ("RCCL (torch.distributed 'nccl')" if backend == "nccl" else backend) if dist else "none (single process)"
     if dry:
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         if dist:
             td.barrier(); td.all_reduce(t, op=td.ReduceOp.MAX)
+        seen = count_ranks("cpu")
         if rank == 0:
             print(json.dumps({"dry_run": True, "metric": "launcher rehearsal only (FW_BENCH_DRY): nothing was measured", "value": None,
-                              "n_gpus": world, "max_rank_plus_one": float(t.item()), "steps": args.steps, "warmup": args.warmup}), flush=True)
+                              "n_gpus": world, "ranks_seen": seen, "backend": backend_name,
+                              "max_rank_plus_one": float(t.item()), "steps": args.steps, "warmup": args.warmup}), flush=True)
         if dist:
             td.barrier(); td.destroy_process_group()
+        if seen != args.gpus:
+            sys.exit(4)
         return
+    # every rank of the job, counted over the collective backend itself, before anything is measured
+    ranks_seen = count_ranks(torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
+    if ranks_seen != args.gpus:
+        if rank == 0:
+            print(json.dumps({"error": f"all-reduce over {backend_name} counted {ranks_seen} rank(s), --gpus asked for {args.gpus}",
+                              "n_gpus_requested": args.gpus, "ranks_seen": ranks_seen, "backend": backend_name}), flush=True)
+        if dist:
+            td.destroy_process_group()
+        sys.exit(4)
     n = args.envs_per_gpu
     task_name, task_cfg, task_words = TASKS[args.task]
     cfg = task_cfg(K, args.dtype)
@@ -455,6 +478,8 @@ def main():
             "value": world * n * args.steps / wall,
             "unit": "env-steps/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
+            "backend": backend_name,
             "steps": args.steps,
             "warmup": args.warmup,
             "repeats": reps,

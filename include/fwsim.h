@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 6
+#define FW_ABI_VERSION 7
 
 #define FW_NUM_SURFACES 5         /* left aileron, right aileron, h-tail, v-tail, main wing */
 #define FW_NUM_ACTUATORS 6        /* 5 surfaces + throttle (aux_state order) */
@@ -396,7 +396,18 @@ int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t 
  * mean policy loss, value loss and entropy loss.  The caller advances its Adam step count by n_minibatches.
  * workspace: caller-owned device buffer of >= fw_ppo_update_workspace_bytes(n_minibatches) bytes (exchange words,
  * gradient hand-off buffer and per-minibatch advantage statistics of THIS call; two learners never share it).
- * The learner-side entry points run on the device their buffers live on, whatever the thread's current device. */
+ * The learner-side entry points run on the device their buffers live on, whatever the thread's current device.
+ * Failure inside the launch: the two / four workgroups of a call wait for each other once or twice per minibatch, every wait
+ * bounded.  A wait that runs out raises FW_PPO_ST_* in the workspace's status word and every workgroup leaves WITHOUT writing
+ * `params` back (mom_m / mom_v are then part-way through the call: restore them before going on).  fw_ppo_update_status reads
+ * the word after the call (it synchronises `hip_stream`): 0 = the call ran to its end.  `paths` (may be NULL) receives which
+ * exchanges went through an XCD's shared L2 rather than device-scope accesses: bit 2 b = workgroup b's gradient swap, bit
+ * 2 b + 1 = its norm exchange, b = 2 * chunk_half + net.  Environment (read per call): FWSIM_PPO_NO_L2_SWAP=1 forces the
+ * device-scope form of every exchange (same arithmetic: results must be bit-identical -- tests/test_protocols_gpu.py);
+ * FWSIM_SPIN_LOG2=k shrinks every wait's budget to 2^k polls (tests provoke the timeout with it). */
+#define FW_PPO_ST_IDS 1u    /* the workgroups never found each other at the start of the call */
+#define FW_PPO_ST_SWAP 2u   /* gradient swap between the two chunk halves of a network */
+#define FW_PPO_ST_NORM 4u   /* gradient-norm exchange between the policy and the value workgroup */
 typedef struct fw_ppo_hyper {
   float lr, clip_range, ent_coef, vf_coef, max_grad_norm, beta1, beta2, eps;
   float adv_mean, adv_std;      /* used when norm_adv == 2 */
@@ -411,6 +422,7 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
                       const float* old_logp, const float* adv, const float* ret, const int32_t* perm,
                       int32_t n_minibatches, int32_t batch_size, int32_t obs_dim, const fw_ppo_hyper* hyper,
                       float* loss_acc, void* workspace, int64_t workspace_bytes, void* hip_stream);
+int32_t fw_ppo_update_status(const void* workspace, int64_t workspace_bytes, uint32_t* status_out, uint32_t* paths_out, void* hip_stream);
 
 /* Rollout collection between two env steps (SB3 OnPolicyAlgorithm.collect_rollouts + VecNormalize reward path,
  * train/train_Fixedwing_Waypoints_v3.py:260,293-310), for the same MlpPolicy / flat parameter image as fw_ppo_update.
@@ -472,8 +484,20 @@ int32_t fw_collect_stats(const void* obs, int32_t obs_is_f64, int32_t N, int32_t
  * statistics buffers by the NEXT fw_collect_step (which needs them first) -- or by fw_collect_finish: call it after the last
  * step of a rollout, before anything else reads (obs_mean, obs_var, obs_count) / the return statistics.  Serves handles on the 8-lanes-per-env mapping at one wave per SIMD (FW_EUNSUPPORTED otherwise: use
  * the three calls).  workspace: caller-owned, fw_collect_step_workspace_bytes(h) bytes, one per handle, prepared ONCE with
- * fw_collect_workspace_init (stream-ordered; not inside a graph that is replayed); the uint32 at (workspace_bytes - 64 + 12) is
- * a status word that stays 0 (1 | 2 | 4: a wave gave up waiting inside the launch -- never expected; 8: workspace not initialised). */
+ * fw_collect_workspace_init (stream-ordered; not inside a graph that is replayed).
+ * Failure inside a launch: the waves of the grid wait for waves in front of them (step waves for their actions, fold waves for
+ * the partial sums, the merge wave for the act waves), every wait bounded.  A wait that runs out does not stop the launch --
+ * the wave goes on with what it has (zero actions, partial sums, an early commit) -- but raises FW_COLLECT_ST_* in the
+ * workspace's status word, the uint32 at (fw_collect_step_workspace_bytes(h) - 64 + 12); the word is sticky until
+ * fw_collect_workspace_init.  Non-zero means: everything collected since the last zero reading is void.  Read it at least once
+ * per rollout -- fw_collect_status (synchronises `hip_stream`) or a copy of that word; rollout.PPO raises RuntimeError.
+ * FWSIM_SPIN_LOG2=k (environment, read per call) shrinks the budgets to 2^k polls: tests provoke the timeouts with it. */
+#define FW_COLLECT_ST_ACTIONS 1u  /* a step wave gave up waiting for its actions (it stepped with zeros) */
+#define FW_COLLECT_ST_FOLD 2u     /* a fold wave summed without every partial, or never saw the merge wave finish */
+#define FW_COLLECT_ST_MERGE 4u    /* the merge wave committed the statistics before every act wave had read the old ones */
+#define FW_COLLECT_ST_NOINIT 8u   /* the workspace was never passed to fw_collect_workspace_init */
+#define FW_COLLECT_ST_EPOCH 16u   /* the merge wave never saw the launch's index published */
+#define FW_COLLECT_ST_NANACT 32u  /* the policy produced a NaN action (diverged weights or statistics): the env stepped with -1 in its place */
 typedef struct fw_collect_args {
   const float* params;                     /* flat parameter image (fw_ppo_update layout) */
   double *obs_mean, *obs_var, *obs_count;  /* VecNormalize observation statistics (in/out) */
@@ -499,6 +523,7 @@ int64_t fw_collect_step_workspace_bytes(fw_handle h);
 int32_t fw_collect_workspace_init(fw_handle h, void* workspace, int64_t workspace_bytes, void* hip_stream);
 int32_t fw_collect_step(fw_handle h, const fw_collect_args* a, void* hip_stream);
 int32_t fw_collect_finish(fw_handle h, const fw_collect_args* a, void* hip_stream);   /* statistics buffers, flags and workspace of `a` only */
+int32_t fw_collect_status(fw_handle h, const void* workspace, int64_t workspace_bytes, uint32_t* status_out, void* hip_stream);
 /* The end of a rollout of T fw_collect_step launches in ONE more launch instead of fw_collect_finish + a value forward + a
  * normalisation + fw_gae: merges the last step's statistics; V(final observation) -> a->value [N] (SB3's last values); the
  * normalised final observation -> a->obs_copy (may be NULL); finalises step T - 1 (a->rew_out = row T - 1 of `rewards`,

@@ -18,7 +18,7 @@ import ctypes as C
 import math
 from typing import Any, Mapping, Optional
 
-FW_ABI_VERSION = 6
+FW_ABI_VERSION = 7
 FW_NUM_SURFACES = 5
 FW_NUM_ACTUATORS = 6
 FW_MAX_TARGETS = 8

@@ -1884,7 +1884,15 @@ int32_t fw_ppo_moment_map(int32_t obs_dim, int32_t* flat_index_of_slot) {
   return FW_OK;
 }
 
-// workspace layout of fw_ppo_update: [0,192) exchange words | gradient hand-off buffer | per-minibatch advantage statistics
+// Dev knob: FWSIM_SPIN_LOG2=k bounds every in-grid wait (fw_collect_step, fw_ppo_update) to 2^k polls instead of its default --
+// tests use it to provoke the timeout paths and assert that the status words surface on the host side.
+static long long spin_budget(long long dflt) {
+  if (const char* e = getenv("FWSIM_SPIN_LOG2")) { const int k = atoi(e); if (k >= 0 && k < 40) return std::min(dflt, 1ll << k); }
+  return dflt;
+}
+
+// workspace layout of fw_ppo_update: [0,192) exchange words (word 22: which exchanges shared an L2, word 23: status, include/fwsim.h) |
+// gradient hand-off buffer | per-minibatch advantage statistics
 static constexpr size_t kPpoWsXch = 24 * sizeof(unsigned long long);
 static constexpr size_t kPpoWsGx = sizeof(float) * 8 * (size_t)kPMomentSlots;
 int64_t fw_ppo_update_workspace_bytes(int32_t n_minibatches) {
@@ -1922,11 +1930,27 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   A.params = params; A.mom_m = mom_m; A.mom_v = mom_v; A.obs = obs; A.act = act; A.old_logp = old_logp; A.adv = adv; A.ret = ret;
   A.perm = perm; A.n_mb = n_minibatches; A.B = batch_size; A.D = obs_dim; A.loss_acc = loss_acc; A.xch = xch; A.gx = gx;
   A.adv_stats = stats;
+  A.spin = spin_budget(kPpoSpin);
+  A.flags = 0;
+  if (const char* e = getenv("FWSIM_PPO_NO_L2_SWAP")) if (atoi(e) != 0) A.flags |= PPO_FLAG_NO_L2_SWAP;
   std::memcpy(&A.H, hyper, sizeof A.H);
   if (batch_size <= 1 && A.H.norm_adv == 1) A.H.norm_adv = 0;      // SB3 skips the normalisation of single-sample minibatches
   const int nhalf = batch_size >= 2 * kPChunk ? 2 : 1;            // two chunk-half blocks per network from 128 samples on
   hipLaunchKernelGGL(fw_ppo_update_kernel, dim3(nhalf == 2 ? 32 : 16), dim3(kPThreads), lds, st, A);      // (every 8th block works -- see the kernel)
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
+  return FW_OK;
+}
+
+int32_t fw_ppo_update_status(const void* workspace, int64_t workspace_bytes, uint32_t* status_out, uint32_t* paths_out, void* hip_stream) {
+  if (!workspace || workspace_bytes < (int64_t)kPpoWsXch || !status_out) { g_err = "fw_ppo_update_status: bad arguments"; return FW_EINVAL; }
+  DeviceGuard g(device_of(workspace));
+  unsigned long long w[2] = {0ull, 0ull};
+  HIP_TRY((fw_env*)nullptr, hipMemcpyAsync(w, (const unsigned long long*)workspace + kPpoWordPaths, sizeof w, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+  HIP_TRY((fw_env*)nullptr, hipStreamSynchronize((hipStream_t)hip_stream));
+  static_assert(kPpoWordStatus == kPpoWordPaths + 1 && kPpoWordStatus < 24, "exchange-word layout");
+  static_assert(FW_PPO_ST_IDS == PPO_ST_IDS && FW_PPO_ST_SWAP == PPO_ST_SWAP && FW_PPO_ST_NORM == PPO_ST_NORM, "status bits of include/fwsim.h");
+  if (paths_out) *paths_out = (uint32_t)w[0];
+  *status_out = (uint32_t)w[1];
   return FW_OK;
 }
 
@@ -1984,7 +2008,8 @@ int64_t fw_collect_step_workspace_bytes(fw_handle h) { return h ? (int64_t)colle
 // checks and argument block shared by fw_collect_step and fw_collect_close
 static int32_t collect_fill(fw_handle h, const fw_collect_args* a, const char* who, bool close, CollectArgs& CA) {
   if (h->lanes_per_env != 8 || h->g8_waves != 1) {
-    h->err = std::string(who) + " serves the 8-lanes-per-env mapping at one wave per SIMD (<= 8192 envs per GPU; <= 4096 with wind); use fw_collect_act / fw_step / fw_collect_stats";
+    h->err = std::string(who) + " serves the 8-lanes-per-env mapping at one wave per SIMD (what fw_create picks for waypoints up to 8192 envs per GPU, 6144 with "
+             "wind, and for the camera tasks up to 16384 envs or at any size with obstacles); use fw_collect_act / fw_step / fw_collect_stats";
     return FW_EUNSUPPORTED;
   }
   const int D = obs_dim_of(&h->cfg), N = h->n;
@@ -2019,6 +2044,7 @@ static int32_t collect_fill(fw_handle h, const fw_collect_args* a, const char* w
   CA.flag_p = (unsigned int*)(ws + W.flag_p); CA.flag_v = (unsigned int*)(ws + W.flag_v);
   CA.sync = (unsigned int*)(ws + W.sync);
   CA.trace = close ? nullptr : (long long*)a->trace;
+  CA.spin = (int32_t)spin_budget(kCollectSpin);
   return FW_OK;
 }
 
@@ -2089,6 +2115,20 @@ int32_t fw_collect_finish(fw_handle h, const fw_collect_args* a, void* hip_strea
   CA.part1 = (double*)(ws + W.part1); CA.tot = (double*)(ws + W.tot); CA.sync = (unsigned int*)(ws + W.sync);
   hipLaunchKernelGGL(fw_collect_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, CA);
   HIP_TRY(h, hipGetLastError());
+  return FW_OK;
+}
+
+int32_t fw_collect_status(fw_handle h, const void* workspace, int64_t workspace_bytes, uint32_t* status_out, void* hip_stream) {
+  if (!h || !status_out) return FW_EINVAL;
+  const CollectWs W = collect_ws(h);
+  if (!workspace || workspace_bytes < (int64_t)W.total) { h->err = "fw_collect_status: workspace smaller than fw_collect_step_workspace_bytes()"; return FW_EINVAL; }
+  static_assert(FW_COLLECT_ST_ACTIONS == CS_ST_ACTIONS && FW_COLLECT_ST_FOLD == CS_ST_FOLD && FW_COLLECT_ST_MERGE == CS_ST_MERGE &&
+                FW_COLLECT_ST_NOINIT == CS_ST_NOINIT && FW_COLLECT_ST_EPOCH == CS_ST_EPOCH && FW_COLLECT_ST_NANACT == CS_ST_NANACT, "status bits of include/fwsim.h");
+  DeviceGuard g(h->device);
+  uint32_t w = 0;
+  HIP_TRY(h, hipMemcpyAsync(&w, (const char*)workspace + W.sync + sizeof(uint32_t) * CS_STATUS, sizeof w, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+  HIP_TRY(h, hipStreamSynchronize((hipStream_t)hip_stream));
+  *status_out = w;
   return FW_OK;
 }
 

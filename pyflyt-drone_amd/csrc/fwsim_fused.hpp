@@ -87,7 +87,13 @@ struct CollectArgs {
   double* tot;                        // [2 D + 2] totals of the pending step (written by the fold waves of the launch that produced it)
   unsigned int* sync;                 // [16] CS_*: launch index of the partials in part1 / of the last merge, readers counter (closing launch), status bits, init mark, launch index of the last merge wave
   long long* trace;                   // null, or [grid][8] wall-clock stamps (10 ns ticks) per workgroup: tools/trace_collect.py
+  int32_t spin;                       // polls a bounded wait may take before it gives up (kCollectSpin; FWSIM_SPIN_LOG2 shrinks it so that tests can provoke a timeout)
 };
+constexpr int kCollectSpin = 1 << 21; // ~ seconds: far beyond any healthy launch
+// CS_STATUS bits (0 = every wait of every launch since fw_collect_workspace_init was answered).  A non-zero word means
+// a launch went on with what it had -- zero actions, partial sums, an early commit -- and everything collected since is
+// void: the caller must drop the rollout and re-initialise the workspace (rollout.PPO raises).
+enum { CS_ST_ACTIONS = 1, CS_ST_FOLD = 2, CS_ST_MERGE = 4, CS_ST_NOINIT = 8, CS_ST_EPOCH = 16, CS_ST_NANACT = 32 };
 
 // fw_collect_close: the GAE scan the value waves run for their own rows once the last values are known
 struct CloseArgs {
@@ -264,38 +270,46 @@ __device__ __forceinline__ void collect_fold_wave(const CollectArgs& CA, int w) 
   double* row = CA.part1 + (size_t)w * slots;
   // slot i belongs to step workgroup (i / mstride) + 8 (i % mstride); groups with fewer members leave their last slot unused
   auto used = [&](int i) { const int g = i / mstride, m = i - g * mstride; return g + kCGroups * m < CA.nblk; };
-  // a slot that has arrived stays in its register: the pass that sees the last partial reads only what was still missing
-  constexpr int kS = 16;                             // slots per lane: 1024 step workgroups = 8192 envs, the mapping's limit
-  double x[kS];
-  unsigned int missing = 0;
-#pragma unroll
-  for (int k = 0; k < kS; ++k) { x[k] = 0.0; const int i = lane + 64 * k; if (i < slots && used(i)) missing |= 1u << k; }
-  bool ok = false;
-  for (int it = 0; it < (1 << 20); ++it) {
-#pragma unroll
-    for (int k = 0; k < kS; ++k) if ((missing >> k) & 1u) x[k] = ld_sc1(row + lane + 64 * k);
-#pragma unroll
-    for (int k = 0; k < kS; ++k) if (((missing >> k) & 1u) && !collect_is_sentinel(x[k])) missing &= ~(1u << k);
-    if (__ballot(missing != 0u) == 0ull) { ok = true; break; }
-    __builtin_amdgcn_s_sleep(8);                     // (~0.2 us: 58 waves polling 512 slots each are traffic the step waves share the fabric with)
-  }
+  // a slot that has arrived stays in its register: the pass that sees the last partial reads only what was still missing.
+  // kS slots per lane and pass = 1024 step workgroups (8192 envs) -- the whole row where the one-wave-per-SIMD mapping is the
+  // fast one; rows beyond that (camera tasks up to 16 384 envs, any N with cylinders) take further passes of the same kind, and
+  // lane l still adds its slots l, l + 64, ... in ascending order.
+  constexpr int kS = 16;
   double v = 0.0;
+  bool ok = true;
+  int budget = CA.spin;
+  for (int base = 0; base < slots; base += 64 * kS) {
+    double x[kS];
+    unsigned int missing = 0;
 #pragma unroll
-  for (int k = 0; k < kS; ++k) v += ((missing >> k) & 1u) ? 0.0 : x[k];     // ascending slot order
+    for (int k = 0; k < kS; ++k) { x[k] = 0.0; const int i = base + lane + 64 * k; if (i < slots && used(i)) missing |= 1u << k; }
+    bool here = false;
+    for (; budget > 0; --budget) {
+#pragma unroll
+      for (int k = 0; k < kS; ++k) if ((missing >> k) & 1u) x[k] = ld_sc1(row + base + lane + 64 * k);
+#pragma unroll
+      for (int k = 0; k < kS; ++k) if (((missing >> k) & 1u) && !collect_is_sentinel(x[k])) missing &= ~(1u << k);
+      if (__ballot(missing != 0u) == 0ull) { here = true; break; }
+      __builtin_amdgcn_s_sleep(8);                   // (~0.2 us: 58 waves polling 512 slots each are traffic the step waves share the fabric with)
+    }
+    ok = ok && here;
+#pragma unroll
+    for (int k = 0; k < kS; ++k) v += ((missing >> k) & 1u) ? 0.0 : x[k];   // ascending slot order
+  }
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   // every act wave has read the totals of the step before (its step waves have finished), the merge wave maybe not yet: it
   // leaves the launch's index in CS_MERGED when it has (the index itself: any chunk's word, all published by now)
   if (ok) {
     ok = false;
     const unsigned int e = ld_flag(CA.flag_p);
-    for (int it = 0; it < (1 << 20); ++it) {
+    for (int it = 0; it < CA.spin; ++it) {
       if (ld_flag(CA.sync + CS_MERGED) == e) { ok = true; break; }
       __builtin_amdgcn_s_sleep(8);
     }
   }
   if (lane == 0) CA.tot[w] = v;
   for (int i = lane; i < slots; i += 64) row[i] = collect_sentinel();
-  if (!ok && lane == 0) atomicOr(CA.sync + CS_STATUS, 2u);
+  if (!ok && lane == 0) atomicOr(CA.sync + CS_STATUS, (unsigned int)CS_ST_FOLD);
 }
 
 // writes the statistics of `Q` (already merged) to the caller's buffers and closes the pending fold
@@ -322,12 +336,29 @@ __device__ __forceinline__ void collect_commit_stats(const CollectArgs& CA, cons
 // every act wave publishes a word after it did (flag_p / flag_v = the launch's index) -- the merge wave watches those, no
 // counter (520 atomics on one word, fired while the step waves poll their flags next to it, cost the hand-off 1.5-4 us);
 // fw_collect_close has no such words and few waves: there they count themselves.
-__device__ __forceinline__ void collect_merge_wave(const CollectArgs& CA, int n_real, bool advance_rng, uint32_t epoch, bool by_flags) {
+__device__ __forceinline__ void collect_merge_wave(const CollectArgs& CA, int n_real, bool advance_rng, bool by_flags) {
   const int lane = threadIdx.x & 63;
   CollectStats Q;
   collect_front_stats(CA, false, Q);
   bool ok = false;
-  for (int it = 0; it < (1 << 21); ++it) {
+  unsigned int epoch = 0;
+  int budget = CA.spin;
+  if (by_flags) {
+    // The launch's index.  Every other wave takes it from the launch counter of a step workgroup that cannot finish before that
+    // wave has published; no step workgroup waits for THIS wave, so a counter could have advanced by the time a late first
+    // load of this wave returns.  It therefore takes the index from the first policy wave's publishing word: between step
+    // launches that word equals what this wave left in CS_MERGED (both zero after fw_collect_workspace_init), launch indices
+    // only grow, so the first value that differs is this launch's.
+    const unsigned int last = ld_flag(CA.sync + CS_MERGED);
+    epoch = last;
+    for (; budget > 0; --budget) {
+      epoch = ld_flag(CA.flag_p);
+      if (epoch != last) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (epoch == last && lane == 0) atomicOr(CA.sync + CS_STATUS, (unsigned int)CS_ST_EPOCH);
+  }
+  for (; budget > 0; --budget) {
     if (by_flags) {
       bool all = true;
       for (int i = lane; i < 2 * CA.n_chunks; i += 64) all = all && ld_flag(i < CA.n_chunks ? CA.flag_p + i : CA.flag_v + (i - CA.n_chunks)) == epoch;
@@ -338,8 +369,8 @@ __device__ __forceinline__ void collect_merge_wave(const CollectArgs& CA, int n_
       __builtin_amdgcn_s_sleep(8);
     }
   }
-  if (!ok && lane == 0) atomicOr(CA.sync + CS_STATUS, 4u);
-  if (lane == 0 && CA.sync[CS_INIT] != kCollectInitMagic) atomicOr(CA.sync + CS_STATUS, 8u);   // workspace never initialised
+  if (!ok && lane == 0) atomicOr(CA.sync + CS_STATUS, (unsigned int)CS_ST_MERGE);
+  if (lane == 0 && CA.sync[CS_INIT] != kCollectInitMagic) atomicOr(CA.sync + CS_STATUS, (unsigned int)CS_ST_NOINIT);   // workspace never initialised
   collect_commit_stats(CA, Q);
   if (lane == 0) {
     if (advance_rng && CA.S.rng) CA.S.rng[1] += 1;
@@ -360,7 +391,7 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   float* lds = reinterpret_cast<float*>(smem_raw);
   const ActArgs& A = CA.A;
   const int aw = (int)blockIdx.x, chunk = CLOSE ? aw : aw >> 1, net = CLOSE ? 1 : aw & 1;
-  if (aw == (CLOSE ? 1 : 2) * CA.n_chunks) { collect_merge_wave(CA, (CLOSE ? 1 : 2) * CA.n_chunks, !CLOSE, epoch, !CLOSE); return; }
+  if (aw == (CLOSE ? 1 : 2) * CA.n_chunks) { collect_merge_wave(CA, (CLOSE ? 1 : 2) * CA.n_chunks, !CLOSE, !CLOSE); return; }
   if (chunk >= CA.n_chunks) return;                                  // padding waves
   const int KO = net == 0 ? 4 : 1;
   const int lane = threadIdx.x;
@@ -428,6 +459,9 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
   collect_front_merge(CA, false, Q);
   // the policy wave's word says "I have read the old statistics" (the merge wave watches it; the fold waves take the launch's
   // index from it) -- the actions themselves need no flag: a step wave sees them replace the NaN it left in their place
+  // (the sampler's key and draw counter are among the "old" words: the merge wave advances the counter once every word is up,
+  // so they must be in registers before this one is raised)
+  asm volatile("" :: "v"(rng_key), "v"(rng_ctr) : "memory");
   if (!CLOSE && net == 0 && lane == 0) st_flag(CA.flag_p + chunk, epoch);
   // ("I have read the old statistics": in a step launch my publishing word says so, the merge wave watches those; in the closing
   // launch a counter at the END of the wave -- in front, every later wait on the memory counter also waited for that atomic's
@@ -494,6 +528,9 @@ __device__ __forceinline__ void collect_act_wave(const CollectArgs& CA, uint32_t
         }
         reinterpret_cast<float4*>(A.act_raw)[row] = make_float4(a[0], a[1], a[2], a[3]);
         A.logp[row] = lp;
+        // fminf(fmaxf(NaN, -1), 1) = -1: the clip below would turn a diverged policy (NaN mean or log_std) into full deflection
+        // and the step waves' "a clipped action is never NaN" would still hold -- so the NaN is reported here instead
+        if (a[0] != a[0] || a[1] != a[1] || a[2] != a[2] || a[3] != a[3]) atomicOr(CA.sync + CS_STATUS, (unsigned int)CS_ST_NANACT);
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] = fminf(fmaxf(a[k], -1.0f), 1.0f);
         // the env's action row: write-through, the step waves of other XCDs read it in this same launch
@@ -569,11 +606,11 @@ __device__ __forceinline__ void collect_wait_actions(const CollectArgs& CA, uint
   const int lane = threadIdx.x & 63;
   const unsigned int* w = CA.flag_v + min(c0 + lane, c1);
   bool ok = false;
-  for (int it = 0; it < (1 << 21); ++it) {                             // ~ seconds: far beyond any healthy launch
+  for (int it = 0; it < CA.spin; ++it) {
     if (__ballot(ld_flag(w) != epoch) == 0ull) { ok = true; break; }
     __builtin_amdgcn_s_sleep(4);
   }
-  if (!ok && lane == 0) atomicOr(CA.sync + CS_STATUS, 1u);
+  if (!ok && lane == 0) atomicOr(CA.sync + CS_STATUS, (unsigned int)CS_ST_ACTIONS);
 }
 // ... and until this lane's env has its actions: the policy wave writes them through over the NaN the env's step wave of the
 // previous launch left there (a clipped action is never NaN), so the four words announce themselves -- no store wait and no
@@ -583,15 +620,15 @@ __device__ __forceinline__ void collect_load_actions(const CollectArgs& CA, cons
   long long* tr = CA.trace ? CA.trace + (size_t)blockIdx.x * 8 : nullptr;
   const int lane = threadIdx.x & 63;
   bool ok = false;
-  for (int it = 0; it < (1 << 21); ++it) {
+  for (int it = 0; it < CA.spin; ++it) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) a4[k] = ld_coherent(ap + k);
     const bool mine = a4[0] == a4[0] && a4[1] == a4[1] && a4[2] == a4[2] && a4[3] == a4[3];
     if (__ballot(!mine) == 0ull) { ok = true; break; }
     __builtin_amdgcn_s_sleep(2);
   }
-  if (!ok) {                                                           // (never expected: go on with zeros rather than NaN)
-    if (lane == 0) atomicOr(CA.sync + CS_STATUS, 1u);
+  if (!ok) {                                                           // (never expected: go on with zeros rather than NaN; the status word voids the rollout)
+    if (lane == 0) atomicOr(CA.sync + CS_STATUS, (unsigned int)CS_ST_ACTIONS);
 #pragma unroll
     for (int k = 0; k < 4; ++k) a4[k] = a4[k] == a4[k] ? a4[k] : (T)0;
   }

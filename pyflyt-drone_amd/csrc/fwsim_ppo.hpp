@@ -187,10 +187,35 @@ struct PpoArgs {
   int32_t n_mb, B, D;
   PpoHyper H;
   float* loss_acc;                   // [3] += policy, value, entropy loss
-  unsigned long long* xch;           // [24] exchange words (norm partials [parity][net][half], gradient flags + 8, XCD ids of the chunk-half blocks + 16), zeroed by the host
+  unsigned long long* xch;           // [24] exchange words (norm partials [parity][net][half], gradient flags + 8, XCD ids of the chunk-half blocks + 16,
+                                     //      kPpoWordPaths, kPpoWordStatus), zeroed by the host
   float* gx;                         // [2 parities][2 nets][2 halves][kPMomentSlots] gradient partials of the chunk halves
   const float* adv_stats;            // [n_mb][2] mean, std of each minibatch's advantages (fw_ppo_adv_stats_kernel)
+  long long spin;                    // polls a wait for another block may take (kPpoSpin; FWSIM_SPIN_LOG2 shrinks it: tests provoke the timeout)
+  int32_t flags;                     // PPO_FLAG_*
 };
+constexpr long long kPpoSpin = 1ll << 26;
+enum { PPO_FLAG_NO_L2_SWAP = 1 };    // FWSIM_PPO_NO_L2_SWAP=1: every exchange through device-scope accesses, as if no two blocks shared an XCD
+// xch[kPpoWordPaths]: which exchanges of this call went through a shared L2 -- bit 2 b: block b's gradient swap, bit 2 b + 1: its
+// norm exchange (b = 2 half + net).  xch[kPpoWordStatus]: 0, or PPO_ST_* of the waits that ran out: the blocks then leave
+// without writing the parameters back (the moments in memory are part-way through the call: the caller must not go on with them).
+constexpr int kPpoWordPaths = 22, kPpoWordStatus = 23;
+enum { PPO_ST_IDS = 1, PPO_ST_SWAP = 2, PPO_ST_NORM = 4 };
+
+// Bounded wait of one thread for a word another block publishes.  `done(word)` ends it; every 256 polls it also looks at the
+// status word, so that one block giving up releases the others at once instead of after their own budgets.  Returns false --
+// and raises `bit` in the status word -- when the budget ran out or somebody else had given up.
+template <typename LOAD, typename DONE>
+__device__ __forceinline__ bool ppo_wait(const PpoArgs& A, LOAD&& load, DONE&& done, unsigned long long bit, unsigned long long& w) {
+  unsigned long long* status = A.xch + kPpoWordStatus;
+  for (long long spins = 0; spins < A.spin; ++spins) {
+    w = load();
+    if (done(w)) return true;
+    if ((spins & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+  }
+  (void)__hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
 
 template <int NET>
 __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const int half, const int nhalf) {
@@ -241,24 +266,27 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   // promises that mapping: each block reads the XCD it really runs on and the pair compares notes once per call; a pair that
   // was split keeps the device-scope fences.
   bool same_xcd = false, same_xcd_net = false;      // ... as my chunk-half partner; as the other network's block of my half
+  bool dead = false;                                // a wait for another block ran out (block-uniform): leave, touching nothing more
   {
     if (t == 0) {
+      red[7] = 0.f;
       const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));      // HW_REG_XCC_ID[3:0]
       __hip_atomic_store(A.xch + 16 + NET * 2 + half, (unsigned long long)(my_xcc + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       auto wait_id = [&](unsigned long long* p_) {
         unsigned long long w = 0;
-        long long spins = 0;
-        do {
-          w = __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (++spins > (1ll << 26)) __builtin_trap();      // the other block is gone: fail loudly instead of hanging
-        } while (w == 0ull);
+        if (!ppo_wait(A, [&]() { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+                      [](unsigned long long x) { return x != 0ull; }, (unsigned long long)PPO_ST_IDS, w)) { red[7] = 1.f; return 0u; }
         return (unsigned)w;
       };
-      red[5] = (nhalf == 2 && wait_id(A.xch + 16 + NET * 2 + (1 - half)) == my_xcc + 1u) ? 1.f : 0.f;
-      red[6] = wait_id(A.xch + 16 + (1 - NET) * 2 + half) == my_xcc + 1u ? 1.f : 0.f;
+      const bool l2ok = !(A.flags & PPO_FLAG_NO_L2_SWAP);
+      const bool sx = l2ok && nhalf == 2 && wait_id(A.xch + 16 + NET * 2 + (1 - half)) == my_xcc + 1u;
+      const bool sn = wait_id(A.xch + 16 + (1 - NET) * 2 + half) == my_xcc + 1u && l2ok;
+      red[5] = sx ? 1.f : 0.f; red[6] = sn ? 1.f : 0.f;
+      if (sx || sn) (void)__hip_atomic_fetch_or(A.xch + kPpoWordPaths, (unsigned long long)((sx ? 1u : 0u) | (sn ? 2u : 0u)) << (2 * (2 * half + NET)),
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    same_xcd = red[5] != 0.f; same_xcd_net = red[6] != 0.f;
+    same_xcd = red[5] != 0.f; same_xcd_net = red[6] != 0.f; dead = red[7] != 0.f;
   }
   const int mt = wave >> 1, nt = wave & 1;
   const int tilesW1 = ((Dp + 31) / 32) * 2;       // 2 or 4 tiles of dW1
@@ -329,7 +357,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   pci += nhalf; if (pci >= cpm) { pmb += 1; pci = half; }
 
 #pragma unroll 1
-  for (int mb = 0; mb < n_mb; ++mb) {
+  for (int mb = 0; mb < n_mb && !dead; ++mb) {
 #ifdef FW_PPO_PROF
     const long long pf0 = PPO_T();
 #endif
@@ -586,11 +614,12 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       if (t == 0) {
         // (relaxed: the ordering is the waves' release / acquire -- or, on a shared L2, their store wait / L1 drop -- around the barriers)
         ppo_word_store(fmine, (unsigned long long)(unsigned)(mb + 1), same_xcd);
-        long long spins = 0;
-        while ((unsigned)ppo_word_load(ftheirs, same_xcd) != (unsigned)(mb + 1))
-          if (++spins > (1ll << 26)) __builtin_trap();                // the partner block is gone: fail loudly instead of hanging
+        unsigned long long w;
+        if (!ppo_wait(A, [&]() { return ppo_word_load(ftheirs, same_xcd); }, [&](unsigned long long x) { return (unsigned)x == (unsigned)(mb + 1); },
+                      (unsigned long long)PPO_ST_SWAP, w)) red[7] = 1.f;       // the partner block is gone: say so and leave instead of hanging
       }
       __syncthreads();
+      if (red[7] != 0.f) { dead = true; break; }
       // The partner's rows: on a shared L2 they are read with device-scope loads -- past this CU's L1, which may still hold the
       // lines from two minibatches ago (`buffer_inv sc0` does not drop them outside tg-split mode: a loop of it and plain loads
       // never saw a word change), served by the L2 the partner's stores sit in.  Otherwise: a device-scope acquire, plain loads.
@@ -654,14 +683,12 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       if (t == 0) {
         ppo_word_store(mine, ((unsigned long long)(unsigned)(mb + 1) << 32) | (unsigned long long)__float_as_uint(ss_mine), same_xcd_net);
         unsigned long long w = 0;
-        long long spins = 0;
-        do {
-          w = ppo_word_load(other, same_xcd_net);
-          if (++spins > (1ll << 26)) __builtin_trap();      // the partner block is gone: fail loudly instead of hanging
-        } while ((unsigned)(w >> 32) != (unsigned)(mb + 1));
+        if (!ppo_wait(A, [&]() { return ppo_word_load(other, same_xcd_net); }, [&](unsigned long long x) { return (unsigned)(x >> 32) == (unsigned)(mb + 1); },
+                      (unsigned long long)PPO_ST_NORM, w)) red[7] = 1.f;     // the other network's block is gone
         red[4] = __uint_as_float((unsigned)w);
       }
       __syncthreads();
+      if (red[7] != 0.f) { dead = true; break; }
       ss_other = red[4];
     }
 #ifdef FW_PPO_PROF
@@ -726,7 +753,8 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #endif
   }
 
-  // ---- write the weights back, report the losses ----
+  // ---- write the weights back, report the losses (a block that gave up leaves the parameters as it found them) ----
+  if (dead) return;
   if (half == 0) {
     for (int i = t; i < Dp * kPH; i += kPThreads) params[oW1 + i] = W.W1[i];
     for (int i = t; i < kPH; i += kPThreads) { params[ob1 + i] = W.b1[i]; params[ob2 + i] = W.b2[i]; }

@@ -511,8 +511,8 @@ class PPOConfig:
     fused_update: bool = True              # run the whole minibatch sequence of train() in one HIP kernel (fw_ppo_update) when it applies
     fused_collect: bool = True             # policy forward / sampling / buffer writes and the reward path as fw_policy_act + fw_rollout_post
     one_launch_collect: bool = True        # the whole vec-step as ONE launch (fw_collect_step) where the env's lane mapping has it (8 lanes per env,
-                                           # one wave per SIMD), fw_collect_act -> fw_step -> fw_collect_stats elsewhere or when False: 41.0 vs 47.9 us
-                                           # per vec-step (waypoints, 4096 envs; DESIGN.md section 4b, tools/trace_collect.py)
+                                           # one wave per SIMD), fw_collect_act -> fw_step -> fw_collect_stats elsewhere or when False: 34.3 vs 47.9 us
+                                           # per vec-step (waypoints, 4096 envs; profiles/r03_rollout_bench*.jsonl)
     detector: str = "none"                 # "cnn": CnnDetectorPolicy over the FPV render (fw_render) of a camera task -- torch path, gradient all-reduce
     image_res: int = 32                    #        side of the rendered image
     cnn_features: int = 32                 #        width of the extractor's output
@@ -548,6 +548,7 @@ class FusedPpoUpdate:
         self.mom_v = torch.zeros_like(self.mom_m)
         self.loss = torch.zeros(16, dtype=torch.float32, device=dev)
         self._ws = None                    # caller-owned scratch of fw_ppo_update (grown here, never inside the call)
+        self.last_paths = 0                # fw_ppo_update_status: which exchanges of the last call went through a shared L2
 
     def _workspace(self, n_mb: int) -> torch.Tensor:
         need = int(_lib.lib().fw_ppo_update_workspace_bytes(n_mb))
@@ -647,6 +648,16 @@ class FusedPpoUpdate:
                                       _p(perm_i32), n_mb, cfg.batch_size, self.D, C.byref(H), _p(self.loss), _p(ws), ws.numel(),
                                       _stream(obs.device))
         _lib.check(rc)
+        # the workgroups of the launch wait for each other, every wait bounded: a wait that ran out left the parameter image
+        # untouched and a status word behind -- surface it BEFORE anything is written back to the module / optimiser (they still
+        # hold the state of before the call)
+        st, paths = C.c_uint32(0), C.c_uint32(0)
+        _lib.check(_lib.lib().fw_ppo_update_status(_p(ws), ws.numel(), C.byref(st), C.byref(paths), _stream(obs.device)))
+        self.last_paths = int(paths.value)
+        if st.value:
+            names = [n for b, n in ((1, "block ids"), (2, "gradient swap"), (4, "norm exchange")) if st.value & b]
+            raise RuntimeError(f"fw_ppo_update gave up inside the launch (status {st.value}: {', '.join(names)} wait ran out); "
+                               "the policy and optimiser were left as they were before the call")
         self.store_to_torch(step0 + n_mb)
         return (self.loss[:3] / n_mb).tolist()
 
@@ -701,6 +712,8 @@ class PPO:
                             and getattr(env.venv, "lanes_per_env", 0) == 8 and getattr(env.venv, "g8_waves", 1) == 1
                             and float(env.gamma) == float(cfg.gamma))
         self._ws_collect = None
+        self._status_host = self._status_event = None      # CS_STATUS of the workspace, copied out after every rollout
+        self._status_pending = False
         # ... and then the rollout ends in one launch too (fw_collect_close), unless the caller brought its own GAE
         self._close_gae = bool(self._one_launch and gae_fn is gae_device)
         self._adv_buf = self._ret_buf = None
@@ -870,9 +883,58 @@ class PPO:
         _lib.check(L.fw_normalize_obs(_p(venv.obs), f64, N, D, _p(env.obs_rms.mean), _p(env.obs_rms.var), _p(env.obs_rms.count), 0,
                                       float(env.clip_obs), float(env.epsilon), _p(self.last_obs), None, None, st))
 
+    # ---- fw_collect_step's status word: "step returns or raises" ------------------------------
+    _COLLECT_STATUS_BITS = ((1, "a step wave gave up waiting for its actions"), (2, "a fold wave summed without every partial sum"),
+                            (4, "the merge wave committed before every act wave had read the old statistics"),
+                            (8, "the workspace was never initialised"), (16, "the merge wave never saw the launch index"),
+                            (32, "the policy produced a NaN action (diverged weights or statistics)"))
+
+    def _queue_collect_status(self) -> None:
+        """After a rollout through fw_collect_step: copy the workspace's status word to pinned host memory behind the rollout
+        (no synchronisation here -- train() and the next collect_rollouts() look at it)."""
+        if not self._one_launch or self._ws_collect is None:
+            return
+        if self._status_host is None:
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._status_event, self._rollout_done = torch.cuda.Event(), torch.cuda.Event()
+            self._status_stream = torch.cuda.Stream(device=self.device)
+        # on a side stream behind the rollout: the next rollout's launches do not queue behind a 4-byte copy (the word is sticky --
+        # bits are only ever OR-ed in -- so a later value is as good)
+        self._rollout_done.record()
+        with torch.cuda.stream(self._status_stream):
+            self._status_stream.wait_event(self._rollout_done)
+            self._status_host.copy_(self._ws_collect.view(torch.int32)[-16 + 3:-16 + 4], non_blocking=True)
+            self._status_event.record()
+        self._status_pending = True
+
+    def check_collect_status(self, wait: bool = True) -> None:
+        """Raise RuntimeError if a wait inside a fw_collect_step launch of the last rollout(s) ran out (the launch then went on
+        with zero actions / partial statistics: everything collected since is void).  SB3's contract for ``VecEnv.step`` is
+        "returns or raises"; a pipe to a dead SubprocVecEnv worker raises there
+        (train/train_Fixedwing_Waypoints_v3.py:251).  ``wait=False`` only looks if the copy has already arrived."""
+        if not self._status_pending:
+            return
+        if wait:
+            self._status_event.synchronize()
+        elif not self._status_event.query():
+            return
+        self._status_pending = False
+        st = int(self._status_host.item())
+        if st == 0:
+            return
+        why = "; ".join(t for b, t in self._COLLECT_STATUS_BITS if st & b)
+        # leave a usable object behind: fresh workspace and action words, no captured graph over the old ones
+        self._ws_collect = None
+        self._g_rollout = None
+        self._warm_rollouts = 0
+        self._act_env.fill_(float("nan"))
+        raise RuntimeError(f"fw_collect_step: status word {st} ({why}); the rollout is void -- buffers and normaliser statistics "
+                           "since the last clean rollout must not be used")
+
     @torch.no_grad()
     def collect_rollouts(self):
         cfg, env = self.cfg, self.env
+        self.check_collect_status(wait=False)      # the previous rollout's word, if its copy has arrived
         if self.last_obs is None:
             self.last_obs = env.reset().clone()
             if self._img:
@@ -903,6 +965,7 @@ class PPO:
         else:
             body()
         self._warm_rollouts += 1
+        self._queue_collect_status()
         if hasattr(env, "sync_statistics"):
             env.sync_statistics()              # sharded job: one small all-reduce per rollout (no-op on one GPU)
         if self._collect_fused and self._close_gae:
@@ -974,6 +1037,7 @@ class PPO:
 
     def train(self):
         cfg = self.cfg
+        self.check_collect_status()                # a void rollout must not reach the update
         obs, act, old_logp, adv, ret = self._update_buffers()
         B = obs.shape[0]
         if self._replicated:                                     # the gathered advantages ARE the global ones
@@ -1076,6 +1140,7 @@ class PPO:
 
     # ---- checkpoint (model + normaliser), train/train_Fixedwing_Waypoints_v3.py:340-347 ----------
     def state_dict(self):
+        self.check_collect_status()                # never checkpoint behind a void rollout
         return {"policy": self.policy.state_dict(), "optimizer": self.optimizer.state_dict(),
                 "vecnormalize": self.env.state_dict(), "num_timesteps": self.num_timesteps}
 

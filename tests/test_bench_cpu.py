@@ -24,6 +24,9 @@ def test_bare_gpus_2_self_launches_two_ranks_and_rank_0_prints_one_line():
     assert len(lines) == 1, lines                         # ONE JSON line, from rank 0
     assert lines[0]["n_gpus"] == 2 and lines[0]["max_rank_plus_one"] == 2.0 and lines[0]["dry_run"] is True
     assert lines[0]["steps"] == 20 and lines[0]["warmup"] == 5
+    # the ranks are counted over the collective backend itself (an all-reduce(SUM) of ones): what lets the driver verify that
+    # N ranks really met -- over RCCL on its 8-GPU node
+    assert lines[0]["ranks_seen"] == 2 and lines[0]["backend"] == "gloo"
 
 
 def test_gpus_that_disagrees_with_the_world_size_exits_non_zero():
@@ -52,4 +55,4 @@ def test_under_a_launcher_the_ranks_agree_with_gpus():
                        env=e, capture_output=True, text=True, timeout=300)
     lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
     assert p.returncode == 0, p.stderr
-    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 7
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 7 and lines[0]["ranks_seen"] == 2

@@ -160,6 +160,23 @@ def test_baseline_size_4096_envs_against_oracle(oracle, lanes3):
     run_lockstep(hip, ora, 24, np.random.default_rng(0), kind="uniform", atol=1e-7, rtol=0)
 
 
+@pytest.mark.parametrize("task,n,steps", [("objlock", 4096, 10), ("combined", 2048, 10), ("combined", 16384, 8)])
+def test_baseline_size_camera_tasks_against_oracle(oracle, task, n, steps):
+    """configs[2] of BASELINE.json (ObjLock, 4096 envs: train/train_objlock.py:27-86), configs[4]'s per-GPU share (combined env,
+    2048 envs: train/train_Fixedwing_Waypoints_ObjLock.py:35-92) and its whole 16 384 envs on the 8-lane mapping fw_create keeps
+    them on -- in lockstep with the oracle over >= 8 agent steps: the camera fires every 3rd agent step (capture interval 12
+    Aviary steps, 4 per agent step), so the window spans capture sub-steps and stale-frame sub-steps alike."""
+    cfg = K.train_objlock_config() if task == "objlock" else K.train_waypoint_objlock_config()
+    hip = P.FixedwingVecEnv(cfg, n, seed=42)
+    assert hip.lanes_per_env == 8
+    ora = oracle.OracleEnv(cfg, n, seed=42)
+    obj = task == "objlock"
+    worst = run_lockstep(hip, ora, steps, np.random.default_rng(0), kind="gentle", atol=2e-5 if obj else 1e-7, rtol=0, state_atol=1e-7)
+    assert worst["obs"] < (2e-5 if obj else 1e-7) and worst["state"] < 1e-7
+    c = hip.get_counters()
+    assert c["launches"] >= steps
+
+
 def test_gimbal_guard_branch(oracle, lanes):
     """pybullet's getEulerFromQuaternion switches formulas at |sin(pitch)| >= 0.99999; the
     kernel takes the Euler->quaternion round trip only there.  Force it."""

@@ -454,7 +454,8 @@ def test_fw_collect_act_normalises_on_load_and_finalises_the_previous_step():
                             R._p(rew1), R._p(st1), None) == K.FW_EINVAL           # finalisation needs the value block
 
 
-@pytest.mark.parametrize("task,n", [("waypoints", 4096), ("waypoints", 1000), ("waypoints", 24), ("waypoints", 8192), ("objlock", 1024), ("combined", 520), ("waypoints_wind", 2048)])
+@pytest.mark.parametrize("task,n", [("waypoints", 4096), ("waypoints", 1000), ("waypoints", 24), ("waypoints", 8192), ("objlock", 1024), ("objlock", 4096), ("combined", 520), ("combined", 2048),
+                                    ("waypoints_wind", 2048)])
 def test_one_launch_vec_step_equals_the_three_launch_collector(task, n):
     """fw_collect_step (act waves + step waves + statistics fold in ONE grid) against fw_collect_act -> fw_step ->
     fw_collect_stats on twin envs, through PPO.collect_rollouts (hipGraph replays included): the same actions, log-probs,
