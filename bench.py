@@ -231,10 +231,34 @@ def collector_rates(task, n):
         t0 = time.perf_counter(); ppo.train(); torch.cuda.synchronize()
         upd = time.perf_counter() - t0
         roll = dt / reps
+        n_mb = hp["n_epochs"] * (T * n // hp["batch_size"])
+        # rooflines of the two learner kernels (tools/learner_accounting.py itemises the algorithmic bytes / flops).
+        # Launch durations here are wall-clock shares of graph replays (a vec-step = one fw_collect_step launch + 1/T of the closing
+        # launch; an update = one fw_ppo_update launch + its host side); profiles/r04_learner_pmc.json holds the rocprofv3 durations
+        # and the counter traffic of the same kernels.
+        from tools import learner_accounting as LA
+        words = TASKS[task][2]
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r04_learner_pmc.json")) as f:
+                kk = json.load(f)["runs"].get(task if n == 4096 else f"{task}_n{n}", {}).get("kernels", {})
+            for name, e in kk.items():
+                if "traffic_bytes_per_launch" in e:
+                    traffic[name.split("_kernel")[0]] = e["traffic_bytes_per_launch"]["total"]
+        except (OSError, KeyError, ValueError):
+            pass
+        acc_c, acc_u = LA.collect_step(n, ppo.env.obs_dim, words), LA.ppo_update(n_mb, hp["batch_size"], ppo.env.obs_dim)
+        roof = {"fw_collect_step": LA.roofline_hbm(acc_c["bytes"], dt * 1e6 / (reps * T), traffic.get("fw_collect")),
+                "fw_ppo_update": LA.roofline_mfma(acc_u["mfma_flops"], upd * 1e6, acc_u["mfma_peak_tflops"], traffic.get("fw_ppo_update"))}
+        roof["fw_collect_step"]["note"] = ("one launch per vec-step; 12.7 of the 19.3 MB are the parameter image read once per act wave from the L2 "
+                                           "(items: tools/learner_accounting.py); the launch is latency-bound (act chain in front of the env step)")
+        roof["fw_ppo_update"]["note"] = (f"{n_mb} sequential minibatches in one launch on {acc_u['workgroups']} workgroups; peak = fp32 MFMA of those CUs "
+                                         f"({acc_u['mfma_peak_tflops']:.2f} TFLOP/s); {acc_u['flops_per_minibatch'] / 1e6:.2f} MFLOP per minibatch")
         return {"note": "informational: rollout collector + PPO update on the same GPU (north_star's other half); `value` above is the physics-only metric",
                 "envs": n, "one_launch_collect": bool(ppo._one_launch), "us_per_vec_step": dt * 1e6 / (reps * T),
-                "collected_env_steps_per_s": reps * T * n / dt, "update_s": upd, "update_minibatches": hp["n_epochs"] * (T * n // hp["batch_size"]),
-                "end_to_end_env_steps_per_s": T * n / (roll + upd), "ppo": hp}
+                "collected_env_steps_per_s": reps * T * n / dt, "update_s": upd, "update_minibatches": n_mb, "us_per_minibatch": upd * 1e6 / n_mb,
+                "update_l2_paths": ppo._fused.last_paths,
+                "end_to_end_env_steps_per_s": T * n / (roll + upd), "ppo": hp, "roofline": roof}
     except Exception as e:          # never let the informational part take the metric down
         return {"error": f"{type(e).__name__}: {e}"}
 

@@ -34,6 +34,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kPH = 64;            // hidden width
 constexpr int kPChunk = 64;        // samples per pass through the networks
 constexpr int kPLdh = kPH + 1;     // row stride of the hidden activations / of W2 in LDS (odd: conflict-free column reads)
+constexpr int kPLdx = 65;          // row stride of the gathered observations in LDS: a CONSTANT (the widest input + 1), so that every operand
+                                   // address of the X-sided products is base + immediate.  (Round 3 had Dp + 1: with a run-time stride hipcc
+                                   // emitted one address add, one scalar reload and one LDS wait PER MFMA of dW1 -- 5.3 k cycles for 32 MFMAs.)
 constexpr int kPThreads = 256;
 
 __host__ __device__ inline int ppo_net_params(int Dp, int KO) { return Dp * kPH + kPH + kPH * kPH + kPH + kPH * KO + KO; }
@@ -77,6 +80,13 @@ __device__ __forceinline__ f32x16 ppo_mfma_tile(const float* A, int sam, int sak
 }
 __device__ __forceinline__ int ppo_acc_row(int v) { return (v >> 2) * 8 + ((threadIdx.x & 63) >> 5) * 4 + (v & 3); }
 
+// (no barrier in front: for callers whose previous readers of red[0..3] are already behind a later barrier)
+__device__ __forceinline__ float ppo_block_sum_nb(float x, float* red) {
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
 __device__ __forceinline__ float ppo_block_sum(float x, float* red) {
   // 256 threads -> all threads get the sum (red: 8 floats of LDS)
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -221,14 +231,14 @@ template <int NET>
 __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const int half, const int nhalf) {
   constexpr int n = NET, KO = NET == 0 ? 4 : 1;
   float* __restrict__ params = A.params;
-  float* __restrict__ mom_m = A.mom_m + (size_t)half * kPMomentSlots; float* __restrict__ mom_v = A.mom_v + (size_t)half * kPMomentSlots;
+  float* __restrict__ mom_m = A.mom_m; float* __restrict__ mom_v = A.mom_v;
   const float* __restrict__ obs = A.obs; const float* __restrict__ act = A.act; const float* __restrict__ old_logp = A.old_logp;
   const float* __restrict__ adv = A.adv; const float* __restrict__ ret = A.ret; const int32_t* __restrict__ perm = A.perm;
   const int n_mb = A.n_mb, B = A.B, D = A.D;
   const PpoHyper H = A.H;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, hh = lane >> 5;
   const int Dp = (D + 1) & ~1;
-  const int ldx = Dp + 1;
+  constexpr int ldx = kPLdx;
 
   // ---- LDS carve-up ----
   float* p = lds;
@@ -290,7 +300,12 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   }
   const int mt = wave >> 1, nt = wave & 1;
   const int tilesW1 = ((Dp + 31) / 32) * 2;       // 2 or 4 tiles of dW1
-  const bool hasW1 = wave < tilesW1;
+  const bool hasW1 = wave < tilesW1;              // this wave OWNS a tile of W1 (hand-off, norm, Adam)
+  // <= 32 observation features: dW1 is the two tiles (0, 0), (0, 1).  Instead of two waves running 32 MFMAs each while the other
+  // two idle, every wave takes one tile over HALF of the chunk's samples (16 MFMAs); waves 2, 3 hand their partial to the
+  // owners through LDS once per minibatch (gW1 of a non-owner is scratch).
+  const bool splitW1 = tilesW1 == 2;
+  const int w1_mt = splitW1 ? 0 : mt, w1_k0 = splitW1 ? (wave >> 1) * 32 : 0, w1_K = splitW1 ? kPChunk / 2 : kPChunk;
   const int hq = t & 3, hs = t >> 2;              // head work: thread (sample or hidden unit hs, quarter / component hq)
 
   float bc1 = powf(H.beta1, (float)H.step0), bc2 = powf(H.beta2, (float)H.step0);     // beta^t
@@ -298,28 +313,53 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   const float invB = 1.0f / (float)B;
 #ifdef FW_PPO_PROF
   long long pf_stats = 0, pf_gather = 0, pf_net = 0, pf_adam = 0, pf_xch = 0, pf_red = 0, pf_ho = 0, pf_norm = 0, pf_tile = 0, pf_scal = 0;
+  long long pf_g[4] = {0, 0, 0, 0}, pf_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // gather: barrier, commit, prefetch issue, barrier; the phases of the chunk pass
 #define PPO_T() ((long long)__builtin_readcyclecounter())
 #endif
 
-  // Gather of a 64-sample chunk, software-pipelined: 4 threads per sample, each holding a quarter of the observation
-  // row, one action component and one scalar in registers until the chunk's turn comes.
+  // Gather of a 64-sample chunk, software-pipelined one chunk ahead (sample indices two ahead: a dependent load fetched in place
+  // stalls the wave for a memory latency before the row loads can even be issued); nothing in `prefetch` waits for a load.
+  // Observation rows: LPR = 8 (or 16) consecutive lanes read one row as float4s -- a row is one or two cache lines whichever
+  // lane asks, and a chunk is 2 (4) load instructions per thread.  (Round 3: 4 threads per sample, a quarter row of single
+  // dwords each -- 7 to 16 scattered loads per thread; the L1's address path, shared by the four waves, took 2.8 k cycles per
+  // chunk to accept them, and the conditional form of the loop cost a branch per element.)  Rows that are not 16-byte aligned
+  // (D % 4 != 0) take the same mapping with dword loads.  Scalars: thread (sample gs, component gk) as before.
   const int gs = t >> 2, gk = t & 3;
-  const int per = (Dp + 3) >> 2, gd0 = gk * per;                          // per <= 16
+  const int NV = (D + 3) >> 2;                                            // float4s per row
+  const int lpr_s = NV <= 8 ? 3 : 4;                                      // log2(lanes per row)
+  const int RPP = kPThreads >> lpr_s, npass = kPChunk / RPP;              // rows per pass: 32 (16); passes: 2 (4)
+  const int xc = t & ((1 << lpr_s) - 1), xs0 = t >> lpr_s;               // my float4 column; my row of pass 0
+  const bool xact = xc < NV, xvec = (D & 3) == 0;
   const int cpm = B / kPChunk;
-  float pre_x[16], pre_a = 0.f, pre_s = 0.f, pre_mu = 0.f, pre_sd = 1.f;
-  // the sample index of a chunk is fetched one chunk ahead of its rows (a dependent load: fetched in place it stalls the wave
-  // for a full memory latency before the row loads can even be issued); nothing in `prefetch` waits for a load
-  int pre_si = 0, imb = 0, ici = half;              // index fetched for the next `prefetch`; the chunk after that one
+  typedef float ppo_x4 __attribute__((ext_vector_type(4)));
+  ppo_x4 pre_x[4];
+  float pre_a = 0.f, pre_s = 0.f, pre_mu = 0.f, pre_sd = 1.f;
+  int pre_xi[4] = {0, 0, 0, 0}, pre_si = 0, imb = 0, ici = half;          // indices fetched for the next `prefetch`; the chunk after that one
   auto fetch_index = [&]() {
-    if (imb < n_mb) pre_si = perm[(size_t)(imb * cpm + ici) * kPChunk + gs];
+    if (imb < n_mb) {
+      const int32_t* pc = perm + (size_t)(imb * cpm + ici) * kPChunk;
+      pre_si = pc[gs];
+#pragma unroll
+      for (int p_ = 0; p_ < 4; ++p_) if (p_ < npass) pre_xi[p_] = pc[xs0 + p_ * RPP];
+    }
     ici += nhalf; if (ici >= cpm) { imb += 1; ici = half; }
   };
   fetch_index();
   auto prefetch = [&](int g) {
     const int si = pre_si;
-    const float* orow = obs + (size_t)si * D;
+    if (xact) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { const int d = gd0 + j; pre_x[j] = (j < per && d < D) ? orow[d] : 0.f; }
+      for (int p_ = 0; p_ < 4; ++p_) {
+        if (p_ < npass) {
+          const float* orow = obs + (size_t)pre_xi[p_] * D;
+          if (xvec) pre_x[p_] = *reinterpret_cast<const ppo_x4*>(orow + 4 * xc);
+          else {
+            const int last = D - 1;                                      // (clamped addresses; the padding is zeroed at commit)
+            pre_x[p_] = ppo_x4{orow[min(4 * xc, last)], orow[min(4 * xc + 1, last)], orow[min(4 * xc + 2, last)], orow[min(4 * xc + 3, last)]};
+          }
+        }
+      }
+    }
     pre_s = 0.f;
     if (NET == 0) {
       pre_a = act[(size_t)si * 4 + gk];
@@ -334,25 +374,45 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   };
   auto commit = [&]() {
     if (NET == 0 && gk == 1 && H.norm_adv != 0) pre_s = (pre_s - pre_mu) / (pre_sd + 1e-8f);
+    if (xact) {                                                           // (4 NV <= 64 < ldx; columns >= D hold zero, columns >= 4 NV are never written)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { const int d = gd0 + j; if (j < per && d < Dp) X[gs * ldx + d] = pre_x[j]; }
+      for (int p_ = 0; p_ < 4; ++p_) {
+        if (p_ < npass) {
+          float* xr = X + (xs0 + p_ * RPP) * ldx + 4 * xc;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xr[k] = 4 * xc + k < D ? pre_x[p_][k] : 0.f;
+        }
+      }
+    }
     if (NET == 0) sA[t] = pre_a;
     sS[t] = pre_s;
   };
   int pmb = 0, pci = half;                          // next chunk to prefetch: minibatch, chunk index inside it
-  if (half == 1) {
-    // private working copy of the Adam moments for the second chunk-half block (same lanes own the same slots)
+  bool gathered = false;                            // the next chunk's inputs are already in X / sA / sS (done inside the hand-off wait)
+  // The Adam moments of the elements this lane owns stay in REGISTERS for the whole call (the compiler parks them in AGPRs): 2 x 32
+  // tile elements (W2, W1) + 2 x NQ per-thread ones.  Round 3 fetched and stored them every minibatch -- ~100 KB through the CU's
+  // 64 B / clk vector-memory path per minibatch, whose store queue the next chunk's gather then had to wait behind (its "issue"
+  // took 2.2 k cycles) -- because 472 registers left no room; the leaner gather and dW1 of round 4 did.  Both chunk halves apply
+  // the same update to the same initial values; half 0 writes the result back at the end.
+  float4 pm[2][4], pv[2][4];
+  {
+    const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane);
 #pragma unroll
-    for (int kind = 0; kind < 2; ++kind) {
-      const int s0 = ppo_tile_slot(n, kind, wave, lane);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        reinterpret_cast<float4*>(mom_m + s0)[q] = reinterpret_cast<const float4*>(A.mom_m + s0)[q];
-        reinterpret_cast<float4*>(mom_v + s0)[q] = reinterpret_cast<const float4*>(A.mom_v + s0)[q];
-      }
+    for (int q = 0; q < 4; ++q) {
+      pm[0][q] = reinterpret_cast<const float4*>(mom_m + s0)[q]; pv[0][q] = reinterpret_cast<const float4*>(mom_v + s0)[q];
+      if (hasW1) { pm[1][q] = reinterpret_cast<const float4*>(mom_m + s1)[q]; pv[1][q] = reinterpret_cast<const float4*>(mom_v + s1)[q]; }
+      else { pm[1][q] = make_float4(0.f, 0.f, 0.f, 0.f); pv[1][q] = pm[1][q]; }
     }
-    for (int q = 0; q < 9; ++q) { mom_m[kPTileSlots + q * kPThreads + t] = A.mom_m[kPTileSlots + q * kPThreads + t]; mom_v[kPTileSlots + q * kPThreads + t] = A.mom_v[kPTileSlots + q * kPThreads + t]; }
   }
+  // per-thread elements: b1[t], b2[t] (t < 64), bo[t] (t < KO), Wo[t / 4][t % 4] (t % 4 < KO), log_std[t] (t < 4, pi block)
+  constexpr int NQ = NET == 0 ? 5 : 4;
+  int sl[NQ];
+  float smm[NQ], svv[NQ];
+  sl[0] = kPTileSlots + (n * 3 + 0) * kPThreads + t; sl[1] = kPTileSlots + (n * 3 + 1) * kPThreads + t;
+  sl[2] = kPTileSlots + (n * 3 + 2) * kPThreads + t; sl[3] = kPTileSlots + (7 + n) * kPThreads + t;
+  if (NET == 0) sl[NQ - 1] = kPTileSlots + 6 * kPThreads + t;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { smm[q] = mom_m[sl[q]]; svv[q] = mom_v[sl[q]]; }
   prefetch(pmb * cpm + pci);
   pci += nhalf; if (pci >= cpm) { pmb += 1; pci = half; }
 
@@ -380,15 +440,34 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #ifdef FW_PPO_PROF
       const long long pf1 = PPO_T();
 #endif
-      __syncthreads();                                                   // the previous chunk's readers of X / sA / sS are done
-      commit();
-      if (pmb < n_mb) {                                                  // the next chunk's loads fly during this chunk's GEMMs
-        prefetch(pmb * cpm + pci);
-        pci += nhalf; if (pci >= cpm) { pmb += 1; pci = half; }
+      if (!gathered) {
+        __syncthreads();                                                 // the previous chunk's readers of X / sA / sS are done
+#ifdef FW_PPO_PROF
+        const long long pg1 = PPO_T(); pf_g[0] += pg1 - pf1;
+#endif
+        commit();
+#ifdef FW_PPO_PROF
+        const long long pg2 = PPO_T(); pf_g[1] += pg2 - pg1;
+#endif
+        if (pmb < n_mb) {                                                // the next chunk's loads fly during this chunk's GEMMs
+          prefetch(pmb * cpm + pci);
+          pci += nhalf; if (pci >= cpm) { pmb += 1; pci = half; }
+        }
+#ifdef FW_PPO_PROF
+        const long long pg3 = PPO_T(); pf_g[2] += pg3 - pg2;
+#endif
+        __syncthreads();
+#ifdef FW_PPO_PROF
+        pf_g[3] += PPO_T() - pg3;
+#endif
       }
-      __syncthreads();
+      gathered = false;
 #ifdef FW_PPO_PROF
       const long long pf2 = PPO_T(); pf_gather += pf2 - pf1;
+      long long pn = pf2;
+#define PPO_PHASE(i) do { const long long t_ = PPO_T(); pf_n[i] += t_ - pn; pn = t_; } while (0)
+#else
+#define PPO_PHASE(i) do { } while (0)
 #endif
       // ---- forward: H1 = tanh(X W1 + b1), H2 = tanh(H1 W2 + b2) ----
       {
@@ -401,6 +480,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         for (int v = 0; v < 16; ++v) H1[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
       }
       __syncthreads();
+      PPO_PHASE(0);
       {
         f32x16 c;
         const float bias = W.b2[nt * 32 + r];
@@ -411,6 +491,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         for (int v = 0; v < 16; ++v) H2[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
       }
       __syncthreads();
+      PPO_PHASE(1);
       // ---- head and loss gradient, on the vector ALU by all four waves (the 64 x KO head is 6 % of a 32 x 32 MFMA tile):
       // thread (sample hs, quarter hq) sums hidden units 16 hq .. 16 hq + 15 for all KO outputs, the four quarters are
       // combined by a butterfly inside the quad, and every lane of the quad then holds the sample's head output ----
@@ -461,6 +542,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         }
       }
       __syncthreads();
+      PPO_PHASE(2);
       // ---- dWo += H2^T gout (before H2 is overwritten): thread (hidden unit hs, quarter hq) over samples 16 hq .. 16 hq + 15 ----
       {
         const float* h2 = H2 + 16 * hq * kPLdh + hs;
@@ -477,6 +559,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         }
       }
       __syncthreads();
+      PPO_PHASE(3);
       // ---- G2 = (gout Wo^T) * (1 - H2^2), in place over H2 (K = KO <= 4) ----
       {
         f32x16 c;
@@ -497,6 +580,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         }
       }
       __syncthreads();
+      PPO_PHASE(4);
       // ---- dW2 += H1^T G2 (rows = input unit), db2 partial ----
       gW2 = ppo_mfma_tile(H1 + mt * 32, 1, kPLdh, H2 + nt * 32, kPLdh, 1, kPChunk, gW2);
       {
@@ -506,6 +590,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         gb2p += sgb;
       }
       __syncthreads();
+      PPO_PHASE(5);
       // ---- G1 = (G2 W2^T) * (1 - H1^2), in place over H1 ----
       {
         f32x16 c;
@@ -520,14 +605,16 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         }
       }
       __syncthreads();
+      PPO_PHASE(6);
       // ---- dW1 += X^T G1 (rows = obs feature, padded to 32 / 64), db1 partial ----
-      if (hasW1) gW1 = ppo_mfma_tile(X + mt * 32, 1, ldx, H1 + nt * 32, kPLdh, 1, kPChunk, gW1);
+      if (hasW1 || splitW1) gW1 = ppo_mfma_tile(X + w1_k0 * ldx + w1_mt * 32, 1, ldx, H1 + w1_k0 * kPLdh + nt * 32, kPLdh, 1, w1_K, gW1);
       {
         float sgb = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) sgb += H1[(wave * 16 + s) * kPLdh + lane];
         gb1p += sgb;
       }
+      PPO_PHASE(7);
 #ifdef FW_PPO_PROF
       pf_net += PPO_T() - pf2;
 #endif
@@ -536,26 +623,6 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #ifdef FW_PPO_PROF
     const long long pf3 = PPO_T();
 #endif
-    // Adam moments of the tiles this wave owns and of this thread's own elements: requested now, consumed after the norm
-    // exchange (their L2 latency hides behind the reductions and the partner's answer)
-    float4 pm[2][4], pv[2][4];
-    {
-      const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        pm[0][q] = reinterpret_cast<const float4*>(mom_m + s0)[q]; pv[0][q] = reinterpret_cast<const float4*>(mom_v + s0)[q];
-        if (hasW1) { pm[1][q] = reinterpret_cast<const float4*>(mom_m + s1)[q]; pv[1][q] = reinterpret_cast<const float4*>(mom_v + s1)[q]; }
-      }
-    }
-    // per-thread elements: b1[t], b2[t] (t < 64), bo[t] (t < KO), Wo[t / 4][t % 4] (t % 4 < KO), log_std[t] (t < 4, pi block)
-    constexpr int NQ = NET == 0 ? 5 : 4;
-    int sl[NQ];
-    float smm[NQ], svv[NQ];
-    sl[0] = kPTileSlots + (n * 3 + 0) * kPThreads + t; sl[1] = kPTileSlots + (n * 3 + 1) * kPThreads + t;
-    sl[2] = kPTileSlots + (n * 3 + 2) * kPThreads + t; sl[3] = kPTileSlots + (7 + n) * kPThreads + t;
-    if (NET == 0) sl[NQ - 1] = kPTileSlots + 6 * kPThreads + t;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) { smm[q] = mom_m[sl[q]]; svv[q] = mom_v[sl[q]]; }
     // ---- finish the per-thread gradients: the four row-block partials of the biases; dWo over the quad's sample quarters;
     // dbo / dlog_std component hq over all samples ----
     float my_gwo = 0.f;
@@ -566,10 +633,21 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       if (hq == k) my_gwo = g;
     }
     for (int o = 4; o < 64; o <<= 1) { gbo_p += __shfl_xor(gbo_p, o, 64); if (NET == 0) gls_p += __shfl_xor(gls_p, o, 64); }
-    __syncthreads();
+    // (no barrier in front: the previous readers of bred / sred -- and of H1, free since the last chunk's dW1 -- are behind the
+    // barriers of the norm exchange and of the end of the previous minibatch)
     bred[wave * kPH + lane] = gb1p; bred[(4 + wave) * kPH + lane] = gb2p;
     if (lane < 4) { sred[wave * 8 + lane] = gbo_p; sred[wave * 8 + 4 + lane] = gls_p; }
+    if (splitW1 && wave >= 2) {                    // the second sample half of dW1's two tiles, to its owners (waves 0, 1) through H1's space
+      float* hx = H1 + (wave - 2) * 64 + lane;      // [element][wave][lane]: conflict-free dwords (H1 is not 16-byte aligned for KO = 1)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) hx[v * 128] = gW1[v];
+    }
     __syncthreads();
+    if (splitW1 && wave < 2) {
+      const float* hx = H1 + wave * 64 + lane;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) gW1[v] += hx[v * 128];
+    }
     float gb1 = 0.f, gb2 = 0.f;
     if (t < kPH) {
 #pragma unroll
@@ -614,6 +692,19 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       if (t == 0) {
         // (relaxed: the ordering is the waves' release / acquire -- or, on a shared L2, their store wait / L1 drop -- around the barriers)
         ppo_word_store(fmine, (unsigned long long)(unsigned)(mb + 1), same_xcd);
+      }
+      // While the partner's partials are on their way (two L2 round trips: ~4 k cycles), the inputs of the NEXT minibatch's first
+      // chunk go to LDS and the loads of the chunk after are issued -- X / sA / sS were last read in this minibatch's chunk
+      // pass, and the barrier behind the poll below stands in for the one a chunk's gather ends with.
+      if (mb + 1 < n_mb) {
+        commit();
+        if (pmb < n_mb) {
+          prefetch(pmb * cpm + pci);
+          pci += nhalf; if (pci >= cpm) { pmb += 1; pci = half; }
+        }
+        gathered = true;
+      }
+      if (t == 0) {
         unsigned long long w;
         if (!ppo_wait(A, [&]() { return ppo_word_load(ftheirs, same_xcd); }, [&](unsigned long long x) { return (unsigned)x == (unsigned)(mb + 1); },
                       (unsigned long long)PPO_ST_SWAP, w)) red[7] = 1.f;       // the partner block is gone: say so and leave instead of hanging
@@ -671,7 +762,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     if (t < KO) ss += my_gbo * my_gbo;
     if (hq < KO) ss += my_gwo * my_gwo;
     if (NET == 0 && t < 4) ss += my_gls * my_gls;
-    const float ss_mine = ppo_block_sum(ss, red);
+    const float ss_mine = ppo_block_sum_nb(ss, red);      // (red[0..3] were last read before the previous minibatch's closing barrier)
     float ss_other = 0.f;
 #ifdef FW_PPO_PROF
     const long long pfx = PPO_T(); pf_norm += pfx - pfb;
@@ -702,29 +793,32 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     // are four dwordx4 loads / stores from one address, with no per-element index arithmetic or branches.
     bc1 *= H.beta1; bc2 *= H.beta2;
     const float c1 = H.lr / (1.0f - bc1), sc2 = 1.0f / sqrtf(1.0f - bc2);      // step size, 1 / sqrt(bias correction 2)
-    auto adam_tile = [&](const f32x16& g, int slot0, float4 (&m4)[4], float4 (&v4)[4], auto&& lds_of /* v -> weight in LDS or nullptr */) {
-      float4* mp = reinterpret_cast<float4*>(mom_m + slot0);
-      float4* vp = reinterpret_cast<float4*>(mom_v + slot0);
+    auto adam_tile = [&](const f32x16& g, float4 (&m4)[4], float4 (&v4)[4], auto&& lds_of /* v -> weight in LDS or nullptr */) {
+      // two elements per instruction where the ISA has a packed form (v_pk_mul_f32 / v_pk_fma_f32: twice the fp32 rate); the
+      // square root and the reciprocal have none
+      typedef float ppo_f2 __attribute__((ext_vector_type(2)));
+      const ppo_f2 b1 = {H.beta1, H.beta1}, ob1 = {1.0f - H.beta1, 1.0f - H.beta1}, b2 = {H.beta2, H.beta2}, ob2 = {1.0f - H.beta2, 1.0f - H.beta2};
       float upd[16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float* mm = reinterpret_cast<float*>(&m4[q]);
         float* vv = reinterpret_cast<float*>(&v4[q]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float gg = g[q * 4 + e] * clipc;
-          mm[e] = H.beta1 * mm[e] + (1.0f - H.beta1) * gg;
-          vv[e] = H.beta2 * vv[e] + (1.0f - H.beta2) * gg * gg;
-          upd[q * 4 + e] = c1 * mm[e] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv[e]) * sc2 + H.eps);
+        for (int e = 0; e < 4; e += 2) {
+          const ppo_f2 gg = ppo_f2{g[q * 4 + e], g[q * 4 + e + 1]} * clipc;
+          const ppo_f2 mn = b1 * ppo_f2{mm[e], mm[e + 1]} + ob1 * gg;
+          const ppo_f2 vn = b2 * ppo_f2{vv[e], vv[e + 1]} + ob2 * (gg * gg);
+          mm[e] = mn[0]; mm[e + 1] = mn[1]; vv[e] = vn[0]; vv[e + 1] = vn[1];
+          const ppo_f2 den = ppo_f2{__builtin_amdgcn_sqrtf(vn[0]), __builtin_amdgcn_sqrtf(vn[1])} * sc2 + H.eps;
+          const ppo_f2 u = (mn * c1) * ppo_f2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+          upd[q * 4 + e] = u[0]; upd[q * 4 + e + 1] = u[1];
         }
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { mp[q] = m4[q]; vp[q] = v4[q]; }
-#pragma unroll
       for (int v = 0; v < 16; ++v) { float* w = lds_of(v); if (w) *w -= upd[v]; }
     };
-    adam_tile(gW2, ppo_tile_slot(n, 0, wave, lane), pm[0], pv[0], [&](int v) { return W.W2 + (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r; });
-    if (hasW1) adam_tile(gW1, ppo_tile_slot(n, 1, wave, lane), pm[1], pv[1],
+    adam_tile(gW2, pm[0], pv[0], [&](int v) { return W.W2 + (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r; });
+    if (hasW1) adam_tile(gW1, pm[1], pv[1],
                          [&](int v) { const int i = mt * 32 + ppo_acc_row(v); return i < D ? W.W1 + i * kPH + nt * 32 + r : (float*)nullptr; });
 #ifdef FW_PPO_PROF
     const long long pfd = PPO_T(); pf_tile += pfd - pfc;
@@ -743,8 +837,6 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         smm[q] = H.beta1 * smm[q] + (1.0f - H.beta1) * gg; svv[q] = H.beta2 * svv[q] + (1.0f - H.beta2) * gg * gg;
       }
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) { mom_m[sl[q]] = smm[q]; mom_v[sl[q]] = svv[q]; }
-#pragma unroll
       for (int q = 0; q < NQ; ++q) if (ws[q]) *ws[q] -= c1 * smm[q] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(svv[q]) * sc2 + H.eps);
     }
     __syncthreads();
@@ -756,6 +848,16 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   // ---- write the weights back, report the losses (a block that gave up leaves the parameters as it found them) ----
   if (dead) return;
   if (half == 0) {
+    {
+      const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        reinterpret_cast<float4*>(mom_m + s0)[q] = pm[0][q]; reinterpret_cast<float4*>(mom_v + s0)[q] = pv[0][q];
+        if (hasW1) { reinterpret_cast<float4*>(mom_m + s1)[q] = pm[1][q]; reinterpret_cast<float4*>(mom_v + s1)[q] = pv[1][q]; }
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { mom_m[sl[q]] = smm[q]; mom_v[sl[q]] = svv[q]; }
+    }
     for (int i = t; i < Dp * kPH; i += kPThreads) params[oW1 + i] = W.W1[i];
     for (int i = t; i < kPH; i += kPThreads) { params[ob1 + i] = W.b1[i]; params[ob2 + i] = W.b2[i]; }
     for (int i = t; i < kPH * kPH; i += kPThreads) params[oW2 + i] = W.W2[(i >> 6) * kPLdh + (i & 63)];
@@ -778,6 +880,8 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     if (NET == 0 && half == 0) {      // the finish section of the policy block, piece by piece
       float* px = A.loss_acc + 11;
       px[0] = (float)pf_red / n_mb; px[1] = (float)pf_ho / n_mb; px[2] = (float)pf_norm / n_mb; px[3] = (float)pf_tile / n_mb; px[4] = (float)pf_scal / n_mb;
+      for (int i = 0; i < 4; ++i) A.loss_acc[16 + i] = (float)pf_g[i] / n_mb;      // (the profiling tool hands a 32-float buffer)
+      for (int i = 0; i < 8; ++i) A.loss_acc[20 + i] = (float)pf_n[i] / n_mb;
     }
 #endif
   }
@@ -796,7 +900,7 @@ __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(PpoArgs A) {
 }
 
 inline size_t ppo_lds_bytes(int D) {
-  const int Dp = (D + 1) & ~1, ldx = Dp + 1;
+  const int Dp = (D + 1) & ~1, ldx = kPLdx;
   size_t f = (size_t)ppo_net_lds_floats(Dp, 4) + 4 + (size_t)kPChunk * ldx + 64 + 2 * (size_t)kPChunk * kPLdh +
              3 * (size_t)kPChunk * 4 + 8 * kPH + 8 + 32;
   return f * sizeof(float);

@@ -23,6 +23,8 @@ e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / 50
 line = {"task": "combined", "envs": n, "res": res, "fw_render_us": us, "pixels_per_s": n * res * res / us * 1e6,
         "image_bytes": out.numel() * 4, "write_GBps": out.numel() * 4 / us / 1e3}
+if len(sys.argv) > 3 and sys.argv[3] == "render_only":        # (counter passes: fw_render alone)
+    print(json.dumps(line)); sys.exit(0)
 T = max(32 * 1024 // n, 1)
 graphs = not (len(sys.argv) > 3 and sys.argv[3] == "eager")
 if os.environ.get("CNN_BENCHMARK"): torch.backends.cudnn.benchmark = True      # MIOpen: search for the fastest algorithm per shape

@@ -1,0 +1,80 @@
+"""Algorithmic work of the learner kernels, per launch -- the numerators of the `roofline` objects in bench.py's `collector`
+and of profiles/rNN_learner_pmc.json (tools/summarize_learner_pmc.py).  Peaks: MI355X_MICROARCH.md (HBM 8 TB/s; fp32 MFMA
+157.3 TFLOP/s per chip = 0.6145 TFLOP/s per CU, 256 CUs).
+
+"Algorithmic" = what the arithmetic needs to be moved once, whoever holds it in cache: every figure below is a count of
+array elements x element size, itemised so that a reader can recompute it.
+"""
+HBM_PEAK_GBPS = 8000.0
+MFMA_F32_TFLOPS_CHIP = 157.3
+CUS = 256
+H = 64                      # hidden width of the reference's MlpPolicy
+
+
+def net_param_bytes(D: int, KO: int) -> int:
+    Dp = (D + 1) & ~1
+    return 4 * (Dp * H + H + H * H + H + H * KO + KO)
+
+
+def net_macs_forward(D: int, KO: int) -> int:
+    return D * H + H * H + H * KO
+
+
+def net_macs_backward(D: int, KO: int) -> int:
+    """dWo, G2 = g Wo^T, dW2, G1 = G2 W2^T, dW1 (no input gradient)."""
+    return 2 * H * KO + 2 * H * H + D * H
+
+
+def collect_step(N: int, D: int, step_words: int, env_word: int = 8, rows_per_act_wave: int = 16) -> dict:
+    """One fw_collect_step launch = one vec-step of the collector: act waves (policy + value forward of every env, buffer rows,
+    finalisation of the previous step), the env step, the VecNormalize partial sums and their fold."""
+    n_chunks = -(-N // rows_per_act_wave)
+    nblk = -(-N // 8)
+    it = {
+        "env_step (fw_step's words per env-step x N)": step_words * env_word * N,
+        "raw observations read by the policy and the value wave": 2 * N * D * env_word,
+        "previous step read by the value waves (reward, two flags)": N * (env_word + 2),
+        "rollout-buffer rows written (obs D, action 4, log-prob, value, reward, start: float32)": N * (D + 8) * 4,
+        "clipped actions written for the step waves": N * 4 * env_word,
+        "parameter image, once per act wave (policy net / value net; served by the L2)": n_chunks * (net_param_bytes(D, 4) + 16 + net_param_bytes(D, 1)),
+        "statistics read by every act wave (mean, var, totals: 4 D + 8 doubles)": 2 * n_chunks * (4 * D + 8) * 8,
+        "partial sums written by the step waves and read by the fold waves": 2 * nblk * (2 * D + 2) * 8,
+    }
+    flops = 2 * N * (net_macs_forward(D, 4) + net_macs_forward(D, 1))
+    return {"bytes": sum(it.values()), "items": it, "mfma_flops": flops}
+
+
+def collect_close(N: int, D: int, T: int, env_word: int = 8, rows_per_act_wave: int = 16) -> dict:
+    n_chunks = -(-N // rows_per_act_wave)
+    it = {
+        "GAE: values, rewards, episode starts read; advantages, returns written ([T, N] float32)": 5 * T * N * 4,
+        "last observation read (raw) and written normalised": N * D * (env_word + 4),
+        "last step read (reward, flags), last values / starts / rewards written": N * (env_word + 2 + 12),
+        "parameter image of the value net, once per wave": n_chunks * net_param_bytes(D, 1),
+    }
+    return {"bytes": sum(it.values()), "items": it, "mfma_flops": 2 * N * net_macs_forward(D, 1)}
+
+
+def ppo_update(n_mb: int, B: int, D: int) -> dict:
+    """One fw_ppo_update launch = n_mb sequential minibatches of B samples through both networks, forward and backward."""
+    macs = B * sum(net_macs_forward(D, ko) + net_macs_backward(D, ko) for ko in (4, 1))
+    blocks = 4 if B >= 128 else 2
+    it = {"gathered rows per minibatch (obs D, action 4, old log-prob, advantage, return: float32) + index": B * ((D + 7) * 4 + 4)}
+    return {"bytes": n_mb * sum(it.values()), "items_per_minibatch": it, "mfma_flops": 2 * n_mb * macs, "flops_per_minibatch": 2 * macs,
+            "workgroups": blocks, "mfma_peak_tflops": blocks * MFMA_F32_TFLOPS_CHIP / CUS}
+
+
+def render(N: int, res: int) -> dict:
+    return {"bytes": N * 2 * res * res * 4, "items": {"mask + depth, float32 [N, 2, res, res] written": N * 2 * res * res * 4}, "mfma_flops": 0}
+
+
+def roofline_hbm(bytes_per_launch: float, launch_us: float, traffic=None) -> dict:
+    ach = bytes_per_launch / (launch_us * 1e-6) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "launch_us": launch_us}
+
+
+def roofline_mfma(flops_per_launch: float, launch_us: float, peak_tflops: float, traffic=None) -> dict:
+    ach = flops_per_launch / (launch_us * 1e-6) / 1e12
+    return {"bound": "mfma", "achieved": ach, "peak": peak_tflops, "unit": "TFLOP/s", "frac": ach / peak_tflops, "traffic": traffic,
+            "algorithmic_flops_per_launch": flops_per_launch, "launch_us": launch_us}
