@@ -394,12 +394,15 @@ int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t 
  * perm[n_minibatches * batch_size]: sample indices of consecutive minibatches (int32, device).
  * batch_size must be a multiple of 64, obs_dim <= 64.  loss_acc[3] (may be NULL) accumulates the per-minibatch
  * mean policy loss, value loss and entropy loss.  The caller advances its Adam step count by n_minibatches.
- * workspace: caller-owned device buffer of >= fw_ppo_update_workspace_bytes(n_minibatches) bytes (exchange words,
- * gradient hand-off buffer and per-minibatch advantage statistics of THIS call; two learners never share it).
+ * workspace: caller-owned device buffer of >= fw_ppo_update_workspace_bytes(n_minibatches, batch_size, obs_dim) bytes: exchange
+ * words, the gradient hand-off buffer and the PACKED ROWS of this call -- a parallel pre-pass (one workgroup per minibatch, all
+ * CUs) writes every minibatch's rows in walking order, observation | action | old log-prob, normalised advantage, return,
+ * (obs_dim rounded up to 4) + 8 floats each, so that the sequential kernel reads each 64-sample chunk as one contiguous block
+ * (144 B per sample and epoch for 28 observations: 189 MB for 20 epochs x 65 536 samples).  Two learners never share it.
  * The learner-side entry points run on the device their buffers live on, whatever the thread's current device.
  * Failure inside the launch: the two / four workgroups of a call wait for each other once or twice per minibatch, every wait
  * bounded.  A wait that runs out raises FW_PPO_ST_* in the workspace's status word and every workgroup leaves WITHOUT writing
- * `params` back (mom_m / mom_v are then part-way through the call: restore them before going on).  fw_ppo_update_status reads
+ * `params`, `mom_m` or `mom_v` back (the moments live in registers during the call).  fw_ppo_update_status reads
  * the word after the call (it synchronises `hip_stream`): 0 = the call ran to its end.  `paths` (may be NULL) receives which
  * exchanges went through an XCD's shared L2 rather than device-scope accesses: bit 2 b = workgroup b's gradient swap, bit
  * 2 b + 1 = its norm exchange, b = 2 * chunk_half + net.  Environment (read per call): FWSIM_PPO_NO_L2_SWAP=1 forces the
@@ -417,7 +420,7 @@ typedef struct fw_ppo_hyper {
 int32_t fw_ppo_param_count(int32_t obs_dim);
 int32_t fw_ppo_moment_count(void);
 int32_t fw_ppo_moment_map(int32_t obs_dim, int32_t* flat_index_of_slot /* host, [fw_ppo_moment_count()] */);
-int64_t fw_ppo_update_workspace_bytes(int32_t n_minibatches);
+int64_t fw_ppo_update_workspace_bytes(int32_t n_minibatches, int32_t batch_size, int32_t obs_dim);
 int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* obs, const float* act,
                       const float* old_logp, const float* adv, const float* ret, const int32_t* perm,
                       int32_t n_minibatches, int32_t batch_size, int32_t obs_dim, const fw_ppo_hyper* hyper,

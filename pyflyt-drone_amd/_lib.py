@@ -102,7 +102,7 @@ def lib() -> C.CDLL:
         L.fw_normalize_obs.restype = i32
         L.fw_normalize_obs.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, C.c_float, C.c_float, vp, vp, vp, vp]
         L.fw_normalize_obs_workspace_bytes.restype = i64; L.fw_normalize_obs_workspace_bytes.argtypes = [i32]
-        L.fw_ppo_update_workspace_bytes.restype = i64; L.fw_ppo_update_workspace_bytes.argtypes = [i32]
+        L.fw_ppo_update_workspace_bytes.restype = i64; L.fw_ppo_update_workspace_bytes.argtypes = [i32, i32, i32]
         L.fw_ppo_param_count.restype = i32; L.fw_ppo_param_count.argtypes = [i32]
         L.fw_ppo_moment_count.restype = i32; L.fw_ppo_moment_count.argtypes = []
         L.fw_ppo_moment_map.restype = i32; L.fw_ppo_moment_map.argtypes = [i32, vp]

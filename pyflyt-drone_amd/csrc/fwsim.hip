@@ -1892,11 +1892,12 @@ static long long spin_budget(long long dflt) {
 }
 
 // workspace layout of fw_ppo_update: [0,192) exchange words (word 22: which exchanges shared an L2, word 23: status, include/fwsim.h) |
-// gradient hand-off buffer | per-minibatch advantage statistics
+// gradient hand-off buffer | the packed rows of every minibatch, in walking order (fw_ppo_pack_kernel)
 static constexpr size_t kPpoWsXch = 24 * sizeof(unsigned long long);
 static constexpr size_t kPpoWsGx = sizeof(float) * 8 * (size_t)kPMomentSlots;
-int64_t fw_ppo_update_workspace_bytes(int32_t n_minibatches) {
-  return n_minibatches > 0 ? (int64_t)(kPpoWsXch + kPpoWsGx + sizeof(float) * 2 * (size_t)n_minibatches) : FW_EINVAL;
+int64_t fw_ppo_update_workspace_bytes(int32_t n_minibatches, int32_t batch_size, int32_t obs_dim) {
+  if (n_minibatches <= 0 || batch_size <= 0 || obs_dim <= 0 || obs_dim > 64) return FW_EINVAL;
+  return (int64_t)(kPpoWsXch + kPpoWsGx + sizeof(float) * (size_t)n_minibatches * (size_t)batch_size * (size_t)ppo_pack_width(obs_dim));
 }
 
 int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* obs, const float* act, const float* old_logp,
@@ -1909,8 +1910,8 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   }
   if (batch_size <= 0 || batch_size % kPChunk != 0) { g_err = "fw_ppo_update: batch_size must be a multiple of 64"; return FW_EINVAL; }
   if (obs_dim <= 0 || obs_dim > 64) { g_err = "fw_ppo_update: obs_dim must be in [1, 64]"; return FW_EINVAL; }
-  if (!workspace || workspace_bytes < fw_ppo_update_workspace_bytes(n_minibatches)) {
-    g_err = "fw_ppo_update: workspace smaller than fw_ppo_update_workspace_bytes(n_minibatches)"; return FW_EINVAL;
+  if (!workspace || workspace_bytes < fw_ppo_update_workspace_bytes(n_minibatches, batch_size, obs_dim)) {
+    g_err = "fw_ppo_update: workspace smaller than fw_ppo_update_workspace_bytes(n_minibatches, batch_size, obs_dim)"; return FW_EINVAL;
   }
   const size_t lds = ppo_lds_bytes(obs_dim);
   if (lds > 160 * 1024) { g_err = "fw_ppo_update: networks do not fit the 160 KB of LDS"; return FW_EINVAL; }
@@ -1922,19 +1923,21 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   // everything the blocks exchange lives in the caller's workspace: two learners (or two streams) never share a word
   unsigned long long* xch = (unsigned long long*)workspace;
   float* gx = (float*)((char*)workspace + kPpoWsXch);
-  float* stats = (float*)((char*)workspace + kPpoWsXch + kPpoWsGx);
+  float* packed = (float*)((char*)workspace + kPpoWsXch + kPpoWsGx);
   HIP_TRY((fw_env*)nullptr, hipMemsetAsync(xch, 0, kPpoWsXch, st));
-  if (hyper->norm_adv == 1 && batch_size > 1)     // per-minibatch advantage statistics, computed in parallel up front
-    hipLaunchKernelGGL(fw_ppo_adv_stats_kernel, dim3(n_minibatches), dim3(64), 0, st, adv, perm, batch_size, stats);
   PpoArgs A;
-  A.params = params; A.mom_m = mom_m; A.mom_v = mom_v; A.obs = obs; A.act = act; A.old_logp = old_logp; A.adv = adv; A.ret = ret;
-  A.perm = perm; A.n_mb = n_minibatches; A.B = batch_size; A.D = obs_dim; A.loss_acc = loss_acc; A.xch = xch; A.gx = gx;
-  A.adv_stats = stats;
+  A.params = params; A.mom_m = mom_m; A.mom_v = mom_v; A.packed = packed;
+  A.n_mb = n_minibatches; A.B = batch_size; A.D = obs_dim; A.loss_acc = loss_acc; A.xch = xch; A.gx = gx;
   A.spin = spin_budget(kPpoSpin);
   A.flags = 0;
   if (const char* e = getenv("FWSIM_PPO_NO_L2_SWAP")) if (atoi(e) != 0) A.flags |= PPO_FLAG_NO_L2_SWAP;
   std::memcpy(&A.H, hyper, sizeof A.H);
   if (batch_size <= 1 && A.H.norm_adv == 1) A.H.norm_adv = 0;      // SB3 skips the normalisation of single-sample minibatches
+  // the parallel pre-pass: every minibatch's rows, in walking order, advantages normalised (one workgroup per minibatch, all CUs)
+  PpoPackArgs P;
+  P.obs = obs; P.act = act; P.old_logp = old_logp; P.adv = adv; P.ret = ret; P.perm = perm; P.B = batch_size; P.D = obs_dim;
+  P.norm_adv = A.H.norm_adv; P.adv_mean = A.H.adv_mean; P.adv_std = A.H.adv_std; P.out = packed;
+  hipLaunchKernelGGL(fw_ppo_pack_kernel, dim3(n_minibatches), dim3(256), 0, st, P);
   const int nhalf = batch_size >= 2 * kPChunk ? 2 : 1;            // two chunk-half blocks per network from 128 samples on
   hipLaunchKernelGGL(fw_ppo_update_kernel, dim3(nhalf == 2 ? 32 : 16), dim3(kPThreads), lds, st, A);      // (every 8th block works -- see the kernel)
   HIP_TRY((fw_env*)nullptr, hipGetLastError());

@@ -550,8 +550,9 @@ class FusedPpoUpdate:
         self._ws = None                    # caller-owned scratch of fw_ppo_update (grown here, never inside the call)
         self.last_paths = 0                # fw_ppo_update_status: which exchanges of the last call went through a shared L2
 
-    def _workspace(self, n_mb: int) -> torch.Tensor:
-        need = int(_lib.lib().fw_ppo_update_workspace_bytes(n_mb))
+    def _workspace(self, n_mb: int, batch_size: int) -> torch.Tensor:
+        # exchange words + gradient hand-off buffer + the packed rows of every minibatch (a parallel pre-pass of the call writes them)
+        need = int(_lib.lib().fw_ppo_update_workspace_bytes(n_mb, batch_size, self.D))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.zeros(need, dtype=torch.uint8, device=self.flat.device)
         return self._ws
@@ -643,7 +644,7 @@ class FusedPpoUpdate:
         for x in (obs, act, old_logp, adv, ret):
             assert x.dtype == torch.float32 and x.is_contiguous()
         assert perm_i32.dtype == torch.int32 and perm_i32.numel() == n_mb * cfg.batch_size
-        ws = self._workspace(n_mb)
+        ws = self._workspace(n_mb, cfg.batch_size)
         rc = _lib.lib().fw_ppo_update(_p(self.flat), _p(self.mom_m), _p(self.mom_v), _p(obs), _p(act), _p(old_logp), _p(adv), _p(ret),
                                       _p(perm_i32), n_mb, cfg.batch_size, self.D, C.byref(H), _p(self.loss), _p(ws), ws.numel(),
                                       _stream(obs.device))

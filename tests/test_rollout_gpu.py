@@ -176,7 +176,8 @@ def test_fused_ppo_update_rejects_what_it_cannot_run():
     H = R._PpoHyper()
     import ctypes as C
     args = [R._p(z)] * 8 + [R._p(z.to(torch.int32))]
-    ws = torch.zeros(int(L.fw_ppo_update_workspace_bytes(1)), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(int(L.fw_ppo_update_workspace_bytes(1, 64, 28)), dtype=torch.uint8, device="cuda")
+    assert L.fw_ppo_update_workspace_bytes(0, 64, 28) == K.FW_EINVAL and L.fw_ppo_update_workspace_bytes(1, 64, 65) == K.FW_EINVAL
     assert L.fw_ppo_update(*args, 1, 100, 28, C.byref(H), None, R._p(ws), ws.numel(), None) == K.FW_EINVAL      # batch not a multiple of 64
     assert L.fw_ppo_update(*args, 1, 64, 65, C.byref(H), None, R._p(ws), ws.numel(), None) == K.FW_EINVAL       # obs_dim too large
     assert L.fw_ppo_update(*args, 0, 64, 28, C.byref(H), None, R._p(ws), ws.numel(), None) == K.FW_EINVAL

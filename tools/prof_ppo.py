@@ -17,7 +17,7 @@ for D, B in ((28, 128), (28, 64), (56, 64), (28, 256)):
     perm = torch.randint(0, S, (n_mb * B,), device="cuda", generator=g, dtype=torch.int32)
     loss = torch.zeros(32, device="cuda")
     H = R._PpoHyper(lr=3e-4, clip_range=0.2, ent_coef=0.001, vf_coef=0.5, max_grad_norm=0.5, beta1=0.9, beta2=0.999, eps=1e-5, norm_adv=1, step0=0)
-    ws = torch.zeros(int(L.fw_ppo_update_workspace_bytes(n_mb)), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(int(L.fw_ppo_update_workspace_bytes(n_mb, B, D)), dtype=torch.uint8, device="cuda")
     def run():
         rc = L.fw_ppo_update(R._p(flat), R._p(m), R._p(v), R._p(obs), R._p(act), R._p(lp), R._p(adv), R._p(ret), R._p(perm), n_mb, B, D,
                              C.byref(H), R._p(loss), R._p(ws), ws.numel(), None)

@@ -17,7 +17,7 @@ from tools import learner_accounting as A
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", f"{rnd}_learner")
 prof = os.path.join(ROOT, "profiles")
-KERNELS = ("fw_collect_kernel", "fw_collect_close_kernel", "fw_ppo_update_kernel", "fw_ppo_adv_stats_kernel", "fw_render_kernel")
+KERNELS = ("fw_collect_kernel", "fw_collect_close_kernel", "fw_ppo_update_kernel", "fw_ppo_pack_kernel", "fw_render_kernel")
 STEP_WORDS = {"waypoints": 94, "waypoints_wind": 94, "objlock": 203, "combined": 193}
 OBS_DIM = {"waypoints": 28, "waypoints_wind": 28, "objlock": 56, "combined": 28}
 HP = {"waypoints": (16, 128, 20), "objlock": (8, 64, 10), "combined": (8, 128, 20)}      # n_steps, batch, epochs of tools/bench_rollout.py
