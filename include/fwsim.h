@@ -485,8 +485,8 @@ int32_t fw_collect_stats(const void* obs, int32_t obs_is_f64, int32_t N, int32_t
  * observation to act on) and this step on return; rew_out / start_out (both or neither) receive the finalisation of the
  * previous step.  The batch sums of a step are folded by "fold waves" at the end of its own launch and merged into the
  * statistics buffers by the NEXT fw_collect_step (which needs them first) -- or by fw_collect_finish: call it after the last
- * step of a rollout, before anything else reads (obs_mean, obs_var, obs_count) / the return statistics.  Serves handles on the 8-lanes-per-env mapping at one wave per SIMD (FW_EUNSUPPORTED otherwise: use
- * the three calls).  workspace: caller-owned, fw_collect_step_workspace_bytes(h) bytes, one per handle, prepared ONCE with
+ * step of a rollout, before anything else reads (obs_mean, obs_var, obs_count) / the return statistics.  Serves handles on the 8-lanes-per-env mapping, either build (FW_EUNSUPPORTED
+ * otherwise -- one lane per env, i.e. beyond 24 576 waypoint envs per GPU: use the three calls).  workspace: caller-owned, fw_collect_step_workspace_bytes(h) bytes, one per handle, prepared ONCE with
  * fw_collect_workspace_init (stream-ordered; not inside a graph that is replayed).
  * Failure inside a launch: the waves of the grid wait for waves in front of them (step waves for their actions, fold waves for
  * the partial sums, the merge wave for the act waves), every wait bounded.  A wait that runs out does not stop the launch --

@@ -977,6 +977,11 @@ template <typename T, bool GENERAL>
 __global__ __launch_bounds__(kWave) void fw_collect_kernel_g8(FW_STEP_ARGS, const CollectArgs CA) { FW_COLLECT_RUN(T, GENERAL, 8, FW_TASK_WAYPOINTS, 1, true); }
 template <typename T, int TKIND>
 __global__ __launch_bounds__(kWave) void fw_collect_kernel_obj_g8(FW_STEP_ARGS, const CollectArgs CA) { FW_COLLECT_RUN(T, true, 8, TKIND, 1, true); }
+// ... and for the two-waves-per-SIMD build of the waypoints kernels (8 192 < N <= 24 576 envs: 12 288 with wind), so that those
+// env counts keep the one-launch collector (round 3 sent them to the three-launch one)
+template <typename T, bool GENERAL>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fw_collect_kernel_g8w2(FW_STEP_ARGS, const CollectArgs CA) { FW_COLLECT_RUN(T, GENERAL, 8, FW_TASK_WAYPOINTS, 2, true); }
 
 // Caller-supplied scenario of the episodes a fw_reset starts (fw_scenario, uploaded to device memory by the host side;
 // doubles indexed by the handle's local env, null = keep the env's own draw).
@@ -1626,12 +1631,15 @@ int collect_step_T(fw_env* h, CollectArgs& CA, const void* actions, void* obs, v
                    int32_t* info, hipStream_t st) {
   const size_t lds = std::max(step_lds_bytes<T>(h), collect_act_lds_bytes(CA.A.D));
   if (lds > 160 * 1024) { h->err = "fw_collect_step: the networks do not fit the LDS next to the step kernel's tile"; return FW_EINVAL; }
+  const bool w2 = h->g8_waves == 2, windy = h->cfg.wind_mode != FW_WIND_OFF, f32 = sizeof(T) != 8;       // (w2: waypoints task only, fw_create)
   const void* fn = h->cfg.task == FW_TASK_OBJLOCK ? (const void*)fw_collect_kernel_obj_g8<T, FW_TASK_OBJLOCK>
                  : h->cfg.task == FW_TASK_WAYPOINT_OBJLOCK ? (const void*)fw_collect_kernel_obj_g8<T, FW_TASK_WAYPOINT_OBJLOCK>
-                 : h->cfg.wind_mode != FW_WIND_OFF ? (const void*)fw_collect_kernel_g8<T, true> : (const void*)fw_collect_kernel_g8<T, false>;
+                 : windy ? (w2 ? (const void*)fw_collect_kernel_g8w2<T, true> : (const void*)fw_collect_kernel_g8<T, true>)
+                         : (w2 ? (const void*)fw_collect_kernel_g8w2<T, false> : (const void*)fw_collect_kernel_g8<T, false>);
   if (lds > 48 * 1024) {                       // opt in once per (device, kernel, size class): only ever raised
-    static size_t have[64][8] = {};
-    const int which = (h->cfg.task == FW_TASK_OBJLOCK ? 0 : h->cfg.task == FW_TASK_WAYPOINT_OBJLOCK ? 1 : h->cfg.wind_mode != FW_WIND_OFF ? 2 : 3) + (sizeof(T) == 8 ? 0 : 4);
+    static size_t have[64][12] = {};
+    const int which = w2 ? 8 + (windy ? 0 : 1) + (f32 ? 2 : 0)
+                         : (h->cfg.task == FW_TASK_OBJLOCK ? 0 : h->cfg.task == FW_TASK_WAYPOINT_OBJLOCK ? 1 : windy ? 2 : 3) + (f32 ? 4 : 0);
     if (h->device < 64 && lds > have[h->device][which]) {
       HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       have[h->device][which] = lds;
@@ -1644,8 +1652,8 @@ int collect_step_T(fw_env* h, CollectArgs& CA, const void* actions, void* obs, v
                      dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term, trunc, (T*)tobs, info, CA)
   if (h->cfg.task == FW_TASK_OBJLOCK) FW_LAUNCH_COLLECT((fw_collect_kernel_obj_g8<T, FW_TASK_OBJLOCK>));
   else if (h->cfg.task == FW_TASK_WAYPOINT_OBJLOCK) FW_LAUNCH_COLLECT((fw_collect_kernel_obj_g8<T, FW_TASK_WAYPOINT_OBJLOCK>));
-  else if (h->cfg.wind_mode != FW_WIND_OFF) FW_LAUNCH_COLLECT((fw_collect_kernel_g8<T, true>));
-  else FW_LAUNCH_COLLECT((fw_collect_kernel_g8<T, false>));
+  else if (windy) { if (w2) FW_LAUNCH_COLLECT((fw_collect_kernel_g8w2<T, true>)); else FW_LAUNCH_COLLECT((fw_collect_kernel_g8<T, true>)); }
+  else { if (w2) FW_LAUNCH_COLLECT((fw_collect_kernel_g8w2<T, false>)); else FW_LAUNCH_COLLECT((fw_collect_kernel_g8<T, false>)); }
   HIP_TRY(h, hipGetLastError());
   return FW_OK;
 }
@@ -1789,8 +1797,10 @@ int32_t fw_render(fw_handle h, int32_t res, float* out, void* hip_stream) {
   K.near_ = c.camera_near; K.far_ = c.camera_far; K.duck_radius = c.duck_radius_per_scale * c.duck_global_scaling; K.obst_radius = c.obstacle_radius;
   const int tile = kWave / h->lanes_per_env;
   hipStream_t st = (hipStream_t)hip_stream;
-  if (c.dtype == FW_F64) hipLaunchKernelGGL(fw_render_kernel<double>, dim3((unsigned)h->n), dim3(256), 0, st, (const double*)h->r_dev, tile, h->n, K, res, out);
-  else hipLaunchKernelGGL(fw_render_kernel<float>, dim3((unsigned)h->n), dim3(256), 0, st, (const float*)h->r_dev, tile, h->n, K, res, out);
+  const size_t lds = sizeof(double) * (size_t)res;       // the image-plane coordinate of every pixel column / row
+  const int threads = 256;                               // (measured at 4096 x 32 x 32: 64 threads per env 73.0 us, 128: 68.5, 256: 62.4)
+  if (c.dtype == FW_F64) hipLaunchKernelGGL(fw_render_kernel<double>, dim3((unsigned)h->n), dim3(threads), lds, st, (const double*)h->r_dev, tile, h->n, K, res, out);
+  else hipLaunchKernelGGL(fw_render_kernel<float>, dim3((unsigned)h->n), dim3(threads), lds, st, (const float*)h->r_dev, tile, h->n, K, res, out);
   HIP_TRY(h, hipGetLastError());
   return FW_OK;
 }
@@ -2010,9 +2020,9 @@ int64_t fw_collect_step_workspace_bytes(fw_handle h) { return h ? (int64_t)colle
 
 // checks and argument block shared by fw_collect_step and fw_collect_close
 static int32_t collect_fill(fw_handle h, const fw_collect_args* a, const char* who, bool close, CollectArgs& CA) {
-  if (h->lanes_per_env != 8 || h->g8_waves != 1) {
-    h->err = std::string(who) + " serves the 8-lanes-per-env mapping at one wave per SIMD (what fw_create picks for waypoints up to 8192 envs per GPU, 6144 with "
-             "wind, and for the camera tasks up to 16384 envs or at any size with obstacles); use fw_collect_act / fw_step / fw_collect_stats";
+  if (h->lanes_per_env != 8) {
+    h->err = std::string(who) + " serves the 8-lanes-per-env mapping (what fw_create picks for waypoints up to 24576 envs per GPU, 12288 with wind, and "
+             "for the camera tasks up to 16384 envs or at any size with obstacles); use fw_collect_act / fw_step / fw_collect_stats";
     return FW_EUNSUPPORTED;
   }
   const int D = obs_dim_of(&h->cfg), N = h->n;
@@ -2088,7 +2098,7 @@ int32_t fw_collect_close(fw_handle h, const fw_collect_args* a, const fw_collect
 
 int32_t fw_collect_workspace_init(fw_handle h, void* workspace, int64_t workspace_bytes, void* hip_stream) {
   if (!h) return FW_EINVAL;
-  if (h->lanes_per_env != 8 || h->g8_waves != 1) { h->err = "fw_collect_workspace_init: this handle's lane mapping has no fw_collect_step"; return FW_EUNSUPPORTED; }
+  if (h->lanes_per_env != 8) { h->err = "fw_collect_workspace_init: this handle's lane mapping has no fw_collect_step"; return FW_EUNSUPPORTED; }
   const CollectWs W = collect_ws(h);
   if (!workspace || workspace_bytes < (int64_t)W.total) { h->err = "fw_collect_workspace_init: workspace smaller than fw_collect_step_workspace_bytes()"; return FW_EINVAL; }
   DeviceGuard g(h->device);
@@ -2103,7 +2113,7 @@ int32_t fw_collect_workspace_init(fw_handle h, void* workspace, int64_t workspac
 
 int32_t fw_collect_finish(fw_handle h, const fw_collect_args* a, void* hip_stream) {
   if (!h || !a) return FW_EINVAL;
-  if (h->lanes_per_env != 8 || h->g8_waves != 1) { h->err = "fw_collect_finish: this handle's lane mapping has no fw_collect_step"; return FW_EUNSUPPORTED; }
+  if (h->lanes_per_env != 8) { h->err = "fw_collect_finish: this handle's lane mapping has no fw_collect_step"; return FW_EUNSUPPORTED; }
   if (!a->obs_mean || !a->obs_var || !a->obs_count || !a->ret_mean || !a->ret_var || !a->ret_count) { h->err = "fw_collect_finish: missing statistics buffers"; return FW_EINVAL; }
   const CollectWs W = collect_ws(h);
   if (!a->workspace || a->workspace_bytes < (int64_t)W.total) { h->err = "fw_collect_finish: workspace smaller than fw_collect_step_workspace_bytes()"; return FW_EINVAL; }

@@ -7,11 +7,21 @@
 //   out[env][1][y][x] = depth-buffer value in [0, 1] of the nearest fragment (duck pixels: the sphere; others: ground or
 //                       cylinder; sky = 1.0), far (t - near) / (t (far - near)) with t clipped to [near, far]
 // at `res` x `res` pixels of the same body-fixed camera (FOV, tilt, offset of fw_config; the focal length scales with the
-// width), for the env's CURRENT pose.  One workgroup per env: the pose, the duck's camera-frame centre and the occlusion flag are
-// computed once into LDS next to the cylinder table, then the 256 threads walk the pixels (x fastest: coalesced float stores).
-// The arithmetic is double whatever the handle's dtype and is written statement by statement like the CPU checker's render (IEEE sqrt and
-// division, no FMA contraction): the duck mask is an exact comparison against 0 at the silhouette, so the test asks for the
-// same bits, not for a tolerance.
+// width), for the env's CURRENT pose.  One workgroup (four waves) per env; a wave takes 8 x 8-pixel tiles.
+//   * The decisions a pixel's value hangs on -- duck silhouette (disc >= 0), cylinder hit (disc >= 0, t > 0, 0 <= z <= h),
+//     nearest fragment -- are the CPU checker's expressions statement by statement in double, IEEE sqrt and division, no FMA
+//     contraction: the mask is an exact comparison against 0 at the silhouette, so the test asks for the same bits, not for a
+//     tolerance.  What round 4 changed is how OFTEN they run.
+//   * Round 3 tested every pixel against every cylinder, square root and division included: 818 vector instructions per
+//     pixel with 20 cylinders, 70 % of the chip's fp64 issue peak -- the kernel was compute-bound at 3 % of the HBM write rate.
+//     A ray hits an (infinite) cylinder iff its horizontal direction lies in the wedge between the two vertical tangent planes
+//     through the camera, and the ray direction is affine in the pixel coordinates: the wedge is two half-planes of the image.
+//     Lane o of the first wave builds them for cylinder o (plus the line-of-sight occlusion test of the duck, one cylinder per
+//     lane instead of a serial loop on one thread); a wave then evaluates, for its tile, both affine forms at the four corner
+//     pixels for every cylinder at once (lane = cylinder x corner) -- an affine form that is negative at all four corners of a
+//     rectangle is negative inside -- and a pixel loops over the surviving cylinders only (bit mask, wave-uniform).  The margin
+//     of the cull is seven orders of magnitude above rounding; what survives is decided by the exact expressions.
+//   * every thread derives the pose / duck constants for itself (same loads, same arithmetic: no broadcast barrier for them).
 #pragma once
 #include "fwsim_device.hpp"
 #include "fwsim_objlock.hpp"
@@ -23,59 +33,100 @@ struct RenderC {            // camera constants in double (built on the host fro
   double tan_half_fov, near_, far_, duck_radius, obst_radius;
 };
 
+constexpr int kRTile = 16;                      // a wave's tile: 16 x 16 pixels, four per lane (rows y0 + lane / 16 + 4 k)
+
 template <typename T>
 __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r, int tile, int n_envs, RenderC K, int res,
                                                         float* __restrict__ out) {
-#pragma clang fp contract(off)                    // this kernel only (block scope): multiply-adds stay two roundings, as in the CPU checker's C
-  __shared__ double s_c[24];                      // R[9] cam[3] zc xc yc k2 | flag nob
-  __shared__ double s_cyl[FW_MAX_OBSTACLES][3];
-  const int env = blockIdx.x, t = threadIdx.x;
+#pragma clang fp contract(off)                    // this kernel only: multiply-adds stay two roundings, as in the CPU checker's C
+  __shared__ double s_pose[28];                   // R[9] cam[3] zc xc yc k2 | Hf Hr Hd (the camera axes in the world frame)
+  __shared__ double s_cyl[FW_MAX_OBSTACLES][4];   // ox, oy, cc, height: cam - axis (horizontal), |.|^2 - radius^2
+  __shared__ float s_wedge[FW_MAX_OBSTACLES][2][3];   // the two tangent half-planes as affine forms g(a, b) = g0 + a g1 + b g2 (>= 0 inside); [.][0][0] = +inf: never cull
+  __shared__ float s_margin[FW_MAX_OBSTACLES];
+  __shared__ int s_blocked;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* s_ab = reinterpret_cast<double*>(smem_raw);      // [res]: (i - u0) / F, the image-plane coordinate of pixel column / row i (the image is square)
+  const int env = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (env >= n_envs) return;
   auto fld = [&](int f) { return (double)r[tile_index(tile, RF_COUNT, f, env)]; };
   int nob = (int)fld(RF_TASK + FW_ST_NUM_OBST);
   nob = nob < 0 ? 0 : (nob > FW_MAX_OBSTACLES ? FW_MAX_OBSTACLES : nob);
-  if (t < 3 * FW_MAX_OBSTACLES) s_cyl[t / 3][t % 3] = (t / 3 < nob) ? fld(RF_TASK + FW_ST_OBST + t) : 0.0;
-  __syncthreads();
-  if (t == 0) {
+  const double W = (double)res, F = 0.5 * W / K.tan_half_fov, u0 = 0.5 * (W - 1.0), near = K.near_, far = K.far_;
+  for (int i = t; i < res; i += (int)blockDim.x) s_ab[i] = ((double)i - u0) / F;      // (one IEEE division per column, not four per pixel)
+  if (t == 0) s_blocked = 0;
+  if (wave == 0) {
+    // the pose, the duck in the camera frame, the ray basis: every lane of the first wave for itself (no broadcast inside the
+    // wave), lane 0 leaves them for the other waves
+    double R[9], cam[3], relw[3], zc, xc, yc, k2, Hf[3], Hr[3], Hd[3];
     const double x = fld(RF_QUAT), y = fld(RF_QUAT + 1), z = fld(RF_QUAT + 2), w = fld(RF_QUAT + 3);
     const double d = x * x + y * y + z * z + w * w, s = 2.0 / d;                 // btMatrix3x3::setRotation
     const double xs = x * s, ys = y * s, zs = z * s, wx = w * xs, wy = w * ys, wz = w * zs;
     const double xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
-    double R[9] = { 1.0 - (yy + zz), xy - wz, xz + wy, xy + wz, 1.0 - (xx + zz), yz - wx, xz - wy, yz + wx, 1.0 - (xx + yy) };
-    double cam[3];
+    R[0] = 1.0 - (yy + zz); R[1] = xy - wz; R[2] = xz + wy; R[3] = xy + wz; R[4] = 1.0 - (xx + zz); R[5] = yz - wx;
+    R[6] = xz - wy; R[7] = yz + wx; R[8] = 1.0 - (xx + yy);
     for (int k = 0; k < 3; ++k) cam[k] = fld(RF_POS + k) + (R[3 * k] * K.cam_off[0] + R[3 * k + 1] * K.cam_off[1] + R[3 * k + 2] * K.cam_off[2]);
     const double Rd = K.duck_radius;
     const double C[3] = { fld(RF_TASK + FW_ST_DUCK_POS), fld(RF_TASK + FW_ST_DUCK_POS + 1), fld(RF_TASK + FW_ST_DUCK_POS + 2) + Rd };
-    const double relw[3] = { C[0] - cam[0], C[1] - cam[1], C[2] - cam[2] };
+    for (int k = 0; k < 3; ++k) relw[k] = C[k] - cam[k];
     double relb[3];
     for (int k = 0; k < 3; ++k) relb[k] = R[k] * relw[0] + R[3 + k] * relw[1] + R[6 + k] * relw[2];       // R^T relw
-    const double zc = relb[0] * K.cam_f[0] + relb[1] * K.cam_f[1] + relb[2] * K.cam_f[2];
-    const double xc = relb[0] * K.cam_r[0] + relb[1] * K.cam_r[1] + relb[2] * K.cam_r[2];
-    const double yc = relb[0] * K.cam_d[0] + relb[1] * K.cam_d[1] + relb[2] * K.cam_d[2];
-    const double k2 = zc * zc + xc * xc + yc * yc - Rd * Rd;
-    bool blocked = false;                                                          // occluded(): the segment cam -> C
-    for (int o = 0; o < nob; ++o) {
-      const double ox = cam[0] - s_cyl[o][0], oy = cam[1] - s_cyl[o][1], hh = s_cyl[o][2];
-      const double a = relw[0] * relw[0] + relw[1] * relw[1], b = 2.0 * (ox * relw[0] + oy * relw[1]);
-      const double cc = ox * ox + oy * oy - K.obst_radius * K.obst_radius;
-      if (a <= 0.0) continue;
-      const double disc = b * b - 4.0 * a * cc;
-      if (disc < 0.0) continue;
-      const double tt = (-b - ::sqrt(disc)) / (2.0 * a);
-      if (tt <= 0.0 || tt >= 1.0) continue;
-      const double zz2 = cam[2] + tt * relw[2];
-      if (zz2 >= 0.0 && zz2 <= hh) blocked = true;
+    zc = relb[0] * K.cam_f[0] + relb[1] * K.cam_f[1] + relb[2] * K.cam_f[2];
+    xc = relb[0] * K.cam_r[0] + relb[1] * K.cam_r[1] + relb[2] * K.cam_r[2];
+    yc = relb[0] * K.cam_d[0] + relb[1] * K.cam_d[1] + relb[2] * K.cam_d[2];
+    k2 = zc * zc + xc * xc + yc * yc - Rd * Rd;
+    for (int k = 0; k < 3; ++k) {                    // (culling only)
+      Hf[k] = R[3 * k] * K.cam_f[0] + R[3 * k + 1] * K.cam_f[1] + R[3 * k + 2] * K.cam_f[2];
+      Hr[k] = R[3 * k] * K.cam_r[0] + R[3 * k + 1] * K.cam_r[1] + R[3 * k + 2] * K.cam_r[2];
+      Hd[k] = R[3 * k] * K.cam_d[0] + R[3 * k + 1] * K.cam_d[1] + R[3 * k + 2] * K.cam_d[2];
     }
-    for (int k = 0; k < 9; ++k) s_c[k] = R[k];
-    for (int k = 0; k < 3; ++k) s_c[9 + k] = cam[k];
-    s_c[12] = zc; s_c[13] = xc; s_c[14] = yc; s_c[15] = k2;
-    s_c[16] = (zc - Rd > K.near_ && zc - Rd < K.far_ && !blocked) ? 1.0 : 0.0;
+    if (lane == 0) {
+      for (int k = 0; k < 9; ++k) s_pose[k] = R[k];
+      for (int k = 0; k < 3; ++k) s_pose[9 + k] = cam[k];
+      s_pose[12] = zc; s_pose[13] = xc; s_pose[14] = yc; s_pose[15] = k2;
+    }
+    if (lane < FW_MAX_OBSTACLES) {                   // lane o: cylinder o
+      bool blocked = false;
+      double ox = 0.0, oy = 0.0, cc = 1.0, hh = 0.0;
+      if (lane < nob) {
+        const double ax = fld(RF_TASK + FW_ST_OBST + 3 * lane), ay = fld(RF_TASK + FW_ST_OBST + 3 * lane + 1);
+        hh = fld(RF_TASK + FW_ST_OBST + 3 * lane + 2);
+        ox = cam[0] - ax; oy = cam[1] - ay;
+        cc = ox * ox + oy * oy - K.obst_radius * K.obst_radius;
+        // occluded(): the segment cam -> duck centre against this cylinder
+        const double a = relw[0] * relw[0] + relw[1] * relw[1], b = 2.0 * (ox * relw[0] + oy * relw[1]);
+        if (a > 0.0) {
+          const double disc = b * b - 4.0 * a * cc;
+          if (disc >= 0.0) {
+            const double tt = (-b - ::sqrt(disc)) / (2.0 * a);
+            if (tt > 0.0 && tt < 1.0) { const double zz2 = cam[2] + tt * relw[2]; if (zz2 >= 0.0 && zz2 <= hh) blocked = true; }
+          }
+        }
+      }
+      s_cyl[lane][0] = ox; s_cyl[lane][1] = oy; s_cyl[lane][2] = cc; s_cyl[lane][3] = hh;
+      // the wedge (culling only; float): with e = axis - cam = (-ox, -oy), a horizontal direction h is inside iff
+      // tan(beta) (h . e) -+ (h x e) >= 0, sin(beta) = radius / |e|, tan(beta) = radius / sqrt(cc)
+      float g[2][3] = {{__builtin_inff(), 0.f, 0.f}, {0.f, 0.f, 0.f}}, margin = 0.f;
+      if (lane < nob && cc > 1e-9) {
+        const float ex = (float)-ox, ey = (float)-oy, tb = (float)(K.obst_radius / ::sqrt(cc));
+        const float H[3][2] = {{(float)Hf[0], (float)Hf[1]}, {(float)Hr[0], (float)Hr[1]}, {(float)Hd[0], (float)Hd[1]}};
+        for (int k = 0; k < 3; ++k) {
+          const float dot = H[k][0] * ex + H[k][1] * ey, crs = H[k][0] * ey - H[k][1] * ex;
+          g[0][k] = tb * dot - crs; g[1][k] = tb * dot + crs;
+        }
+        // seven orders of magnitude above float rounding, relative to the forms' scale |h| |e| (1 + tan beta), |h| <= 1 + |a| + |b|
+        margin = 1e-4f * (1.0f + tb) * sqrtf(ex * ex + ey * ey) * (1.0f + 2.0f * (float)(K.tan_half_fov > 1.0 ? K.tan_half_fov : 1.0));
+      }
+      for (int k = 0; k < 3; ++k) { s_wedge[lane][0][k] = g[0][k]; s_wedge[lane][1][k] = g[1][k]; }
+      s_margin[lane] = margin;
+      if (blocked) s_blocked = 1;
+    }
   }
   __syncthreads();
-  const double W = (double)res, F = 0.5 * W / K.tan_half_fov, u0 = 0.5 * (W - 1.0), near = K.near_, far = K.far_;
-  const double zc = s_c[12], xc = s_c[13], yc = s_c[14], k2 = s_c[15];
-  const bool duck_possible = s_c[16] != 0.0;
-  const double cam0 = s_c[9], cam1 = s_c[10], cam2 = s_c[11];
+  double R[9], cam[3];
+  for (int k = 0; k < 9; ++k) R[k] = s_pose[k];
+  for (int k = 0; k < 3; ++k) cam[k] = s_pose[9 + k];
+  const double zc = s_pose[12], xc = s_pose[13], yc = s_pose[14], k2 = s_pose[15];
+  const bool duck_possible = zc - K.duck_radius > near && zc - K.duck_radius < far && s_blocked == 0;
   float* img = out + (size_t)env * 2 * res * res;
   auto depth_buffer_of = [&](double tv) {
 #pragma clang fp contract(off)
@@ -83,40 +134,72 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
     if (tv > far) tv = far;
     return far * (tv - near) / (tv * (far - near));
   };
-  for (int px = t; px < res * res; px += 256) {
-    const int yi = px / res, xi = px - yi * res;
-    const double a = ((double)xi - u0) / F, b = ((double)yi - u0) / F;
-    bool is_duck = false;
-    double t_duck = 0.0;
-    if (duck_possible) {
-      const double q = 1.0 + a * a + b * b, p = zc + a * xc + b * yc, disc = p * p - q * k2;
-      if (disc >= 0.0 && p > 0.0) { t_duck = (p - ::sqrt(disc)) / q; is_duck = t_duck > near && t_duck < far; }
-    }
-    double dv;
-    if (is_duck) dv = depth_buffer_of(t_duck);
-    else {
-      double db[3], dw[3];
-      for (int k = 0; k < 3; ++k) db[k] = K.cam_f[k] + a * K.cam_r[k] + b * K.cam_d[k];
-      for (int k = 0; k < 3; ++k) dw[k] = s_c[3 * k] * db[0] + s_c[3 * k + 1] * db[1] + s_c[3 * k + 2] * db[2];
-      double best = far;                                                           // ray_depth()
-      if (dw[2] < 0.0) { const double tg = -cam2 / dw[2]; if (tg > 0.0 && tg < best) best = tg; }
-      for (int o = 0; o < nob; ++o) {
-        const double ox = cam0 - s_cyl[o][0], oy = cam1 - s_cyl[o][1], hh = s_cyl[o][2];
-        const double qa = dw[0] * dw[0] + dw[1] * dw[1], qb = 2.0 * (ox * dw[0] + oy * dw[1]);
-        const double cc = ox * ox + oy * oy - K.obst_radius * K.obst_radius;
-        if (qa <= 0.0) continue;
-        const double disc = qb * qb - 4.0 * qa * cc;
-        if (disc < 0.0) continue;
-        const double tc = (-qb - ::sqrt(disc)) / (2.0 * qa);
-        if (tc <= 0.0) continue;
-        const double zz2 = cam2 + tc * dw[2];
-        if (zz2 < 0.0 || zz2 > hh) continue;
-        if (tc < best) best = tc;
+  const int tpr = (res + kRTile - 1) / kRTile, ntiles = tpr * tpr;
+  for (int tl = wave; tl < ntiles; tl += (int)(blockDim.x >> 6)) {
+    const int ty = tl / tpr, tx = tl - ty * tpr;
+    const int x0 = tx * kRTile, y0 = ty * kRTile, x1 = min(x0 + kRTile, res) - 1, y1 = min(y0 + kRTile, res) - 1;
+    // ---- cull: lane (cylinder c = lane / 4, corner = lane % 4), in two rounds for up to 32 cylinders ----
+    unsigned int alive = 0u;
+    for (int base = 0; base < nob; base += 16) {
+      const int c = base + (lane >> 2), corner = lane & 3;
+      bool in0 = false, in1 = false;                 // this corner is inside half-plane 0 / 1 of cylinder c (with the margin)
+      if (c < nob) {
+        const float a = (float)s_ab[(corner & 1) ? x1 : x0], b = (float)s_ab[(corner & 2) ? y1 : y0];
+        const float m = s_margin[c];
+        in0 = s_wedge[c][0][0] + a * s_wedge[c][0][1] + b * s_wedge[c][0][2] >= -m;
+        in1 = s_wedge[c][1][0] + a * s_wedge[c][1][1] + b * s_wedge[c][1][2] >= -m;
       }
-      dv = depth_buffer_of(best < near ? near : best);
+      // a half-plane that holds none of the four corners holds no pixel of the tile
+      const unsigned long long b0 = __ballot(in0), b1 = __ballot(in1);
+      const int q = lane & ~3;
+      const bool keep = ((b0 >> q) & 0xFull) != 0ull && ((b1 >> q) & 0xFull) != 0ull;
+      const unsigned long long kb = __ballot(keep && (lane & 3) == 0);
+      for (int i = 0; i < 16; ++i) if ((kb >> (4 * i)) & 1ull) alive |= 1u << (base + i);
     }
-    img[px] = is_duck ? 1.0f : 0.0f;
-    img[(size_t)res * res + px] = (float)dv;
+    // ---- pixels of the tile: column x0 + lane % 16, rows y0 + lane / 16 + 4 k ----
+    const int xi = x0 + (lane & (kRTile - 1));
+#pragma unroll 1
+    for (int k = 0; k < kRTile / 4; ++k) {
+      const int yi = y0 + (lane >> 4) + 4 * k;
+      if (xi >= res || yi >= res) continue;
+      const double a = s_ab[xi], b = s_ab[yi];
+      bool is_duck = false;
+      double t_duck = 0.0;
+      if (duck_possible) {
+        const double q = 1.0 + a * a + b * b, p = zc + a * xc + b * yc, disc = p * p - q * k2;
+        if (disc >= 0.0 && p > 0.0) { t_duck = (p - ::sqrt(disc)) / q; is_duck = t_duck > near && t_duck < far; }
+      }
+      double dv;
+      if (is_duck) dv = depth_buffer_of(t_duck);
+      else {
+        double db[3], dw[3];
+        for (int j = 0; j < 3; ++j) db[j] = K.cam_f[j] + a * K.cam_r[j] + b * K.cam_d[j];
+        for (int j = 0; j < 3; ++j) dw[j] = R[3 * j] * db[0] + R[3 * j + 1] * db[1] + R[3 * j + 2] * db[2];
+        double best = far;                                                           // ray_depth()
+        if (dw[2] < 0.0) { const double tg = -cam[2] / dw[2]; if (tg > 0.0 && tg < best) best = tg; }
+        const double qa = dw[0] * dw[0] + dw[1] * dw[1];
+        if (qa > 0.0) {
+          unsigned int m = alive;
+          while (m) {
+            const int o = __ffs((int)m) - 1;
+            m &= m - 1u;
+            const double ox = s_cyl[o][0], oy = s_cyl[o][1], cc = s_cyl[o][2], hh = s_cyl[o][3];
+            const double qb = 2.0 * (ox * dw[0] + oy * dw[1]);
+            const double disc = qb * qb - 4.0 * qa * cc;
+            if (disc < 0.0) continue;
+            const double tc = (-qb - ::sqrt(disc)) / (2.0 * qa);
+            if (tc <= 0.0) continue;
+            const double zz2 = cam[2] + tc * dw[2];
+            if (zz2 < 0.0 || zz2 > hh) continue;
+            if (tc < best) best = tc;
+          }
+        }
+        dv = depth_buffer_of(best < near ? near : best);
+      }
+      const int px = yi * res + xi;
+      img[px] = is_duck ? 1.0f : 0.0f;
+      img[(size_t)res * res + px] = (float)dv;
+    }
   }
 }
 

@@ -708,10 +708,9 @@ class PPO:
             # (NaN = "not there yet": fw_collect_step's step waves see their actions replace it and put it back)
             self._act_env = torch.full((env.num_envs, 4), float("nan"), dtype=env.venv.torch_dtype, device=self.device)
             self._tval = torch.zeros(env.num_envs, dtype=torch.float32, device=self.device)
-        # one launch per vec-step (fw_collect_step) where the handle's lane mapping has it: 8 lanes per env at one wave per SIMD
+        # one launch per vec-step (fw_collect_step) where the handle's lane mapping has it: 8 lanes per env (either build)
         self._one_launch = (self._collect_fused and bool(cfg.one_launch_collect) and hasattr(env.venv, "_h")
-                            and getattr(env.venv, "lanes_per_env", 0) == 8 and getattr(env.venv, "g8_waves", 1) == 1
-                            and float(env.gamma) == float(cfg.gamma))
+                            and getattr(env.venv, "lanes_per_env", 0) == 8 and float(env.gamma) == float(cfg.gamma))
         self._ws_collect = None
         self._status_host = self._status_event = None      # CS_STATUS of the workspace, copied out after every rollout
         self._status_pending = False

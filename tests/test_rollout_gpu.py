@@ -455,8 +455,8 @@ def test_fw_collect_act_normalises_on_load_and_finalises_the_previous_step():
                             R._p(rew1), R._p(st1), None) == K.FW_EINVAL           # finalisation needs the value block
 
 
-@pytest.mark.parametrize("task,n", [("waypoints", 4096), ("waypoints", 1000), ("waypoints", 24), ("waypoints", 8192), ("objlock", 1024), ("objlock", 4096), ("combined", 520), ("combined", 2048),
-                                    ("waypoints_wind", 2048)])
+@pytest.mark.parametrize("task,n", [("waypoints", 4096), ("waypoints", 1000), ("waypoints", 24), ("waypoints", 8192), ("waypoints", 12288), ("objlock", 1024), ("objlock", 4096),
+                                    ("combined", 520), ("combined", 2048), ("waypoints_wind", 2048), ("waypoints_wind", 8192)])
 def test_one_launch_vec_step_equals_the_three_launch_collector(task, n):
     """fw_collect_step (act waves + step waves + statistics fold in ONE grid) against fw_collect_act -> fw_step ->
     fw_collect_stats on twin envs, through PPO.collect_rollouts (hipGraph replays included): the same actions, log-probs,
@@ -470,6 +470,7 @@ def test_one_launch_vec_step_equals_the_three_launch_collector(task, n):
         env = P.FixedwingVecEnv(cfgs[task](), n, seed=21)
         ppo = R.PPO(R.VecNormalizeDevice(env), R.PPOConfig(n_steps=8, batch_size=64, n_epochs=1, seed=3, one_launch_collect=one))
         assert ppo._collect_fused and ppo._one_launch == one
+        assert env.g8_waves == (2 if (task == "waypoints" and n > 8192) or (task == "waypoints_wind" and n > 6144) else 1)      # (the two-wave build has its own collect kernel)
         bufs = []
         for _ in range(5):                                     # eager, capture, three replays
             ppo.collect_rollouts()
