@@ -712,7 +712,7 @@ class PPO:
         self._one_launch = (self._collect_fused and bool(cfg.one_launch_collect) and hasattr(env.venv, "_h")
                             and getattr(env.venv, "lanes_per_env", 0) == 8 and float(env.gamma) == float(cfg.gamma))
         self._ws_collect = None
-        self._status_host = self._status_event = None      # CS_STATUS of the workspace, copied out after every rollout
+        self._status_host = None           # CS_STATUS of the workspace, copied to pinned memory as the last command of every rollout
         self._status_pending = False
         # ... and then the rollout ends in one launch too (fw_collect_close), unless the caller brought its own GAE
         self._close_gae = bool(self._one_launch and gae_fn is gae_device)
@@ -861,8 +861,10 @@ class PPO:
                 c.adv, c.ret, c.T = self._adv_buf.data_ptr(), self._ret_buf.data_ptr(), T
                 c.gae_gamma, c.gae_lambda = float(cfg.gamma), float(cfg.gae_lambda)
                 _lib.check(L.fw_collect_close(venv._h, C.byref(a), C.byref(c), st), venv._h)
+                self._queue_collect_status()
                 return
             _lib.check(L.fw_collect_finish(venv._h, C.byref(a), st), venv._h)      # the last step's statistics (each step's are merged by the next launch)
+            self._queue_collect_status()
         for t in (range(T) if not self._one_launch else ()):
             act(t, 3, self.buf_val[t], t - 1 if t > 0 else None)
             venv.step_tensor(self._act_env)
@@ -890,33 +892,26 @@ class PPO:
                             (32, "the policy produced a NaN action (diverged weights or statistics)"))
 
     def _queue_collect_status(self) -> None:
-        """After a rollout through fw_collect_step: copy the workspace's status word to pinned host memory behind the rollout
-        (no synchronisation here -- train() and the next collect_rollouts() look at it)."""
+        """Last command of a rollout through fw_collect_step (inside the captured graph when there is one): the workspace's status
+        word goes to pinned host memory -- 4 bytes behind the closing launch, nothing between two replays (an event + side-stream
+        copy per rollout cost 19 us of gaps per 16-step rollout).  train() / state_dict() / the next collect_rollouts() look at it."""
         if not self._one_launch or self._ws_collect is None:
             return
         if self._status_host is None:
             self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-            self._status_event, self._rollout_done = torch.cuda.Event(), torch.cuda.Event()
-            self._status_stream = torch.cuda.Stream(device=self.device)
-        # on a side stream behind the rollout: the next rollout's launches do not queue behind a 4-byte copy (the word is sticky --
-        # bits are only ever OR-ed in -- so a later value is as good)
-        self._rollout_done.record()
-        with torch.cuda.stream(self._status_stream):
-            self._status_stream.wait_event(self._rollout_done)
-            self._status_host.copy_(self._ws_collect.view(torch.int32)[-16 + 3:-16 + 4], non_blocking=True)
-            self._status_event.record()
-        self._status_pending = True
+        self._status_host.copy_(self._ws_collect.view(torch.int32)[-16 + 3:-16 + 4], non_blocking=True)
 
     def check_collect_status(self, wait: bool = True) -> None:
         """Raise RuntimeError if a wait inside a fw_collect_step launch of the last rollout(s) ran out (the launch then went on
         with zero actions / partial statistics: everything collected since is void).  SB3's contract for ``VecEnv.step`` is
         "returns or raises"; a pipe to a dead SubprocVecEnv worker raises there
-        (train/train_Fixedwing_Waypoints_v3.py:251).  ``wait=False`` only looks if the copy has already arrived."""
-        if not self._status_pending:
+        (train/train_Fixedwing_Waypoints_v3.py:251).  ``wait=False`` only looks if the stream has drained (no synchronisation)."""
+        if not self._status_pending or self._status_host is None:
             return
+        stream = torch.cuda.current_stream(self.device)
         if wait:
-            self._status_event.synchronize()
-        elif not self._status_event.query():
+            stream.synchronize()
+        elif not stream.query():
             return
         self._status_pending = False
         st = int(self._status_host.item())
@@ -965,7 +960,7 @@ class PPO:
         else:
             body()
         self._warm_rollouts += 1
-        self._queue_collect_status()
+        self._status_pending = self._one_launch
         if hasattr(env, "sync_statistics"):
             env.sync_statistics()              # sharded job: one small all-reduce per rollout (no-op on one GPU)
         if self._collect_fused and self._close_gae:

@@ -9,7 +9,7 @@
 # large-N roofline evidence: FETCH/WRITE_SIZE and SQ_INSTS_VALU at N = 2^20 on the one-lane-per-env mapping).
 set -o pipefail
 export TMPDIR=/tmp
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 OUT=gpurun_out/${ROUND}_prof
 ENVS=${ENVS:-4096}
 EXTRA="--envs-per-gpu $ENVS"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collector benches of a round: one-launch (fw_collect_step) against the three-launch collector per task / env count, and the
 # in-launch timeline of fw_collect_step.  Run on the GPU box from the repo root; summaries land in gpurun_out/${ROUND}_profiles/.
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 OUT=gpurun_out/${ROUND}_profiles
 mkdir -p "$OUT"
 rm -f "$OUT/${ROUND}_rollout_bench.jsonl" "$OUT/${ROUND}_rollout_bench_three_launch.jsonl"

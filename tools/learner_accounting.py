@@ -64,6 +64,14 @@ def ppo_update(n_mb: int, B: int, D: int) -> dict:
             "workgroups": blocks, "mfma_peak_tflops": blocks * MFMA_F32_TFLOPS_CHIP / CUS}
 
 
+def ppo_pack(n_mb: int, B: int, D: int) -> dict:
+    """The parallel pre-pass of fw_ppo_update: every minibatch's rows gathered and written in walking order."""
+    Dq = ((D + 3) & ~3) + 8
+    it = {"rows gathered (obs D, action 4, old log-prob, advantage x 2 (statistics + row), return: float32) + index": n_mb * B * ((D + 8) * 4 + 4),
+          "packed rows written ((D rounded up to 4) + 8 floats)": n_mb * B * Dq * 4}
+    return {"bytes": sum(it.values()), "items": it, "mfma_flops": 0}
+
+
 def render(N: int, res: int) -> dict:
     return {"bytes": N * 2 * res * res * 4, "items": {"mask + depth, float32 [N, 2, res, res] written": N * 2 * res * res * 4}, "mfma_flops": 0}
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel statistics of one collector / update bench run (tools/bench_rollout.py): per-kernel launch counts and
 # durations of fw_collect_step's kernel, fw_gae, fw_ppo_update ...  Run on the GPU box from the repo root.
-ROUND=${ROUND:-r03}; TASK=${1:-waypoints}; ENVS=${2:-4096}
+ROUND=${ROUND:-r04}; TASK=${1:-waypoints}; ENVS=${2:-4096}
 OUT=$PWD/gpurun_out/${ROUND}_profiles; mkdir -p "$OUT"
 export TMPDIR=/tmp
 D=/tmp/prof_rollout_$$; rm -rf "$D"

@@ -90,9 +90,12 @@ for key in sorted(os.listdir(src)):
         elif k.startswith("fw_ppo_update_kernel"):
             T, B, ep = HP.get(task, (16, 128, 20))
             acct = A.ppo_update(ep * (T * envs // B), B, D)
+        elif k.startswith("fw_ppo_pack"):
+            T, B, ep = HP.get(task, (16, 128, 20))
+            acct = A.ppo_pack(ep * (T * envs // B), B, D)
         elif k.startswith("fw_render"):
             acct = A.render(envs, 32)
-        if k.startswith("fw_ppo_update_kernel") and "max_us" in e:
+        if k.startswith(("fw_ppo_update_kernel", "fw_ppo_pack_kernel")) and "max_us" in e:
             # the bench run launches this kernel for two configurations (the reference's minibatch size, then batch 4096): the
             # reference-hyper-parameter launches are the long ones
             e["avg_us_all_launches"] = e["avg_us"]; e["avg_us"] = e["max_us"]

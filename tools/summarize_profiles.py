@@ -13,7 +13,7 @@ import csv, json, os, re, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", f"{rnd}_prof")
 prof = os.path.join(ROOT, "profiles")
 WORDS = {"waypoints": 94, "waypoints_wind": 94, "objlock": 203, "combined": 193}
