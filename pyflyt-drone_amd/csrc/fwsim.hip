@@ -459,7 +459,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   // sat in front of the epilogue's loads (stored action, waypoints of the observation): vector memory operations retire in order
   // on gfx9, so those loads paid the stores' acknowledgement, ~2 k cycles in every wave.  The wind-free headline kernel has no such
   // loads (actions and waypoints ride in registers) and keeps storing at the latch point.
-  // (The camera kernels would gain the same way -- but with the stash their plain builds trip the compiler hazard of section 3
+  // (The camera kernels would gain the same way -- but with the stash their plain builds trip the compiler hazard of section 4
   // of DESIGN.md at the mask-row join, and the hazard-free form of that join costs 3-4 us; they keep the latch-point stores.)
   constexpr bool STASH = (!DEFER && !HASOBJ) || COLLECT;
   double* latch = STASH ? reinterpret_cast<double*>(smem_raw + Dg.stash_off) : nullptr;        // [EPW][4]: reward, done, (num_reached, flags), (strike, step_count)

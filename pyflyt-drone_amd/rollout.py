@@ -511,8 +511,8 @@ class PPOConfig:
     fused_update: bool = True              # run the whole minibatch sequence of train() in one HIP kernel (fw_ppo_update) when it applies
     fused_collect: bool = True             # policy forward / sampling / buffer writes and the reward path as fw_policy_act + fw_rollout_post
     one_launch_collect: bool = True        # the whole vec-step as ONE launch (fw_collect_step) where the env's lane mapping has it (8 lanes per env,
-                                           # one wave per SIMD), fw_collect_act -> fw_step -> fw_collect_stats elsewhere or when False: 34.3 vs 47.9 us
-                                           # per vec-step (waypoints, 4096 envs; profiles/r03_rollout_bench*.jsonl)
+                                           # one wave per SIMD), fw_collect_act -> fw_step -> fw_collect_stats elsewhere or when False: 34.9 vs 47.9 us
+                                           # per vec-step (waypoints, 4096 envs; profiles/r04_rollout_bench*.jsonl)
     detector: str = "none"                 # "cnn": CnnDetectorPolicy over the FPV render (fw_render) of a camera task -- torch path, gradient all-reduce
     image_res: int = 32                    #        side of the rendered image
     cnn_features: int = 32                 #        width of the extractor's output

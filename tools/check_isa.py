@@ -1,4 +1,4 @@
-"""Build-time guard against a register-allocator hazard seen with hipcc 7.2 on these kernels (DESIGN.md section 3,
+"""Build-time guard against a register-allocator hazard seen with hipcc 7.2 on these kernels (DESIGN.md section 4 "Compiler hazard guard"; CHANGELOG.md rounds 2-3,
 "Spills at divergent joins").
 
 When a VGPR is spilled to an AGPR (or to scratch) at the top of the block where divergent control flow re-joins, the spill
