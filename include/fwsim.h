@@ -387,7 +387,7 @@ int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t 
  *   Dp = obs_dim rounded up to even, the pad row is zero), then log_std[4].
  * Adam moments mom_m / mom_v (float32, fw_ppo_moment_count() elements each) are in the kernel's "slot" order, in
  * which every lane's elements are contiguous: fw_ppo_moment_map(obs_dim, out) gives the flat parameter index of
- * each slot (-1 for padding and for the kernel's working area in the second half), which is all a caller needs to
+ * each slot (-1 for padding and for the unused second half of the buffers), which is all a caller needs to
  * move them to and from its optimiser.  The slot order belongs to a library build (round 3 moved Wo's moments): persist
  * moments in the optimiser's own order, never in slot order.
  * obs[S,obs_dim], act[S,4], old_logp[S], adv[S], ret[S]: the rollout buffer (float32, device);

@@ -1886,7 +1886,7 @@ int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t 
 }
 
 int32_t fw_ppo_param_count(int32_t obs_dim) { return obs_dim > 0 ? ppo_total_params((obs_dim + 1) & ~1) : FW_EINVAL; }
-int32_t fw_ppo_moment_count(void) { return 2 * kPMomentSlots; }   // second half: working copy of the second chunk-half blocks
+int32_t fw_ppo_moment_count(void) { return 2 * kPMomentSlots; }   // (second half: unused since round 4 -- the moments live in registers during a call; kept for the ABI's buffer size)
 int32_t fw_ppo_moment_map(int32_t obs_dim, int32_t* flat_index_of_slot) {
   if (obs_dim <= 0 || obs_dim > 64 || !flat_index_of_slot) { g_err = "fw_ppo_moment_map: bad arguments"; return FW_EINVAL; }
   ppo_moment_map(obs_dim, flat_index_of_slot);

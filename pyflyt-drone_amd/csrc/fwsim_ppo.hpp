@@ -5,13 +5,14 @@
 //
 // Why a kernel: with thousands of envs one update is ~10^4 *sequential* minibatch steps of a 12 k-parameter
 // network.  As framework ops that is ~30 launches per step and the update, not the simulator, bounds
-// end-to-end throughput (4.5 s per 65 536-sample update).  Here ONE workgroup walks the whole minibatch
-// sequence: weights stay in LDS for the entire call, activations of a 64-sample chunk live in LDS, every
+// end-to-end throughput (4.5 s per 65 536-sample update).  Here one workgroup per (network, chunk half) walks the whole
+// minibatch sequence: weights stay in LDS for the entire call, activations of a 64-sample chunk live in LDS, every
 // GEMM (forward, dW = A^T G, dX = G W^T) is the same strided 32x32 tile routine on `v_mfma_f32_32x32x2_f32`
 // (exact fp32, so parity with the torch path is fp32 rounding), weight-gradient tiles accumulate in
 // registers across chunks, and each lane applies gradient clipping + Adam to exactly the elements it holds
 // (no gradient staging, no second kernel).  The path is sequential by definition of SGD; the only parallelism
-// is inside a minibatch, which is why it is one CU and not a grid.
+// is inside a minibatch, which is why it is four CUs and not a grid.  The rows themselves are gathered by a parallel
+// pre-pass (fw_ppo_pack_kernel) so that nothing on the sequential path depends on an index.
 //
 // Flat parameter layout (floats), used for params / exp_avg / exp_avg_sq alike (rollout.py builds it):
 //   for net in (pi, vf):  W1[Dp][64]  b1[64]  W2[64][64]  b2[64]  Wo[64][KO]  bo[KO]     (KO = 4 / 1)
@@ -204,17 +205,18 @@ __global__ __launch_bounds__(256) void fw_ppo_pack_kernel(PpoPackArgs P) {
 // jointly, exchanged once per minibatch through one 64-bit word each (tag | partial sum of squares, device-scope
 // atomics).  Minibatches of >= 128 samples are additionally split over two workgroups per network, each running
 // every other 64-sample chunk; the pair swaps its gradient partials through global memory (release / acquire at
-// device scope, double-buffered by minibatch parity), after which both hold the same sum and apply the same Adam
-// step to their own LDS copy of the weights (the second one on a private copy of the moments).  grid = 2 or 4;
-// all blocks are always co-resident, every spin is bounded.
+// device scope -- or, on a shared XCD, store wait / loads past the L1 -- double-buffered by minibatch parity), after which
+// both hold the same sum and apply the same Adam step to their own LDS copy of the weights and their own register copy of
+// the moments.  2 or 4 working blocks, always co-resident; every wait is bounded and a wait that runs out ends the call with
+// a status word instead of a result (ppo_wait, include/fwsim.h FW_PPO_ST_*).
 // Work split of the 256 threads of a block (4 waves, one per SIMD, fixed for the whole call):
 //   * every 64 x 64 product (H1, H2, G2, G1, dW2) is 2 x 2 tiles of 32 x 32: wave w owns tile (w >> 1, w & 1);
-//   * dW1 is ceil(Dp / 32) x 2 tiles (waves 0-1 or all four); the head products (64 x KO, masked to KO columns)
-//     are 2 row tiles on waves 0-1;
-//   * bias gradients are column sums: thread (wave q, lane n) sums rows 16 q .. 16 q + 15 of column n;
-//   * the per-sample loss runs one sample per lane on wave 0.
-// Each lane applies clipping + Adam to the accumulator elements it holds (their moments stay in global memory / L2,
-// in slot order; held in registers for the whole call they push the kernel past the 512-register budget).
+//   * dW1 is ceil(Dp / 32) x 2 tiles: all four waves own one (> 32 features), or waves 0-1 own them and every wave computes
+//     one over half of the chunk's samples (<= 32 features; the halves meet in LDS once per minibatch);
+//   * the 64 x KO head, its loss gradient and dWo run on the vector ALU: thread (sample or hidden unit, quarter / component);
+//   * bias gradients are column sums: thread (wave q, lane n) sums rows 16 q .. 16 q + 15 of column n.
+// Each lane applies clipping + Adam to the accumulator elements it holds; their moments are loaded once (slot order:
+// ppo_moment_map), live in registers (AGPRs) for the whole call and are written back by the first chunk half at the end.
 // Exchange words between two blocks.  `l2` = both run on one XCD: the word is written through this CU's L1 into the shared L2 and
 // read by an atomic OR of zero -- atomics execute in the L2 -- instead of device-scope accesses that travel to memory.
 __device__ __forceinline__ void ppo_word_store(unsigned long long* p, unsigned long long v, bool l2) {
@@ -804,9 +806,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     const float total_norm = sqrtf(ss_mine + ss_other);
     const float clipc = fminf(H.max_grad_norm / (total_norm + 1e-6f), 1.0f);
 
-    // ---- Adam on the elements each lane holds.  The moments live in global memory (L2) in "slot" order
-    // (ppo_moment_map): the 16 accumulator elements of a lane are 16 consecutive floats, so a tile's moments
-    // are four dwordx4 loads / stores from one address, with no per-element index arithmetic or branches.
+    // ---- Adam on the elements each lane holds (moments: registers, see above) ----
     bc1 *= H.beta1; bc2 *= H.beta2;
     const float c1 = H.lr / (1.0f - bc1), sc2 = 1.0f / sqrtf(1.0f - bc2);      // step size, 1 / sqrt(bias correction 2)
     auto adam_tile = [&](const f32x16& g, float4 (&m4)[4], float4 (&v4)[4], auto&& lds_of /* v -> weight in LDS (rows the network does not have: the lane's sink word) */) {
