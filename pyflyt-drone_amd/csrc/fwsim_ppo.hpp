@@ -361,14 +361,15 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   // chunk ahead -- float4 e of the chunk by thread e % 256 in pass e / 256 (coalesced: a wave-level load is 1 KB in a row) --
   // and scattered to X / sA / sS when the chunk's turn comes.  Where a float4 lands is the same for every chunk: computed once.
   const int cpm = B / kPChunk;
-  const int W4 = ((D + 3) >> 2) + 2, npass = (kPChunk * W4 + kPThreads - 1) / kPThreads;      // 9 float4s per row, 3 passes (obs 28); 16, 4 (obs 56)
+  const int W4 = ((D + 3) >> 2) + 2, npass = (kPChunk * W4 + kPThreads - 1) / kPThreads;      // 9 float4s per row, 3 passes (obs 28); 16, 4 (obs 56); 18, 5 (obs 64)
   typedef float ppo_x4 __attribute__((ext_vector_type(4)));
-  ppo_x4 pre_x[4];
-  int pre_dst[4];                                    // LDS destination (float offset) of pass p's float4; < 0: nothing of mine / not this network's
+  constexpr int kPass = 5;                           // 64 rows x (16 + 2) float4s / 256 threads, rounded up (obs 57 .. 64; 28: 3, 56: 4)
+  ppo_x4 pre_x[kPass];
+  int pre_dst[kPass];                                    // LDS destination (float offset) of pass p's float4; < 0: nothing of mine / not this network's
   {
     const int Dv4 = W4 - 2;
 #pragma unroll
-    for (int p_ = 0; p_ < 4; ++p_) {
+    for (int p_ = 0; p_ < kPass; ++p_) {
       const int e = t + p_ * kPThreads, row = e / W4, q = e - row * W4;
       int d = -1;
       if (p_ < npass && e < kPChunk * W4) {
@@ -382,11 +383,11 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   auto prefetch = [&](int g) {
     const ppo_x4* src = reinterpret_cast<const ppo_x4*>(A.packed) + (size_t)g * (kPChunk * W4) + t;
 #pragma unroll
-    for (int p_ = 0; p_ < 4; ++p_) if (p_ < npass && pre_dst[p_] >= 0) pre_x[p_] = src[p_ * kPThreads];
+    for (int p_ = 0; p_ < kPass; ++p_) if (p_ < npass && pre_dst[p_] >= 0) pre_x[p_] = src[p_ * kPThreads];
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int p_ = 0; p_ < 4; ++p_) {
+    for (int p_ = 0; p_ < kPass; ++p_) {
       if (p_ < npass && pre_dst[p_] >= 0) {
         float* d = lds + pre_dst[p_];
 #pragma unroll

@@ -145,12 +145,16 @@ def _filled_ppo(fused, d, bs, n_epochs, T=4, n=256, seed=5, scope="minibatch", s
     return ppo
 
 
-@pytest.mark.parametrize("d,bs,scope", [(28, 128, "minibatch"), (56, 64, "minibatch"), (28, 64, "global"), (27, 256, "minibatch")])
+@pytest.mark.parametrize("d,bs,scope", [(28, 128, "minibatch"), (56, 64, "minibatch"), (28, 64, "global"), (27, 256, "minibatch"),
+                                        (5, 64, "minibatch"),        # a row narrower than two float4s, not 16-byte aligned
+                                        (28, 192, "minibatch"),      # three chunks per minibatch: the chunk halves run 2 and 1 of them
+                                        (64, 128, "global")])        # the widest input: four dW1 tiles, no split
 def test_fused_ppo_update_matches_the_torch_path(d, bs, scope):
     """fw_ppo_update (one kernel for the whole minibatch sequence) against the plain torch PPO.train() on the same
     buffers, permutations, initial weights and Adam state: parameters, Adam moments and step count agree to fp32
     rounding after 2 epochs (16-32 sequential minibatch steps), and again after a second call (warm Adam state)."""
-    a, b = _filled_ppo(True, d, bs, 2, scope=scope), _filled_ppo(False, d, bs, 2, scope=scope)
+    T_ = 3 if bs == 192 else 4                      # (3 x 256 samples divide into 192-sample minibatches)
+    a, b = _filled_ppo(True, d, bs, 2, T=T_, scope=scope), _filled_ppo(False, d, bs, 2, T=T_, scope=scope)
     for p, q in zip(a.policy.parameters(), b.policy.parameters()):
         assert torch.equal(p, q)
     for rnd in range(2):
@@ -159,7 +163,7 @@ def test_fused_ppo_update_matches_the_torch_path(d, bs, scope):
         for (na, p), (nb_, q) in zip(a.policy.named_parameters(), b.policy.named_parameters()):
             torch.testing.assert_close(p, q, rtol=2e-3, atol=2e-5, msg=lambda m: f"{na} round {rnd}: {m}")
             sa, sb = a.optimizer.state[p], b.optimizer.state[q]
-            assert float(sa["step"]) == float(sb["step"]) == (rnd + 1) * 2 * (4 * 256 // bs)
+            assert float(sa["step"]) == float(sb["step"]) == (rnd + 1) * 2 * (T_ * 256 // bs)
             torch.testing.assert_close(sa["exp_avg"], sb["exp_avg"], rtol=5e-3, atol=1e-6)
             torch.testing.assert_close(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=5e-3, atol=1e-9)
         for k in ("policy_loss", "value_loss"):
