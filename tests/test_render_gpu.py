@@ -46,7 +46,7 @@ def _directed_state(oracle, s, rng, nobs):
 @pytest.mark.parametrize("task", ["objlock", "combined"])
 def test_render_matches_the_oracle_pixel_by_pixel_on_directed_poses(oracle, lanes, task):
     rng = np.random.default_rng(31)
-    for res, nobs in ((64, 20), (33, 5), (128, 0)):
+    for res, nobs in ((64, 20), (33, 5), (128, 0), (7, 20)):        # (7: one ragged tile; 33: tiles of 16, 16 and 1 columns)
         if task == "objlock":
             cfg = K.objlock_config(motor_noise=False, auto_reset=False, flight_dome_size=1e5, num_obstacles=max(nobs, 1), obstacle_radius=2.0,
                                    duck_global_scaling=60.0)
@@ -65,7 +65,7 @@ def test_render_matches_the_oracle_pixel_by_pixel_on_directed_poses(oracle, lane
         np.testing.assert_allclose(got[:, 1], want[:, 1], rtol=0, atol=1e-7, err_msg=f"depth channel, res {res}")
         ducks = (want[:, 0].sum(axis=(1, 2)) > 0).sum()
         cyl = ((want[:, 1] < 0.999) & (want[:, 0] == 0)).any(axis=(1, 2)).sum()
-        assert ducks >= n // 5 and (nobs == 0 or cyl >= n // 10), (res, ducks, cyl)
+        assert res < 16 or (ducks >= n // 5 and (nobs == 0 or cyl >= n // 10)), (res, ducks, cyl)      # (the poses are aimed for images of >= 16 pixels)
         hip.close()
 
 
