@@ -23,8 +23,11 @@
 //   the last 2 D + 2 blocks     "fold waves", one per partial-sum word (collect_fold_wave).
 // Workgroups are dispatched in block order and every wave waits only for waves in front of it (act waves for nobody, step
 // waves for act waves, fold waves for step waves and the merge wave), so every word a wave waits for belongs to a wave that
-// is already running or done: no deadlock whatever the residency.  A wait that runs out (it never should) raises a status
-// bit and the wave goes on with what it finds; tests assert the word stays 0.
+// is already running or done: no deadlock whatever the residency.  Every wait is bounded (CollectArgs::spin); one that runs
+// out -- it never should; in-order dispatch is true in practice and promised nowhere -- raises a bit of the sticky status word
+// (CS_ST_*, include/fwsim.h FW_COLLECT_ST_*) and the wave goes on with what it finds, so that the grid always drains.  The
+// product reads the word once per rollout (rollout.PPO.check_collect_status: the graph's last node copies it to pinned memory)
+// and raises before the rollout is used; tests provoke the timeouts with FWSIM_SPIN_LOG2 and assert exactly that.
 //
 // The statistics of VecNormalize.step_wait (observation moments, discounted-return tracker) need a reduction over ALL envs
 // between the env step and the next policy forward.  Versions of this round, in order (waypoints, 4096 envs, us per
