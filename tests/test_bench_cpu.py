@@ -56,3 +56,24 @@ def test_under_a_launcher_the_ranks_agree_with_gpus():
     lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
     assert p.returncode == 0, p.stderr
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 7 and lines[0]["ranks_seen"] == 2
+
+
+def test_learner_accounting_matches_the_documented_figures():
+    """tools/learner_accounting.py is the numerator of every learner roofline (bench.py `collector.roofline`,
+    profiles/r04_learner_pmc.json): the documented figures follow from it."""
+    sys.path.insert(0, ROOT)
+    from tools import learner_accounting as A
+    c = A.collect_step(4096, 28, 94)
+    assert c["bytes"] == sum(c["items"].values()) == 19_301_376
+    assert c["items"]["env_step (fw_step's words per env-step x N)"] == 94 * 8 * 4096
+    u = A.ppo_update(10240, 128, 28)
+    assert u["workgroups"] == 4 and abs(u["mfma_peak_tflops"] - 4 * 157.3 / 256) < 1e-12
+    # forward + backward MACs of both networks per sample: (28 x 64 + 64 x 64 + 64 x KO) + (2 x 64 x KO + 2 x 64 x 64 + 28 x 64)
+    macs = sum((28 * 64 + 64 * 64 + 64 * ko) + (2 * 64 * ko + 2 * 64 * 64 + 28 * 64) for ko in (4, 1))
+    assert u["flops_per_minibatch"] == 2 * 128 * macs == 8_372_224
+    assert A.ppo_update(5120, 64, 56)["workgroups"] == 2
+    r = A.roofline_mfma(u["mfma_flops"], 147_394.5, u["mfma_peak_tflops"])
+    assert abs(r["frac"] - 0.2367) < 5e-4                      # profiles/r04_learner_pmc.json: fw_ppo_update_kernel, waypoints
+    assert A.render(4096, 32)["bytes"] == 33_554_432
+    p = A.ppo_pack(10240, 128, 28)
+    assert p["items"]["packed rows written ((D rounded up to 4) + 8 floats)"] == 10240 * 128 * 36 * 4
