@@ -901,20 +901,33 @@ class PPO:
             self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._status_host.copy_(self._ws_collect.view(torch.int32)[-16 + 3:-16 + 4], non_blocking=True)
 
-    def check_collect_status(self, wait: bool = True) -> None:
+    def check_collect_status(self, wait: bool = True, collective: bool = False) -> None:
         """Raise RuntimeError if a wait inside a fw_collect_step launch of the last rollout(s) ran out (the launch then went on
         with zero actions / partial statistics: everything collected since is void).  SB3's contract for ``VecEnv.step`` is
         "returns or raises"; a pipe to a dead SubprocVecEnv worker raises there
-        (train/train_Fixedwing_Waypoints_v3.py:251).  ``wait=False`` only looks if the stream has drained (no synchronisation)."""
-        if not self._status_pending or self._status_host is None:
+        (train/train_Fixedwing_Waypoints_v3.py:251).  ``wait=False`` only looks if the stream has drained (no synchronisation).
+        ``collective=True`` (a point every rank of a sharded job reaches: train()): the ranks agree on the union of their words, so
+        that all of them raise together instead of one leaving the others in the next collective."""
+        td = _dist() if (collective and self._one_launch) else None      # (the same configuration on every rank: all or none take this branch)
+        if td is None and (not self._status_pending or self._status_host is None):
             return
-        stream = torch.cuda.current_stream(self.device)
-        if wait:
-            stream.synchronize()
-        elif not stream.query():
-            return
-        self._status_pending = False
-        st = int(self._status_host.item())
+        st = 0
+        if self._status_pending and self._status_host is not None:
+            stream = torch.cuda.current_stream(self.device)
+            if wait:
+                stream.synchronize()
+            elif not stream.query():
+                return
+            self._status_pending = False
+            st = int(self._status_host.item())
+        if td is not None:
+            bits = torch.tensor([float(bool(st & b)) for b, _ in self._COLLECT_STATUS_BITS], dtype=torch.float64, device=self.device)
+            counts = all_reduce_sum_(bits).tolist()
+            st_all = sum(b for (b, _), c in zip(self._COLLECT_STATUS_BITS, counts) if c > 0)
+            if st_all and not st:
+                self._ws_collect = None; self._g_rollout = None; self._warm_rollouts = 0
+                self._act_env.fill_(float("nan"))
+                raise RuntimeError(f"fw_collect_step: another rank of the job reported status word {st_all}; the rollout is void on every rank")
         if st == 0:
             return
         why = "; ".join(t for b, t in self._COLLECT_STATUS_BITS if st & b)
@@ -1032,7 +1045,7 @@ class PPO:
 
     def train(self):
         cfg = self.cfg
-        self.check_collect_status()                # a void rollout must not reach the update
+        self.check_collect_status(collective=True)     # a void rollout must not reach the update -- on any rank
         obs, act, old_logp, adv, ret = self._update_buffers()
         B = obs.shape[0]
         if self._replicated:                                     # the gathered advantages ARE the global ones
