@@ -74,3 +74,30 @@ def sharded_training(rank, world, task, n_envs, n_steps, batch_size, n_epochs, i
     return dict(facts=facts, checks=checks, weights=flat, stats=stats, counters=ctr, num_timesteps=ppo.num_timesteps,
                 allgather_bytes=ppo.allgather_bytes, allgather_ms=ppo.allgather_ms, first_obs=first_obs,
                 logs=dict(ppo.logs), finite=bool(np.isfinite(flat).all()))
+
+
+def status_agreement(rank, world, n_envs):
+    """Both ranks collect a clean rollout; rank 1's copy of the collector status word is then poisoned (as if a wait inside one of
+    ITS launches had run out).  train() is the collective point: both ranks must raise, rank 0 on rank 1's word."""
+    import torch
+    import pyflyt_drone_amd as P
+    from pyflyt_drone_amd import config as K
+    from pyflyt_drone_amd import rollout as R
+    torch.cuda.set_device(0)
+    venv = P.FixedwingVecEnv(K.train_waypoints_v3_config(), n_envs, device=0, seed=42, global_env_offset=rank * n_envs)
+    ppo = R.PPO(R.VecNormalizeDevice(venv), R.PPOConfig(n_steps=4, batch_size=128, n_epochs=1, seed=42))
+    assert ppo._one_launch
+    ppo.collect_rollouts()
+    torch.cuda.synchronize()
+    assert int(ppo._status_host.item()) == 0
+    if rank == 1:
+        ppo._status_host.fill_(2)                     # "a fold wave summed without every partial sum"
+    try:
+        ppo.train()
+    except RuntimeError as e:
+        msg = str(e)
+    else:
+        msg = "no error"
+    # the object is usable afterwards on both ranks
+    ppo.collect_rollouts(); ppo.train()
+    return dict(msg=msg, checksum=ppo.replica_checksum())

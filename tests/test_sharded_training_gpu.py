@@ -37,3 +37,12 @@ def test_allreduce_mode_keeps_the_replicas_identical_on_the_gpu(two_ranks):
         assert r["checks"] == [0.0, 0.0], "replicas diverged"
         assert r["finite"]
     assert np.array_equal(a["weights"], b["weights"])
+
+
+def test_every_rank_raises_when_one_rank_reports_a_collector_timeout(two_ranks):
+    """The status word of fw_collect_step is rank-local; the update is a collective point.  If only the rank with the non-zero word
+    raised, the others would sit in the rollout all-gather: the ranks agree on the union of their words first."""
+    a, b = two_ranks("status_agreement", n_envs=512)
+    assert "another rank of the job reported status word 2" in a["msg"], a["msg"]
+    assert "status word 2" in b["msg"] and "fold wave" in b["msg"], b["msg"]
+    assert a["checksum"] == 0.0 and b["checksum"] == 0.0
