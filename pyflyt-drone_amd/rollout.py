@@ -659,8 +659,13 @@ class FusedPpoUpdate:
             names = [n for b, n in ((1, "block ids"), (2, "gradient swap"), (4, "norm exchange")) if st.value & b]
             raise RuntimeError(f"fw_ppo_update gave up inside the launch (status {st.value}: {', '.join(names)} wait ran out); "
                                "the policy and optimiser were left as they were before the call")
-        self.store_to_torch(step0 + n_mb)
+        self._pending_step = step0 + n_mb      # commit() moves the result into the module / optimiser
         return (self.loss[:3] / n_mb).tolist()
+
+    def commit(self) -> None:
+        """Second half of an update: the new parameters and moments go from the flat images to the module / optimiser.  Kept apart
+        from run() so that a sharded job can first agree that the launch ran to its end on EVERY rank."""
+        self.store_to_torch(self._pending_step)
 
 
 class PPO:
@@ -1066,8 +1071,20 @@ class PPO:
                 self._fused = FusedPpoUpdate(self.policy, self.optimizer, self.env.obs_dim)
             perm = torch.cat([torch.randperm(B, device=self.device, generator=self.perm_gen) for _ in range(cfg.n_epochs)]).to(torch.int32)
             nb = cfg.n_epochs * (B // bs)
-            la = self._fused.run(cfg, obs.contiguous(), act.contiguous(), old_logp.contiguous(), adv.contiguous(), ret.contiguous(),
-                                 perm, nb, float(g_mean), float(g_std))
+            err = None
+            try:
+                la = self._fused.run(cfg, obs.contiguous(), act.contiguous(), old_logp.contiguous(), adv.contiguous(), ret.contiguous(),
+                                     perm, nb, float(g_mean), float(g_std))
+            except RuntimeError as e:          # a workgroup of the launch gave up (status word): nothing was written back on this rank
+                err = e
+            if self._replicated:               # ... and in a sharded job no rank may go on alone: the replicas would part ways
+                bad = all_reduce_sum_(torch.tensor([1.0 if err is not None else 0.0], dtype=torch.float64, device=self.device))
+                if float(bad.item()) > 0 and err is None:
+                    err = RuntimeError("fw_ppo_update gave up on another rank of the job; this rank's update is discarded with it")
+            if err is not None:
+                self._flat_current = False     # the flat image holds a result that was not committed
+                raise err
+            self._fused.commit()
             self._g_update = None              # the torch-path graph (if any) holds stale Adam state
             self._flat_current = True          # store_to_torch left flat == the module parameters
             self.logs = {"policy_loss": la[0], "value_loss": la[1], "entropy_loss": la[2],

@@ -100,4 +100,18 @@ def status_agreement(rank, world, n_envs):
         msg = "no error"
     # the object is usable afterwards on both ranks
     ppo.collect_rollouts(); ppo.train()
-    return dict(msg=msg, checksum=ppo.replica_checksum())
+    # ... and the same for the update: rank 1's fw_ppo_update is made to give up (one poll per wait); rank 0's runs to its end
+    import os
+    ppo.collect_rollouts()
+    torch.cuda.synchronize()
+    if rank == 1:
+        os.environ["FWSIM_SPIN_LOG2"] = "0"
+    try:
+        ppo.train()
+    except RuntimeError as e:
+        msg2 = str(e)
+    else:
+        msg2 = "no error"
+    finally:
+        os.environ.pop("FWSIM_SPIN_LOG2", None)
+    return dict(msg=msg, msg2=msg2, checksum=ppo.replica_checksum())

@@ -45,4 +45,6 @@ def test_every_rank_raises_when_one_rank_reports_a_collector_timeout(two_ranks):
     a, b = two_ranks("status_agreement", n_envs=512)
     assert "another rank of the job reported status word 2" in a["msg"], a["msg"]
     assert "status word 2" in b["msg"] and "fold wave" in b["msg"], b["msg"]
-    assert a["checksum"] == 0.0 and b["checksum"] == 0.0
+    assert "gave up on another rank" in a["msg2"], a["msg2"]
+    assert "fw_ppo_update gave up inside the launch" in b["msg2"], b["msg2"]
+    assert a["checksum"] == 0.0 and b["checksum"] == 0.0      # rank 0 discarded its (completed) update with rank 1's: still replicas
