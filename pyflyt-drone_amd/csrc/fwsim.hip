@@ -1604,8 +1604,9 @@ int ensure_learner_lds(int dev, int which, size_t bytes) {
   static size_t have[64][2] = {};
   if (dev < 0 || dev >= 64) { g_err = "device index out of range"; return FW_EINVAL; }
   if (bytes <= have[dev][which]) return FW_OK;
-  const void* fn = which == 0 ? (const void*)fw_ppo_update_kernel : (const void*)fw_policy_act_kernel;
+  const void* fn = which == 0 ? (const void*)fw_ppo_update_kernel<64> : (const void*)fw_policy_act_kernel;
   HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (which == 0) HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   have[dev][which] = bytes;
   return FW_OK;
 }
@@ -1901,10 +1902,10 @@ static long long spin_budget(long long dflt) {
   return dflt;
 }
 
-// workspace layout of fw_ppo_update: [0,192) exchange words (word 22: which exchanges shared an L2, word 23: status, include/fwsim.h) |
+// workspace layout of fw_ppo_update: [0,512) exchange words (kPpoWordPaths: which exchanges shared an L2, kPpoWordStatus: include/fwsim.h) |
 // gradient hand-off buffer | the packed rows of every minibatch, in walking order (fw_ppo_pack_kernel)
-static constexpr size_t kPpoWsXch = 24 * sizeof(unsigned long long);
-static constexpr size_t kPpoWsGx = sizeof(float) * 8 * (size_t)kPMomentSlots;
+static constexpr size_t kPpoWsXch = kPpoWords * sizeof(unsigned long long);
+static constexpr size_t kPpoWsGx = sizeof(float) * 4 * kPMaxSplit * (size_t)kPGxSlots;
 int64_t fw_ppo_update_workspace_bytes(int32_t n_minibatches, int32_t batch_size, int32_t obs_dim) {
   if (n_minibatches <= 0 || batch_size <= 0 || obs_dim <= 0 || obs_dim > 64) return FW_EINVAL;
   return (int64_t)(kPpoWsXch + kPpoWsGx + sizeof(float) * (size_t)n_minibatches * (size_t)batch_size * (size_t)ppo_pack_width(obs_dim));
@@ -1918,7 +1919,7 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   if (!params || !mom_m || !mom_v || !obs || !act || !old_logp || !adv || !ret || !perm || !hyper || n_minibatches <= 0) {
     g_err = "fw_ppo_update: bad arguments"; return FW_EINVAL;
   }
-  if (batch_size <= 0 || batch_size % kPChunk != 0) { g_err = "fw_ppo_update: batch_size must be a multiple of 64"; return FW_EINVAL; }
+  if (batch_size <= 0 || batch_size % 32 != 0) { g_err = "fw_ppo_update: batch_size must be a multiple of 32"; return FW_EINVAL; }
   if (obs_dim <= 0 || obs_dim > 64) { g_err = "fw_ppo_update: obs_dim must be in [1, 64]"; return FW_EINVAL; }
   if (!workspace || workspace_bytes < fw_ppo_update_workspace_bytes(n_minibatches, batch_size, obs_dim)) {
     g_err = "fw_ppo_update: workspace smaller than fw_ppo_update_workspace_bytes(n_minibatches, batch_size, obs_dim)"; return FW_EINVAL;
@@ -1941,6 +1942,7 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   A.spin = spin_budget(kPpoSpin);
   A.flags = 0;
   if (const char* e = getenv("FWSIM_PPO_NO_L2_SWAP")) if (atoi(e) != 0) A.flags |= PPO_FLAG_NO_L2_SWAP;
+  if (const char* e = getenv("FWSIM_PPO_WRITER")) if (!strcmp(e, "last")) A.flags |= PPO_FLAG_WRITER_LAST;
   std::memcpy(&A.H, hyper, sizeof A.H);
   if (batch_size <= 1 && A.H.norm_adv == 1) A.H.norm_adv = 0;      // SB3 skips the normalisation of single-sample minibatches
   // the parallel pre-pass: every minibatch's rows, in walking order, advantages normalised (one workgroup per minibatch, all CUs)
@@ -1948,8 +1950,16 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   P.obs = obs; P.act = act; P.old_logp = old_logp; P.adv = adv; P.ret = ret; P.perm = perm; P.B = batch_size; P.D = obs_dim;
   P.norm_adv = A.H.norm_adv; P.adv_mean = A.H.adv_mean; P.adv_std = A.H.adv_std; P.out = packed;
   hipLaunchKernelGGL(fw_ppo_pack_kernel, dim3(n_minibatches), dim3(256), 0, st, P);
-  const int nhalf = batch_size >= 2 * kPChunk ? 2 : 1;            // two chunk-half blocks per network from 128 samples on
-  hipLaunchKernelGGL(fw_ppo_update_kernel, dim3(nhalf == 2 ? 32 : 16), dim3(kPThreads), lds, st, A);      // (every 8th block works -- see the kernel)
+  PpoSplit cut = ppo_split(batch_size);             // samples per pass and blocks per network (128 samples: 32 x 4)
+  if (const char* e = getenv("FWSIM_PPO_SPLIT")) {  // dev knob "CHxN" (64x2 = round 3's cut): A / B measurements, tests of every form
+    int ch = 0, ns = 0;
+    if (sscanf(e, "%dx%d", &ch, &ns) == 2 && (ch == 32 || ch == 64) && (ns == 1 || ns == 2 || ns == 4) && batch_size % ch == 0 && batch_size / ch >= ns) {
+      cut.ch = ch; cut.nsplit = ns;
+    } else { g_err = "fw_ppo_update: FWSIM_PPO_SPLIT must be CHxN with CH in {32, 64}, N in {1, 2, 4}, N chunks of CH samples in a minibatch"; return FW_EINVAL; }
+  }
+  const dim3 grid(16 * cut.nsplit);                 // (every 8th block works -- see the kernel)
+  if (cut.ch == 64) hipLaunchKernelGGL(fw_ppo_update_kernel<64>, grid, dim3(kPThreads), lds, st, A);
+  else hipLaunchKernelGGL(fw_ppo_update_kernel<32>, grid, dim3(kPThreads), lds, st, A);
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;
 }
@@ -1960,7 +1970,7 @@ int32_t fw_ppo_update_status(const void* workspace, int64_t workspace_bytes, uin
   unsigned long long w[2] = {0ull, 0ull};
   HIP_TRY((fw_env*)nullptr, hipMemcpyAsync(w, (const unsigned long long*)workspace + kPpoWordPaths, sizeof w, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
   HIP_TRY((fw_env*)nullptr, hipStreamSynchronize((hipStream_t)hip_stream));
-  static_assert(kPpoWordStatus == kPpoWordPaths + 1 && kPpoWordStatus < 24, "exchange-word layout");
+  static_assert(kPpoWordStatus == kPpoWordPaths + 1 && kPpoWordStatus < kPpoWords, "exchange-word layout");
   static_assert(FW_PPO_ST_IDS == PPO_ST_IDS && FW_PPO_ST_SWAP == PPO_ST_SWAP && FW_PPO_ST_NORM == PPO_ST_NORM, "status bits of include/fwsim.h");
   if (paths_out) *paths_out = (uint32_t)w[0];
   *status_out = (uint32_t)w[1];

@@ -31,9 +31,11 @@ struct PpoHyper {
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPH = 64;            // hidden width
-constexpr int kPChunk = 64;        // samples per pass through the networks
+constexpr int kPChunk = 64;        // samples per pass through the networks (the 32-sample form of the kernel: template parameter CH)
+constexpr int kPMaxSplit = 4;      // blocks per network a minibatch is split over, at most
 constexpr int kPLdh = kPH + 1;     // row stride of the hidden activations / of W2 in LDS (odd: conflict-free column reads)
 constexpr int kPLdx = 65;          // row stride of the gathered observations in LDS: a CONSTANT (the widest input + 1), so that every operand
                                    // address of the X-sided products is base + immediate.  (Round 3 had Dp + 1: with a run-time stride hipcc
@@ -81,16 +83,63 @@ __device__ __forceinline__ f32x16 ppo_mfma_tile(const float* A, int sam, int sak
 }
 __device__ __forceinline__ int ppo_acc_row(int v) { return (v >> 2) * 8 + ((threadIdx.x & 63) >> 5) * 4 + (v & 3); }
 
+// The 32-sample form: a 32 x 64 product is 2 x 4 tiles of 16 x 16 on v_mfma_f32_16x16x4_f32 (the same MAC rate as 32x32x2); wave w
+// owns output columns 16 w .. 16 w + 15 for both row tiles (one B operand feeds two MFMAs, two independent accumulator chains hide
+// the 40-cycle dependent latency behind the 32-cycle issue).  Operand layout: lane l supplies A(l % 16, l / 16) and B(l / 16, l % 16);
+// accumulator register v of lane l is C(4 (l / 16) + v, l % 16).  Which k a lane group supplies is free as long as A and B agree:
+// group g = l / 16 takes k = koff(g) + step with koff = 16 g (K = 64) or {0, 16, 8, 24}[g] (K = 32), so that the two groups of a
+// half-wave are 16 floats apart and, with the odd row strides of the LDS images, every operand read is bank-conflict free both
+// along rows (activations as A, W as B) and along columns (W2^T as B).
+// c0 / c1 += A(rows 0-15 / 16-31, K) * B(K, 16 columns); A(m, k) = A[m * sam + k * sak], B(k, n) = B[k * sbk + n * sbn]; K = 4 STEPS.
+template <int STEPS>
+__device__ __forceinline__ void ppo_mfma16_pair(const float* A, int sam, int sak, const float* B, int sbk, int sbn, f32x4& c0, f32x4& c1) {
+  static_assert(STEPS == 8 || STEPS == 16, "K = 32 or 64");
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int koff = STEPS == 16 ? 16 * g : ((g & 1) * 16 + (g >> 1) * 8);
+  const float* a0 = A + i * sam + koff * sak;
+  const float* a1 = a0 + 16 * sam;
+  const float* b = B + koff * sbk + i * sbn;
+  float av0[STEPS], av1[STEPS], bv[STEPS];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) { av0[s] = a0[s * sak]; av1[s] = a1[s * sak]; bv[s] = b[s * sbk]; }
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[s], bv[s], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[s], bv[s], c1, 0, 0, 0);
+  }
+}
+
+// Cross-lane sums on the vector ALU (DPP inside a row of 16 lanes, v_permlane16_swap / v_permlane32_swap across the rows) instead
+// of __shfl_xor, which is ds_bpermute_b32: an LDS round trip (~120 cycles) per butterfly step on a path where every step is exposed.
+template <int CTRL> __device__ __forceinline__ float ppo_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E;     // quad_perm [1,0,3,2] / [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;               // lane i <-> 7 - i of each 8: "the other quad" for values that are uniform inside a quad
+constexpr int kDppRowMirror = 0x140;                // lane i <-> 15 - i of each row: "the other 8" for values that are uniform inside an 8
+constexpr int kDppRor4 = 0x124, kDppRor8 = 0x128;   // rotate inside the row of 16
+// every lane l gets x[l % 16] + x[l % 16 + 16] + x[l % 16 + 32] + x[l % 16 + 48], summed in the same order everywhere
+__device__ __forceinline__ float ppo_sum_rows(float x) {
+  typedef unsigned ppo_u2 __attribute__((ext_vector_type(2)));
+  const ppo_u2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);      // {rows 0 0 2 2, rows 1 1 3 3}
+  const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const ppo_u2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);      // {lower half twice, upper half twice}
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float ppo_wave_sum(float x) {
+  x += ppo_dpp<kDppXor1>(x); x += ppo_dpp<kDppXor2>(x); x += ppo_dpp<kDppHalfMirror>(x); x += ppo_dpp<kDppRowMirror>(x);
+  return ppo_sum_rows(x);
+}
 // (no barrier in front: for callers whose previous readers of red[0..3] are already behind a later barrier)
 __device__ __forceinline__ float ppo_block_sum_nb(float x, float* red) {
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  x = ppo_wave_sum(x);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
   __syncthreads();
   return red[0] + red[1] + red[2] + red[3];
 }
 __device__ __forceinline__ float ppo_block_sum(float x, float* red) {
   // 256 threads -> all threads get the sum (red: 8 floats of LDS)
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  x = ppo_wave_sum(x);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
   __syncthreads();
@@ -106,10 +155,6 @@ __device__ __forceinline__ float ppo_tanh(float x) {
   const float big = copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f), x);
   return ax < 0.25f ? small : big;
 }
-__device__ __forceinline__ float ppo_wave_sum(float x) {
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-  return x;
-}
 
 // Adam moments are kept in "slot" order: slot = ((net * 3 + kind) * 4 + wave) * 1024 + lane * 16 + v for the
 // accumulator tiles (kind 0 = W2, 1 = W1; kind 2 is unused since round 3), then kPTileSlots + q * 256 + thread for the
@@ -118,6 +163,12 @@ __device__ __forceinline__ float ppo_wave_sum(float x) {
 constexpr int kPTileSlots = 2 * 3 * 4 * 64 * 16;
 constexpr int kPMomentSlots = kPTileSlots + 9 * kPThreads;
 __host__ __device__ inline int ppo_tile_slot(int net, int kind, int wave, int lane) { return (((net * 3 + kind) * 4 + wave) * 64 + lane) * 16; }
+// A block's gradient partial in the exchange buffer: [kind W2 | W1][wave][quarter q of the lane's 16 elements][lane][4] for the tiles -- one wave-level
+// 16-byte access is 1 KB in a row (the partners read it past their L1: every access is a request to the L2, and in moment-slot order, 64 bytes
+// per lane, each request would touch 64 lines for 16 bytes apiece) -- then the five per-thread elements [5][256].
+constexpr int kPGxTile = 2 * 4 * 4 * 64 * 4;
+constexpr int kPGxSlots = kPGxTile + 5 * kPThreads;
+__host__ __device__ inline int ppo_gx_tile(int kind, int wave, int lane) { return (kind * 4 + wave) * 4 * 256 + lane * 4; }      // + q * 256
 
 // flat parameter index of every moment slot (-1 = padding); host side of the layout above
 inline void ppo_moment_map(int D, int32_t* flat_of_slot) {
@@ -239,18 +290,23 @@ struct PpoArgs {
   int32_t n_mb, B, D;
   PpoHyper H;
   float* loss_acc;                   // [3] += policy, value, entropy loss
-  unsigned long long* xch;           // [24] exchange words (norm partials [parity][net][half], gradient flags + 8, XCD ids of the chunk-half blocks + 16,
-                                     //      kPpoWordPaths, kPpoWordStatus), zeroed by the host
-  float* gx;                         // [2 parities][2 nets][2 halves][kPMomentSlots] gradient partials of the chunk halves
+  unsigned long long* xch;           // [kPpoWords] exchange words (norm partials [parity][net][part], gradient flags + kPpoWordFlags, XCD ids of
+                                     //      the blocks [net][part] + kPpoWordIds, kPpoWordPaths, kPpoWordStatus), zeroed by the host
+  float* gx;                         // [2 parities][2 nets][kPMaxSplit parts][kPGxSlots] gradient partials of the blocks of a network
   long long spin;                    // polls a wait for another block may take (kPpoSpin; FWSIM_SPIN_LOG2 shrinks it: tests provoke the timeout)
   int32_t flags;                     // PPO_FLAG_*
 };
 constexpr long long kPpoSpin = 1ll << 26;
-enum { PPO_FLAG_NO_L2_SWAP = 1 };    // FWSIM_PPO_NO_L2_SWAP=1: every exchange through device-scope accesses, as if no two blocks shared an XCD
+enum { PPO_FLAG_NO_L2_SWAP = 1,      // FWSIM_PPO_NO_L2_SWAP=1: every exchange through device-scope accesses, as if no two blocks shared an XCD
+       PPO_FLAG_WRITER_LAST = 2 };   // FWSIM_PPO_WRITER=last: the LAST block of each network writes the result back instead of the first (tests: every
+                                     // block of a network must end the call with the same bits)
 // xch[kPpoWordPaths]: which exchanges of this call went through a shared L2 -- bit 2 b: block b's gradient swap, bit 2 b + 1: its
-// norm exchange (b = 2 half + net).  xch[kPpoWordStatus]: 0, or PPO_ST_* of the waits that ran out: the blocks then leave
+// norm exchange (b = 2 part + net).  xch[kPpoWordStatus]: 0, or PPO_ST_* of the waits that ran out: the blocks then leave
 // without writing the parameters back (the moments in memory are part-way through the call: the caller must not go on with them).
-constexpr int kPpoWordPaths = 22, kPpoWordStatus = 23;
+constexpr int kPpoWordFlags = 4 * kPMaxSplit, kPpoWordIds = 8 * kPMaxSplit, kPpoWordPaths = 46, kPpoWordStatus = 47;
+constexpr int kPpoWordLoss = 48;     // [net][part]: the blocks' loss sums (float bits), added up in a fixed order by the block that finishes last
+constexpr int kPpoWordDone = kPpoWordLoss + 2 * kPMaxSplit, kPpoWords = 64;      // (kPpoWordDone: how many blocks have finished)
+static_assert(kPpoWordIds + 2 * kPMaxSplit <= kPpoWordPaths && kPpoWordDone < kPpoWords, "exchange-word layout");
 enum { PPO_ST_IDS = 1, PPO_ST_SWAP = 2, PPO_ST_NORM = 4 };
 
 // Bounded wait of one thread for a word another block publishes.  `done(word)` ends it; every 256 polls it also looks at the
@@ -268,28 +324,36 @@ __device__ __forceinline__ bool ppo_wait(const PpoArgs& A, LOAD&& load, DONE&& d
   return false;
 }
 
-template <int NET>
-__device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const int half, const int nhalf) {
+// CH = samples per pass through the network (64: 2 x 2 tiles of 32 x 32 per product; 32: 2 x 4 tiles of 16 x 16, see ppo_mfma16_pair);
+// part / nsplit: this block's place among the blocks of its network (chunk c of a minibatch is run by block c % nsplit).
+template <int NET, int CH>
+__device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const int part, const int nsplit) {
+  static_assert(CH == 64 || CH == 32, "chunk size");
   constexpr int n = NET, KO = NET == 0 ? 4 : 1;
   float* __restrict__ params = A.params;
   float* __restrict__ mom_m = A.mom_m; float* __restrict__ mom_v = A.mom_v;
   const int n_mb = A.n_mb, B = A.B, D = A.D;
   const PpoHyper H = A.H;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, hh = lane >> 5;
+  const int t = threadIdx.x, lane = t & 63, r = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // (a scalar: everything decided per wave -- tile ownership above all -- branches, not exec masks)
   const int Dp = (D + 1) & ~1;
   constexpr int ldx = kPLdx;
+  // W1 in LDS.  CH = 64: [Dp][64] as in memory.  CH = 32: the 16x16x4 products walk K in steps of 32 or 64 (zero rows behind the last
+  // feature) and want the odd row stride (ppo_mfma16_pair).
+  constexpr int ldw1 = CH == 64 ? kPH : kPLdh;
+  const int K1 = CH == 64 ? Dp : (Dp <= 32 ? 32 : 64);
 
   // ---- LDS carve-up ----
   float* p = lds;
   PpoNetLds W;
-  W.W1 = p; p += Dp * kPH; W.b1 = p; p += kPH; W.W2 = p; p += kPH * kPLdh; W.b2 = p; p += kPH; W.Wo = p; p += kPH * KO; W.bo = p; p += KO;
+  W.W1 = p; p += K1 * ldw1; W.b1 = p; p += kPH; W.W2 = p; p += kPH * kPLdh; W.b2 = p; p += kPH; W.Wo = p; p += kPH * KO; W.bo = p; p += KO;
   float* log_std = p; p += 4;
-  float* X = p;  p += kPChunk * ldx + 64;         // (+64: the padded dW1 tile reads a few floats past the last row)
-  float* H1 = p; p += kPChunk * kPLdh;
-  float* H2 = p; p += kPChunk * kPLdh;
-  float* gout = p; p += kPChunk * 4;              // head output, then dL/d(head output) of the chunk
-  float* sA = p; p += kPChunk * 4;                // gathered actions
-  float* sS = p; p += kPChunk * 4;                // per-sample scalars: old_logp, adv (normalised), ret, -
+  float* X = p;  p += CH * ldx + 64;              // (+64: the padded dW1 tile reads a few floats past the last row)
+  float* H1 = p; p += CH * kPLdh;
+  float* H2 = p; p += CH * kPLdh;                 // (>= 2048 floats: dW1's split partials pass through it)
+  float* gout = p; p += CH * 4;                   // head output, then dL/d(head output) of the chunk
+  float* sA = p; p += CH * 4;                     // gathered actions
+  float* sS = p; p += CH * 4;                     // per-sample scalars: old_logp, adv (normalised), ret, -
   float* bred = p; p += 2 * 4 * kPH;              // bias-gradient partials [b1 | b2][wave][64]
   float* red = p; p += 8;
   float* sred = p; p += 32;                       // per wave: the four components of dbo and of dlog_std over its samples
@@ -301,27 +365,29 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   const int oLs = nP0 + ppo_net_params(Dp, 1);
 
   // ---- load the weights once ----
-  for (int i = t; i < Dp * kPH; i += kPThreads) W.W1[i] = params[oW1 + i];
+  for (int i = t; i < K1 * ldw1; i += kPThreads) W.W1[i] = 0.f;
+  __syncthreads();
+  for (int i = t; i < Dp * kPH; i += kPThreads) W.W1[(i >> 6) * ldw1 + (i & 63)] = params[oW1 + i];
   for (int i = t; i < kPH; i += kPThreads) { W.b1[i] = params[ob1 + i]; W.b2[i] = params[ob2 + i]; }
   for (int i = t; i < kPH * kPH; i += kPThreads) W.W2[(i >> 6) * kPLdh + (i & 63)] = params[oW2 + i];
   for (int i = t; i < kPH * KO + KO; i += kPThreads) W.Wo[i] = params[oWo + i];              // Wo and bo are contiguous in both images
   if (t < 4) log_std[t] = params[oLs + t];
-  for (int i = t; i < kPChunk * ldx + 64; i += kPThreads) X[i] = 0.f;                           // incl. the pad the dW1 tiles read
+  for (int i = t; i < CH * ldx + 64; i += kPThreads) X[i] = 0.f;                                // incl. the pad the dW1 tiles read
   __syncthreads();
 
-  // The two chunk-half blocks of a network swap their gradient partials once per minibatch.  If both run on the same XCD
+  // The blocks of a network swap their gradient partials once per minibatch.  If all of them run on the same XCD
   // they share an L2: the swap then needs no device-scope release / acquire (a write-back and an invalidate of the WHOLE L2,
   // ~12 k cycles per minibatch with the misses that follow) -- the vector L1 writes through, so the producer only waits for
   // its stores and the consumer only reads past its own L1.  The launch puts them there (blocks b and b + 8), but nothing
-  // promises that mapping: each block reads the XCD it really runs on and the pair compares notes once per call; a pair that
-  // was split keeps the device-scope fences.
-  bool same_xcd = false, same_xcd_net = false;      // ... as my chunk-half partner; as the other network's block of my half
+  // promises that mapping: each block reads the XCD it really runs on and they compare notes once per call; blocks that
+  // were split keep the device-scope fences.
+  bool same_xcd = false, same_xcd_net = false;      // ... as every other block of my network; as the other network's block of my part
   bool dead = false;                                // a wait for another block ran out (block-uniform): leave, touching nothing more
   {
     if (t == 0) {
       red[7] = 0.f;
       const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));      // HW_REG_XCC_ID[3:0]
-      __hip_atomic_store(A.xch + 16 + NET * 2 + half, (unsigned long long)(my_xcc + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(A.xch + kPpoWordIds + NET * kPMaxSplit + part, (unsigned long long)(my_xcc + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       auto wait_id = [&](unsigned long long* p_) {
         unsigned long long w = 0;
         if (!ppo_wait(A, [&]() { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
@@ -329,10 +395,11 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         return (unsigned)w;
       };
       const bool l2ok = !(A.flags & PPO_FLAG_NO_L2_SWAP);
-      const bool sx = l2ok && nhalf == 2 && wait_id(A.xch + 16 + NET * 2 + (1 - half)) == my_xcc + 1u;
-      const bool sn = wait_id(A.xch + 16 + (1 - NET) * 2 + half) == my_xcc + 1u && l2ok;
+      bool sx = l2ok && nsplit > 1;
+      for (int q = 0; q < nsplit; ++q) if (q != part && wait_id(A.xch + kPpoWordIds + NET * kPMaxSplit + q) != my_xcc + 1u) sx = false;
+      const bool sn = wait_id(A.xch + kPpoWordIds + (1 - NET) * kPMaxSplit + part) == my_xcc + 1u && l2ok;
       red[5] = sx ? 1.f : 0.f; red[6] = sn ? 1.f : 0.f;
-      if (sx || sn) (void)__hip_atomic_fetch_or(A.xch + kPpoWordPaths, (unsigned long long)((sx ? 1u : 0u) | (sn ? 2u : 0u)) << (2 * (2 * half + NET)),
+      if (sx || sn) (void)__hip_atomic_fetch_or(A.xch + kPpoWordPaths, (unsigned long long)((sx ? 1u : 0u) | (sn ? 2u : 0u)) << (2 * (2 * part + NET)),
                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
@@ -345,23 +412,28 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   // two idle, every wave takes one tile over HALF of the chunk's samples (16 MFMAs); waves 2, 3 hand their partial to the
   // owners through LDS once per minibatch (gW1 of a non-owner is scratch).
   const bool splitW1 = tilesW1 == 2;
-  const int w1_mt = splitW1 ? 0 : mt, w1_k0 = splitW1 ? (wave >> 1) * 32 : 0, w1_K = splitW1 ? kPChunk / 2 : kPChunk;
-  const int hq = t & 3, hs = t >> 2;              // head work: thread (sample or hidden unit hs, quarter / component hq)
+  const int w1_mt = splitW1 ? 0 : mt, w1_k0 = splitW1 ? (wave >> 1) * (CH / 2) : 0, w1_K = splitW1 ? CH / 2 : CH;
+  // head work: thread (sample hs, slice hq of the hidden units; component hq of the action where hq < 4) -- 4 slices of 16 units per
+  // sample with 64 samples, 8 slices of 8 with 32; dWo and the elements of Wo: thread (hidden unit us, sample quarter / component uq)
+  constexpr int HSL = kPThreads / CH, HPER = kPH / HSL;
+  const int hq = t % HSL, hs = t / HSL;
+  const int uq = t & 3, us = t >> 2;
+  const int l16 = lane & 15, g16 = lane >> 4;     // (CH = 32) column and row group of the 16 x 16 accumulator tiles
 
   float bc1 = powf(H.beta1, (float)H.step0), bc2 = powf(H.beta2, (float)H.step0);     // beta^t
   float acc_l = 0.f;                              // loss sum (wave 0 lanes, reduced at the end)
   const float invB = 1.0f / (float)B;
 #ifdef FW_PPO_PROF
   long long pf_stats = 0, pf_gather = 0, pf_net = 0, pf_adam = 0, pf_xch = 0, pf_red = 0, pf_ho = 0, pf_norm = 0, pf_tile = 0, pf_scal = 0;
-  long long pf_g[4] = {0, 0, 0, 0}, pf_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // gather: barrier, commit, prefetch issue, barrier; the phases of the chunk pass
+  long long pf_g[4] = {0, 0, 0, 0}, pf_n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_h[6] = {0, 0, 0, 0, 0, 0};      // pf_h: the hand-off, piece by piece      // gather: barrier, commit, prefetch issue, barrier; the phases of the chunk pass
 #define PPO_T() ((long long)__builtin_readcyclecounter())
 #endif
 
   // Inputs of a 64-sample chunk: one contiguous block of the packed array (fw_ppo_pack_kernel), 64 x W4 float4s, fetched one
   // chunk ahead -- float4 e of the chunk by thread e % 256 in pass e / 256 (coalesced: a wave-level load is 1 KB in a row) --
   // and scattered to X / sA / sS when the chunk's turn comes.  Where a float4 lands is the same for every chunk: computed once.
-  const int cpm = B / kPChunk;
-  const int W4 = ((D + 3) >> 2) + 2, npass = (kPChunk * W4 + kPThreads - 1) / kPThreads;      // 9 float4s per row, 3 passes (obs 28); 16, 4 (obs 56); 18, 5 (obs 64)
+  const int cpm = B / CH;
+  const int W4 = ((D + 3) >> 2) + 2, npass = (CH * W4 + kPThreads - 1) / kPThreads;      // 64 samples: 9 float4s per row, 3 passes (obs 28); 16, 4 (obs 56); 18, 5 (obs 64)
   typedef float ppo_x4 __attribute__((ext_vector_type(4)));
   constexpr int kPass = 5;                           // 64 rows x (16 + 2) float4s / 256 threads, rounded up (obs 57 .. 64; 28: 3, 56: 4)
   ppo_x4 pre_x[kPass];
@@ -372,7 +444,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     for (int p_ = 0; p_ < kPass; ++p_) {
       const int e = t + p_ * kPThreads, row = e / W4, q = e - row * W4;
       int d = -1;
-      if (p_ < npass && e < kPChunk * W4) {
+      if (p_ < npass && e < CH * W4) {
         if (q < Dv4) d = (int)(X - lds) + row * ldx + 4 * q;          // (the row's zero padding lands on columns that hold zero anyway)
         else if (q == Dv4) d = NET == 0 ? (int)(sA - lds) + row * 4 : -1;
         else d = (int)(sS - lds) + row * 4;                           // old log-prob, advantage (normalised), return, -
@@ -381,7 +453,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     }
   }
   auto prefetch = [&](int g) {
-    const ppo_x4* src = reinterpret_cast<const ppo_x4*>(A.packed) + (size_t)g * (kPChunk * W4) + t;
+    const ppo_x4* src = reinterpret_cast<const ppo_x4*>(A.packed) + (size_t)g * (CH * W4) + t;
 #pragma unroll
     for (int p_ = 0; p_ < kPass; ++p_) if (p_ < npass && pre_dst[p_] >= 0) pre_x[p_] = src[p_ * kPThreads];
   };
@@ -395,13 +467,13 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       }
     }
   };
-  int pmb = 0, pci = half;                          // next chunk to prefetch: minibatch, chunk index inside it
+  int pmb = 0, pci = part;                          // next chunk to prefetch: minibatch, chunk index inside it
   bool gathered = false;                            // the next chunk's inputs are already in X / sA / sS (done inside the hand-off wait)
   // The Adam moments of the elements this lane owns stay in REGISTERS for the whole call (the compiler parks them in AGPRs): 2 x 32
   // tile elements (W2, W1) + 2 x NQ per-thread ones.  Round 3 fetched and stored them every minibatch -- ~100 KB through the CU's
   // 64 B / clk vector-memory path per minibatch, whose store queue the next chunk's gather then had to wait behind (its "issue"
   // took 2.2 k cycles) -- because 472 registers left no room; the leaner gather and dW1 of round 4 did.  Both chunk halves apply
-  // the same update to the same initial values; half 0 writes the result back at the end.
+  // the same update to the same initial values; part 0 writes the result back at the end.
   float4 pm[2][4], pv[2][4];
   {
     const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane);
@@ -422,7 +494,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #pragma unroll
   for (int q = 0; q < NQ; ++q) { smm[q] = mom_m[sl[q]]; svv[q] = mom_v[sl[q]]; }
   prefetch(pmb * cpm + pci);
-  pci += nhalf; if (pci >= cpm) { pmb += 1; pci = half; }
+  pci += nsplit; if (pci >= cpm) { pmb += 1; pci = part; }
 
 #pragma unroll 1
   for (int mb = 0; mb < n_mb && !dead; ++mb) {
@@ -435,7 +507,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     // gradient accumulators of this minibatch (registers)
     f32x16 gW2, gW1;
     float gb1p = 0.f, gb2p = 0.f;                                     // column-sum partials of this thread's 16 rows
-    float gWoq[KO];                                                   // dWo[hidden unit hs][0 .. KO) over the samples 16 hq .. 16 hq + 15 of every chunk
+    float gWoq[KO];                                                   // dWo[hidden unit us][0 .. KO) over sample quarter uq of every chunk
     float gbo_p = 0.f, gls_p = 0.f;                                   // component hq of dbo / dlog_std over this thread's samples
 #pragma unroll
     for (int v = 0; v < 16; ++v) { gW2[v] = 0.f; gW1[v] = 0.f; }
@@ -443,7 +515,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     for (int k = 0; k < KO; ++k) gWoq[k] = 0.f;
 
 #pragma unroll 1
-    for (int c0 = half * kPChunk; c0 < B; c0 += nhalf * kPChunk) {
+    for (int c0 = part * CH; c0 < B; c0 += nsplit * CH) {
       // ---- gather the chunk ----
 #ifdef FW_PPO_PROF
       const long long pf1 = PPO_T();
@@ -459,7 +531,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #endif
         if (pmb < n_mb) {                                                // the next chunk's loads fly during this chunk's GEMMs
           prefetch(pmb * cpm + pci);
-          pci += nhalf; if (pci >= cpm) { pmb += 1; pci = half; }
+          pci += nsplit; if (pci >= cpm) { pmb += 1; pci = part; }
         }
 #ifdef FW_PPO_PROF
         const long long pg3 = PPO_T(); pf_g[2] += pg3 - pg2;
@@ -478,7 +550,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #define PPO_PHASE(i) do { } while (0)
 #endif
       // ---- forward: H1 = tanh(X W1 + b1), H2 = tanh(H1 W2 + b2) ----
-      {
+      if constexpr (CH == 64) {
         f32x16 c;
         const float bias = W.b1[nt * 32 + r];
 #pragma unroll
@@ -486,10 +558,18 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         c = ppo_mfma_tile(X + mt * 32 * ldx, ldx, 1, W.W1 + nt * 32, kPH, 1, Dp, c);
 #pragma unroll
         for (int v = 0; v < 16; ++v) H1[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
+      } else {
+        const float bias = W.b1[wave * 16 + l16];
+        f32x4 c0 = {bias, bias, bias, bias}, c1 = c0;
+        if (K1 == 32) ppo_mfma16_pair<8>(X, ldx, 1, W.W1 + wave * 16, ldw1, 1, c0, c1);
+        else ppo_mfma16_pair<16>(X, ldx, 1, W.W1 + wave * 16, ldw1, 1, c0, c1);
+        float* hp = H1 + (g16 * 4) * kPLdh + wave * 16 + l16;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { hp[v * kPLdh] = ppo_tanh(c0[v]); hp[(16 + v) * kPLdh] = ppo_tanh(c1[v]); }
       }
       __syncthreads();
       PPO_PHASE(0);
-      {
+      if constexpr (CH == 64) {
         f32x16 c;
         const float bias = W.b2[nt * 32 + r];
 #pragma unroll
@@ -497,20 +577,27 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         c = ppo_mfma_tile(H1 + mt * 32 * kPLdh, kPLdh, 1, W.W2 + nt * 32, kPLdh, 1, kPH, c);
 #pragma unroll
         for (int v = 0; v < 16; ++v) H2[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
+      } else {
+        const float bias = W.b2[wave * 16 + l16];
+        f32x4 c0 = {bias, bias, bias, bias}, c1 = c0;
+        ppo_mfma16_pair<16>(H1, kPLdh, 1, W.W2 + wave * 16, kPLdh, 1, c0, c1);
+        float* hp = H2 + (g16 * 4) * kPLdh + wave * 16 + l16;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { hp[v * kPLdh] = ppo_tanh(c0[v]); hp[(16 + v) * kPLdh] = ppo_tanh(c1[v]); }
       }
       __syncthreads();
       PPO_PHASE(1);
       // ---- head and loss gradient, on the vector ALU by all four waves (the 64 x KO head is 6 % of a 32 x 32 MFMA tile):
-      // thread (sample hs, quarter hq) sums hidden units 16 hq .. 16 hq + 15 for all KO outputs, the four quarters are
-      // combined by a butterfly inside the quad, and every lane of the quad then holds the sample's head output ----
+      // thread (sample hs, slice hq) sums hidden units HPER hq .. HPER hq + HPER - 1 for all KO outputs, the slices are
+      // combined by a butterfly inside the group, and every lane of the group then holds the sample's head output ----
       {
         float o[KO];
 #pragma unroll
         for (int k = 0; k < KO; ++k) o[k] = 0.f;
-        const float* h2 = H2 + hs * kPLdh + 16 * hq;
-        const float* wo = W.Wo + 16 * hq * KO;
+        const float* h2 = H2 + hs * kPLdh + HPER * hq;
+        const float* wo = W.Wo + HPER * hq * KO;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < HPER; ++j) {
           const float h = h2[j];
           if (KO == 4) {
             const float4 w4 = reinterpret_cast<const float4*>(wo)[j];
@@ -520,16 +607,23 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
           }
         }
 #pragma unroll
-        for (int k = 0; k < KO; ++k) { o[k] += __shfl_xor(o[k], 1, 64); o[k] += __shfl_xor(o[k], 2, 64); o[k] += W.bo[k]; }
+        for (int k = 0; k < KO; ++k) {
+          o[k] += ppo_dpp<kDppXor1>(o[k]); o[k] += ppo_dpp<kDppXor2>(o[k]);
+          if (HSL == 8) o[k] += ppo_dpp<kDppHalfMirror>(o[k]);
+          o[k] += W.bo[k];
+        }
         const int s = hs;
         if (NET == 0) {
-          // log pi(a|s), ratio, clipped surrogate (SB3 PPO.train): lane hq of the quad takes action component hq
-          const float mu = hq == 0 ? o[0] : hq == 1 ? o[KO > 1 ? 1 : 0] : hq == 2 ? o[KO > 2 ? 2 : 0] : o[KO > 3 ? 3 : 0];
-          const float ls = log_std[hq];
+          // log pi(a|s), ratio, clipped surrogate (SB3 PPO.train): lane hc of the group's first quad takes action component hc
+          // (32-sample form: the second quad of a group of 8 computes along and contributes nothing)
+          const int hc = hq & 3;
+          const bool hl = hq < 4;
+          const float mu = hc == 0 ? o[0] : hc == 1 ? o[KO > 1 ? 1 : 0] : hc == 2 ? o[KO > 2 ? 2 : 0] : o[KO > 3 ? 3 : 0];
+          const float ls = log_std[hc];
           const float iv = expf(-2.0f * ls);                  // 1 / sigma^2
-          const float z = sA[s * 4 + hq] - mu;
+          const float z = sA[s * 4 + hc] - mu;
           float logp = -0.5f * z * z * iv - ls - 0.9189385332046727f;
-          logp += __shfl_xor(logp, 1, 64); logp += __shfl_xor(logp, 2, 64);
+          logp += ppo_dpp<kDppXor1>(logp); logp += ppo_dpp<kDppXor2>(logp);
           const float a = sS[s * 4 + 1];
           const float ratio = expf(logp - sS[s * 4 + 0]);
           const float rc = fminf(fmaxf(ratio, 1.0f - H.clip_range), 1.0f + H.clip_range);
@@ -540,8 +634,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
           const bool inside = ratio >= 1.0f - H.clip_range && ratio <= 1.0f + H.clip_range;
           const float coef = (l1 < l2 || (l1 == l2 && inside)) ? -a * ratio * invB : (l1 == l2 ? -0.5f * a * ratio * invB : 0.f);
           const float g = coef * z * iv;                                  // dL/dmu_k = dL/dlogp * (a_k - mu_k) / sigma_k^2
-          gls_p += coef * (z * z * iv - 1.0f);                            // dL/dlog_std_k of this thread's samples
-          gout[s * 4 + hq] = g; gbo_p += g;
+          if (hl) {
+            gls_p += coef * (z * z * iv - 1.0f);                          // dL/dlog_std_k of this thread's samples
+            gout[s * 4 + hc] = g; gbo_p += g;
+          }
         } else {
           const float dv = o[0] - sS[s * 4 + 2];
           if (hq == 0) acc_l += dv * dv;
@@ -551,12 +647,12 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       }
       __syncthreads();
       PPO_PHASE(2);
-      // ---- dWo += H2^T gout (before H2 is overwritten): thread (hidden unit hs, quarter hq) over samples 16 hq .. 16 hq + 15 ----
+      // ---- dWo += H2^T gout (before H2 is overwritten): thread (hidden unit us, quarter uq) over a quarter of the chunk's samples ----
       {
-        const float* h2 = H2 + 16 * hq * kPLdh + hs;
-        const float* go = gout + 16 * hq * 4;
+        const float* h2 = H2 + (CH / 4) * uq * kPLdh + us;
+        const float* go = gout + (CH / 4) * uq * 4;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < CH / 4; ++j) {
           const float h = h2[j * kPLdh];
           if (KO == 4) {
             const float4 g4 = reinterpret_cast<const float4*>(go)[j];
@@ -569,7 +665,22 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       __syncthreads();
       PPO_PHASE(3);
       // ---- G2 = (gout Wo^T) * (1 - H2^2), in place over H2 (K = KO <= 4) ----
-      {
+      if constexpr (CH == 32) {
+        float* hp = H2 + (g16 * 4) * kPLdh + wave * 16 + l16;
+        float hv0[4], hv1[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { hv0[v] = hp[v * kPLdh]; hv1[v] = hp[(16 + v) * kPLdh]; }
+        const int k = g16 < KO ? g16 : 0;
+        const float a0 = g16 < KO ? gout[l16 * 4 + k] : 0.f, a1 = g16 < KO ? gout[(16 + l16) * 4 + k] : 0.f;
+        const float bv = g16 < KO ? W.Wo[(wave * 16 + l16) * KO + k] : 0.f;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, z4, 0, 0, 0);
+        const f32x4 c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, z4, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { hv0[v] = c0[v] * (1.0f - hv0[v] * hv0[v]); hv1[v] = c1[v] * (1.0f - hv1[v] * hv1[v]); }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { hp[v * kPLdh] = hv0[v]; hp[(16 + v) * kPLdh] = hv1[v]; }
+      } else {
         // (the 16 activations this lane rescales are fetched in one batch ahead of the products: written as read-modify-write
         // per element the compiler keeps every LDS read behind the previous element's write -- 16 exposed LDS round trips)
         float* hp = H2 + (mt * 32 + hh * 4) * kPLdh + nt * 32 + r;
@@ -594,17 +705,28 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       __syncthreads();
       PPO_PHASE(4);
       // ---- dW2 += H1^T G2 (rows = input unit), db2 partial ----
-      gW2 = ppo_mfma_tile(H1 + mt * 32, 1, kPLdh, H2 + nt * 32, kPLdh, 1, kPChunk, gW2);
+      gW2 = ppo_mfma_tile(H1 + mt * 32, 1, kPLdh, H2 + nt * 32, kPLdh, 1, CH, gW2);
       {
         float sgb = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) sgb += H2[(wave * 16 + s) * kPLdh + lane];
+        for (int s = 0; s < CH / 4; ++s) sgb += H2[(wave * (CH / 4) + s) * kPLdh + lane];
         gb2p += sgb;
       }
       __syncthreads();
       PPO_PHASE(5);
       // ---- G1 = (G2 W2^T) * (1 - H1^2), in place over H1 ----
-      {
+      if constexpr (CH == 32) {
+        float* hp = H1 + (g16 * 4) * kPLdh + wave * 16 + l16;
+        float hv0[4], hv1[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { hv0[v] = hp[v * kPLdh]; hv1[v] = hp[(16 + v) * kPLdh]; }
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+        ppo_mfma16_pair<16>(H2, kPLdh, 1, W.W2 + wave * 16 * kPLdh, 1, kPLdh, c0, c1);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { hv0[v] = c0[v] * (1.0f - hv0[v] * hv0[v]); hv1[v] = c1[v] * (1.0f - hv1[v] * hv1[v]); }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { hp[v * kPLdh] = hv0[v]; hp[(16 + v) * kPLdh] = hv1[v]; }
+      } else {
         float* hp = H1 + (mt * 32 + hh * 4) * kPLdh + nt * 32 + r;      // (as for G2: the reads leave ahead of the products)
         float hv[16];
 #pragma unroll
@@ -625,7 +747,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       {
         float sgb = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) sgb += H1[(wave * 16 + s) * kPLdh + lane];
+        for (int s = 0; s < CH / 4; ++s) sgb += H1[(wave * (CH / 4) + s) * kPLdh + lane];
         gb1p += sgb;
       }
       PPO_PHASE(7);
@@ -643,22 +765,26 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #pragma unroll
     for (int k = 0; k < KO; ++k) {
       float g = gWoq[k];
-      g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64);
-      if (hq == k) my_gwo = g;
+      g += ppo_dpp<kDppXor1>(g); g += ppo_dpp<kDppXor2>(g);
+      if (uq == k) my_gwo = g;
     }
-    for (int o = 4; o < 64; o <<= 1) { gbo_p += __shfl_xor(gbo_p, o, 64); if (NET == 0) gls_p += __shfl_xor(gls_p, o, 64); }
-    // (no barrier in front: the previous readers of bred / sred -- and of H1, free since the last chunk's dW1 -- are behind the
-    // barriers of the norm exchange and of the end of the previous minibatch)
+    // component (lane % HSL) over the wave's lanes: rotations inside the row, then across the rows
+    if (HSL == 4) { gbo_p += ppo_dpp<kDppRor4>(gbo_p); if (NET == 0) gls_p += ppo_dpp<kDppRor4>(gls_p); }
+    gbo_p += ppo_dpp<kDppRor8>(gbo_p); gbo_p = ppo_sum_rows(gbo_p);
+    if (NET == 0) { gls_p += ppo_dpp<kDppRor8>(gls_p); gls_p = ppo_sum_rows(gls_p); }
+    // (no barrier in front: the previous readers of bred / sred are behind the barriers of the norm exchange and of the end of the
+    // previous minibatch; H2, which carries dW1's split partials, was last read in the G1 phase, a barrier ago -- H1 is still being
+    // read by slower waves' dW1)
     bred[wave * kPH + lane] = gb1p; bred[(4 + wave) * kPH + lane] = gb2p;
     if (lane < 4) { sred[wave * 8 + lane] = gbo_p; sred[wave * 8 + 4 + lane] = gls_p; }
-    if (splitW1 && wave >= 2) {                    // the second sample half of dW1's two tiles, to its owners (waves 0, 1) through H1's space
-      float* hx = H1 + (wave - 2) * 64 + lane;      // [element][wave][lane]: conflict-free dwords (H1 is not 16-byte aligned for KO = 1)
+    if (splitW1 && wave >= 2) {                    // the second sample half of dW1's two tiles, to its owners (waves 0, 1) through H2's space
+      float* hx = H2 + (wave - 2) * 64 + lane;      // [element][wave][lane]: conflict-free dwords (2048 floats; H2 is not 16-byte aligned for KO = 1)
 #pragma unroll
       for (int v = 0; v < 16; ++v) hx[v * 128] = gW1[v];
     }
     __syncthreads();
     if (splitW1 && wave < 2) {
-      const float* hx = H1 + wave * 64 + lane;
+      const float* hx = H2 + wave * 64 + lane;
 #pragma unroll
       for (int v = 0; v < 16; ++v) gW1[v] += hx[v * 128];
     }
@@ -672,94 +798,127 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       if (t < KO) my_gbo = sred[t] + sred[8 + t] + sred[16 + t] + sred[24 + t];
       if (NET == 0) {
         my_gls = sred[4 + t] + sred[12 + t] + sred[20 + t] + sred[28 + t];
-        if (half == 0) my_gls -= H.ent_coef;   // entropy bonus: entropy_loss = -mean(sum_k (c + log_std_k)) -> d/dlog_std_k = -ent_coef (once)
+        if (part == 0) my_gls -= H.ent_coef;   // entropy bonus: entropy_loss = -mean(sum_k (c + log_std_k)) -> d/dlog_std_k = -ent_coef (once)
       }
     }
 
 #ifdef FW_PPO_PROF
     const long long pfa = PPO_T(); pf_red += pfa - pf3;
 #endif
-    // ---- chunk halves: swap gradient partials with the partner block of this network, keep the sum ----
-    if (nhalf == 2) {
-      float* mine = A.gx + (size_t)((mb & 1) * 4 + NET * 2 + half) * kPMomentSlots;
-      const float* theirs = A.gx + (size_t)((mb & 1) * 4 + NET * 2 + (1 - half)) * kPMomentSlots;
-      unsigned long long* fmine = A.xch + 8 + (mb & 1) * 4 + NET * 2 + half;
-      unsigned long long* ftheirs = A.xch + 8 + (mb & 1) * 4 + NET * 2 + (1 - half);
-      const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane);
-      // Plain vector stores / loads bracketed by a device-scope release (every storing wave, before the barrier and the
-      // flag) and acquire (after the flag).  (Tried instead of the fences: per-word sc1 atomics -- 27.4 vs 23.9 us; sc1 dwordx4
-      // stores / loads by inline asm -- hand-off 12 k -> 9 k cycles but the chunk passes slow down by as much: no gain; round 3:
-      // thread-to-thread self-announcing 8-byte write-through words polled by the receiver, no barrier / flag / fence --
-      // 14.5 k cycles: the memory system serves small device-scope accesses slowly.  Also measured, no gain: the tile partials
-      // stored before the bias reductions (the wait moves, 8.7 k -> 7.9 k for the pair of sections), a register copy of the
+    // ---- swap gradient partials with the other blocks of this network (all to all), keep the sum ----
+    if (nsplit > 1) {
+      float* gxb = A.gx + (size_t)((mb & 1) * 2 + NET) * kPMaxSplit * kPGxSlots;
+      float* mine = gxb + (size_t)part * kPGxSlots;
+      unsigned long long* fl = A.xch + kPpoWordFlags + ((mb & 1) * 2 + NET) * kPMaxSplit;
+      const int g0 = ppo_gx_tile(0, wave, lane), g1 = ppo_gx_tile(1, wave, lane);
+      // Plain vector stores, partner loads past the L1, bracketed by a device-scope release (every storing wave, before the barrier
+      // and the flag) and acquire (after the flag) unless the blocks share an L2.  (Tried instead of the fences: per-word sc1 atomics
+      // -- 27.4 vs 23.9 us; round 3: thread-to-thread self-announcing 8-byte write-through words polled by the receiver, no barrier /
+      // flag / fence -- 14.5 k cycles: the memory system serves small device-scope accesses slowly.  Also measured, no gain: the tile
+      // partials stored before the bias reductions (the wait moves, 8.7 k -> 7.9 k for the pair of sections), a register copy of the
       // lane's own weights so that Adam needs no LDS read (tile Adam 5.5 k -> 5.1 k, the chunk pass +1 k: 32 more live registers).)
-      const int sq = kPTileSlots + t;
+      const int sq = kPGxTile + t;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        reinterpret_cast<float4*>(mine + s0)[q] = make_float4(gW2[4 * q], gW2[4 * q + 1], gW2[4 * q + 2], gW2[4 * q + 3]);
-        if (hasW1) reinterpret_cast<float4*>(mine + s1)[q] = make_float4(gW1[4 * q], gW1[4 * q + 1], gW1[4 * q + 2], gW1[4 * q + 3]);
+        *reinterpret_cast<float4*>(mine + g0 + q * 256) = make_float4(gW2[4 * q], gW2[4 * q + 1], gW2[4 * q + 2], gW2[4 * q + 3]);
+        if (hasW1) *reinterpret_cast<float4*>(mine + g1 + q * 256) = make_float4(gW1[4 * q], gW1[4 * q + 1], gW1[4 * q + 2], gW1[4 * q + 3]);
       }
       mine[sq] = gb1; mine[sq + kPThreads] = gb2; mine[sq + 2 * kPThreads] = my_gbo; mine[sq + 3 * kPThreads] = my_gls; mine[sq + 4 * kPThreads] = my_gwo;
-      if (same_xcd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my stores are in the L2 the partner reads from
-      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // every storing wave: write back to where the partner can see it
+      // (the builtin, not inline assembly: the compiler's own wait-count bookkeeping must see that the stores are done, or it waits for
+      // them one by one between the loads further down -- and with them, in order, for those loads)
+      if (same_xcd) __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): my stores are in the L2 the partners read from
+      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // every storing wave: write back to where the partners can see it
       __syncthreads();
+#ifdef FW_PPO_PROF
+      long long ph = PPO_T(); pf_h[0] += ph - pfa;
+#define PPO_HO(i) do { const long long t_ = PPO_T(); pf_h[i] += t_ - ph; ph = t_; } while (0)
+#else
+#define PPO_HO(i) do { } while (0)
+#endif
       if (t == 0) {
         // (relaxed: the ordering is the waves' release / acquire -- or, on a shared L2, their store wait / L1 drop -- around the barriers)
-        ppo_word_store(fmine, (unsigned long long)(unsigned)(mb + 1), same_xcd);
+        ppo_word_store(fl + part, (unsigned long long)(unsigned)(mb + 1), same_xcd);
       }
-      // While the partner's partials are on their way (two L2 round trips: ~4 k cycles), the inputs of the NEXT minibatch's first
+      // While the partners' partials are on their way (two L2 round trips: ~4 k cycles), the inputs of the NEXT minibatch's first
       // chunk go to LDS and the loads of the chunk after are issued -- X / sA / sS were last read in this minibatch's chunk
       // pass, and the barrier behind the poll below stands in for the one a chunk's gather ends with.
       if (mb + 1 < n_mb) {
         commit();
         if (pmb < n_mb) {
           prefetch(pmb * cpm + pci);
-          pci += nhalf; if (pci >= cpm) { pmb += 1; pci = half; }
+          pci += nsplit; if (pci >= cpm) { pmb += 1; pci = part; }
         }
         gathered = true;
       }
-      if (t == 0) {
+      PPO_HO(1);
+      if (t < nsplit && t != part) {               // thread q waits for block q
         unsigned long long w;
-        if (!ppo_wait(A, [&]() { return ppo_word_load(ftheirs, same_xcd); }, [&](unsigned long long x) { return (unsigned)x == (unsigned)(mb + 1); },
-                      (unsigned long long)PPO_ST_SWAP, w)) red[7] = 1.f;       // the partner block is gone: say so and leave instead of hanging
+        if (!ppo_wait(A, [&]() { return ppo_word_load(fl + t, same_xcd); }, [&](unsigned long long x) { return (unsigned)x == (unsigned)(mb + 1); },
+                      (unsigned long long)PPO_ST_SWAP, w)) red[7] = 1.f;       // a partner block is gone: say so and leave instead of hanging
       }
+      PPO_HO(2);
       __syncthreads();
+      PPO_HO(3);
       if (red[7] != 0.f) { dead = true; break; }
-      // The partner's rows: on a shared L2 they are read with device-scope loads -- past this CU's L1, which may still hold the
-      // lines from two minibatches ago (`buffer_inv sc0` does not drop them outside tg-split mode: a loop of it and plain loads
-      // never saw a word change), served by the L2 the partner's stores sit in.  Otherwise: a device-scope acquire, plain loads.
+      // The partners' rows are read past this CU's L1 (sc1 loads; the L1 may still hold the lines from two minibatches ago, and
+      // `buffer_inv sc0` does not drop them outside tg-split mode: a loop of it and plain loads never saw a word change), served
+      // by the L2 the partners' stores sit in -- after a device-scope acquire when the blocks do not share one.  Buffer loads:
+      // the builtin takes the cache policy, so the compiler schedules and waits for them itself.  (Round 3 / 4 had them as inline
+      // assembly with a hand-placed wait; the compiler, not knowing that they were loads, put waits for older operations between
+      // them, which -- the counter retires in order -- serialised the partners: 4.3 k cycles for 39 loads.)
+      // Partner j of 1 (2 blocks) or 3 (4 blocks) = the other blocks in ascending order.
       typedef float ppo_f4 __attribute__((ext_vector_type(4)));
-      ppo_f4 ta[4], tb[4];
-      float tsc[5];
-      if (same_xcd) {
+      typedef unsigned int ppo_u4 __attribute__((ext_vector_type(4)));
+      ppo_f4 ta[3][4], tb[3][4];
+      float tsc[3][5];
+      const int np = nsplit - 1;
+      if (!same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gxb, 0, kPMaxSplit * kPGxSlots * (int)sizeof(float), 0x00020000);
+      constexpr int kSc1 = 16;                     // cache-policy bit of the raw buffer loads
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(ta[q]) : "v"(theirs + s0 + 4 * q) : "memory");
-          if (hasW1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(tb[q]) : "v"(theirs + s1 + 4 * q) : "memory");
-          else tb[q] = ppo_f4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 3; ++j) {
+        if (j < np) {
+          const int base = (j < part ? j : j + 1) * kPGxSlots * (int)sizeof(float);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const ppo_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (g0 + q * 256) * 4, 0, kSc1);
+            ta[j][q] = ppo_f4{__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[2]), __uint_as_float(a[3])};
+            if (hasW1) {
+              const ppo_u4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (g1 + q * 256) * 4, 0, kSc1);
+              tb[j][q] = ppo_f4{__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3])};
+            } else tb[j][q] = ppo_f4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int q = 0; q < 5; ++q) tsc[j][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, base + (sq + q * kPThreads) * 4, 0, kSc1));
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { ta[j][q] = ppo_f4{0.f, 0.f, 0.f, 0.f}; tb[j][q] = ta[j][q]; }
+#pragma unroll
+          for (int q = 0; q < 5; ++q) tsc[j][q] = 0.f;
         }
-#pragma unroll
-        for (int q = 0; q < 5; ++q) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(tsc[q]) : "v"(theirs + sq + q * kPThreads) : "memory");
-        // (one wait for the lot, tied to every value so that no use is scheduled ahead of it)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ta[0]), "+v"(ta[1]), "+v"(ta[2]), "+v"(ta[3]), "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3]),
-                     "+v"(tsc[0]), "+v"(tsc[1]), "+v"(tsc[2]), "+v"(tsc[3]), "+v"(tsc[4]) :: "memory");
-      } else {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 a = reinterpret_cast<const float4*>(theirs + s0)[q];
-          ta[q] = ppo_f4{a.x, a.y, a.z, a.w};
-          if (hasW1) { const float4 b = reinterpret_cast<const float4*>(theirs + s1)[q]; tb[q] = ppo_f4{b.x, b.y, b.z, b.w}; } else tb[q] = ppo_f4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int q = 0; q < 5; ++q) tsc[q] = theirs[sq + q * kPThreads];
       }
+      PPO_HO(4);
+      // Every block must end up with the same bits: the four partials p0 .. p3 are summed as (p0 + p1) + (p2 + p3) everywhere (own partial
+      // in registers, the others as loaded; fp addition commutes).  Two blocks: own + partner.
+      auto sum4 = [&](auto own, auto t0, auto t1, auto t2) {
+        if (np == 1) return own + t0;
+        return part < 2 ? (own + t0) + (t1 + t2) : (t0 + t1) + (own + t2);
+      };
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        gW2[4 * q] += ta[q][0]; gW2[4 * q + 1] += ta[q][1]; gW2[4 * q + 2] += ta[q][2]; gW2[4 * q + 3] += ta[q][3];
-        if (hasW1) { gW1[4 * q] += tb[q][0]; gW1[4 * q + 1] += tb[q][1]; gW1[4 * q + 2] += tb[q][2]; gW1[4 * q + 3] += tb[q][3]; }
+        const ppo_f4 o2 = {gW2[4 * q], gW2[4 * q + 1], gW2[4 * q + 2], gW2[4 * q + 3]};
+        const ppo_f4 r2 = sum4(o2, ta[0][q], ta[1][q], ta[2][q]);
+        gW2[4 * q] = r2[0]; gW2[4 * q + 1] = r2[1]; gW2[4 * q + 2] = r2[2]; gW2[4 * q + 3] = r2[3];
+        if (hasW1) {
+          const ppo_f4 o1 = {gW1[4 * q], gW1[4 * q + 1], gW1[4 * q + 2], gW1[4 * q + 3]};
+          const ppo_f4 r1 = sum4(o1, tb[0][q], tb[1][q], tb[2][q]);
+          gW1[4 * q] = r1[0]; gW1[4 * q + 1] = r1[1]; gW1[4 * q + 2] = r1[2]; gW1[4 * q + 3] = r1[3];
+        }
       }
-      gb1 += tsc[0]; gb2 += tsc[1]; my_gbo += tsc[2]; my_gls += tsc[3]; my_gwo += tsc[4];
+      gb1 = sum4(gb1, tsc[0][0], tsc[1][0], tsc[2][0]); gb2 = sum4(gb2, tsc[0][1], tsc[1][1], tsc[2][1]);
+      my_gbo = sum4(my_gbo, tsc[0][2], tsc[1][2], tsc[2][2]); my_gls = sum4(my_gls, tsc[0][3], tsc[1][3], tsc[2][3]);
+      my_gwo = sum4(my_gwo, tsc[0][4], tsc[1][4], tsc[2][4]);
+      PPO_HO(5);
     }
 
 #ifdef FW_PPO_PROF
@@ -770,7 +929,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     // the two blocks share), issued now and first used behind this block's own norm: the block that arrives second (the policy
     // block, as a rule) finds the word there and never polls.  A stale or missing word only means the poll below runs.
     unsigned long long spec_w = 0ull;
-    if (t == 0) spec_w = __hip_atomic_load(A.xch + (mb & 1) * 4 + (1 - NET) * 2 + half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) spec_w = __hip_atomic_load(A.xch + ((mb & 1) * 2 + (1 - NET)) * kPMaxSplit + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float ss = 0.f;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
@@ -779,7 +938,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     }
     if (t < kPH) ss += gb1 * gb1 + gb2 * gb2;
     if (t < KO) ss += my_gbo * my_gbo;
-    if (hq < KO) ss += my_gwo * my_gwo;
+    if (uq < KO) ss += my_gwo * my_gwo;
     if (NET == 0 && t < 4) ss += my_gls * my_gls;
     const float ss_mine = ppo_block_sum_nb(ss, red);      // (red[0..3] were last read before the previous minibatch's closing barrier)
     float ss_other = 0.f;
@@ -788,8 +947,8 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #endif
     {
       // one 64-bit word per block and minibatch parity: (minibatch + 1) << 32 | float bits
-      unsigned long long* mine = A.xch + (mb & 1) * 4 + NET * 2 + half;
-      unsigned long long* other = A.xch + (mb & 1) * 4 + (1 - NET) * 2 + half;
+      unsigned long long* mine = A.xch + ((mb & 1) * 2 + NET) * kPMaxSplit + part;
+      unsigned long long* other = A.xch + ((mb & 1) * 2 + (1 - NET)) * kPMaxSplit + part;
       if (t == 0) {
         ppo_word_store(mine, ((unsigned long long)(unsigned)(mb + 1) << 32) | (unsigned long long)__float_as_uint(ss_mine), same_xcd_net);
         unsigned long long w = spec_w;
@@ -841,7 +1000,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     };
     adam_tile(gW2, pm[0], pv[0], [&](int v) { return W.W2 + (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r; });
     if (hasW1) adam_tile(gW1, pm[1], pv[1],
-                         [&](int v) { const int i = mt * 32 + ppo_acc_row(v); return i < D ? W.W1 + i * kPH + nt * 32 + r : sink + t; });
+                         [&](int v) { const int i = mt * 32 + ppo_acc_row(v); return i < D ? W.W1 + i * ldw1 + nt * 32 + r : sink + t; });
 #ifdef FW_PPO_PROF
     const long long pfd = PPO_T(); pf_tile += pfd - pfc;
 #endif
@@ -851,7 +1010,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       gs[0] = gb1; ws[0] = t < kPH ? W.b1 + t : nullptr;
       gs[1] = gb2; ws[1] = t < kPH ? W.b2 + t : nullptr;
       gs[2] = my_gbo; ws[2] = t < KO ? W.bo + t : nullptr;
-      gs[3] = my_gwo; ws[3] = hq < KO ? W.Wo + hs * KO + hq : nullptr;
+      gs[3] = my_gwo; ws[3] = uq < KO ? W.Wo + us * KO + uq : nullptr;
       if (NET == 0) { gs[NQ - 1] = my_gls; ws[NQ - 1] = t < 4 ? log_std + t : nullptr; }
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
@@ -869,7 +1028,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 
   // ---- write the weights back, report the losses (a block that gave up leaves the parameters as it found them) ----
   if (dead) return;
-  if (half == 0) {
+  if (part == ((A.flags & PPO_FLAG_WRITER_LAST) ? nsplit - 1 : 0)) {
     {
       const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane);
 #pragma unroll
@@ -880,7 +1039,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #pragma unroll
       for (int q = 0; q < NQ; ++q) { mom_m[sl[q]] = smm[q]; mom_v[sl[q]] = svv[q]; }
     }
-    for (int i = t; i < Dp * kPH; i += kPThreads) params[oW1 + i] = W.W1[i];
+    for (int i = t; i < Dp * kPH; i += kPThreads) params[oW1 + i] = W.W1[(i >> 6) * ldw1 + (i & 63)];
     for (int i = t; i < kPH; i += kPThreads) { params[ob1 + i] = W.b1[i]; params[ob2 + i] = W.b2[i]; }
     for (int i = t; i < kPH * kPH; i += kPThreads) params[oW2 + i] = W.W2[(i >> 6) * kPLdh + (i & 63)];
     for (int i = t; i < kPH * KO + KO; i += kPThreads) params[oWo + i] = W.Wo[i];
@@ -888,21 +1047,31 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   }
   const float lsum = ppo_block_sum(acc_l, red);
   if (t == 0 && A.loss_acc) {
-    if (NET == 0) {
+    // The losses: every block leaves its sum in its own word; the block that finishes last adds them up in a fixed order (a float
+    // atomicAdd per block would make the logged value depend on which of four blocks came first).
+    __hip_atomic_store(A.xch + kPpoWordLoss + NET * kPMaxSplit + part, (unsigned long long)__float_as_uint(lsum * invB), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long before = __hip_atomic_fetch_add(A.xch + kPpoWordDone, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == (unsigned long long)(2 * nsplit - 1)) {
+      for (int net = 0; net < 2; ++net) {
+        float l = 0.f;
+        for (int q = 0; q < nsplit; ++q)
+          l += __uint_as_float((unsigned)__hip_atomic_load(A.xch + kPpoWordLoss + net * kPMaxSplit + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        atomicAdd(&A.loss_acc[net], l);                               // sums over minibatches of the per-minibatch means
+      }
+    }
+    if (NET == 0 && part == 0) {
       float ent = 0.f;
       for (int k = 0; k < 4; ++k) ent += 1.4189385332046727f + log_std[k];
-      atomicAdd(&A.loss_acc[0], lsum * invB);                       // sums over minibatches of the per-minibatch means
-      if (half == 0) atomicAdd(&A.loss_acc[2], -ent * (float)n_mb); // entropy loss at the final log_std (it is state-independent)
-    } else {
-      atomicAdd(&A.loss_acc[1], lsum * invB);
+      atomicAdd(&A.loss_acc[2], -ent * (float)n_mb);                  // entropy loss at the final log_std (it is state-independent)
     }
 #ifdef FW_PPO_PROF
     float* pr = A.loss_acc + 3 + NET * 4;
     pr[0] = (float)pf_xch / n_mb; pr[1] = (float)pf_gather / n_mb; pr[2] = (float)pf_net / n_mb; pr[3] = (float)pf_adam / n_mb;
-    if (NET == 0 && half == 0) {      // the finish section of the policy block, piece by piece
+    if (NET == 0 && part == 0) {      // the finish section of the policy block, piece by piece
       float* px = A.loss_acc + 11;
       px[0] = (float)pf_red / n_mb; px[1] = (float)pf_ho / n_mb; px[2] = (float)pf_norm / n_mb; px[3] = (float)pf_tile / n_mb; px[4] = (float)pf_scal / n_mb;
-      for (int i = 0; i < 4; ++i) A.loss_acc[16 + i] = (float)pf_g[i] / n_mb;      // (the profiling tool hands a 32-float buffer)
+      for (int i = 0; i < 4; ++i) A.loss_acc[16 + i] = (float)pf_h[i] / n_mb;      // (the profiling tool hands a 32-float buffer)
+      A.loss_acc[28] = (float)pf_h[4] / n_mb; A.loss_acc[29] = (float)pf_h[5] / n_mb; (void)pf_g;
       for (int i = 0; i < 8; ++i) A.loss_acc[20 + i] = (float)pf_n[i] / n_mb;
     }
 #endif
@@ -912,18 +1081,33 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 // 256 threads per block, dynamic LDS = ppo_lds_bytes().  Every 8th block of the grid works (the others leave at once): where
 // workgroups are dealt round-robin to the 8 XCDs that puts all working blocks on ONE XCD, whose L2 then carries their
 // exchanges (checked at run time, see ppo_net_body).  Working block i = blockIdx / 8 runs network i & 1 (0: policy, 1: value)
-// on chunk half i >> 1; grid = 16 (one block per network) or 32 (two chunk halves per network).
+// as part i >> 1 of gridDim / 16 blocks per network (1, 2 or 4).
+template <int CH>
 __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(PpoArgs A) {
   extern __shared__ __align__(16) float lds[];
   if (blockIdx.x & 7) return;
   const int i = (int)blockIdx.x >> 3;
-  const int half = i >> 1, nhalf = gridDim.x > 16 ? 2 : 1;
-  if ((i & 1) == 0) ppo_net_body<0>(A, lds, half, nhalf); else ppo_net_body<1>(A, lds, half, nhalf);
+  const int part = i >> 1, nsplit = (int)gridDim.x >> 4;
+  if ((i & 1) == 0) ppo_net_body<0, CH>(A, lds, part, nsplit); else ppo_net_body<1, CH>(A, lds, part, nsplit);
+}
+
+// How a minibatch of B samples is cut: samples per pass (64 or 32) and blocks per network.  The path is sequential, so the
+// smaller the share of a block the better -- down to 32 samples (below that the 16 x 16 tiles no longer fill four waves) and
+// up to four blocks (each reads every other block's partials).
+struct PpoSplit { int ch, nsplit; };
+inline PpoSplit ppo_split(int B) {
+  auto cut = [&](int ch) { PpoSplit s; s.ch = ch; const int c = B / ch; s.nsplit = c >= 4 ? 4 : c >= 2 ? 2 : 1; return s; };
+  auto passes = [&](PpoSplit s) { return (B / s.ch + s.nsplit - 1) / s.nsplit; };       // of the busiest block
+  const PpoSplit s32 = cut(32);
+  if (B % 64 != 0) return s32;
+  const PpoSplit s64 = cut(64);
+  return 5 * passes(s64) <= 3 * passes(s32) ? s64 : s32;      // (a 64-sample pass costs ~5/3 of a 32-sample one)
 }
 
 inline size_t ppo_lds_bytes(int D) {
-  const int Dp = (D + 1) & ~1, ldx = kPLdx;
-  size_t f = (size_t)ppo_net_lds_floats(Dp, 4) + 4 + (size_t)kPChunk * ldx + 64 + 2 * (size_t)kPChunk * kPLdh +
+  (void)D;                                          // (sized for the larger of the two forms: W1 as 64 rows of 65)
+  const int ldx = kPLdx;
+  size_t f = (size_t)(kPH * kPLdh + kPH + kPH * kPLdh + kPH + kPH * 4 + 4) + 4 + (size_t)kPChunk * ldx + 64 + 2 * (size_t)kPChunk * kPLdh +
              3 * (size_t)kPChunk * 4 + 8 * kPH + 8 + 32 + kPThreads;
   return f * sizeof(float);
 }

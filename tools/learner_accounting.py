@@ -55,10 +55,24 @@ def collect_close(N: int, D: int, T: int, env_word: int = 8, rows_per_act_wave: 
     return {"bytes": sum(it.values()), "items": it, "mfma_flops": 2 * N * net_macs_forward(D, 1)}
 
 
+def ppo_split(B: int):
+    """csrc/fwsim_ppo.hpp ppo_split: (samples per pass, blocks per network) of a B-sample minibatch."""
+    def cut(ch):
+        c = B // ch
+        return ch, (4 if c >= 4 else 2 if c >= 2 else 1)
+    def passes(s):
+        return (B // s[0] + s[1] - 1) // s[1]
+    s32 = cut(32)
+    if B % 64:
+        return s32
+    s64 = cut(64)
+    return s64 if 5 * passes(s64) <= 3 * passes(s32) else s32
+
+
 def ppo_update(n_mb: int, B: int, D: int) -> dict:
     """One fw_ppo_update launch = n_mb sequential minibatches of B samples through both networks, forward and backward."""
     macs = B * sum(net_macs_forward(D, ko) + net_macs_backward(D, ko) for ko in (4, 1))
-    blocks = 4 if B >= 128 else 2
+    blocks = 2 * ppo_split(B)[1]
     it = {"gathered rows per minibatch (obs D, action 4, old log-prob, advantage, return: float32) + index": B * ((D + 7) * 4 + 4)}
     return {"bytes": n_mb * sum(it.values()), "items_per_minibatch": it, "mfma_flops": 2 * n_mb * macs, "flops_per_minibatch": 2 * macs,
             "workgroups": blocks, "mfma_peak_tflops": blocks * MFMA_F32_TFLOPS_CHIP / CUS}
