@@ -7,11 +7,16 @@
 //   out[env][1][y][x] = depth-buffer value in [0, 1] of the nearest fragment (duck pixels: the sphere; others: ground or
 //                       cylinder; sky = 1.0), far (t - near) / (t (far - near)) with t clipped to [near, far]
 // at `res` x `res` pixels of the same body-fixed camera (FOV, tilt, offset of fw_config; the focal length scales with the
-// width), for the env's CURRENT pose.  One workgroup (four waves) per env; a wave takes 8 x 8-pixel tiles.
-//   * The decisions a pixel's value hangs on -- duck silhouette (disc >= 0), cylinder hit (disc >= 0, t > 0, 0 <= z <= h),
-//     nearest fragment -- are the CPU checker's expressions statement by statement in double, IEEE sqrt and division, no FMA
-//     contraction: the mask is an exact comparison against 0 at the silhouette, so the test asks for the same bits, not for a
-//     tolerance.  What round 4 changed is how OFTEN they run.
+// width), for the env's CURRENT pose.  One workgroup (four waves) per env; a wave takes 16 x 16-pixel tiles.
+//   * The duck MASK is an exact comparison against 0 at the silhouette, so the test asks for the same bits, not for a tolerance:
+//     the pose, the duck in the camera frame and the silhouette discriminant are the CPU checker's expressions statement by
+//     statement in double, no FMA contraction (multiplications and additions only: cheap); the clip-plane test of a duck pixel
+//     takes the fast quotient below and falls back to the IEEE sequences inside 1e-9 of a clip plane.
+//   * The DEPTH channel is a float32 within 1e-7 of the checker's, not the same bits: it is computed on 1 / t -- the ray direction
+//     as an affine form of the pixel coordinates (Hf + a Hr + b Hd: 6 fused multiply-adds instead of 27 operations), the ground's
+//     1 / t a multiple of the direction's z (no division), a cylinder's from v_rsq / v_rcp seeds with Newton steps (~1 ulp of
+//     double), the depth-buffer value c1 (1 - near / t) -- which took the vector instructions of a launch from 23.1 M to a third.
+//     A cylinder's edge or top can fall on the other side of a pixel centre than in the checker only inside ~1e-15 of it.
 //   * Round 3 tested every pixel against every cylinder, square root and division included: 818 vector instructions per
 //     pixel with 20 cylinders, 70 % of the chip's fp64 issue peak -- the kernel was compute-bound at 3 % of the HBM write rate.
 //     A ray hits an (infinite) cylinder iff its horizontal direction lies in the wedge between the two vertical tangent planes
@@ -31,9 +36,13 @@ namespace fwsim {
 struct RenderC {            // camera constants in double (built on the host from fw_config)
   double cam_f[3], cam_r[3], cam_d[3], cam_off[3];
   double tan_half_fov, near_, far_, duck_radius, obst_radius;
+  double inv_near, inv_far, db_c1;      // 1 / near, 1 / far, far / (far - near): the depth-buffer value of a fragment at depth t is db_c1 (1 - near / t)
 };
 
-constexpr int kRTile = 16;                      // a wave's tile: 16 x 16 pixels, four per lane (rows y0 + lane / 16 + 4 k)
+// A wave's tile: a strip of 4 columns x 64 rows, four pixels per lane (column x0 + lane % 4, rows y0 + lane / 4 + 16 k).  Cylinders are
+// vertical and the camera rolls little: what a cylinder covers is a band of columns, and a narrow strip is crossed by few of them
+// (16 x 16 tiles kept ~4 of 20 cylinders alive per tile, every one of them ~40 vector instructions for every pixel of the tile).
+constexpr int kRTileW = 4, kRTileH = 64;
 
 template <typename T>
 __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r, int tile, int n_envs, RenderC K, int res,
@@ -53,10 +62,10 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
   nob = nob < 0 ? 0 : (nob > FW_MAX_OBSTACLES ? FW_MAX_OBSTACLES : nob);
   const double W = (double)res, F = 0.5 * W / K.tan_half_fov, u0 = 0.5 * (W - 1.0), near = K.near_, far = K.far_;
   for (int i = t; i < res; i += (int)blockDim.x) s_ab[i] = ((double)i - u0) / F;      // (one IEEE division per column, not four per pixel)
-  if (t == 0) s_blocked = 0;
-  if (wave == 0) {
-    // the pose, the duck in the camera frame, the ray basis: every lane of the first wave for itself (no broadcast inside the
-    // wave), lane 0 leaves them for the other waves
+  if (wave == (env & ((int)(blockDim.x >> 6) - 1))) {
+    // the pose, the duck in the camera frame, the ray basis: every lane of ONE wave for itself (no broadcast inside the wave), lane 0
+    // leaves them for the other waves.  Which wave rotates with the env: a workgroup's wave i runs on SIMD i, and with the pixel loop
+    // as short as it now is the set-up would otherwise queue sixteen deep on SIMD 0 of every CU
     double R[9], cam[3], relw[3], zc, xc, yc, k2, Hf[3], Hr[3], Hd[3];
     const double x = fld(RF_QUAT), y = fld(RF_QUAT + 1), z = fld(RF_QUAT + 2), w = fld(RF_QUAT + 3);
     const double d = x * x + y * y + z * z + w * w, s = 2.0 / d;                 // btMatrix3x3::setRotation
@@ -83,7 +92,10 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
       for (int k = 0; k < 9; ++k) s_pose[k] = R[k];
       for (int k = 0; k < 3; ++k) s_pose[9 + k] = cam[k];
       s_pose[12] = zc; s_pose[13] = xc; s_pose[14] = yc; s_pose[15] = k2;
+      for (int k = 0; k < 3; ++k) { s_pose[16 + k] = Hf[k]; s_pose[19 + k] = Hr[k]; s_pose[22 + k] = Hd[k]; }
+      s_pose[25] = cam[2] > 0.0 ? -1.0 / cam[2] : 0.0;
     }
+    bool blocked_any = false;
     if (lane < FW_MAX_OBSTACLES) {                   // lane o: cylinder o
       bool blocked = false;
       double ox = 0.0, oy = 0.0, cc = 1.0, hh = 0.0;
@@ -118,84 +130,92 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
       }
       for (int k = 0; k < 3; ++k) { s_wedge[lane][0][k] = g[0][k]; s_wedge[lane][1][k] = g[1][k]; }
       s_margin[lane] = margin;
-      if (blocked) s_blocked = 1;
+      blocked_any = blocked;
     }
+    blocked_any = __any(blocked_any);
+    if (lane == 0) s_blocked = blocked_any ? 1 : 0;
   }
   __syncthreads();
-  double R[9], cam[3];
-  for (int k = 0; k < 9; ++k) R[k] = s_pose[k];
-  for (int k = 0; k < 3; ++k) cam[k] = s_pose[9 + k];
+  double cam[3], Hf[3], Hr[3], Hd[3];
+  for (int k = 0; k < 3; ++k) { cam[k] = s_pose[9 + k]; Hf[k] = s_pose[16 + k]; Hr[k] = s_pose[19 + k]; Hd[k] = s_pose[22 + k]; }
   const double zc = s_pose[12], xc = s_pose[13], yc = s_pose[14], k2 = s_pose[15];
+  const double inv_near = K.inv_near, inv_far = K.inv_far, db_c1 = K.db_c1;
+  const double kground = s_pose[25];                                                 // -1 / (camera height); 0 for a camera at or below the ground (it sees none: 1 / t stays at 1 / far)
   const bool duck_possible = zc - K.duck_radius > near && zc - K.duck_radius < far && s_blocked == 0;
   float* img = out + (size_t)env * 2 * res * res;
-  auto depth_buffer_of = [&](double tv) {
-#pragma clang fp contract(off)
-    if (tv < near) tv = near;
-    if (tv > far) tv = far;
-    return far * (tv - near) / (tv * (far - near));
-  };
-  const int tpr = (res + kRTile - 1) / kRTile, ntiles = tpr * tpr;
+  const int tpr = (res + kRTileW - 1) / kRTileW, ntiles = tpr * ((res + kRTileH - 1) / kRTileH);
   for (int tl = wave; tl < ntiles; tl += (int)(blockDim.x >> 6)) {
     const int ty = tl / tpr, tx = tl - ty * tpr;
-    const int x0 = tx * kRTile, y0 = ty * kRTile, x1 = min(x0 + kRTile, res) - 1, y1 = min(y0 + kRTile, res) - 1;
-    // ---- cull: lane (cylinder c = lane / 4, corner = lane % 4), in two rounds for up to 32 cylinders ----
+    const int x0 = tx * kRTileW, y0 = ty * kRTileH, x1 = min(x0 + kRTileW, res) - 1, y1 = min(y0 + kRTileH, res) - 1;
+    // ---- cull: lane c looks at cylinder c -- a half-plane that holds none of the four corners of the tile holds no pixel of it ----
     unsigned int alive = 0u;
-    for (int base = 0; base < nob; base += 16) {
-      const int c = base + (lane >> 2), corner = lane & 3;
-      bool in0 = false, in1 = false;                 // this corner is inside half-plane 0 / 1 of cylinder c (with the margin)
-      if (c < nob) {
-        const float a = (float)s_ab[(corner & 1) ? x1 : x0], b = (float)s_ab[(corner & 2) ? y1 : y0];
-        const float m = s_margin[c];
-        in0 = s_wedge[c][0][0] + a * s_wedge[c][0][1] + b * s_wedge[c][0][2] >= -m;
-        in1 = s_wedge[c][1][0] + a * s_wedge[c][1][1] + b * s_wedge[c][1][2] >= -m;
+    {
+      bool keep = false;
+      if (lane < nob) {
+        const float a0 = (float)s_ab[x0], a1 = (float)s_ab[x1], b0 = (float)s_ab[y0], b1 = (float)s_ab[y1];
+        const float m = -s_margin[lane];
+        bool in[2];
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+          const float g0 = s_wedge[lane][hp][0], g1 = s_wedge[lane][hp][1], g2 = s_wedge[lane][hp][2];
+          const float u0_ = g0 + a0 * g1, u1_ = g0 + a1 * g1, v0_ = b0 * g2, v1_ = b1 * g2;
+          in[hp] = u0_ + v0_ >= m || u1_ + v0_ >= m || u0_ + v1_ >= m || u1_ + v1_ >= m;
+        }
+        keep = in[0] && in[1];
       }
-      // a half-plane that holds none of the four corners holds no pixel of the tile
-      const unsigned long long b0 = __ballot(in0), b1 = __ballot(in1);
-      const int q = lane & ~3;
-      const bool keep = ((b0 >> q) & 0xFull) != 0ull && ((b1 >> q) & 0xFull) != 0ull;
-      const unsigned long long kb = __ballot(keep && (lane & 3) == 0);
-      for (int i = 0; i < 16; ++i) if ((kb >> (4 * i)) & 1ull) alive |= 1u << (base + i);
+      alive = (unsigned int)__ballot(keep);          // (FW_MAX_OBSTACLES <= 32 cylinders: the low word)
     }
-    // ---- pixels of the tile: column x0 + lane % 16, rows y0 + lane / 16 + 4 k ----
-    const int xi = x0 + (lane & (kRTile - 1));
+    // ---- pixels of the tile ----
+    const int xi = x0 + (lane & (kRTileW - 1));
 #pragma unroll 1
-    for (int k = 0; k < kRTile / 4; ++k) {
-      const int yi = y0 + (lane >> 4) + 4 * k;
+    for (int k = 0; k < kRTileW * kRTileH / 64; ++k) {
+      const int yi = y0 + (lane >> 2) + (64 / kRTileW) * k;
+      if (y0 + (64 / kRTileW) * k >= res) break;                                       // (wave-uniform: the strip is taller than the image)
       if (xi >= res || yi >= res) continue;
       const double a = s_ab[xi], b = s_ab[yi];
       bool is_duck = false;
-      double t_duck = 0.0;
+      double inv_t = 0.0;                                                            // 1 / (view-axis depth) of the nearest fragment
       if (duck_possible) {
-        const double q = 1.0 + a * a + b * b, p = zc + a * xc + b * yc, disc = p * p - q * k2;
-        if (disc >= 0.0 && p > 0.0) { t_duck = (p - ::sqrt(disc)) / q; is_duck = t_duck > near && t_duck < far; }
+        const double q = 1.0 + a * a + b * b, p = zc + a * xc + b * yc, disc = p * p - q * k2;       // (the checker's expressions: the silhouette)
+        if (disc >= 0.0 && p > 0.0) {
+          const double num = p - M<double>::sqrt_(disc);
+          if (num > 0.0) {
+            inv_t = M<double>::div_(q, num);
+            is_duck = inv_t < inv_near && inv_t > inv_far;
+            if (::fabs(inv_t - inv_near) <= 1e-9 * inv_near || ::fabs(inv_t - inv_far) <= 1e-9 * inv_far) {       // at a clip plane: the checker's own sequence decides
+              const double t_duck = (p - ::sqrt(disc)) / q;
+              is_duck = t_duck > near && t_duck < far;
+            }
+          }
+        }
       }
-      double dv;
-      if (is_duck) dv = depth_buffer_of(t_duck);
-      else {
-        double db[3], dw[3];
-        for (int j = 0; j < 3; ++j) db[j] = K.cam_f[j] + a * K.cam_r[j] + b * K.cam_d[j];
-        for (int j = 0; j < 3; ++j) dw[j] = R[3 * j] * db[0] + R[3 * j + 1] * db[1] + R[3 * j + 2] * db[2];
-        double best = far;                                                           // ray_depth()
-        if (dw[2] < 0.0) { const double tg = -cam[2] / dw[2]; if (tg > 0.0 && tg < best) best = tg; }
-        const double qa = dw[0] * dw[0] + dw[1] * dw[1];
+      if (!is_duck) {
+        const double dwx = fma(b, Hd[0], fma(a, Hr[0], Hf[0])), dwy = fma(b, Hd[1], fma(a, Hr[1], Hf[1])), dwz = fma(b, Hd[2], fma(a, Hr[2], Hf[2]));
+        inv_t = inv_far;                                                             // ray_depth(): best = far ...
+        const double ig = dwz * kground;                                             // ... the ground at t = -cam z / dw z (dw z < 0, t > 0) ...
+        if (dwz < 0.0 && ig > inv_t) inv_t = ig;
+        const double qa = fma(dwx, dwx, dwy * dwy);
         if (qa > 0.0) {
           unsigned int m = alive;
-          while (m) {
+          while (m) {                                                                // ... the cylinders this tile can see
             const int o = __ffs((int)m) - 1;
             m &= m - 1u;
             const double ox = s_cyl[o][0], oy = s_cyl[o][1], cc = s_cyl[o][2], hh = s_cyl[o][3];
-            const double qb = 2.0 * (ox * dw[0] + oy * dw[1]);
-            const double disc = qb * qb - 4.0 * qa * cc;
+            const double hb = fma(ox, dwx, oy * dwy);                                // t = (-hb - sqrt(hb^2 - qa cc)) / qa
+            const double disc = fma(hb, hb, -(qa * cc));
             if (disc < 0.0) continue;
-            const double tc = (-qb - ::sqrt(disc)) / (2.0 * qa);
-            if (tc <= 0.0) continue;
-            const double zz2 = cam[2] + tc * dw[2];
-            if (zz2 < 0.0 || zz2 > hh) continue;
-            if (tc < best) best = tc;
+            const double num = -hb - M<double>::sqrt_(disc);
+            if (!(num > 0.0)) continue;
+            const double ic = M<double>::div_(qa, num);
+            const double zi = fma(cam[2], ic, dwz);                                  // z / t of the hit: 0 <= z <= height
+            if (zi < 0.0 || zi > hh * ic) continue;
+            if (ic > inv_t) inv_t = ic;
           }
         }
-        dv = depth_buffer_of(best < near ? near : best);
       }
+      inv_t = inv_t > inv_near ? inv_near : inv_t;                                   // t clipped to [near, far]
+      inv_t = inv_t < inv_far ? inv_far : inv_t;
+      const double dv = db_c1 * fma(-near, inv_t, 1.0);                              // far (t - near) / (t (far - near))
       const int px = yi * res + xi;
       img[px] = is_duck ? 1.0f : 0.0f;
       img[(size_t)res * res + px] = (float)dv;
