@@ -150,6 +150,7 @@ def _filled_ppo(fused, d, bs, n_epochs, T=4, n=256, seed=5, scope="minibatch", s
                                         (28, 192, "minibatch"),      # three chunks per minibatch: the chunk halves run 2 and 1 of them
                                         (64, 128, "global"),         # the widest input: four dW1 tiles, no split
                                         (28, 96, "minibatch"),       # three 32-sample chunks over two blocks
+                                        (28, 32, "minibatch"),       # one 32-sample pass: one block per network, no swap
                                         (40, 512, "minibatch")])     # 64-sample chunks over four blocks, 2 each; K = 64 rows of W1 in the 32-sample form
 @pytest.mark.parametrize("split", [None, "64x2", "32x2", "64x1"])
 def test_fused_ppo_update_matches_the_torch_path(d, bs, scope, split, monkeypatch):

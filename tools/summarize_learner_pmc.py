@@ -58,8 +58,12 @@ for key in sorted(os.listdir(src)):
             for row in csv.DictReader(f):
                 k = short(row["Name"])
                 if k.startswith(KERNELS):
-                    dur[k] = {"full_name": row["Name"][:120], "launches": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3,
-                              "min_us": float(row["MinNs"]) / 1e3, "max_us": float(row["MaxNs"]) / 1e3}
+                    e = {"full_name": row["Name"][:120], "launches": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3,
+                         "min_us": float(row["MinNs"]) / 1e3, "max_us": float(row["MaxNs"]) / 1e3}
+                    # fw_ppo_update_kernel<32> / <64>: the bench run's second configuration (batch 4096) runs the other instantiation;
+                    # the reference-hyper-parameter launches are the long ones
+                    if k not in dur or e["max_us"] > dur[k]["max_us"]:
+                        dur[k] = e
     ctr = defaultdict(lambda: defaultdict(list))
     for sub in ("fetch", "write", "sq", "mfma", "lds"):
         p = os.path.join(d, sub, "p_counter_collection.csv")
