@@ -1604,9 +1604,13 @@ int ensure_learner_lds(int dev, int which, size_t bytes) {
   static size_t have[64][2] = {};
   if (dev < 0 || dev >= 64) { g_err = "device index out of range"; return FW_EINVAL; }
   if (bytes <= have[dev][which]) return FW_OK;
-  const void* fn = which == 0 ? (const void*)fw_ppo_update_kernel<64> : (const void*)fw_policy_act_kernel;
+  const void* fn = which == 0 ? (const void*)fw_ppo_update_kernel<64, false> : (const void*)fw_policy_act_kernel;
   HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  if (which == 0) HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (which == 0) {
+    HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  }
   have[dev][which] = bytes;
   return FW_OK;
 }
@@ -1903,10 +1907,10 @@ static long long spin_budget(long long dflt) {
   return dflt;
 }
 
-// workspace layout of fw_ppo_update: [0,512) exchange words (kPpoWordPaths: which exchanges shared an L2, kPpoWordStatus: include/fwsim.h) |
+// workspace layout of fw_ppo_update: [0,640) exchange words (kPpoWordPaths: which exchanges shared an L2, kPpoWordStatus: include/fwsim.h) |
 // gradient hand-off buffer | the packed rows of every minibatch, in walking order (fw_ppo_pack_kernel)
 static constexpr size_t kPpoWsXch = kPpoWords * sizeof(unsigned long long);
-static constexpr size_t kPpoWsGx = sizeof(float) * 4 * kPMaxSplit * (size_t)kPGxSlots;
+static constexpr size_t kPpoWsGx = sizeof(float) * (4 * kPMaxSplit * (size_t)kPGxSlots + kPWxFloats);      // gradient partials, then the weight quarters
 int64_t fw_ppo_update_workspace_bytes(int32_t n_minibatches, int32_t batch_size, int32_t obs_dim) {
   if (n_minibatches <= 0 || batch_size <= 0 || obs_dim <= 0 || obs_dim > 64) return FW_EINVAL;
   return (int64_t)(kPpoWsXch + kPpoWsGx + sizeof(float) * (size_t)n_minibatches * (size_t)batch_size * (size_t)ppo_pack_width(obs_dim));
@@ -1940,6 +1944,7 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   PpoArgs A;
   A.params = params; A.mom_m = mom_m; A.mom_v = mom_v; A.packed = packed;
   A.n_mb = n_minibatches; A.B = batch_size; A.D = obs_dim; A.loss_acc = loss_acc; A.xch = xch; A.gx = gx;
+  A.wx = gx + 4 * kPMaxSplit * (size_t)kPGxSlots;
   A.spin = spin_budget(kPpoSpin);
   A.flags = 0;
   if (const char* e = getenv("FWSIM_PPO_NO_L2_SWAP")) if (atoi(e) != 0) A.flags |= PPO_FLAG_NO_L2_SWAP;
@@ -1958,9 +1963,14 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
       cut.ch = ch; cut.nsplit = ns;
     } else { g_err = "fw_ppo_update: FWSIM_PPO_SPLIT must be CHxN with CH in {32, 64}, N in {1, 2, 4}, N chunks of CH samples in a minibatch"; return FW_EINVAL; }
   }
+  // four blocks per network: gradient tiles by reduce-scatter, updated weights by all-gather (FWSIM_PPO_RS=0: all-to-all, as for two blocks)
+  bool rs = cut.nsplit == kPMaxSplit;
+  if (const char* e = getenv("FWSIM_PPO_RS")) if (atoi(e) == 0) rs = false;
   const dim3 grid(16 * cut.nsplit);                 // (every 8th block works -- see the kernel)
-  if (cut.ch == 64) hipLaunchKernelGGL(fw_ppo_update_kernel<64>, grid, dim3(kPThreads), lds, st, A);
-  else hipLaunchKernelGGL(fw_ppo_update_kernel<32>, grid, dim3(kPThreads), lds, st, A);
+  if (cut.ch == 64 && rs) hipLaunchKernelGGL((fw_ppo_update_kernel<64, true>), grid, dim3(kPThreads), lds, st, A);
+  else if (cut.ch == 64) hipLaunchKernelGGL((fw_ppo_update_kernel<64, false>), grid, dim3(kPThreads), lds, st, A);
+  else if (rs) hipLaunchKernelGGL((fw_ppo_update_kernel<32, true>), grid, dim3(kPThreads), lds, st, A);
+  else hipLaunchKernelGGL((fw_ppo_update_kernel<32, false>), grid, dim3(kPThreads), lds, st, A);
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;
 }

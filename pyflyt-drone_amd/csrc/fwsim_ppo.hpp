@@ -268,19 +268,17 @@ __global__ __launch_bounds__(256) void fw_ppo_pack_kernel(PpoPackArgs P) {
 //   * bias gradients are column sums: thread (wave q, lane n) sums rows 16 q .. 16 q + 15 of column n.
 // Each lane applies clipping + Adam to the accumulator elements it holds; their moments are loaded once (slot order:
 // ppo_moment_map), live in registers (AGPRs) for the whole call and are written back by the first chunk half at the end.
-// Exchange words between two blocks.  `l2` = both run on one XCD: the word is written through this CU's L1 into the shared L2 and
-// read by an atomic OR of zero -- atomics execute in the L2 -- instead of device-scope accesses that travel to memory.
+// Exchange words between blocks.  `l2` = they run on one XCD: the word is written through this CU's L1 into the shared L2 (a
+// workgroup-scope store) instead of with a device-scope store.  Polls are device-scope loads (past the L1, served by the L2) in
+// both cases.  (Rounds 3 / 4 polled with an atomic OR of zero on the shared-L2 path: with up to seven lanes of eight blocks
+// polling words of one line, the atomics queued behind each other in the L2 -- 0.87 k -> 0.40 k cycles per flag poll, 11.1 ->
+// 10.3 us per minibatch with plain loads.)
 __device__ __forceinline__ void ppo_word_store(unsigned long long* p, unsigned long long v, bool l2) {
   if (l2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned long long ppo_word_load(unsigned long long* p, bool l2) {
-  if (l2) {
-    unsigned long long r;
-    const unsigned long long zero = 0ull;
-    asm volatile("global_atomic_or_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p), "v"(zero) : "memory");
-    return r;
-  }
+  (void)l2;
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -293,6 +291,7 @@ struct PpoArgs {
   unsigned long long* xch;           // [kPpoWords] exchange words (norm partials [parity][net][part], gradient flags + kPpoWordFlags, XCD ids of
                                      //      the blocks [net][part] + kPpoWordIds, kPpoWordPaths, kPpoWordStatus), zeroed by the host
   float* gx;                         // [2 parities][2 nets][kPMaxSplit parts][kPGxSlots] gradient partials of the blocks of a network
+  float* wx;                         // [kPWxFloats] updated weight quarters (reduce-scatter form)
   long long spin;                    // polls a wait for another block may take (kPpoSpin; FWSIM_SPIN_LOG2 shrinks it: tests provoke the timeout)
   int32_t flags;                     // PPO_FLAG_*
 };
@@ -305,8 +304,11 @@ enum { PPO_FLAG_NO_L2_SWAP = 1,      // FWSIM_PPO_NO_L2_SWAP=1: every exchange t
 // without writing the parameters back (the moments in memory are part-way through the call: the caller must not go on with them).
 constexpr int kPpoWordFlags = 4 * kPMaxSplit, kPpoWordIds = 8 * kPMaxSplit, kPpoWordPaths = 46, kPpoWordStatus = 47;
 constexpr int kPpoWordLoss = 48;     // [net][part]: the blocks' loss sums (float bits), added up in a fixed order by the block that finishes last
-constexpr int kPpoWordDone = kPpoWordLoss + 2 * kPMaxSplit, kPpoWords = 64;      // (kPpoWordDone: how many blocks have finished)
-static_assert(kPpoWordIds + 2 * kPMaxSplit <= kPpoWordPaths && kPpoWordDone < kPpoWords, "exchange-word layout");
+constexpr int kPpoWordDone = kPpoWordLoss + 2 * kPMaxSplit;      // how many blocks have finished
+constexpr int kPpoWordFlags2 = 64, kPpoWords = kPpoWordFlags2 + 4 * kPMaxSplit;      // flags of the weight all-gather [parity][net][part] (reduce-scatter form)
+static_assert(kPpoWordIds + 2 * kPMaxSplit <= kPpoWordPaths && kPpoWordDone < kPpoWordFlags2, "exchange-word layout");
+// The updated weights a block owns in the reduce-scatter form, for the others to fetch: [net][part][kind W2 | W1][wave][lane][4]
+constexpr int kPWxFloats = 2 * kPMaxSplit * 2 * 1024;
 enum { PPO_ST_IDS = 1, PPO_ST_SWAP = 2, PPO_ST_NORM = 4 };
 
 // Bounded wait of one thread for a word another block publishes.  `done(word)` ends it; every 256 polls it also looks at the
@@ -326,7 +328,12 @@ __device__ __forceinline__ bool ppo_wait(const PpoArgs& A, LOAD&& load, DONE&& d
 
 // CH = samples per pass through the network (64: 2 x 2 tiles of 32 x 32 per product; 32: 2 x 4 tiles of 16 x 16, see ppo_mfma16_pair);
 // part / nsplit: this block's place among the blocks of its network (chunk c of a minibatch is run by block c % nsplit).
-template <int NET, int CH>
+// RS (four blocks per network only): the gradient swap is a reduce-scatter -- block q fetches, of every block's partial, only the
+// tiles of wave q (a quarter), sums them, takes its share of the clipping norm from them and applies Adam to that quarter alone --
+// followed by an all-gather of the updated WEIGHTS.  A block then pulls 47 + 24 KB past its L1 per minibatch instead of 111 KB
+// (that path runs at ~20 B / clk: the swap was 9.4 k of the minibatch's 28.1 k cycles) and does a quarter of the tile Adam, for one
+// more latency round.  Thread (wave w, lane l) of block q owns elements 4 w .. 4 w + 3 of lane l of wave q's W2 and W1 tiles.
+template <int NET, int CH, bool RS>
 __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const int part, const int nsplit) {
   static_assert(CH == 64 || CH == 32, "chunk size");
   constexpr int n = NET, KO = NET == 0 ? 4 : 1;
@@ -358,6 +365,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   float* red = p; p += 8;
   float* sred = p; p += 32;                       // per wave: the four components of dbo and of dlog_std over its samples
   float* sink = p; p += kPThreads;                // one word per thread: where the Adam of a W1 tile "updates" the rows the network does not have
+  float* red8 = p; p += 8;                        // (RS) the eight blocks' shares of the squared gradient norm
 
   // flat offsets of this net
   const int nP0 = ppo_net_params(Dp, 4);
@@ -397,7 +405,8 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       const bool l2ok = !(A.flags & PPO_FLAG_NO_L2_SWAP);
       bool sx = l2ok && nsplit > 1;
       for (int q = 0; q < nsplit; ++q) if (q != part && wait_id(A.xch + kPpoWordIds + NET * kPMaxSplit + q) != my_xcc + 1u) sx = false;
-      const bool sn = wait_id(A.xch + kPpoWordIds + (1 - NET) * kPMaxSplit + part) == my_xcc + 1u && l2ok;
+      bool sn = wait_id(A.xch + kPpoWordIds + (1 - NET) * kPMaxSplit + part) == my_xcc + 1u && l2ok;
+      if (RS) for (int q = 0; q < nsplit; ++q) if (q != part && wait_id(A.xch + kPpoWordIds + (1 - NET) * kPMaxSplit + q) != my_xcc + 1u) sn = false;      // (the norm gathers all eight words)
       red[5] = sx ? 1.f : 0.f; red[6] = sn ? 1.f : 0.f;
       if (sx || sn) (void)__hip_atomic_fetch_or(A.xch + kPpoWordPaths, (unsigned long long)((sx ? 1u : 0u) | (sn ? 2u : 0u)) << (2 * (2 * part + NET)),
                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -475,7 +484,15 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   // took 2.2 k cycles) -- because 472 registers left no room; the leaner gather and dW1 of round 4 did.  Both chunk halves apply
   // the same update to the same initial values; part 0 writes the result back at the end.
   float4 pm[2][4], pv[2][4];
-  {
+  float4 rm[2], rv[2];                              // RS: the moments of the 4 + 4 elements this thread owns (wave `part`'s tiles)
+  const bool ownW1 = RS && part < tilesW1;
+  const int rs_row = (part >> 1) * 32 + wave * 8 + hh * 4, rs_col = (part & 1) * 32 + r;      // RS: element e of mine is W[rs_row + e][rs_col]
+  if constexpr (RS) {
+    const int s0 = ppo_tile_slot(n, 0, part, lane) + 4 * wave, s1 = ppo_tile_slot(n, 1, part, lane) + 4 * wave;
+    rm[0] = *reinterpret_cast<const float4*>(mom_m + s0); rv[0] = *reinterpret_cast<const float4*>(mom_v + s0);
+    if (ownW1) { rm[1] = *reinterpret_cast<const float4*>(mom_m + s1); rv[1] = *reinterpret_cast<const float4*>(mom_v + s1); }
+    else { rm[1] = make_float4(0.f, 0.f, 0.f, 0.f); rv[1] = rm[1]; }
+  } else {
     const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -805,7 +822,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #ifdef FW_PPO_PROF
     const long long pfa = PPO_T(); pf_red += pfa - pf3;
 #endif
-    // ---- swap gradient partials with the other blocks of this network (all to all), keep the sum ----
+    // ---- swap gradient partials with the other blocks of this network (all to all, or tiles by reduce-scatter), keep the sum ----
+    typedef float ppo_f4 __attribute__((ext_vector_type(4)));
+    ppo_f4 g2q = {0.f, 0.f, 0.f, 0.f}, g1q = g2q;       // RS: the summed gradient of the 4 + 4 tile elements this thread owns
     if (nsplit > 1) {
       float* gxb = A.gx + (size_t)((mb & 1) * 2 + NET) * kPMaxSplit * kPGxSlots;
       float* mine = gxb + (size_t)part * kPGxSlots;
@@ -823,7 +842,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         *reinterpret_cast<float4*>(mine + g0 + q * 256) = make_float4(gW2[4 * q], gW2[4 * q + 1], gW2[4 * q + 2], gW2[4 * q + 3]);
         if (hasW1) *reinterpret_cast<float4*>(mine + g1 + q * 256) = make_float4(gW1[4 * q], gW1[4 * q + 1], gW1[4 * q + 2], gW1[4 * q + 3]);
       }
-      mine[sq] = gb1; mine[sq + kPThreads] = gb2; mine[sq + 2 * kPThreads] = my_gbo; mine[sq + 3 * kPThreads] = my_gls; mine[sq + 4 * kPThreads] = my_gwo;
+      // (per-thread elements: Wo's by every thread, the biases / log_std by threads of the first wave only)
+      mine[sq + 4 * kPThreads] = my_gwo;
+      if (wave == 0) { mine[sq] = gb1; mine[sq + kPThreads] = gb2; mine[sq + 2 * kPThreads] = my_gbo; mine[sq + 3 * kPThreads] = my_gls; }
       // (the builtin, not inline assembly: the compiler's own wait-count bookkeeping must see that the stores are done, or it waits for
       // them one by one between the loads further down -- and with them, in order, for those loads)
       if (same_xcd) __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): my stores are in the L2 the partners read from
@@ -867,20 +888,33 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       // assembly with a hand-placed wait; the compiler, not knowing that they were loads, put waits for older operations between
       // them, which -- the counter retires in order -- serialised the partners: 4.3 k cycles for 39 loads.)
       // Partner j of 1 (2 blocks) or 3 (4 blocks) = the other blocks in ascending order.
-      typedef float ppo_f4 __attribute__((ext_vector_type(4)));
       typedef unsigned int ppo_u4 __attribute__((ext_vector_type(4)));
       ppo_f4 ta[3][4], tb[3][4];
+      ppo_f4 qa[4], qb[4];                         // RS: wave `part`'s W2 / W1 tile elements 4 w .. 4 w + 3 of every block's partial, in block order
       float tsc[3][5];
       const int np = nsplit - 1;
       if (!same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gxb, 0, kPMaxSplit * kPGxSlots * (int)sizeof(float), 0x00020000);
       constexpr int kSc1 = 16;                     // cache-policy bit of the raw buffer loads
+      if constexpr (RS) {
+        const int o0 = (ppo_gx_tile(0, part, lane) + wave * 256) * 4, o1 = (ppo_gx_tile(1, part, lane) + wave * 256) * 4;
+#pragma unroll
+        for (int b_ = 0; b_ < 4; ++b_) {           // (own partial included: it comes back from the L2 my stores went to)
+          const ppo_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, b_ * kPGxSlots * (int)sizeof(float) + o0, 0, kSc1);
+          qa[b_] = ppo_f4{__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[2]), __uint_as_float(a[3])};
+          if (ownW1) {
+            const ppo_u4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, b_ * kPGxSlots * (int)sizeof(float) + o1, 0, kSc1);
+            qb[b_] = ppo_f4{__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3])};
+          } else qb[b_] = ppo_f4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         if (j < np) {
           const int base = (j < part ? j : j + 1) * kPGxSlots * (int)sizeof(float);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
+            if (RS) break;                         // (the tiles went the other way)
             const ppo_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (g0 + q * 256) * 4, 0, kSc1);
             ta[j][q] = ppo_f4{__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[2]), __uint_as_float(a[3])};
             if (hasW1) {
@@ -889,7 +923,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
             } else tb[j][q] = ppo_f4{0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
-          for (int q = 0; q < 5; ++q) tsc[j][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, base + (sq + q * kPThreads) * 4, 0, kSc1));
+          for (int q = 0; q < 5; ++q) {
+            if (q == 4 || wave == 0) tsc[j][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, base + (sq + q * kPThreads) * 4, 0, kSc1));
+            else tsc[j][q] = 0.f;
+          }
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) { ta[j][q] = ppo_f4{0.f, 0.f, 0.f, 0.f}; tb[j][q] = ta[j][q]; }
@@ -904,8 +941,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         if (np == 1) return own + t0;
         return part < 2 ? (own + t0) + (t1 + t2) : (t0 + t1) + (own + t2);
       };
+      if constexpr (RS) { g2q = (qa[0] + qa[1]) + (qa[2] + qa[3]); g1q = (qb[0] + qb[1]) + (qb[2] + qb[3]); }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+        if (RS) break;
         const ppo_f4 o2 = {gW2[4 * q], gW2[4 * q + 1], gW2[4 * q + 2], gW2[4 * q + 3]};
         const ppo_f4 r2 = sum4(o2, ta[0][q], ta[1][q], ta[2][q]);
         gW2[4 * q] = r2[0]; gW2[4 * q + 1] = r2[1]; gW2[4 * q + 2] = r2[2]; gW2[4 * q + 3] = r2[3];
@@ -931,21 +970,50 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     unsigned long long spec_w = 0ull;
     if (t == 0) spec_w = __hip_atomic_load(A.xch + ((mb & 1) * 2 + (1 - NET)) * kPMaxSplit + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float ss = 0.f;
+    if constexpr (RS) {                                   // my quarter of the tiles; the per-thread elements (every block holds their sums) count once
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      ss += gW2[v] * gW2[v];
-      if (hasW1 && mt * 32 + ppo_acc_row(v) < D) ss += gW1[v] * gW1[v];
+      for (int e = 0; e < 4; ++e) {
+        ss += g2q[e] * g2q[e];
+        if (ownW1 && rs_row + e < D) ss += g1q[e] * g1q[e];
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        ss += gW2[v] * gW2[v];
+        if (hasW1 && mt * 32 + ppo_acc_row(v) < D) ss += gW1[v] * gW1[v];
+      }
     }
-    if (t < kPH) ss += gb1 * gb1 + gb2 * gb2;
-    if (t < KO) ss += my_gbo * my_gbo;
-    if (uq < KO) ss += my_gwo * my_gwo;
-    if (NET == 0 && t < 4) ss += my_gls * my_gls;
+    if (!RS || part == 0) {
+      if (t < kPH) ss += gb1 * gb1 + gb2 * gb2;
+      if (t < KO) ss += my_gbo * my_gbo;
+      if (uq < KO) ss += my_gwo * my_gwo;
+      if (NET == 0 && t < 4) ss += my_gls * my_gls;
+    }
     const float ss_mine = ppo_block_sum_nb(ss, red);      // (red[0..3] were last read before the previous minibatch's closing barrier)
     float ss_other = 0.f;
 #ifdef FW_PPO_PROF
     const long long pfx = PPO_T(); pf_norm += pfx - pfb;
 #endif
-    {
+    if constexpr (RS) {
+      // all eight shares, summed in word order by everybody: lane i of the first wave fetches word i
+      unsigned long long* words = A.xch + (mb & 1) * 2 * kPMaxSplit;
+      const int me = NET * kPMaxSplit + part;
+      if (t == 0) ppo_word_store(words + me, ((unsigned long long)(unsigned)(mb + 1) << 32) | (unsigned long long)__float_as_uint(ss_mine), same_xcd_net);
+      if (t < 2 * kPMaxSplit) {
+        unsigned long long w = (unsigned long long)__float_as_uint(ss_mine);
+        if (t != me && !ppo_wait(A, [&]() { return ppo_word_load(words + t, same_xcd_net); }, [&](unsigned long long x) { return (unsigned)(x >> 32) == (unsigned)(mb + 1); },
+                                 (unsigned long long)PPO_ST_NORM, w)) red[7] = 1.f;     // a block is gone
+        red8[t] = __uint_as_float((unsigned)w);
+      }
+      __syncthreads();
+      if (red[7] != 0.f) { dead = true; break; }
+      ss_other = 0.f;
+      float tot = red8[0];
+#pragma unroll
+      for (int i = 1; i < 2 * kPMaxSplit; ++i) tot += red8[i];
+      ss_other = tot;                                      // (the total; ss_mine is not added again below)
+      (void)spec_w;
+    } else {
       // one 64-bit word per block and minibatch parity: (minibatch + 1) << 32 | float bits
       unsigned long long* mine = A.xch + ((mb & 1) * 2 + NET) * kPMaxSplit + part;
       unsigned long long* other = A.xch + ((mb & 1) * 2 + (1 - NET)) * kPMaxSplit + part;
@@ -963,7 +1031,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #ifdef FW_PPO_PROF
     const long long pfc = PPO_T(); pf_xch += pfc - pfx;
 #endif
-    const float total_norm = sqrtf(ss_mine + ss_other);
+    const float total_norm = sqrtf(RS ? ss_other : ss_mine + ss_other);
     const float clipc = fminf(H.max_grad_norm / (total_norm + 1e-6f), 1.0f);
 
     // ---- Adam on the elements each lane holds (moments: registers, see above) ----
@@ -998,9 +1066,46 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #pragma unroll
       for (int v = 0; v < 16; ++v) *lds_of(v) = wv[v] - upd[v];
     };
+    float* const wxn = A.wx + (size_t)NET * kPMaxSplit * 2 * 1024;                       // (RS) this network's weight quarters
+    unsigned long long* const fl2 = A.xch + kPpoWordFlags2 + ((mb & 1) * 2 + NET) * kPMaxSplit;
+    if constexpr (RS) {
+      // Adam on the quarter this block owns: 4 + 4 elements per thread; the new weights go to this block's LDS image and to the exchange
+      // buffer, from where the other three blocks fetch them below (they hold the same old weights, so the copies stay the same bits)
+      auto adam4 = [&](const ppo_f4& g, float4& m4, float4& v4, float (&wv)[4]) {
+        float* mm = reinterpret_cast<float*>(&m4);
+        float* vv = reinterpret_cast<float*>(&v4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gg = g[e] * clipc;
+          const float mn = H.beta1 * mm[e] + (1.0f - H.beta1) * gg, vn = H.beta2 * vv[e] + (1.0f - H.beta2) * (gg * gg);
+          mm[e] = mn; vv[e] = vn;
+          wv[e] -= (mn * c1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vn) * sc2 + H.eps);
+        }
+      };
+      float* w2p = W.W2 + rs_row * kPLdh + rs_col;
+      float* w1p[4];
+      float wv2[4], wv1[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        w1p[e] = (ownW1 && rs_row + e < D) ? W.W1 + (rs_row + e) * ldw1 + rs_col : sink + t;
+        wv2[e] = w2p[e * kPLdh]; wv1[e] = *w1p[e];
+      }
+      adam4(g2q, rm[0], rv[0], wv2);
+      if (ownW1) adam4(g1q, rm[1], rv[1], wv1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { w2p[e * kPLdh] = wv2[e]; *w1p[e] = wv1[e]; }
+      float* mine_w = wxn + (size_t)(part * 2) * 1024 + (wave * 64 + lane) * 4;
+      *reinterpret_cast<float4*>(mine_w) = make_float4(wv2[0], wv2[1], wv2[2], wv2[3]);
+      if (ownW1) *reinterpret_cast<float4*>(mine_w + 1024) = make_float4(wv1[0], wv1[1], wv1[2], wv1[3]);
+      if (same_xcd) __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), as for the partials
+      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+      if (t == 0) ppo_word_store(fl2 + part, (unsigned long long)(unsigned)(mb + 1), same_xcd);
+    } else {
     adam_tile(gW2, pm[0], pv[0], [&](int v) { return W.W2 + (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r; });
     if (hasW1) adam_tile(gW1, pm[1], pv[1],
                          [&](int v) { const int i = mt * 32 + ppo_acc_row(v); return i < D ? W.W1 + i * ldw1 + nt * 32 + r : sink + t; });
+    }
 #ifdef FW_PPO_PROF
     const long long pfd = PPO_T(); pf_tile += pfd - pfc;
 #endif
@@ -1020,6 +1125,38 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #pragma unroll
       for (int q = 0; q < NQ; ++q) if (ws[q]) *ws[q] -= c1 * smm[q] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(svv[q]) * sc2 + H.eps);
     }
+    if constexpr (RS) {
+      // ---- all-gather of the updated weights: the other three quarters, from the blocks that own them ----
+      if (t < nsplit && t != part) {
+        unsigned long long w;
+        if (!ppo_wait(A, [&]() { return ppo_word_load(fl2 + t, same_xcd); }, [&](unsigned long long x) { return (unsigned)x == (unsigned)(mb + 1); },
+                      (unsigned long long)PPO_ST_SWAP, w)) red[7] = 1.f;
+      }
+      __syncthreads();
+      if (red[7] != 0.f) { dead = true; break; }
+      if (!same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      typedef unsigned int ppo_u4 __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(wxn, 0, kPMaxSplit * 2 * 1024 * (int)sizeof(float), 0x00020000);
+      ppo_u4 wa[3], wb[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int pj = j < part ? j : j + 1;
+        const int o = ((pj * 2) * 1024 + (wave * 64 + lane) * 4) * (int)sizeof(float);
+        wa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, o, 0, 16);
+        if (pj < tilesW1) wb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, o + 1024 * (int)sizeof(float), 0, 16);
+        else wb[j] = ppo_u4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int pj = j < part ? j : j + 1;
+        const int row = (pj >> 1) * 32 + wave * 8 + hh * 4, col = (pj & 1) * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          W.W2[(row + e) * kPLdh + col] = __uint_as_float(wa[j][e]);
+          if (pj < tilesW1 && row + e < D) W.W1[(row + e) * ldw1 + col] = __uint_as_float(wb[j][e]);
+        }
+      }
+    }
     __syncthreads();
 #ifdef FW_PPO_PROF
     { const long long pfe = PPO_T(); pf_adam += pfe - pf3; pf_scal += pfe - pfd; }
@@ -1028,11 +1165,17 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 
   // ---- write the weights back, report the losses (a block that gave up leaves the parameters as it found them) ----
   if (dead) return;
+  if constexpr (RS) {                               // the tile moments: every block its quarter
+    const int s0 = ppo_tile_slot(n, 0, part, lane) + 4 * wave, s1 = ppo_tile_slot(n, 1, part, lane) + 4 * wave;
+    *reinterpret_cast<float4*>(mom_m + s0) = rm[0]; *reinterpret_cast<float4*>(mom_v + s0) = rv[0];
+    if (ownW1) { *reinterpret_cast<float4*>(mom_m + s1) = rm[1]; *reinterpret_cast<float4*>(mom_v + s1) = rv[1]; }
+  }
   if (part == ((A.flags & PPO_FLAG_WRITER_LAST) ? nsplit - 1 : 0)) {
     {
       const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+        if (RS) break;
         reinterpret_cast<float4*>(mom_m + s0)[q] = pm[0][q]; reinterpret_cast<float4*>(mom_v + s0)[q] = pv[0][q];
         if (hasW1) { reinterpret_cast<float4*>(mom_m + s1)[q] = pm[1][q]; reinterpret_cast<float4*>(mom_v + s1)[q] = pv[1][q]; }
       }
@@ -1082,13 +1225,13 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 // workgroups are dealt round-robin to the 8 XCDs that puts all working blocks on ONE XCD, whose L2 then carries their
 // exchanges (checked at run time, see ppo_net_body).  Working block i = blockIdx / 8 runs network i & 1 (0: policy, 1: value)
 // as part i >> 1 of gridDim / 16 blocks per network (1, 2 or 4).
-template <int CH>
+template <int CH, bool RS>
 __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(PpoArgs A) {
   extern __shared__ __align__(16) float lds[];
   if (blockIdx.x & 7) return;
   const int i = (int)blockIdx.x >> 3;
-  const int part = i >> 1, nsplit = (int)gridDim.x >> 4;
-  if ((i & 1) == 0) ppo_net_body<0, CH>(A, lds, part, nsplit); else ppo_net_body<1, CH>(A, lds, part, nsplit);
+  const int part = i >> 1, nsplit = RS ? kPMaxSplit : (int)gridDim.x >> 4;
+  if ((i & 1) == 0) ppo_net_body<0, CH, RS>(A, lds, part, nsplit); else ppo_net_body<1, CH, RS>(A, lds, part, nsplit);
 }
 
 // How a minibatch of B samples is cut: samples per pass (64 or 32) and blocks per network.  The path is sequential, so the
@@ -1108,7 +1251,7 @@ inline size_t ppo_lds_bytes(int D) {
   (void)D;                                          // (sized for the larger of the two forms: W1 as 64 rows of 65)
   const int ldx = kPLdx;
   size_t f = (size_t)(kPH * kPLdh + kPH + kPH * kPLdh + kPH + kPH * 4 + 4) + 4 + (size_t)kPChunk * ldx + 64 + 2 * (size_t)kPChunk * kPLdh +
-             3 * (size_t)kPChunk * 4 + 8 * kPH + 8 + 32 + kPThreads;
+             3 * (size_t)kPChunk * 4 + 8 * kPH + 8 + 32 + kPThreads + 8;
   return f * sizeof(float);
 }
 

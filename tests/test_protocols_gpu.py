@@ -31,13 +31,16 @@ def _bits(t):
     return t.detach().contiguous().view(torch.int32)
 
 
-@pytest.mark.parametrize("d,bs,split", [(28, 128, None), (56, 64, None), (28, 192, None), (27, 256, None), (28, 128, "64x2"), (28, 256, "32x4")])
+@pytest.mark.parametrize("d,bs,split", [(28, 128, None), (56, 64, None), (28, 192, None), (27, 256, None), (28, 128, "64x2"), (28, 256, "32x4"),
+                                         (28, 128, "all-to-all"), (40, 512, "all-to-all")])
 def test_every_block_of_a_network_ends_the_update_with_the_same_bits(d, bs, split, monkeypatch):
     """The blocks of a network (up to four) each apply Adam to their own LDS copy of the weights and their own register copy of the
     moments, from gradient sums they each form themselves out of the same four partials: the sums must be formed in the same order
     everywhere, or the copies drift apart.  FWSIM_PPO_WRITER=last makes the last block write the result back instead of the first."""
     T, n = (3, 256) if bs == 192 else (4, 256)
-    if split is not None:
+    if split == "all-to-all":                       # (default with four blocks: reduce-scatter of the gradient tiles + all-gather of the weights)
+        monkeypatch.setenv("FWSIM_PPO_RS", "0")
+    elif split is not None:
         monkeypatch.setenv("FWSIM_PPO_SPLIT", split)
     runs = {}
     for last in (False, True):
@@ -55,8 +58,10 @@ def test_every_block_of_a_network_ends_the_update_with_the_same_bits(d, bs, spli
         assert torch.equal(_bits(x), _bits(y)), "the first and the last block of a network hold different bits"
 
 
-@pytest.mark.parametrize("d,bs", [(28, 128), (56, 64), (27, 256)])
-def test_ppo_update_is_bit_identical_on_the_shared_l2_and_the_device_scope_path(d, bs, monkeypatch):
+@pytest.mark.parametrize("d,bs,form", [(28, 128, "rs"), (56, 64, "rs"), (27, 256, "rs"), (28, 128, "all-to-all")])
+def test_ppo_update_is_bit_identical_on_the_shared_l2_and_the_device_scope_path(d, bs, form, monkeypatch):
+    if form == "all-to-all":
+        monkeypatch.setenv("FWSIM_PPO_RS", "0")
     T, n = 4, 256
     n_epochs = math.ceil(10240 / (T * n // bs))                      # >= 10 240 sequential minibatches
     runs = {}

@@ -152,12 +152,16 @@ def _filled_ppo(fused, d, bs, n_epochs, T=4, n=256, seed=5, scope="minibatch", s
                                         (28, 96, "minibatch"),       # three 32-sample chunks over two blocks
                                         (28, 32, "minibatch"),       # one 32-sample pass: one block per network, no swap
                                         (40, 512, "minibatch")])     # 64-sample chunks over four blocks, 2 each; K = 64 rows of W1 in the 32-sample form
-@pytest.mark.parametrize("split", [None, "64x2", "32x2", "64x1"])
+@pytest.mark.parametrize("split", [None, "64x2", "32x2", "64x1", "all-to-all"])
 def test_fused_ppo_update_matches_the_torch_path(d, bs, scope, split, monkeypatch):
     """fw_ppo_update (one kernel for the whole minibatch sequence) against the plain torch PPO.train() on the same
     buffers, permutations, initial weights and Adam state: parameters, Adam moments and step count agree to fp32
     rounding after 2 epochs (16-32 sequential minibatch steps), and again after a second call (warm Adam state)."""
-    if split is not None:                           # dev knob: every cut of a minibatch (samples per pass x blocks per network) the kernel has
+    if split == "all-to-all":                       # four blocks per network with the gradient swap of the two-block cut (default: reduce-scatter + weight all-gather)
+        if bs < 128:
+            pytest.skip("fewer than four blocks per network")
+        monkeypatch.setenv("FWSIM_PPO_RS", "0")
+    elif split is not None:                         # dev knob: every cut of a minibatch (samples per pass x blocks per network) the kernel has
         ch, ns = (int(x) for x in split.split("x"))
         if bs % ch or bs // ch < ns:
             pytest.skip("this cut does not divide the minibatch")

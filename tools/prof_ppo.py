@@ -25,4 +25,4 @@ for D, B in ((28, 128), (28, 64), (56, 64), (28, 256)):
     run(); torch.cuda.synchronize()
     t0 = time.perf_counter(); run(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     l = loss.tolist()
-    print(f"D={D} B={B}: {dt / n_mb * 1e6:.1f} us/minibatch; cycles/minibatch pi: exchange {l[3]:.0f} gather {l[4]:.0f} net {l[5]:.0f} norm+adam {l[6]:.0f} | V: exchange {l[7]:.0f} gather {l[8]:.0f} net {l[9]:.0f} norm+adam {l[10]:.0f} || pi finish: reductions {l[11]:.0f} hand-off {l[12]:.0f} norm {l[13]:.0f} tile Adam {l[14]:.0f} thread Adam + barrier {l[15]:.0f} || pi hand-off: stores + wait + barrier {l[16]:.0f} flag + next gather {l[17]:.0f} poll (thread 0) {l[18]:.0f} barrier {l[19]:.0f} loads {l[28]:.0f} sums {l[29]:.0f} || pi chunk phases (per minibatch): L1 {l[20]:.0f} L2 {l[21]:.0f} head {l[22]:.0f} dWo {l[23]:.0f} G2 {l[24]:.0f} dW2 {l[25]:.0f} G1 {l[26]:.0f} dW1 {l[27]:.0f}", flush=True)
+    print(f"D={D} B={B}: {dt / n_mb * 1e6:.1f} us/minibatch; cycles/minibatch pi: exchange {l[3]:.0f} gather {l[4]:.0f} net {l[5]:.0f} norm+adam {l[6]:.0f} | V: exchange {l[7]:.0f} gather {l[8]:.0f} net {l[9]:.0f} norm+adam {l[10]:.0f} || pi finish: reductions {l[11]:.0f} hand-off {l[12]:.0f} norm {l[13]:.0f} tile Adam {l[14]:.0f} thread Adam (+ weight all-gather) + barrier {l[15]:.0f} || pi hand-off: stores + wait + barrier {l[16]:.0f} flag + next gather {l[17]:.0f} poll (thread 0) {l[18]:.0f} barrier {l[19]:.0f} loads {l[28]:.0f} sums {l[29]:.0f} || pi chunk phases (per minibatch): L1 {l[20]:.0f} L2 {l[21]:.0f} head {l[22]:.0f} dWo {l[23]:.0f} G2 {l[24]:.0f} dW2 {l[25]:.0f} G1 {l[26]:.0f} dW1 {l[27]:.0f}", flush=True)
