@@ -392,7 +392,7 @@ int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t 
  * moments in the optimiser's own order, never in slot order.
  * obs[S,obs_dim], act[S,4], old_logp[S], adv[S], ret[S]: the rollout buffer (float32, device);
  * perm[n_minibatches * batch_size]: sample indices of consecutive minibatches (int32, device).
- * batch_size must be a multiple of 32, obs_dim <= 64.  loss_acc[3] (may be NULL) accumulates the per-minibatch
+ * batch_size must be a multiple of 16, obs_dim <= 64.  loss_acc[3] (may be NULL) accumulates the per-minibatch
  * mean policy loss, value loss and entropy loss.  The caller advances its Adam step count by n_minibatches.
  * workspace: caller-owned device buffer of >= fw_ppo_update_workspace_bytes(n_minibatches, batch_size, obs_dim) bytes: exchange
  * words, the gradient hand-off buffer and the PACKED ROWS of this call -- a parallel pre-pass (one workgroup per minibatch, all

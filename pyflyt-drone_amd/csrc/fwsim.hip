@@ -1610,6 +1610,8 @@ int ensure_learner_lds(int dev, int which, size_t bytes) {
     HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   }
   have[dev][which] = bytes;
   return FW_OK;
@@ -1924,7 +1926,7 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   if (!params || !mom_m || !mom_v || !obs || !act || !old_logp || !adv || !ret || !perm || !hyper || n_minibatches <= 0) {
     g_err = "fw_ppo_update: bad arguments"; return FW_EINVAL;
   }
-  if (batch_size <= 0 || batch_size % 32 != 0) { g_err = "fw_ppo_update: batch_size must be a multiple of 32"; return FW_EINVAL; }
+  if (batch_size <= 0 || batch_size % 16 != 0) { g_err = "fw_ppo_update: batch_size must be a multiple of 16"; return FW_EINVAL; }
   if (obs_dim <= 0 || obs_dim > 64) { g_err = "fw_ppo_update: obs_dim must be in [1, 64]"; return FW_EINVAL; }
   if (!workspace || workspace_bytes < fw_ppo_update_workspace_bytes(n_minibatches, batch_size, obs_dim)) {
     g_err = "fw_ppo_update: workspace smaller than fw_ppo_update_workspace_bytes(n_minibatches, batch_size, obs_dim)"; return FW_EINVAL;
@@ -1956,12 +1958,12 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   P.obs = obs; P.act = act; P.old_logp = old_logp; P.adv = adv; P.ret = ret; P.perm = perm; P.B = batch_size; P.D = obs_dim;
   P.norm_adv = A.H.norm_adv; P.adv_mean = A.H.adv_mean; P.adv_std = A.H.adv_std; P.out = packed;
   hipLaunchKernelGGL(fw_ppo_pack_kernel, dim3(n_minibatches), dim3(256), 0, st, P);
-  PpoSplit cut = ppo_split(batch_size);             // samples per pass and blocks per network (128 samples: 32 x 4)
+  PpoSplit cut = ppo_split(batch_size);             // samples per pass and blocks per network (128 samples: 32 x 4, 64: 16 x 4)
   if (const char* e = getenv("FWSIM_PPO_SPLIT")) {  // dev knob "CHxN" (64x2 = round 3's cut): A / B measurements, tests of every form
     int ch = 0, ns = 0;
-    if (sscanf(e, "%dx%d", &ch, &ns) == 2 && (ch == 32 || ch == 64) && (ns == 1 || ns == 2 || ns == 4) && batch_size % ch == 0 && batch_size / ch >= ns) {
+    if (sscanf(e, "%dx%d", &ch, &ns) == 2 && (ch == 16 || ch == 32 || ch == 64) && (ns == 1 || ns == 2 || ns == 4) && batch_size % ch == 0 && batch_size / ch >= ns) {
       cut.ch = ch; cut.nsplit = ns;
-    } else { g_err = "fw_ppo_update: FWSIM_PPO_SPLIT must be CHxN with CH in {32, 64}, N in {1, 2, 4}, N chunks of CH samples in a minibatch"; return FW_EINVAL; }
+    } else { g_err = "fw_ppo_update: FWSIM_PPO_SPLIT must be CHxN with CH in {16, 32, 64}, N in {1, 2, 4}, N chunks of CH samples in a minibatch"; return FW_EINVAL; }
   }
   // four blocks per network: gradient tiles by reduce-scatter, updated weights by all-gather (FWSIM_PPO_RS=0: all-to-all, as for two blocks)
   bool rs = cut.nsplit == kPMaxSplit;
@@ -1969,8 +1971,10 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   const dim3 grid(16 * cut.nsplit);                 // (every 8th block works -- see the kernel)
   if (cut.ch == 64 && rs) hipLaunchKernelGGL((fw_ppo_update_kernel<64, true>), grid, dim3(kPThreads), lds, st, A);
   else if (cut.ch == 64) hipLaunchKernelGGL((fw_ppo_update_kernel<64, false>), grid, dim3(kPThreads), lds, st, A);
-  else if (rs) hipLaunchKernelGGL((fw_ppo_update_kernel<32, true>), grid, dim3(kPThreads), lds, st, A);
-  else hipLaunchKernelGGL((fw_ppo_update_kernel<32, false>), grid, dim3(kPThreads), lds, st, A);
+  else if (cut.ch == 32 && rs) hipLaunchKernelGGL((fw_ppo_update_kernel<32, true>), grid, dim3(kPThreads), lds, st, A);
+  else if (cut.ch == 32) hipLaunchKernelGGL((fw_ppo_update_kernel<32, false>), grid, dim3(kPThreads), lds, st, A);
+  else if (rs) hipLaunchKernelGGL((fw_ppo_update_kernel<16, true>), grid, dim3(kPThreads), lds, st, A);
+  else hipLaunchKernelGGL((fw_ppo_update_kernel<16, false>), grid, dim3(kPThreads), lds, st, A);
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;
 }

@@ -90,22 +90,26 @@ __device__ __forceinline__ int ppo_acc_row(int v) { return (v >> 2) * 8 + ((thre
 // group g = l / 16 takes k = koff(g) + step with koff = 16 g (K = 64) or {0, 16, 8, 24}[g] (K = 32), so that the two groups of a
 // half-wave are 16 floats apart and, with the odd row strides of the LDS images, every operand read is bank-conflict free both
 // along rows (activations as A, W as B) and along columns (W2^T as B).
-// c0 / c1 += A(rows 0-15 / 16-31, K) * B(K, 16 columns); A(m, k) = A[m * sam + k * sak], B(k, n) = B[k * sbk + n * sbn]; K = 4 STEPS.
-template <int STEPS>
-__device__ __forceinline__ void ppo_mfma16_pair(const float* A, int sam, int sak, const float* B, int sbk, int sbn, f32x4& c0, f32x4& c1) {
+// c[rt] += A(rows 16 rt .. 16 rt + 15, K) * B(K, 16 columns), rt < RT (2: 32-sample passes, 1: 16-sample passes -- one accumulator
+// chain, the MFMAs then issue every 40 cycles instead of every 32); A(m, k) = A[m * sam + k * sak], B(k, n) = B[k * sbk + n * sbn]; K = 4 STEPS.
+template <int STEPS, int RT>
+__device__ __forceinline__ void ppo_mfma16_rows(const float* A, int sam, int sak, const float* B, int sbk, int sbn, f32x4 (&c)[RT]) {
   static_assert(STEPS == 8 || STEPS == 16, "K = 32 or 64");
   const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
   const int koff = STEPS == 16 ? 16 * g : ((g & 1) * 16 + (g >> 1) * 8);
-  const float* a0 = A + i * sam + koff * sak;
-  const float* a1 = a0 + 16 * sam;
+  const float* a = A + i * sam + koff * sak;
   const float* b = B + koff * sbk + i * sbn;
-  float av0[STEPS], av1[STEPS], bv[STEPS];
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) { av0[s] = a0[s * sak]; av1[s] = a1[s * sak]; bv[s] = b[s * sbk]; }
+  float av[RT][STEPS], bv[STEPS];
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[s], bv[s], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[s], bv[s], c1, 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) av[rt][s] = a[rt * 16 * sam + s * sak];
+    bv[s] = b[s * sbk];
+  }
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][s], bv[s], c[rt], 0, 0, 0);
   }
 }
 
@@ -326,7 +330,7 @@ __device__ __forceinline__ bool ppo_wait(const PpoArgs& A, LOAD&& load, DONE&& d
   return false;
 }
 
-// CH = samples per pass through the network (64: 2 x 2 tiles of 32 x 32 per product; 32: 2 x 4 tiles of 16 x 16, see ppo_mfma16_pair);
+// CH = samples per pass through the network (64: 2 x 2 tiles of 32 x 32 per product; 32 / 16: 2 / 1 x 4 tiles of 16 x 16, see ppo_mfma16_rows);
 // part / nsplit: this block's place among the blocks of its network (chunk c of a minibatch is run by block c % nsplit).
 // RS (four blocks per network only): the gradient swap is a reduce-scatter -- block q fetches, of every block's partial, only the
 // tiles of wave q (a quarter), sums them, takes its share of the clipping norm from them and applies Adam to that quarter alone --
@@ -335,7 +339,8 @@ __device__ __forceinline__ bool ppo_wait(const PpoArgs& A, LOAD&& load, DONE&& d
 // more latency round.  Thread (wave w, lane l) of block q owns elements 4 w .. 4 w + 3 of lane l of wave q's W2 and W1 tiles.
 template <int NET, int CH, bool RS>
 __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const int part, const int nsplit) {
-  static_assert(CH == 64 || CH == 32, "chunk size");
+  static_assert(CH == 64 || CH == 32 || CH == 16, "chunk size");
+  constexpr int RT = CH == 64 ? 1 : CH / 16;     // row tiles of 16 in the 16 x 16 forms
   constexpr int n = NET, KO = NET == 0 ? 4 : 1;
   float* __restrict__ params = A.params;
   float* __restrict__ mom_m = A.mom_m; float* __restrict__ mom_v = A.mom_v;
@@ -346,7 +351,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   const int Dp = (D + 1) & ~1;
   constexpr int ldx = kPLdx;
   // W1 in LDS.  CH = 64: [Dp][64] as in memory.  CH = 32: the 16x16x4 products walk K in steps of 32 or 64 (zero rows behind the last
-  // feature) and want the odd row stride (ppo_mfma16_pair).
+  // feature) and want the odd row stride (ppo_mfma16_rows).
   constexpr int ldw1 = CH == 64 ? kPH : kPLdh;
   const int K1 = CH == 64 ? Dp : (Dp <= 32 ? 32 : 64);
 
@@ -357,7 +362,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   float* log_std = p; p += 4;
   float* X = p;  p += CH * ldx + 64;              // (+64: the padded dW1 tile reads a few floats past the last row)
   float* H1 = p; p += CH * kPLdh;
-  float* H2 = p; p += CH * kPLdh;                 // (>= 2048 floats: dW1's split partials pass through it)
+  float* H2 = p; p += CH * kPLdh > 2112 ? CH * kPLdh : 2112;      // (>= 2048 floats: dW1's split partials pass through it)
   float* gout = p; p += CH * 4;                   // head output, then dL/d(head output) of the chunk
   float* sA = p; p += CH * 4;                     // gathered actions
   float* sS = p; p += CH * 4;                     // per-sample scalars: old_logp, adv (normalised), ret, -
@@ -577,12 +582,16 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         for (int v = 0; v < 16; ++v) H1[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
       } else {
         const float bias = W.b1[wave * 16 + l16];
-        f32x4 c0 = {bias, bias, bias, bias}, c1 = c0;
-        if (K1 == 32) ppo_mfma16_pair<8>(X, ldx, 1, W.W1 + wave * 16, ldw1, 1, c0, c1);
-        else ppo_mfma16_pair<16>(X, ldx, 1, W.W1 + wave * 16, ldw1, 1, c0, c1);
+        f32x4 c[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) c[rt] = f32x4{bias, bias, bias, bias};
+        if (K1 == 32) ppo_mfma16_rows<8, RT>(X, ldx, 1, W.W1 + wave * 16, ldw1, 1, c);
+        else ppo_mfma16_rows<16, RT>(X, ldx, 1, W.W1 + wave * 16, ldw1, 1, c);
         float* hp = H1 + (g16 * 4) * kPLdh + wave * 16 + l16;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { hp[v * kPLdh] = ppo_tanh(c0[v]); hp[(16 + v) * kPLdh] = ppo_tanh(c1[v]); }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) hp[(16 * rt + v) * kPLdh] = ppo_tanh(c[rt][v]);
       }
       __syncthreads();
       PPO_PHASE(0);
@@ -596,11 +605,15 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         for (int v = 0; v < 16; ++v) H2[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
       } else {
         const float bias = W.b2[wave * 16 + l16];
-        f32x4 c0 = {bias, bias, bias, bias}, c1 = c0;
-        ppo_mfma16_pair<16>(H1, kPLdh, 1, W.W2 + wave * 16, kPLdh, 1, c0, c1);
+        f32x4 c[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) c[rt] = f32x4{bias, bias, bias, bias};
+        ppo_mfma16_rows<16, RT>(H1, kPLdh, 1, W.W2 + wave * 16, kPLdh, 1, c);
         float* hp = H2 + (g16 * 4) * kPLdh + wave * 16 + l16;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { hp[v * kPLdh] = ppo_tanh(c0[v]); hp[(16 + v) * kPLdh] = ppo_tanh(c1[v]); }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) hp[(16 * rt + v) * kPLdh] = ppo_tanh(c[rt][v]);
       }
       __syncthreads();
       PPO_PHASE(1);
@@ -626,7 +639,8 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #pragma unroll
         for (int k = 0; k < KO; ++k) {
           o[k] += ppo_dpp<kDppXor1>(o[k]); o[k] += ppo_dpp<kDppXor2>(o[k]);
-          if (HSL == 8) o[k] += ppo_dpp<kDppHalfMirror>(o[k]);
+          if (HSL >= 8) o[k] += ppo_dpp<kDppHalfMirror>(o[k]);
+          if (HSL == 16) o[k] += ppo_dpp<kDppRowMirror>(o[k]);
           o[k] += W.bo[k];
         }
         const int s = hs;
@@ -682,21 +696,27 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       __syncthreads();
       PPO_PHASE(3);
       // ---- G2 = (gout Wo^T) * (1 - H2^2), in place over H2 (K = KO <= 4) ----
-      if constexpr (CH == 32) {
+      if constexpr (CH != 64) {
         float* hp = H2 + (g16 * 4) * kPLdh + wave * 16 + l16;
-        float hv0[4], hv1[4];
+        float hv[RT][4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { hv0[v] = hp[v * kPLdh]; hv1[v] = hp[(16 + v) * kPLdh]; }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) hv[rt][v] = hp[(16 * rt + v) * kPLdh];
         const int k = g16 < KO ? g16 : 0;
-        const float a0 = g16 < KO ? gout[l16 * 4 + k] : 0.f, a1 = g16 < KO ? gout[(16 + l16) * 4 + k] : 0.f;
         const float bv = g16 < KO ? W.Wo[(wave * 16 + l16) * KO + k] : 0.f;
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, z4, 0, 0, 0);
-        const f32x4 c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, z4, 0, 0, 0);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { hv0[v] = c0[v] * (1.0f - hv0[v] * hv0[v]); hv1[v] = c1[v] * (1.0f - hv1[v] * hv1[v]); }
+        for (int rt = 0; rt < RT; ++rt) {
+          const float av = g16 < KO ? gout[(16 * rt + l16) * 4 + k] : 0.f;
+          const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, z4, 0, 0, 0);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { hp[v * kPLdh] = hv0[v]; hp[(16 + v) * kPLdh] = hv1[v]; }
+          for (int v = 0; v < 4; ++v) hv[rt][v] = c[v] * (1.0f - hv[rt][v] * hv[rt][v]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) hp[(16 * rt + v) * kPLdh] = hv[rt][v];
       } else {
         // (the 16 activations this lane rescales are fetched in one batch ahead of the products: written as read-modify-write
         // per element the compiler keeps every LDS read behind the previous element's write -- 16 exposed LDS round trips)
@@ -732,17 +752,21 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       __syncthreads();
       PPO_PHASE(5);
       // ---- G1 = (G2 W2^T) * (1 - H1^2), in place over H1 ----
-      if constexpr (CH == 32) {
+      if constexpr (CH != 64) {
         float* hp = H1 + (g16 * 4) * kPLdh + wave * 16 + l16;
-        float hv0[4], hv1[4];
+        float hv[RT][4];
+        f32x4 c[RT];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { hv0[v] = hp[v * kPLdh]; hv1[v] = hp[(16 + v) * kPLdh]; }
-        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-        ppo_mfma16_pair<16>(H2, kPLdh, 1, W.W2 + wave * 16 * kPLdh, 1, kPLdh, c0, c1);
+        for (int rt = 0; rt < RT; ++rt) {
+          c[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { hv0[v] = c0[v] * (1.0f - hv0[v] * hv0[v]); hv1[v] = c1[v] * (1.0f - hv1[v] * hv1[v]); }
+          for (int v = 0; v < 4; ++v) hv[rt][v] = hp[(16 * rt + v) * kPLdh];
+        }
+        ppo_mfma16_rows<16, RT>(H2, kPLdh, 1, W.W2 + wave * 16 * kPLdh, 1, kPLdh, c);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { hp[v * kPLdh] = hv0[v]; hp[(16 + v) * kPLdh] = hv1[v]; }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) hp[(16 * rt + v) * kPLdh] = c[rt][v] * (1.0f - hv[rt][v] * hv[rt][v]);
       } else {
         float* hp = H1 + (mt * 32 + hh * 4) * kPLdh + nt * 32 + r;      // (as for G2: the reads leave ahead of the products)
         float hv[16];
@@ -787,8 +811,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     }
     // component (lane % HSL) over the wave's lanes: rotations inside the row, then across the rows
     if (HSL == 4) { gbo_p += ppo_dpp<kDppRor4>(gbo_p); if (NET == 0) gls_p += ppo_dpp<kDppRor4>(gls_p); }
-    gbo_p += ppo_dpp<kDppRor8>(gbo_p); gbo_p = ppo_sum_rows(gbo_p);
-    if (NET == 0) { gls_p += ppo_dpp<kDppRor8>(gls_p); gls_p = ppo_sum_rows(gls_p); }
+    if (HSL <= 8) { gbo_p += ppo_dpp<kDppRor8>(gbo_p); if (NET == 0) gls_p += ppo_dpp<kDppRor8>(gls_p); }
+    gbo_p = ppo_sum_rows(gbo_p);
+    if (NET == 0) gls_p = ppo_sum_rows(gls_p);
     // (no barrier in front: the previous readers of bred / sred are behind the barriers of the norm exchange and of the end of the
     // previous minibatch; H2, which carries dW1's split partials, was last read in the G1 phase, a barrier ago -- H1 is still being
     // read by slower waves' dW1)
@@ -1240,11 +1265,13 @@ __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(PpoArgs A) {
 struct PpoSplit { int ch, nsplit; };
 inline PpoSplit ppo_split(int B) {
   auto cut = [&](int ch) { PpoSplit s; s.ch = ch; const int c = B / ch; s.nsplit = c >= 4 ? 4 : c >= 2 ? 2 : 1; return s; };
-  auto passes = [&](PpoSplit s) { return (B / s.ch + s.nsplit - 1) / s.nsplit; };       // of the busiest block
-  const PpoSplit s32 = cut(32);
-  if (B % 64 != 0) return s32;
-  const PpoSplit s64 = cut(64);
-  return 5 * passes(s64) <= 3 * passes(s32) ? s64 : s32;      // (a 64-sample pass costs ~5/3 of a 32-sample one)
+  // passes of the busiest block x what a pass costs (64 samples : 32 : 16 ~ 10 : 6 : 4), + 1 where the blocks of a network are two:
+  // they swap whole gradients, four swap quarters
+  auto cost = [&](PpoSplit s) { return ((B / s.ch + s.nsplit - 1) / s.nsplit) * (s.ch == 64 ? 10 : s.ch == 32 ? 6 : 4) + (s.nsplit == 2 ? 1 : 0); };
+  PpoSplit best = cut(16);
+  if (B % 32 == 0 && cost(cut(32)) <= cost(best)) best = cut(32);
+  if (B % 64 == 0 && cost(cut(64)) <= cost(best)) best = cut(64);
+  return best;
 }
 
 inline size_t ppo_lds_bytes(int D) {

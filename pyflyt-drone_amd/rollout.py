@@ -569,7 +569,7 @@ class FusedPpoUpdate:
 
     @staticmethod
     def applies(policy, cfg, obs_dim: int, batch_size: int, device) -> bool:
-        return cfg.fused_update and batch_size % 32 == 0 and FusedPpoUpdate.fits(policy, obs_dim, device)
+        return cfg.fused_update and batch_size % 16 == 0 and FusedPpoUpdate.fits(policy, obs_dim, device)
 
     def _slots(self):
         """(tensor, flat offset, view shape in the flat image, needs transpose) per parameter, in layout order."""

@@ -67,13 +67,13 @@ def test_learner_accounting_matches_the_documented_figures():
     assert c["bytes"] == sum(c["items"].values()) == 19_301_376
     assert c["items"]["env_step (fw_step's words per env-step x N)"] == 94 * 8 * 4096
     u = A.ppo_update(10240, 128, 28)
-    assert A.ppo_split(128) == (32, 4) and A.ppo_split(64) == (32, 2) and A.ppo_split(256) == (64, 4) and A.ppo_split(4096) == (64, 4)
-    assert A.ppo_split(192) == (32, 4) and A.ppo_split(96) == (32, 2) and A.ppo_split(32) == (32, 1)      # csrc/fwsim_ppo.hpp ppo_split
+    assert A.ppo_split(128) == (32, 4) and A.ppo_split(64) == (16, 4) and A.ppo_split(256) == (64, 4) and A.ppo_split(4096) == (64, 4)
+    assert A.ppo_split(192) == (32, 4) and A.ppo_split(96) == (16, 4) and A.ppo_split(32) == (16, 2) and A.ppo_split(16) == (16, 1)      # csrc/fwsim_ppo.hpp ppo_split
     assert u["workgroups"] == 8 and abs(u["mfma_peak_tflops"] - 8 * 157.3 / 256) < 1e-12
     # forward + backward MACs of both networks per sample: (28 x 64 + 64 x 64 + 64 x KO) + (2 x 64 x KO + 2 x 64 x 64 + 28 x 64)
     macs = sum((28 * 64 + 64 * 64 + 64 * ko) + (2 * 64 * ko + 2 * 64 * 64 + 28 * 64) for ko in (4, 1))
     assert u["flops_per_minibatch"] == 2 * 128 * macs == 8_372_224
-    assert A.ppo_update(5120, 64, 56)["workgroups"] == 4
+    assert A.ppo_update(5120, 64, 56)["workgroups"] == 8
     r = A.roofline_mfma(u["mfma_flops"], 116_178.8, u["mfma_peak_tflops"])
     assert abs(r["frac"] - 0.1501) < 5e-4                      # profiles/r04_learner_pmc.json: fw_ppo_update_kernel, waypoints
     assert A.render(4096, 32)["bytes"] == 33_554_432

@@ -150,9 +150,11 @@ def _filled_ppo(fused, d, bs, n_epochs, T=4, n=256, seed=5, scope="minibatch", s
                                         (28, 192, "minibatch"),      # three chunks per minibatch: the chunk halves run 2 and 1 of them
                                         (64, 128, "global"),         # the widest input: four dW1 tiles, no split
                                         (28, 96, "minibatch"),       # three 32-sample chunks over two blocks
-                                        (28, 32, "minibatch"),       # one 32-sample pass: one block per network, no swap
+                                        (28, 32, "minibatch"),       # two 16-sample passes on two blocks
+                                        (28, 48, "minibatch"),       # three 16-sample passes on two blocks
+                                        (28, 16, "minibatch"),       # one pass, one block per network: no swap
                                         (40, 512, "minibatch")])     # 64-sample chunks over four blocks, 2 each; K = 64 rows of W1 in the 32-sample form
-@pytest.mark.parametrize("split", [None, "64x2", "32x2", "64x1", "all-to-all"])
+@pytest.mark.parametrize("split", [None, "64x2", "32x2", "64x1", "16x4", "16x1", "all-to-all"])
 def test_fused_ppo_update_matches_the_torch_path(d, bs, scope, split, monkeypatch):
     """fw_ppo_update (one kernel for the whole minibatch sequence) against the plain torch PPO.train() on the same
     buffers, permutations, initial weights and Adam state: parameters, Adam moments and step count agree to fp32
@@ -166,7 +168,7 @@ def test_fused_ppo_update_matches_the_torch_path(d, bs, scope, split, monkeypatc
         if bs % ch or bs // ch < ns:
             pytest.skip("this cut does not divide the minibatch")
         monkeypatch.setenv("FWSIM_PPO_SPLIT", split)
-    T_ = 3 if bs in (192, 96) else 4                # (3 x 256 samples divide into 192- / 96-sample minibatches)
+    T_ = 3 if bs in (192, 96, 48) else 4            # (3 x 256 samples divide into 192- / 96- / 48-sample minibatches)
     a, b = _filled_ppo(True, d, bs, 2, T=T_, scope=scope), _filled_ppo(False, d, bs, 2, T=T_, scope=scope)
     for p, q in zip(a.policy.parameters(), b.policy.parameters()):
         assert torch.equal(p, q)
@@ -195,7 +197,7 @@ def test_fused_ppo_update_rejects_what_it_cannot_run():
     args = [R._p(z)] * 8 + [R._p(z.to(torch.int32))]
     ws = torch.zeros(int(L.fw_ppo_update_workspace_bytes(1, 64, 28)), dtype=torch.uint8, device="cuda")
     assert L.fw_ppo_update_workspace_bytes(0, 64, 28) == K.FW_EINVAL and L.fw_ppo_update_workspace_bytes(1, 64, 65) == K.FW_EINVAL
-    assert L.fw_ppo_update(*args, 1, 100, 28, C.byref(H), None, R._p(ws), ws.numel(), None) == K.FW_EINVAL      # batch not a multiple of 32
+    assert L.fw_ppo_update(*args, 1, 100, 28, C.byref(H), None, R._p(ws), ws.numel(), None) == K.FW_EINVAL      # batch not a multiple of 16
     assert L.fw_ppo_update(*args, 1, 64, 65, C.byref(H), None, R._p(ws), ws.numel(), None) == K.FW_EINVAL       # obs_dim too large
     assert L.fw_ppo_update(*args, 0, 64, 28, C.byref(H), None, R._p(ws), ws.numel(), None) == K.FW_EINVAL
     assert L.fw_ppo_update(*args, 1, 64, 28, C.byref(H), None, None, 0, None) == K.FW_EINVAL                    # no workspace

@@ -60,13 +60,14 @@ def ppo_split(B: int):
     def cut(ch):
         c = B // ch
         return ch, (4 if c >= 4 else 2 if c >= 2 else 1)
-    def passes(s):
-        return (B // s[0] + s[1] - 1) // s[1]
-    s32 = cut(32)
-    if B % 64:
-        return s32
-    s64 = cut(64)
-    return s64 if 5 * passes(s64) <= 3 * passes(s32) else s32
+    def cost(s):
+        return ((B // s[0] + s[1] - 1) // s[1]) * {64: 10, 32: 6, 16: 4}[s[0]] + (1 if s[1] == 2 else 0)
+    best = cut(16)
+    if B % 32 == 0 and cost(cut(32)) <= cost(best):
+        best = cut(32)
+    if B % 64 == 0 and cost(cut(64)) <= cost(best):
+        best = cut(64)
+    return best
 
 
 def ppo_update(n_mb: int, B: int, D: int) -> dict:
