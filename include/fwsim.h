@@ -397,18 +397,20 @@ int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t 
  * workspace: caller-owned device buffer of >= fw_ppo_update_workspace_bytes(n_minibatches, batch_size, obs_dim) bytes: exchange
  * words, the gradient hand-off buffer and the PACKED ROWS of this call -- a parallel pre-pass (one workgroup per minibatch, all
  * CUs) writes every minibatch's rows in walking order, observation | action | old log-prob, normalised advantage, return,
- * (obs_dim rounded up to 4) + 8 floats each, so that the sequential kernel reads each 32- / 64-sample pass as one contiguous block
+ * (obs_dim rounded up to 4) + 8 floats each, so that the sequential kernel reads each 16- / 32- / 64-sample pass as one contiguous block
  * (144 B per sample and epoch for 28 observations: 189 MB for 20 epochs x 65 536 samples).  Two learners never share it.
  * The learner-side entry points run on the device their buffers live on, whatever the thread's current device.
  * The call runs on 2, 4 or 8 workgroups: (policy, value) x 1, 2 or 4 workgroups per network that share every minibatch (128
- * samples: 4 x 32) and swap their gradient partials once per minibatch; all of them end the call with the same bits.
+ * samples: 4 x 32, 64: 4 x 16) and exchange gradients (and, with four, updated weights) once per minibatch; all of them end the call
+ * with the same bits.
  * Failure inside the launch: the workgroups of a call wait for each other once or twice per minibatch, every wait
  * bounded.  A wait that runs out raises FW_PPO_ST_* in the workspace's status word and every workgroup leaves WITHOUT writing
  * `params`, `mom_m` or `mom_v` back (the moments live in registers during the call).  fw_ppo_update_status reads
  * the word after the call (it synchronises `hip_stream`): 0 = the call ran to its end.  `paths` (may be NULL) receives which
  * exchanges went through an XCD's shared L2 rather than device-scope accesses: bit 2 b = workgroup b's gradient swap, bit
  * 2 b + 1 = its norm exchange, b = 2 * part + net (part = the workgroup's index inside its network).  Environment (read per call):
- * FWSIM_PPO_SPLIT=CHxN forces the cut (CH = 32 / 64 samples per pass, N = 1 / 2 / 4 workgroups per network); FWSIM_PPO_NO_L2_SWAP=1 forces the
+ * FWSIM_PPO_SPLIT=CHxN forces the cut (CH = 16 / 32 / 64 samples per pass, N = 1 / 2 / 4 workgroups per network); FWSIM_PPO_RS=0 makes four
+ * workgroups swap whole gradients all-to-all instead of reduce-scatter + weight all-gather; FWSIM_PPO_NO_L2_SWAP=1 forces the
  * device-scope form of every exchange (same arithmetic: results must be bit-identical -- tests/test_protocols_gpu.py);
  * FWSIM_SPIN_LOG2=k shrinks every wait's budget to 2^k polls (tests provoke the timeout with it). */
 #define FW_PPO_ST_IDS 1u    /* the workgroups never found each other at the start of the call */
