@@ -73,7 +73,8 @@ class EvalResult:
 @torch.no_grad()
 def evaluate_policy(policy, env, n_eval_episodes: int = 10, deterministic: bool = True,
                     callback: Optional[Callable[[dict], None]] = None, max_vec_steps: Optional[int] = None,
-                    generator: Optional[torch.Generator] = None, use_graph: Optional[bool] = None) -> EvalResult:
+                    generator: Optional[torch.Generator] = None, use_graph: Optional[bool] = None,
+                    use_fused: Optional[bool] = None) -> EvalResult:
     """Run ``policy`` on ``env`` (a :class:`~.rollout.VecNormalizeDevice` over a device env,
     normally with ``training=False, norm_reward=False``) until ``n_eval_episodes`` episodes are
     complete.  ``callback(info_dict)`` is called for every finished episode with the keys the
@@ -82,7 +83,12 @@ def evaluate_policy(policy, env, n_eval_episodes: int = 10, deterministic: bool 
     Deterministic evaluations on the GPU run as replays of a captured hipGraph of 8 vec-steps with the episode bookkeeping
     on the device (``use_graph``; default: whenever possible): an evaluation of 16 envs flying 1800-step episodes is ~30
     framework ops per step, and read back after every step it cost as much wall clock as 0.4 M training steps.  Both paths
-    return the same episodes in the same order; ``callback`` is then called once the evaluation is over."""
+    return the same episodes in the same order; ``callback`` is then called once the evaluation is over.
+
+    ``use_fused`` (default: whenever possible -- the reference's MlpPolicy on a device env with the 8-lane mapping, an
+    evaluation normaliser with frozen statistics): a vec-step of the replayed evaluation is ONE ``fw_collect_step`` launch in
+    its deterministic, statistics-frozen form (normalisation, policy forward on the matrix cores, clip, env step) instead of
+    ~20 framework ops; the policy's actions then agree with the torch forward to fp32 rounding, not to the bit."""
     venv = env.venv
     n = env.num_envs
     targets = np.array([(n_eval_episodes + i) // n for i in range(n)], dtype=np.int64)
@@ -90,7 +96,7 @@ def evaluate_policy(policy, env, n_eval_episodes: int = 10, deterministic: bool 
         use_graph = (deterministic and generator is None and torch.device(env.device).type == "cuda" and hasattr(venv, "step_tensor")
                      and not getattr(policy, "uses_image", False))        # (a CNN front end keeps MIOpen out of captures)
     if use_graph:
-        return _evaluate_replayed(policy, env, targets, callback, max_vec_steps)
+        return ReplayedEvaluation(policy, env, targets, callback, use_fused=use_fused).run(max_vec_steps)
     counts = np.zeros(n, dtype=np.int64)
     cur_rew = torch.zeros(n, dtype=torch.float64, device=env.device)
     cur_len = torch.zeros(n, dtype=torch.int64, device=env.device)
@@ -169,9 +175,12 @@ class ReplayedEvaluation:
     training that continues on the main stream (the PPO update keeps four of the 256 CUs busy); ``ready()`` / ``result()``
     collect it.  The policy handed in must not change while it runs (EvalCallback evaluates a copy of the weights)."""
 
-    def __init__(self, policy, env, targets: np.ndarray, callback=None):
+    def __init__(self, policy, env, targets: np.ndarray, callback=None, use_fused: Optional[bool] = None):
         self.policy, self.env, self.callback = policy, env, callback
         venv, n, dev = env.venv, env.num_envs, env.device
+        self.fused = self._fused_applies(policy, env) if use_fused is None else bool(use_fused)
+        if self.fused and not self._fused_applies(policy, env):
+            raise ValueError("use_fused=True needs the MlpPolicy, a device env on the 8-lane mapping and an evaluation normaliser (training=False)")
         self.venv, self.n, self.dev, self.targets = venv, n, dev, targets
         self.E = E = max(int(targets.max()), 1)
         self.has_info = hasattr(venv, "info")
@@ -190,12 +199,84 @@ class ReplayedEvaluation:
         self.side = torch.cuda.Stream(device=dev)
         self.done_event = None
         self.steps = 0
+        if self.fused:
+            self._fused_setup()
+
+    # ---- a vec-step as ONE fw_collect_step launch (deterministic, statistics frozen) ----
+    @staticmethod
+    def _fused_applies(policy, env) -> bool:
+        from . import _lib
+        from .rollout import FusedPpoUpdate
+        venv = env.venv
+        if not (hasattr(venv, "_h") and hasattr(venv, "step_tensor") and torch.device(env.device).type == "cuda"):
+            return False
+        if env.training or not env.norm_obs or not FusedPpoUpdate.fits(policy, env.obs_dim, torch.device(env.device)):
+            return False
+        return int(_lib.lib().fw_lanes_per_env(venv._h)) in (8, 16)
+
+    def _fused_setup(self) -> None:
+        from . import _lib
+        from .rollout import FusedPpoUpdate
+        env, venv, dev, n = self.env, self.venv, self.dev, self.n
+        L = _lib.lib()
+        f = FusedPpoUpdate(self.policy, None, env.obs_dim)
+        f.load_params_from_torch()
+        self._flat = f.flat                                         # the kernel's parameter image of the policy being evaluated
+        self._act_env = torch.full((n, 4), float("nan"), dtype=venv.torch_dtype, device=dev)      # NaN = "not there yet" (fw_collect_step)
+        self._act_raw = torch.zeros((n, 4), dtype=torch.float32, device=dev)                     # rollout-buffer rows the launch fills: not looked at
+        self._logp, self._val = torch.zeros(n, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.float32, device=dev)
+        self._rng = torch.zeros(2, dtype=torch.int64, device=dev)
+        nb = int(L.fw_collect_step_workspace_bytes(venv._h))
+        self._ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
+        self._ws_ready = False
+
+    def _fused_step(self) -> torch.Tensor:
+        import ctypes as C
+        from . import _lib
+        from .rollout import _stream
+        env, venv = self.env, self.venv
+        L, st = _lib.lib(), _stream(self.dev)
+        if not self._ws_ready:
+            _lib.check(L.fw_collect_workspace_init(venv._h, self._ws.data_ptr(), self._ws.numel() * 8, st), venv._h)
+            self._ws_ready = True
+        a = K.FwCollectArgs()
+        a.params = self._flat.data_ptr()
+        a.obs_mean, a.obs_var, a.obs_count = env.obs_rms.mean.data_ptr(), env.obs_rms.var.data_ptr(), env.obs_rms.count.data_ptr()
+        a.returns = env.returns.data_ptr()
+        a.ret_mean, a.ret_var, a.ret_count = env.ret_rms.mean.data_ptr(), env.ret_rms.var.data_ptr(), env.ret_rms.count.data_ptr()
+        a.rng = self._rng.data_ptr()
+        a.act_raw, a.logp, a.value = self._act_raw.data_ptr(), self._logp.data_ptr(), self._val.data_ptr()
+        a.act_env = self._act_env.data_ptr()
+        a.obs, a.reward = venv.obs.data_ptr(), venv.rewards.data_ptr()
+        a.terminated, a.truncated = venv.terminated.data_ptr(), venv.truncated.data_ptr()
+        a.terminal_obs, a.info_i32 = venv.terminal_obs.data_ptr(), venv.info.data_ptr()
+        a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel() * 8
+        a.gamma = float(env.gamma)
+        a.clip_obs, a.eps_obs, a.clip_reward, a.eps_reward = float(env.clip_obs), float(env.epsilon), float(env.clip_reward), float(env.epsilon)
+        a.update_obs, a.update_ret, a.norm_reward, a.deterministic = 0, 0, 0, 1
+        _lib.check(L.fw_collect_step(venv._h, C.byref(a), st), venv._h)
+        return (venv.terminated | venv.truncated).to(torch.bool)
+
+    def _fused_check(self) -> None:
+        """fw_collect_step's status word: a wait inside one of the launches ran out -> the evaluation is void ("returns or raises")"""
+        import ctypes as C
+        from . import _lib
+        from .rollout import _stream
+        if not self.fused or not self._ws_ready:
+            return
+        stw = C.c_uint32(0)
+        _lib.check(_lib.lib().fw_collect_status(self.venv._h, self._ws.data_ptr(), self._ws.numel() * 8, C.byref(stw), _stream(self.dev)), self.venv._h)
+        if stw.value:
+            raise RuntimeError(f"fw_collect_step: status word {stw.value} during the evaluation; its figures are void")
 
     def _body(self):
         venv, ar, tg, E, counts = self.venv, self.ar, self.tg, self.E, self.counts
-        actions, _, _ = self.policy(self.obs, deterministic=True, generator=None, **policy_inputs(self.policy, self.env))
-        o, _, dones, _, _ = self.env.step(actions.clamp(-1.0, 1.0).to(venv.torch_dtype))
-        self.obs.copy_(o)
+        if self.fused:
+            dones = self._fused_step()
+        else:
+            actions, _, _ = self.policy(self.obs, deterministic=True, generator=None, **policy_inputs(self.policy, self.env))
+            o, _, dones, _, _ = self.env.step(actions.clamp(-1.0, 1.0).to(venv.torch_dtype))
+            self.obs.copy_(o)
         self.cur_rew.add_(venv.rewards.to(torch.float64))            # un-normalised reward of the wrapped env
         self.cur_len.add_(1); self.step_ctr.add_(1)
         take = dones & (counts < tg)
@@ -247,6 +328,7 @@ class ReplayedEvaluation:
             self.done_event.synchronize()
         else:
             self.side.synchronize()
+        self._fused_check()
         n, has_info = self.n, self.has_info
         res = EvalResult([], [])
         c_h = torch.minimum(self.counts, self.tg).cpu().numpy()
@@ -259,10 +341,6 @@ class ReplayedEvaluation:
             if self.callback is not None:
                 self.callback(info)
         return res
-
-
-def _evaluate_replayed(policy, env, targets: np.ndarray, callback, max_vec_steps) -> "EvalResult":
-    return ReplayedEvaluation(policy, env, targets, callback).run(max_vec_steps)
 
 
 def start_evaluation(policy, env, n_eval_episodes: int = 10, callback=None) -> ReplayedEvaluation:

@@ -57,13 +57,46 @@ def test_replayed_evaluation_returns_the_episodes_of_the_step_by_step_loop(task)
             torch.manual_seed(0)
             pol = R.MlpPolicy(env.obs_dim).cuda()
         infos = []
-        r = evaluate.evaluate_policy(pol, env, n_eval_episodes=61, deterministic=True, callback=infos.append, use_graph=use_graph)
+        r = evaluate.evaluate_policy(pol, env, n_eval_episodes=61, deterministic=True, callback=infos.append, use_graph=use_graph,
+                                     use_fused=False)             # (the torch ops on both sides: the same bits)
         out.append((r, infos))
     (a, ia), (b, ib) = out
     assert len(a.episode_rewards) == 61 == len(b.episode_rewards)
     assert a.episode_lengths == b.episode_lengths and a.episode_rewards == b.episode_rewards
     assert a.num_targets_reached == b.num_targets_reached and a.is_success == b.is_success and a.duck_strike == b.duck_strike
     assert ia == ib
+
+
+@pytest.mark.parametrize("task", ["waypoints", "objlock"])
+def test_fused_evaluation_flies_the_episodes_of_the_torch_evaluation(task):
+    """evaluate_policy's default where it applies: a vec-step of the evaluation is ONE fw_collect_step launch (deterministic, statistics
+    frozen) instead of the framework ops.  The policy forward is then the kernel's (fp32 MFMA), equal to torch's to rounding: the
+    episodes are the same ones -- same number, same order, lengths and outcomes equal but for an episode that ends on a knife's edge,
+    rewards equal to ~1e-4 relative."""
+    cfg = _wp_cfg() if task == "waypoints" else K.train_objlock_config(max_duration_seconds=3.0)
+    pol = None
+    out = []
+    for fused in (False, True):
+        venv = P.FixedwingVecEnv(cfg, 24, seed=9)
+        env = R.VecNormalizeDevice(venv, training=False, norm_reward=False)
+        with torch.no_grad():                                      # statistics as after some training: not the identity
+            env.obs_rms.mean.copy_(torch.linspace(-0.2, 0.3, env.obs_dim, dtype=torch.float64, device="cuda"))
+            env.obs_rms.var.copy_(torch.linspace(0.5, 2.0, env.obs_dim, dtype=torch.float64, device="cuda"))
+        if pol is None:
+            torch.manual_seed(0)
+            pol = R.MlpPolicy(env.obs_dim).cuda()
+        infos = []
+        job = evaluate.ReplayedEvaluation(pol, env, __import__("numpy").array([(61 + i) // 24 for i in range(24)]), infos.append, use_fused=fused)
+        assert job.fused == fused
+        out.append((job.run(None), infos))
+    (a, ia), (b, ib) = out
+    assert len(a.episode_rewards) == 61 == len(b.episode_rewards)
+    same = [x == y for x, y in zip(a.episode_lengths, b.episode_lengths)]
+    assert sum(same) >= 58, (a.episode_lengths, b.episode_lengths)
+    for k, ok in enumerate(same):
+        if ok:
+            assert b.episode_rewards[k] == pytest.approx(a.episode_rewards[k], rel=2e-3, abs=2e-3), k
+    assert sum(x == y for x, y in zip(a.is_success, b.is_success)) >= 58
 
 
 def test_eval_harness_objlock_reports_duck_strike_rate():
