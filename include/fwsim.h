@@ -361,6 +361,14 @@ int32_t fw_gae(const float* rewards, const float* values, const float* episode_s
                const float* last_values, const float* last_dones, float* advantages, float* returns,
                int32_t T, int32_t N, float gamma, float gae_lambda, void* hip_stream);
 
+/* Episode bookkeeping of an evaluation loop (SB3 evaluate_policy; evaluate.ReplayedEvaluation): after a vec-step, add `reward` [N]
+ * (env dtype) to cur_rew and 1 to cur_len; where terminated | truncated and counts[i] < targets[i], record the episode (reward, length,
+ * the vec-step index, the info row) in slot counts[i] of env i ([N, E] buffers; info may be NULL) and count it; clear the accumulators of
+ * finished episodes; advance step_ctr[0].  One launch, all buffers on the device. */
+int32_t fw_eval_track(const void* reward, int32_t reward_is_f64, const uint8_t* terminated, const uint8_t* truncated, const int32_t* info,
+                      int32_t info_dim, const int64_t* targets, int64_t* counts, double* cur_rew, int64_t* cur_len, int64_t* step_ctr,
+                      double* fin_rew, int64_t* fin_len, int64_t* fin_step, int32_t* fin_info, int32_t N, int32_t E, void* hip_stream);
+
 /* VecNormalize step (SB3 VecNormalize.step_wait + RunningMeanStd.update, Chan et al. merge),
  * fused: one pass over obs[N,D] (env dtype T_in = double|float per `in_is_f64`) that
  *   (a) if `update` != 0 merges the batch moments into (mean[D], var[D], count[1]) (double),

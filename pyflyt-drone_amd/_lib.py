@@ -20,7 +20,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 EXPORTS = (
     "fw_sizeof_config", "fw_abi_version", "fw_state_dim", "fw_obs_dim", "fw_validate_config", "fw_create", "fw_reset",
     "fw_step", "fw_seed", "fw_get_state", "fw_set_state", "fw_get_counters", "fw_observe", "fw_render", "fw_num_envs", "fw_lanes_per_env", "fw_last_error",
-    "fw_destroy", "fw_gae", "fw_normalize_obs", "fw_normalize_obs_workspace_bytes", "fw_ppo_update_workspace_bytes", "fw_ppo_param_count", "fw_ppo_moment_count", "fw_ppo_moment_map", "fw_ppo_update", "fw_policy_act", "fw_policy_terminal_value", "fw_rollout_post", "fw_collect_act", "fw_collect_stats", "fw_collect_stats_workspace_bytes", "fw_collect_step", "fw_collect_finish", "fw_collect_step_workspace_bytes", "fw_collect_workspace_init", "fw_collect_close", "fw_collect_status", "fw_ppo_update_status",
+    "fw_destroy", "fw_gae", "fw_eval_track", "fw_normalize_obs", "fw_normalize_obs_workspace_bytes", "fw_ppo_update_workspace_bytes", "fw_ppo_param_count", "fw_ppo_moment_count", "fw_ppo_moment_map", "fw_ppo_update", "fw_policy_act", "fw_policy_terminal_value", "fw_rollout_post", "fw_collect_act", "fw_collect_stats", "fw_collect_stats_workspace_bytes", "fw_collect_step", "fw_collect_finish", "fw_collect_step_workspace_bytes", "fw_collect_workspace_init", "fw_collect_close", "fw_collect_status", "fw_ppo_update_status",
 )
 
 
@@ -98,6 +98,8 @@ def lib() -> C.CDLL:
         L.fw_last_error.restype = C.c_char_p; L.fw_last_error.argtypes = [vp]
         L.fw_destroy.restype = i32; L.fw_destroy.argtypes = [vp]
         L.fw_gae.restype = i32
+        L.fw_eval_track.restype = i32
+        L.fw_eval_track.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
         L.fw_gae.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_float, vp]
         L.fw_normalize_obs.restype = i32
         L.fw_normalize_obs.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, C.c_float, C.c_float, vp, vp, vp, vp]

@@ -1869,6 +1869,21 @@ int32_t fw_gae(const float* rewards, const float* values, const float* episode_s
   return FW_OK;
 }
 
+int32_t fw_eval_track(const void* reward, int32_t reward_is_f64, const uint8_t* terminated, const uint8_t* truncated, const int32_t* info,
+                      int32_t info_dim, const int64_t* targets, int64_t* counts, double* cur_rew, int64_t* cur_len, int64_t* step_ctr,
+                      double* fin_rew, int64_t* fin_len, int64_t* fin_step, int32_t* fin_info, int32_t N, int32_t E, void* hip_stream) {
+  if (!reward || !terminated || !truncated || !targets || !counts || !cur_rew || !cur_len || !step_ctr || !fin_rew || !fin_len || !fin_step ||
+      N <= 0 || E <= 0 || (info && (info_dim <= 0 || !fin_info))) { g_err = "fw_eval_track: bad arguments"; return FW_EINVAL; }
+  EvalTrackArgs A;
+  A.reward = reward; A.reward_is_f64 = reward_is_f64; A.terminated = terminated; A.truncated = truncated; A.info = info; A.info_dim = info_dim;
+  A.targets = targets; A.counts = counts; A.cur_rew = cur_rew; A.cur_len = cur_len; A.step_ctr = step_ctr;
+  A.fin_rew = fin_rew; A.fin_len = fin_len; A.fin_step = fin_step; A.fin_info = fin_info; A.N = N; A.E = E;
+  DeviceGuard g(device_of(reward));
+  hipLaunchKernelGGL(fw_eval_track_kernel, dim3(1), dim3(256), 0, (hipStream_t)hip_stream, A);
+  HIP_TRY((fw_env*)nullptr, hipGetLastError());
+  return FW_OK;
+}
+
 int64_t fw_normalize_obs_workspace_bytes(int32_t D) { return D > 0 ? (int64_t)sizeof(double) * 64 * 2 * D : FW_EINVAL; }
 
 int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t D, double* mean, double* var,

@@ -30,6 +30,41 @@ __global__ __launch_bounds__(256) void fw_gae_kernel(const float* __restrict__ r
   }
 }
 
+// Episode bookkeeping of an evaluation (evaluate.ReplayedEvaluation, SB3's evaluate_policy loop): one vec-step's rewards and dones into
+// the running accumulators, a finished episode into the next slot of its env -- what the harness did with ~20 framework ops.
+// One workgroup: the step counter is read by everybody and advanced once, behind the barrier.
+struct EvalTrackArgs {
+  const void* reward; int32_t reward_is_f64;
+  const uint8_t *terminated, *truncated;
+  const int32_t* info; int32_t info_dim;     // may be NULL
+  const int64_t* targets;                    // [N] episodes wanted of each env
+  int64_t* counts;                           // [N] episodes taken so far
+  double* cur_rew; int64_t* cur_len;         // [N] accumulators of the running episodes
+  int64_t* step_ctr;                         // [1] vec-steps so far
+  double* fin_rew; int64_t *fin_len, *fin_step; int32_t* fin_info;      // [N, E] (fin_info [N, E, info_dim])
+  int32_t N, E;
+};
+__global__ __launch_bounds__(256) void fw_eval_track_kernel(EvalTrackArgs A) {
+  const long long step = A.step_ctr[0] + 1;
+  for (int i = threadIdx.x; i < A.N; i += (int)blockDim.x) {
+    const double r = A.reward_is_f64 ? reinterpret_cast<const double*>(A.reward)[i] : (double)reinterpret_cast<const float*>(A.reward)[i];
+    const double cr = A.cur_rew[i] + r;
+    const long long cl = A.cur_len[i] + 1;
+    const bool done = (A.terminated[i] | A.truncated[i]) != 0;
+    const long long c = A.counts[i];
+    if (done && c < A.targets[i]) {
+      const size_t s = (size_t)i * A.E + (size_t)(c < A.E ? c : A.E - 1);
+      A.fin_rew[s] = cr; A.fin_len[s] = cl; A.fin_step[s] = step;
+      if (A.info) for (int k = 0; k < A.info_dim; ++k) A.fin_info[s * A.info_dim + k] = A.info[(size_t)i * A.info_dim + k];
+      A.counts[i] = c + 1;
+    }
+    A.cur_rew[i] = done ? 0.0 : cr;
+    A.cur_len[i] = done ? 0 : cl;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) A.step_ctr[0] = step;
+}
+
 // K4a: per-column batch moments of obs[N,D] (two-pass-free: shifted sums in double), one
 // workgroup per column chunk; K4b merges them into the running statistics (Chan et al.) and
 // K4c normalises.  N*D is small (4096 x 28), so the three launches are latency-trivial and

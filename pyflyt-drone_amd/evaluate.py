@@ -230,7 +230,7 @@ class ReplayedEvaluation:
         self._ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
         self._ws_ready = False
 
-    def _fused_step(self) -> torch.Tensor:
+    def _fused_step(self) -> None:
         import ctypes as C
         from . import _lib
         from .rollout import _stream
@@ -255,7 +255,14 @@ class ReplayedEvaluation:
         a.clip_obs, a.eps_obs, a.clip_reward, a.eps_reward = float(env.clip_obs), float(env.epsilon), float(env.clip_reward), float(env.epsilon)
         a.update_obs, a.update_ret, a.norm_reward, a.deterministic = 0, 0, 0, 1
         _lib.check(L.fw_collect_step(venv._h, C.byref(a), st), venv._h)
-        return (venv.terminated | venv.truncated).to(torch.bool)
+        # ... and the episode bookkeeping of the step in one more (fw_eval_track)
+        fi = self.fin_info
+        _lib.check(L.fw_eval_track(venv.rewards.data_ptr(), int(venv.rewards.dtype == torch.float64), venv.terminated.data_ptr(),
+                                   venv.truncated.data_ptr(), venv.info.data_ptr() if fi is not None else None,
+                                   int(venv.info.shape[1]) if fi is not None else 0, self.tg.data_ptr(), self.counts.data_ptr(),
+                                   self.cur_rew.data_ptr(), self.cur_len.data_ptr(), self.step_ctr.data_ptr(), self.fin_rew.data_ptr(),
+                                   self.fin_len.data_ptr(), self.fin_step.data_ptr(), fi.data_ptr() if fi is not None else None,
+                                   self.n, self.E, st))
 
     def _fused_check(self) -> None:
         """fw_collect_step's status word: a wait inside one of the launches ran out -> the evaluation is void ("returns or raises")"""
@@ -272,7 +279,8 @@ class ReplayedEvaluation:
     def _body(self):
         venv, ar, tg, E, counts = self.venv, self.ar, self.tg, self.E, self.counts
         if self.fused:
-            dones = self._fused_step()
+            self._fused_step()
+            return
         else:
             actions, _, _ = self.policy(self.obs, deterministic=True, generator=None, **policy_inputs(self.policy, self.env))
             o, _, dones, _, _ = self.env.step(actions.clamp(-1.0, 1.0).to(venv.torch_dtype))
