@@ -99,6 +99,51 @@ def test_fused_evaluation_flies_the_episodes_of_the_torch_evaluation(task):
     assert sum(x == y for x, y in zip(a.is_success, b.is_success)) >= 58
 
 
+def test_fw_eval_track_is_the_bookkeeping_of_the_torch_loop():
+    """fw_eval_track (one launch) against the framework ops it replaces in evaluate.ReplayedEvaluation._body, on random step outputs:
+    accumulators, slots of finished episodes, info rows, episode counts and the step counter agree exactly over 200 steps."""
+    import ctypes as C
+    from pyflyt_drone_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    n, E, idim = 37, 3, K.FW_INFO_DIM
+    tg = torch.randint(1, E + 1, (n,), device="cuda", generator=g)
+    def fresh():
+        return dict(counts=torch.zeros(n, dtype=torch.int64, device="cuda"), cur_rew=torch.zeros(n, dtype=torch.float64, device="cuda"),
+                    cur_len=torch.zeros(n, dtype=torch.int64, device="cuda"), step=torch.zeros((), dtype=torch.int64, device="cuda"),
+                    fin_rew=torch.zeros((n, E), dtype=torch.float64, device="cuda"), fin_len=torch.zeros((n, E), dtype=torch.int64, device="cuda"),
+                    fin_step=torch.zeros((n, E), dtype=torch.int64, device="cuda"), fin_info=torch.zeros((n, E, idim), dtype=torch.int32, device="cuda"))
+    a, b = fresh(), fresh()
+    ar = torch.arange(n, device="cuda")
+    for dtype in (torch.float64, torch.float32):
+        for t in range(100):
+            rew = torch.randn(n, device="cuda", generator=g, dtype=torch.float64).to(dtype)
+            term = (torch.rand(n, device="cuda", generator=g) < 0.07).to(torch.uint8)
+            trunc = (torch.rand(n, device="cuda", generator=g) < 0.03).to(torch.uint8)
+            info = torch.randint(0, 9, (n, idim), device="cuda", generator=g, dtype=torch.int32)
+            # the torch ops
+            dones = (term | trunc).bool()
+            a["cur_rew"].add_(rew.to(torch.float64)); a["cur_len"].add_(1); a["step"].add_(1)
+            take = dones & (a["counts"] < tg)
+            slot = a["counts"].clamp(max=E - 1)
+            a["fin_rew"][ar, slot] = torch.where(take, a["cur_rew"], a["fin_rew"][ar, slot])
+            a["fin_len"][ar, slot] = torch.where(take, a["cur_len"], a["fin_len"][ar, slot])
+            a["fin_step"][ar, slot] = torch.where(take, a["step"].expand(n), a["fin_step"][ar, slot])
+            a["fin_info"][ar, slot] = torch.where(take[:, None], info, a["fin_info"][ar, slot])
+            a["counts"].add_(take.to(torch.int64))
+            a["cur_rew"].masked_fill_(dones, 0.0); a["cur_len"].masked_fill_(dones, 0)
+            # the launch
+            rc = L.fw_eval_track(rew.data_ptr(), int(dtype == torch.float64), term.data_ptr(), trunc.data_ptr(), info.data_ptr(), idim,
+                                 tg.data_ptr(), b["counts"].data_ptr(), b["cur_rew"].data_ptr(), b["cur_len"].data_ptr(), b["step"].data_ptr(),
+                                 b["fin_rew"].data_ptr(), b["fin_len"].data_ptr(), b["fin_step"].data_ptr(), b["fin_info"].data_ptr(), n, E, None)
+            assert rc == 0
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert int(a["counts"].sum()) > n and int(a["step"]) == 200
+    assert L.fw_eval_track(None, 1, None, None, None, 0, None, None, None, None, None, None, None, None, None, n, E, None) == K.FW_EINVAL
+
+
 def test_eval_harness_objlock_reports_duck_strike_rate():
     venv = P.FixedwingVecEnv(K.train_objlock_config(max_duration_seconds=3.0), 32, seed=1)
     env = R.VecNormalizeDevice(venv, training=False, norm_reward=False)
