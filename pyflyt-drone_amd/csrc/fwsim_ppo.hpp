@@ -5,14 +5,14 @@
 //
 // Why a kernel: with thousands of envs one update is ~10^4 *sequential* minibatch steps of a 12 k-parameter
 // network.  As framework ops that is ~30 launches per step and the update, not the simulator, bounds
-// end-to-end throughput (4.5 s per 65 536-sample update).  Here one workgroup per (network, chunk half) walks the whole
-// minibatch sequence: weights stay in LDS for the entire call, activations of a 64-sample chunk live in LDS, every
-// GEMM (forward, dW = A^T G, dX = G W^T) is the same strided 32x32 tile routine on `v_mfma_f32_32x32x2_f32`
-// (exact fp32, so parity with the torch path is fp32 rounding), weight-gradient tiles accumulate in
-// registers across chunks, and each lane applies gradient clipping + Adam to exactly the elements it holds
-// (no gradient staging, no second kernel).  The path is sequential by definition of SGD; the only parallelism
-// is inside a minibatch, which is why it is four CUs and not a grid.  The rows themselves are gathered by a parallel
-// pre-pass (fw_ppo_pack_kernel) so that nothing on the sequential path depends on an index.
+// end-to-end throughput (4.5 s per 65 536-sample update).  Here up to four workgroups per network walk the whole
+// minibatch sequence, each its share of every minibatch: weights stay in LDS for the entire call, activations of a 16- / 32- /
+// 64-sample pass live in LDS, every GEMM (forward, dW = A^T G, dX = G W^T) is a tile routine on `v_mfma_f32_32x32x2_f32` /
+// `v_mfma_f32_16x16x4_f32` (exact fp32, so parity with the torch path is fp32 rounding), weight-gradient tiles accumulate in
+// registers across passes, and clipping + Adam are applied in registers to the elements a thread owns (no second kernel).
+// The path is sequential by definition of SGD; the only parallelism is inside a minibatch, which is why it is eight CUs and not
+// a grid.  The rows themselves are gathered by a parallel pre-pass (fw_ppo_pack_kernel) so that nothing on the sequential path
+// depends on an index.
 //
 // Flat parameter layout (floats), used for params / exp_avg / exp_avg_sq alike (rollout.py builds it):
 //   for net in (pi, vf):  W1[Dp][64]  b1[64]  W2[64][64]  b2[64]  Wo[64][KO]  bo[KO]     (KO = 4 / 1)
@@ -256,22 +256,24 @@ __global__ __launch_bounds__(256) void fw_ppo_pack_kernel(PpoPackArgs P) {
   }
 }
 
-// One workgroup per network (pi / V) -- the two networks share nothing but the scalar gradient norm that SB3 clips
-// jointly, exchanged once per minibatch through one 64-bit word each (tag | partial sum of squares, device-scope
-// atomics).  Minibatches of >= 128 samples are additionally split over two workgroups per network, each running
-// every other 64-sample chunk; the pair swaps its gradient partials through global memory (release / acquire at
-// device scope -- or, on a shared XCD, store wait / loads past the L1 -- double-buffered by minibatch parity), after which
-// both hold the same sum and apply the same Adam step to their own LDS copy of the weights and their own register copy of
-// the moments.  2 or 4 working blocks, always co-resident; every wait is bounded and a wait that runs out ends the call with
-// a status word instead of a result (ppo_wait, include/fwsim.h FW_PPO_ST_*).
-// Work split of the 256 threads of a block (4 waves, one per SIMD, fixed for the whole call):
-//   * every 64 x 64 product (H1, H2, G2, G1, dW2) is 2 x 2 tiles of 32 x 32: wave w owns tile (w >> 1, w & 1);
+// The two networks (pi / V) share nothing but the scalar gradient norm that SB3 clips jointly, exchanged once per minibatch
+// through 64-bit words (tag | partial sum of squares).  A minibatch is cut over 1, 2 or 4 workgroups per network (ppo_split),
+// block q running passes q, q + nsplit, ...; per minibatch they exchange gradients through global memory (release / acquire at
+// device scope -- or, on a shared XCD, store wait / loads past the L1 -- double-buffered by minibatch parity).  Two blocks: each
+// reads the other's whole partial, both hold the same sum and apply the same Adam step to their own LDS copy of the weights and
+// their own register copy of the moments.  Four blocks (RS): reduce-scatter of the tiles, Adam on a quarter, all-gather of the
+// new weights (see ppo_net_body).  2, 4 or 8 working blocks, always co-resident; every wait is bounded and a wait that runs out
+// ends the call with a status word instead of a result (ppo_wait, include/fwsim.h FW_PPO_ST_*).
+// Work split of the 256 threads of a block (4 waves, one per SIMD, fixed for the whole call), 64-sample passes:
+//   * every 64 x 64 product (H1, H2, G2, G1, dW2) is 2 x 2 tiles of 32 x 32: wave w owns tile (w >> 1, w & 1) -- 32- / 16-sample
+//     passes: H1, H2, G2, G1 are 2 / 1 x 4 tiles of 16 x 16, wave w owns columns 16 w ..; dW2 / dW1 stay 32 x 32 tiles per wave;
 //   * dW1 is ceil(Dp / 32) x 2 tiles: all four waves own one (> 32 features), or waves 0-1 own them and every wave computes
 //     one over half of the chunk's samples (<= 32 features; the halves meet in LDS once per minibatch);
 //   * the 64 x KO head, its loss gradient and dWo run on the vector ALU: thread (sample or hidden unit, quarter / component);
 //   * bias gradients are column sums: thread (wave q, lane n) sums rows 16 q .. 16 q + 15 of column n.
 // Each lane applies clipping + Adam to the accumulator elements it holds; their moments are loaded once (slot order:
-// ppo_moment_map), live in registers (AGPRs) for the whole call and are written back by the first chunk half at the end.
+// ppo_moment_map), live in registers (AGPRs) for the whole call and are written back by the first block at the end (RS: every
+// block the quarter it owns).
 // Exchange words between blocks.  `l2` = they run on one XCD: the word is written through this CU's L1 into the shared L2 (a
 // workgroup-scope store) instead of with a device-scope store.  Polls are device-scope loads (past the L1, served by the L2) in
 // both cases.  (Rounds 3 / 4 polled with an atomic OR of zero on the shared-L2 path: with up to seven lanes of eight blocks

@@ -172,7 +172,7 @@ class ReplayedEvaluation:
     ``run()`` drives it from the host (one look at the episode counters per replay of ``_REPLAY_STEPS`` steps).
     ``launch()`` enqueues the WHOLE evaluation on a side stream -- as many replays as the longest possible episodes need,
     ``episodes per env x (max_steps + 2)`` vec-steps -- and returns at once: the evaluation (a few envs) then runs beside the
-    training that continues on the main stream (the PPO update keeps four of the 256 CUs busy); ``ready()`` / ``result()``
+    training that continues on the main stream (the PPO update keeps eight of the 256 CUs busy); ``ready()`` / ``result()``
     collect it.  The policy handed in must not change while it runs (EvalCallback evaluates a copy of the weights)."""
 
     def __init__(self, policy, env, targets: np.ndarray, callback=None, use_fused: Optional[bool] = None):
