@@ -150,14 +150,33 @@ __device__ __forceinline__ float ppo_block_sum(float x, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// tanh to ~1e-7 absolute: odd series near 0 (no cancellation), 1 - 2 / (e^{2x} + 1) elsewhere (v_exp_f32 + v_rcp_f32)
+// tanh to ~1e-7 absolute: odd series near 0 (no cancellation), 1 - 2 / (e^{2x} + 1) elsewhere (v_exp_f32 + v_rcp_f32; e^{2x} -> 0 / inf
+// give -1 / +1 without a clamp).  The pair form is the same arithmetic on packed fp32 (v_pk_mul / v_pk_fma: two values per
+// instruction for everything but the exponential, the reciprocal and the select) -- the epilogues of the update spend ~80 cycles
+// per value on this function; collector and update must share it (the ratio of a fresh sample is exactly 1).
+typedef float ppo_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ppo_f2 ppo_tanh2(ppo_f2 x) {
+  const ppo_f2 x2 = x * x;
+  ppo_f2 p = __builtin_elementwise_fma(x2, ppo_f2{0.021869488f, 0.021869488f}, ppo_f2{-0.053968254f, -0.053968254f});
+  p = __builtin_elementwise_fma(x2, p, ppo_f2{0.13333334f, 0.13333334f});
+  p = __builtin_elementwise_fma(x2, p, ppo_f2{-0.33333334f, -0.33333334f});
+  p = __builtin_elementwise_fma(x2, p, ppo_f2{1.0f, 1.0f});
+  const ppo_f2 small = x * p;
+  const ppo_f2 t = x * 2.8853900817779268f;
+  const ppo_f2 e1 = ppo_f2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;      // e^{2x} + 1
+  const ppo_f2 rc = {__builtin_amdgcn_rcpf(e1[0]), __builtin_amdgcn_rcpf(e1[1])};
+  const ppo_f2 big = __builtin_elementwise_fma(rc, ppo_f2{-2.0f, -2.0f}, ppo_f2{1.0f, 1.0f});
+  return ppo_f2{fabsf(x[0]) < 0.25f ? small[0] : big[0], fabsf(x[1]) < 0.25f ? small[1] : big[1]};
+}
 __device__ __forceinline__ float ppo_tanh(float x) {
-  const float ax = fabsf(x);
   const float x2 = x * x;
-  const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
-  const float e = __builtin_amdgcn_exp2f(fminf(ax, 12.0f) * 2.8853900817779268f);      // e^{2|x|}
-  const float big = copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f), x);
-  return ax < 0.25f ? small : big;
+  float p = fmaf(x2, 0.021869488f, -0.053968254f);
+  p = fmaf(x2, p, 0.13333334f);
+  p = fmaf(x2, p, -0.33333334f);
+  p = fmaf(x2, p, 1.0f);
+  const float small = x * p;
+  const float big = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.8853900817779268f) + 1.0f), -2.0f, 1.0f);
+  return fabsf(x) < 0.25f ? small : big;
 }
 
 // Adam moments are kept in "slot" order: slot = ((net * 3 + kind) * 4 + wave) * 1024 + lane * 16 + v for the
@@ -581,7 +600,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         for (int v = 0; v < 16; ++v) c[v] = bias;
         c = ppo_mfma_tile(X + mt * 32 * ldx, ldx, 1, W.W1 + nt * 32, kPH, 1, Dp, c);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) H1[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
+        for (int v = 0; v < 16; v += 2) {
+          const ppo_f2 h = ppo_tanh2(ppo_f2{c[v], c[v + 1]});
+          H1[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = h[0]; H1[(mt * 32 + ppo_acc_row(v + 1)) * kPLdh + nt * 32 + r] = h[1];
+        }
       } else {
         const float bias = W.b1[wave * 16 + l16];
         f32x4 c[RT];
@@ -593,7 +615,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-          for (int v = 0; v < 4; ++v) hp[(16 * rt + v) * kPLdh] = ppo_tanh(c[rt][v]);
+          for (int v = 0; v < 4; v += 2) {
+            const ppo_f2 h = ppo_tanh2(ppo_f2{c[rt][v], c[rt][v + 1]});
+            hp[(16 * rt + v) * kPLdh] = h[0]; hp[(16 * rt + v + 1) * kPLdh] = h[1];
+          }
       }
       __syncthreads();
       PPO_PHASE(0);
@@ -604,7 +629,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         for (int v = 0; v < 16; ++v) c[v] = bias;
         c = ppo_mfma_tile(H1 + mt * 32 * kPLdh, kPLdh, 1, W.W2 + nt * 32, kPLdh, 1, kPH, c);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) H2[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = ppo_tanh(c[v]);
+        for (int v = 0; v < 16; v += 2) {
+          const ppo_f2 h = ppo_tanh2(ppo_f2{c[v], c[v + 1]});
+          H2[(mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r] = h[0]; H2[(mt * 32 + ppo_acc_row(v + 1)) * kPLdh + nt * 32 + r] = h[1];
+        }
       } else {
         const float bias = W.b2[wave * 16 + l16];
         f32x4 c[RT];
@@ -615,7 +643,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-          for (int v = 0; v < 4; ++v) hp[(16 * rt + v) * kPLdh] = ppo_tanh(c[rt][v]);
+          for (int v = 0; v < 4; v += 2) {
+            const ppo_f2 h = ppo_tanh2(ppo_f2{c[rt][v], c[rt][v + 1]});
+            hp[(16 * rt + v) * kPLdh] = h[0]; hp[(16 * rt + v + 1) * kPLdh] = h[1];
+          }
       }
       __syncthreads();
       PPO_PHASE(1);

@@ -504,7 +504,10 @@ def test_one_launch_vec_step_equals_the_three_launch_collector(task, n):
     assert status == 0, "a step wave's wait for its actions ran out"
     assert ra == rb == 5 * 8
     assert ca == cb and (ca["resets"] > 0 or n < 100), (ca, cb)
-    torch.testing.assert_close(sa, sb, rtol=1e-9, atol=1e-9)           # (another fold order: 1e-12 of a column's scale)
+    torch.testing.assert_close(sa[:-n], sb[:-n], rtol=1e-9, atol=1e-9)   # (another fold order: 1e-12 of a column's scale)
+    # the per-env return trackers follow the rewards, which follow the actions: the two collectors' policy forwards (16 x 16 x 4 tiles in
+    # the act waves, 32 x 32 x 2 in fw_collect_act) agree to fp32 rounding, not to the bit
+    torch.testing.assert_close(sa[-n:], sb[-n:], rtol=1e-7, atol=1e-7)
     for it, (x, y) in enumerate(zip(ba, bb)):
         for name, u, v in zip(("obs", "act", "logp", "val", "rew", "start", "last_values", "last_starts", "adv", "ret", "last_obs"), x, y):
             torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-5, msg=lambda m: f"rollout {it} {name}: {m}")
