@@ -548,6 +548,8 @@ class FusedPpoUpdate:
         self.mom_v = torch.zeros_like(self.mom_m)
         self.loss = torch.zeros(16, dtype=torch.float32, device=dev)
         self._ws = None                    # caller-owned scratch of fw_ppo_update (grown here, never inside the call)
+        self.synced = False                # flat / mom_m / mom_v are what the module and the optimiser hold (set by commit(); whoever changes
+        self._step = 0                     # either behind this object's back clears it: PPO does wherever it clears _flat_current)
         self.last_paths = 0                # fw_ppo_update_status: which exchanges of the last call went through a shared L2
 
     def _workspace(self, n_mb: int, batch_size: int) -> torch.Tensor:
@@ -634,7 +636,10 @@ class FusedPpoUpdate:
                 st["step"] = step
 
     def run(self, cfg, obs, act, old_logp, adv, ret, perm_i32, n_mb: int, g_mean: float, g_std: float):
-        step0 = self.load_from_torch()
+        # (the images of the previous call are still current when nothing else touched the module / optimiser: ~70 small copies and a
+        # host sync less per update)
+        step0 = self._step if self.synced else self.load_from_torch()
+        self.synced = False                # until commit(): the kernel is about to move the images
         pg = self.opt.param_groups[0]
         H = _PpoHyper(lr=pg["lr"], clip_range=cfg.clip_range, ent_coef=cfg.ent_coef, vf_coef=cfg.vf_coef,
                       max_grad_norm=cfg.max_grad_norm, beta1=pg["betas"][0], beta2=pg["betas"][1], eps=pg["eps"],
@@ -666,6 +671,7 @@ class FusedPpoUpdate:
         """Second half of an update: the new parameters and moments go from the flat images to the module / optimiser.  Kept apart
         from run() so that a sharded job can first agree that the launch ran to its end on EVERY rank."""
         self.store_to_torch(self._pending_step)
+        self._step, self.synced = self._pending_step, True
 
 
 class PPO:
@@ -1083,6 +1089,7 @@ class PPO:
                     err = RuntimeError("fw_ppo_update gave up on another rank of the job; this rank's update is discarded with it")
             if err is not None:
                 self._flat_current = False     # the flat image holds a result that was not committed
+                self._fused.synced = False
                 raise err
             self._fused.commit()
             self._g_update = None              # the torch-path graph (if any) holds stale Adam state
@@ -1091,6 +1098,8 @@ class PPO:
                          "adv_mean": float(g_mean), "adv_std": float(g_std)}
             return
         self._flat_current = False             # the torch path below moves the module parameters
+        if self._fused is not None:
+            self._fused.synced = False
         use_graph = self._graphs and B % bs == 0
         if use_graph and self._g_update is None:
             self._idx = torch.zeros(bs, dtype=torch.long, device=self.device)
@@ -1133,6 +1142,19 @@ class PPO:
         la = (self._loss_acc / nb).tolist()                      # the only host sync of the update
         self.logs = {"policy_loss": la[0], "value_loss": la[1], "entropy_loss": la[2],
                      "adv_mean": float(g_mean), "adv_std": float(g_std)}
+
+    # does self._fused.flat hold the current policy parameters?  Clearing it also tells the fused update that its images (parameters
+    # AND Adam moments) may be behind the module / optimiser: it then reloads them at its next call instead of reusing them
+    @property
+    def _flat_current(self) -> bool:
+        return self.__dict__.get("_flat_current_", False)
+
+    @_flat_current.setter
+    def _flat_current(self, v: bool) -> None:
+        self.__dict__["_flat_current_"] = bool(v)
+        f = self.__dict__.get("_fused")
+        if not v and f is not None:
+            f.synced = False
 
     @property
     def world_size(self) -> int:
@@ -1179,5 +1201,7 @@ class PPO:
         self.policy.load_state_dict(sd["policy"]); self.optimizer.load_state_dict(sd["optimizer"])
         self.invalidate_graphs()           # the optimiser's state tensors were replaced, normaliser scalars may differ
         self._flat_current = False
+        if self._fused is not None:
+            self._fused.synced = False
         self.env.load_state_dict(sd["vecnormalize"])
         self.num_timesteps = 0 if reset_num_timesteps else int(sd["num_timesteps"])
