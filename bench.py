@@ -234,13 +234,14 @@ def collector_rates(task, n):
         n_mb = hp["n_epochs"] * (T * n // hp["batch_size"])
         # rooflines of the two learner kernels (tools/learner_accounting.py itemises the algorithmic bytes / flops).
         # Launch durations here are wall-clock shares of graph replays (a vec-step = one fw_collect_step launch + 1/T of the closing
-        # launch; an update = one fw_ppo_update launch + its host side); profiles/r04_learner_pmc.json holds the rocprofv3 durations
+        # launch; an update = one fw_ppo_update launch + its host side); profiles/rNN_learner_pmc.json (latest round) holds the rocprofv3 durations
         # and the counter traffic of the same kernels.
         from tools import learner_accounting as LA
         words = TASKS[task][2]
         traffic = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_learner_pmc.json")) as f:
+            import glob
+            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_learner_pmc.json")))[-1]) as f:      # the latest round's
                 kk = json.load(f)["runs"].get(task if n == 4096 else f"{task}_n{n}", {}).get("kernels", {})
             for name, e in kk.items():
                 if "traffic_bytes_per_launch" in e:
@@ -248,19 +249,92 @@ def collector_rates(task, n):
         except (OSError, KeyError, ValueError):
             pass
         acc_c, acc_u = LA.collect_step(n, ppo.env.obs_dim, words), LA.ppo_update(n_mb, hp["batch_size"], ppo.env.obs_dim)
-        roof = {"fw_collect_step": LA.roofline_hbm(acc_c["bytes"], dt * 1e6 / (reps * T), traffic.get("fw_collect")),
+        roof = {"fw_collect_step": LA.roofline_hbm(acc_c["bytes"], dt * 1e6 / (reps * T), traffic.get("fw_collect"), acc_c["l2_served_bytes"]),
                 "fw_ppo_update": LA.roofline_mfma(acc_u["mfma_flops"], upd * 1e6, acc_u["mfma_peak_tflops"], traffic.get("fw_ppo_update"))}
-        roof["fw_collect_step"]["note"] = ("one launch per vec-step; 12.7 of the 19.3 MB are the parameter image read once per act wave from the L2 "
+        roof["fw_collect_step"]["note"] = ("one launch per vec-step; `frac` is priced on the unique bytes (every buffer once); the parameter image and the "
+                                           "statistics fetched again by every act wave never leave the L2 and are listed as l2_served_bytes "
                                            "(items: tools/learner_accounting.py); the launch is latency-bound (act chain in front of the env step)")
         roof["fw_ppo_update"]["note"] = (f"{n_mb} sequential minibatches in one launch on {acc_u['workgroups']} workgroups; peak = fp32 MFMA of those CUs "
                                          f"({acc_u['mfma_peak_tflops']:.2f} TFLOP/s); {acc_u['flops_per_minibatch'] / 1e6:.2f} MFLOP per minibatch")
         return {"note": "informational: rollout collector + PPO update on the same GPU (north_star's other half); `value` above is the physics-only metric",
                 "envs": n, "one_launch_collect": bool(ppo._one_launch), "us_per_vec_step": dt * 1e6 / (reps * T),
                 "collected_env_steps_per_s": reps * T * n / dt, "update_s": upd, "update_minibatches": n_mb, "us_per_minibatch": upd * 1e6 / n_mb,
-                "update_l2_paths": ppo._fused.last_paths,
+                "update_l2_paths": ppo._fused.last_paths if ppo._fused is not None else None,
+                "collect_fallbacks": int(ppo.collect_fallbacks),
                 "end_to_end_env_steps_per_s": T * n / (roll + upd), "ppo": hp, "roofline": roof}
     except Exception as e:          # never let the informational part take the metric down
         return {"error": f"{type(e).__name__}: {e}"}
+
+
+def collector_rates_sharded(task, n, world, rank, local_rank, barrier):
+    """world > 1: the same informational object as `collector`, for the SHARDED job -- every rank owns n envs, n_steps holds the
+    reference's 65 536 samples per update (rollout.n_steps_for: 16 / world steps of 4096 envs), statistics all-reduce once per
+    rollout, ONE all-gather of the rollout shards per update, the update replicated on every rank.  What
+    the number is for: DESIGN section 7 predicts "collection scales with the ranks, the replicated update does not" -- end to end
+    stays near the one-GPU rate at the reference's 128-sample minibatches -- and this measures it on the job's own backend.
+    Every rank calls it (collectives inside); max over ranks of the wall times."""
+    import torch.distributed as td
+    from pyflyt_drone_amd import rollout as R
+    try:
+        cfg = TASKS[task][1](K, "float64")
+        T = R.n_steps_for(65536, n, world)
+        hp = dict(n_steps=T, batch_size=128, n_epochs=20)
+        ppo = R.PPO(R.VecNormalizeDevice(P.FixedwingVecEnv(cfg, n, device=local_rank, seed=42, global_env_offset=rank * n)), R.PPOConfig(**hp))
+        for _ in range(2):
+            ppo.collect_rollouts(); ppo.train()
+        def timed(fn, reps):
+            barrier(); t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            barrier()
+            t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64)
+            if td.get_backend() == "nccl":
+                t = t.to(ppo.device)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            return float(t.item())
+        roll = timed(ppo.collect_rollouts, 10)
+        def it():
+            ppo.collect_rollouts(); ppo.train()
+        ppo.train()                                    # (the rollouts above were collected without an update in between: start from a fresh pair)
+        e2e = timed(it, 3)
+        samples = T * n * world
+        return {"note": "informational: sharded rollout collector + replicated PPO update (one all-gather of the rollout shards per update); "
+                        "`value` above is the physics-only metric",
+                "envs_per_rank": n, "world": world, "n_steps": T, "samples_per_update": samples, "one_launch_collect": bool(ppo._one_launch),
+                "collect_fallbacks": int(ppo.collect_fallbacks), "us_per_vec_step": roll * 1e6 / T,
+                "collected_env_steps_per_s": samples / roll, "iteration_s": e2e, "update_s_estimate": e2e - roll,
+                "update_allgather_ms": float(ppo.allgather_ms), "update_allgather_bytes_per_rank": float(ppo.allgather_bytes),
+                "replica_checksum": float(ppo.replica_checksum()), "end_to_end_env_steps_per_s": samples / e2e, "ppo": hp}
+    except Exception as e:          # never let the informational part take the metric down
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+class Watchdog:
+    """The sharded `collector` object is the one part of the line that runs collectives nobody could rehearse on the real fabric
+    before the driver's scaling run.  If it has not come back after `seconds`, every rank leaves on its own clock -- rank 0
+    prints the line it already has (without the object) first -- instead of sitting in a collective until RCCL's own timeout
+    takes the measured physics line down with it."""
+
+    def __init__(self, seconds, rank, line_fn):
+        import threading
+        self._t = threading.Timer(seconds, self._fire)
+        self._t.daemon = True
+        self.rank, self.line_fn = rank, line_fn
+
+    def _fire(self):
+        if self.rank == 0:
+            try:
+                print(self.line_fn(), flush=True)
+            finally:
+                os._exit(0)
+        time.sleep(2.0)
+        os._exit(0)
+
+    def __enter__(self):
+        self._t.start(); return self
+
+    def __exit__(self, *a):
+        self._t.cancel()
 
 
 def self_launch(args):
@@ -351,15 +425,28 @@ def main():
             td.all_reduce(ones, op=td.ReduceOp.SUM)
         return int(round(float(ones.item())))
 
+    def gather_per_rank(x, device):
+        """[x of rank 0, x of rank 1, ...] on every rank (one small all-gather over the job's backend)."""
+        if not dist:
+            return [float(x)]
+        mine = torch.tensor([float(x)], dtype=torch.float64, device=device)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        td.all_gather(parts, mine)
+        return [float(q.item()) for q in parts]
+
     backend_name = ("RCCL (torch.distributed 'nccl')" if backend == "nccl" else backend) if dist else "none (single process)"
     if dry:
+        if os.environ.get("FW_BENCH_DRY_DIE_RANK") == str(rank):      # tests: a rank that dies must take the job down, not hang it
+            os._exit(9)
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        per_rank = [float(rank + 1)]
         if dist:
             td.barrier(); td.all_reduce(t, op=td.ReduceOp.MAX)
+            per_rank = gather_per_rank(float(rank + 1), "cpu")
         seen = count_ranks("cpu")
         if rank == 0:
             print(json.dumps({"dry_run": True, "metric": "launcher rehearsal only (FW_BENCH_DRY): nothing was measured", "value": None,
-                              "n_gpus": world, "ranks_seen": seen, "backend": backend_name,
+                              "n_gpus": world, "ranks_seen": seen, "backend": backend_name, "per_rank": per_rank,
                               "max_rank_plus_one": float(t.item()), "steps": args.steps, "warmup": args.warmup}), flush=True)
         if dist:
             td.barrier(); td.destroy_process_group()
@@ -413,6 +500,9 @@ def main():
         walls.append(wall); devs.append(ev0.elapsed_time(ev1))
     wall = float(np.median(walls))
     dev_ms = float(np.median(devs))
+    # every rank's OWN clock beside the max-reduced one: the launch time its HIP events saw (median region), so that a slow GPU or a
+    # rank that waits in the barriers shows in the scaling record instead of disappearing in the max
+    per_rank_ms = gather_per_rank(dev_ms / args.steps, env.device if backend == "nccl" else "cpu")
 
     # Update-time exchange of a sharded training job: ONE all-gather of the rank's rollout shard
     # (obs 28 + action 4 + log-prob + advantage + return = 35 float32 per sample, 16 steps x 4096 envs = 65 536 samples per
@@ -495,6 +585,15 @@ def main():
                 ach = lane_instr * n / launch_s / 1e12
                 valu = {"bound": "valu64", "achieved": ach, "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s", "frac": ach / VALU_PEAK_TLANE,
                         "lane_instructions_per_env_step": lane_instr, "source": f"profiles/{rnd}_valu_count.json"}
+    out = None
+    sharded = None
+
+    def line():
+        o = dict(out)
+        if dist and not args.no_collector:
+            o["collector"] = sharded if sharded is not None else {"error": "the sharded collector did not come back within its time limit; the line was printed without it"}
+        return json.dumps(o)
+
     if rank == 0:
         out = {
             "metric": "env-steps/sec at N parallel envs (FixedwingWaypoints)" if args.task == "waypoints"
@@ -530,11 +629,19 @@ def main():
         }
         if allgather is not None:
             out["update_allgather"] = allgather
+        if dist:
+            out["per_rank_kernel_ms_per_step"] = per_rank_ms
+            out["per_rank_kernel_ms_per_step_min"], out["per_rank_kernel_ms_per_step_max"] = min(per_rank_ms), max(per_rank_ms)
         if not args.no_cpu_baseline and world == 1:          # timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, n)
         if world == 1 and not args.no_collector and not args.no_cpu_baseline and n <= 8192:
             out["collector"] = collector_rates(args.task, n)
-        print(json.dumps(out), flush=True)
+    if dist and not args.no_collector and n <= 8192:
+        env.close()
+        with Watchdog(float(os.environ.get("FW_BENCH_COLLECTOR_TIMEOUT", "150")), rank, line):
+            sharded = collector_rates_sharded(args.task, n, world, rank, local_rank, barrier)
+    if rank == 0:
+        print(line(), flush=True)
     if dist:
         td.barrier()
         td.destroy_process_group()

@@ -408,22 +408,29 @@ int32_t fw_normalize_obs(const void* obs, int32_t in_is_f64, int32_t N, int32_t 
  * (obs_dim rounded up to 4) + 8 floats each, so that the sequential kernel reads each 16- / 32- / 64-sample pass as one contiguous block
  * (144 B per sample and epoch for 28 observations: 189 MB for 20 epochs x 65 536 samples).  Two learners never share it.
  * The learner-side entry points run on the device their buffers live on, whatever the thread's current device.
- * The call runs on 2, 4 or 8 workgroups: (policy, value) x 1, 2 or 4 workgroups per network that share every minibatch (128
- * samples: 4 x 32, 64: 4 x 16) and exchange gradients (and, with four, updated weights) once per minibatch; all of them end the call
+ * The call runs on 2, 4, 8 or 16 workgroups: (policy, value) x 1, 2, 4 or 8 workgroups per network that share every minibatch (128
+ * samples: 8 x 16, 64: 4 x 16) and exchange gradients (and, from four on, updated weights) once per minibatch; all of them end the call
  * with the same bits.
- * Failure inside the launch: the workgroups of a call wait for each other once or twice per minibatch, every wait
- * bounded.  A wait that runs out raises FW_PPO_ST_* in the workspace's status word and every workgroup leaves WITHOUT writing
- * `params`, `mom_m` or `mom_v` back (the moments live in registers during the call).  fw_ppo_update_status reads
+ * Failure inside the launch: the workgroups of a call wait for each other two or three times per minibatch, every wait
+ * bounded.  A wait that runs out raises FW_PPO_ST_* in the workspace's status word and the workgroups leave.  `params`, `mom_m`
+ * and `mom_v` are written back only behind a verdict every workgroup waits for at the end of the call (the last one to get through
+ * its final minibatch reads the status word and says "write" or "do not"): a workgroup that gave up never arrives, so in that case
+ * NOBODY writes and the three buffers are exactly as they were before the call.  The one exception is a verdict wait that itself
+ * runs out (FW_PPO_ST_COMMIT): some workgroups may then have written their share.  The contract is therefore: status 0 = the
+ * buffers hold the result; any other status = treat `params`, `mom_m`, `mom_v` as UNDEFINED and restore them from the caller's own
+ * copies (rollout.FusedPpoUpdate reloads them from the module / optimiser, which it only overwrites after status 0).
+ * fw_ppo_update_status reads
  * the word after the call (it synchronises `hip_stream`): 0 = the call ran to its end.  `paths` (may be NULL) receives which
  * exchanges went through an XCD's shared L2 rather than device-scope accesses: bit 2 b = workgroup b's gradient swap, bit
  * 2 b + 1 = its norm exchange, b = 2 * part + net (part = the workgroup's index inside its network).  Environment (read per call):
- * FWSIM_PPO_SPLIT=CHxN forces the cut (CH = 16 / 32 / 64 samples per pass, N = 1 / 2 / 4 workgroups per network); FWSIM_PPO_RS=0 makes four
- * workgroups swap whole gradients all-to-all instead of reduce-scatter + weight all-gather; FWSIM_PPO_NO_L2_SWAP=1 forces the
+ * FWSIM_PPO_SPLIT=CHxN forces the cut (CH = 16 / 32 / 64 samples per pass, N = 1 / 2 / 4 / 8 workgroups per network); FWSIM_PPO_RS=0 makes
+ * (up to four) workgroups swap whole gradients all-to-all instead of reduce-scatter + weight all-gather; FWSIM_PPO_NO_L2_SWAP=1 forces the
  * device-scope form of every exchange (same arithmetic: results must be bit-identical -- tests/test_protocols_gpu.py);
  * FWSIM_SPIN_LOG2=k shrinks every wait's budget to 2^k polls (tests provoke the timeout with it). */
 #define FW_PPO_ST_IDS 1u    /* the workgroups never found each other at the start of the call */
 #define FW_PPO_ST_SWAP 2u   /* gradient swap between the workgroups of a network */
 #define FW_PPO_ST_NORM 4u   /* gradient-norm exchange between the policy and the value workgroup */
+#define FW_PPO_ST_COMMIT 8u /* the closing verdict did not arrive: some workgroups may have written their results, others not */
 typedef struct fw_ppo_hyper {
   float lr, clip_range, ent_coef, vf_coef, max_grad_norm, beta1, beta2, eps;
   float adv_mean, adv_std;      /* used when norm_adv == 2 */

@@ -75,6 +75,8 @@ def save(path: str, ppo, include_env_state: bool = True) -> str:
 def snapshot(ppo, include_env_state: bool = True) -> dict:
     """What :func:`save` writes, as host tensors: taken now, written later (:func:`write`) -- the evaluation callback keeps
     the weights it is evaluating until it knows whether they are the best so far."""
+    if hasattr(ppo, "check_collect_status"):
+        ppo.check_collect_status()             # never snapshot behind a void rollout (as PPO.state_dict(); the best-model path comes through here)
     venv = ppo.env.venv
     sd = {
         "format_version": FORMAT_VERSION,

@@ -1604,14 +1604,13 @@ int ensure_learner_lds(int dev, int which, size_t bytes) {
   static size_t have[64][2] = {};
   if (dev < 0 || dev >= 64) { g_err = "device index out of range"; return FW_EINVAL; }
   if (bytes <= have[dev][which]) return FW_OK;
-  const void* fn = which == 0 ? (const void*)fw_ppo_update_kernel<64, false> : (const void*)fw_policy_act_kernel;
-  HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   if (which == 0) {
-    HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_ppo_update_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    const void* fns[] = {(const void*)fw_ppo_update_kernel<64, 0>, (const void*)fw_ppo_update_kernel<32, 0>, (const void*)fw_ppo_update_kernel<16, 0>,
+                         (const void*)fw_ppo_update_kernel<64, 4>, (const void*)fw_ppo_update_kernel<32, 4>, (const void*)fw_ppo_update_kernel<16, 4>,
+                         (const void*)fw_ppo_update_kernel<64, 8>, (const void*)fw_ppo_update_kernel<32, 8>, (const void*)fw_ppo_update_kernel<16, 8>};
+    for (const void* fn : fns) HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  } else {
+    HIP_TRY((fw_env*)nullptr, hipFuncSetAttribute((const void*)fw_policy_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   }
   have[dev][which] = bytes;
   return FW_OK;
@@ -1924,7 +1923,7 @@ static long long spin_budget(long long dflt) {
   return dflt;
 }
 
-// workspace layout of fw_ppo_update: [0,640) exchange words (kPpoWordPaths: which exchanges shared an L2, kPpoWordStatus: include/fwsim.h) |
+// workspace layout of fw_ppo_update: [0, kPpoWords x 8) exchange words (kPpoWordPaths: which exchanges shared an L2, kPpoWordStatus: include/fwsim.h) |
 // gradient hand-off buffer | the packed rows of every minibatch, in walking order (fw_ppo_pack_kernel)
 static constexpr size_t kPpoWsXch = kPpoWords * sizeof(unsigned long long);
 static constexpr size_t kPpoWsGx = sizeof(float) * (4 * kPMaxSplit * (size_t)kPGxSlots + kPWxFloats);      // gradient partials, then the weight quarters
@@ -1973,23 +1972,24 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   P.obs = obs; P.act = act; P.old_logp = old_logp; P.adv = adv; P.ret = ret; P.perm = perm; P.B = batch_size; P.D = obs_dim;
   P.norm_adv = A.H.norm_adv; P.adv_mean = A.H.adv_mean; P.adv_std = A.H.adv_std; P.out = packed;
   hipLaunchKernelGGL(fw_ppo_pack_kernel, dim3(n_minibatches), dim3(256), 0, st, P);
-  PpoSplit cut = ppo_split(batch_size);             // samples per pass and blocks per network (128 samples: 32 x 4, 64: 16 x 4)
-  if (const char* e = getenv("FWSIM_PPO_SPLIT")) {  // dev knob "CHxN" (64x2 = round 3's cut): A / B measurements, tests of every form
+  // four / eight blocks per network: gradient tiles by reduce-scatter, updated weights by all-gather (FWSIM_PPO_RS=0: all-to-all, as for two
+  // blocks -- written for up to four, so the cut is then chosen among round 4's)
+  bool rs_env = true;
+  if (const char* e = getenv("FWSIM_PPO_RS")) if (atoi(e) == 0) rs_env = false;
+  PpoSplit cut = ppo_split(batch_size, rs_env ? kPMaxSplit : 4);      // samples per pass and blocks per network (128 samples: 16 x 8, 64: 16 x 4)
+  if (const char* e = getenv("FWSIM_PPO_SPLIT")) {  // dev knob "CHxN" (64x2 = round 3's cut, 32x4 = round 4's for 128 samples): A / B measurements, tests of every form
     int ch = 0, ns = 0;
-    if (sscanf(e, "%dx%d", &ch, &ns) == 2 && (ch == 16 || ch == 32 || ch == 64) && (ns == 1 || ns == 2 || ns == 4) && batch_size % ch == 0 && batch_size / ch >= ns) {
+    if (sscanf(e, "%dx%d", &ch, &ns) == 2 && (ch == 16 || ch == 32 || ch == 64) && (ns == 1 || ns == 2 || ns == 4 || (ns == 8 && rs_env)) && batch_size % ch == 0 && batch_size / ch >= ns) {
       cut.ch = ch; cut.nsplit = ns;
-    } else { g_err = "fw_ppo_update: FWSIM_PPO_SPLIT must be CHxN with CH in {16, 32, 64}, N in {1, 2, 4}, N chunks of CH samples in a minibatch"; return FW_EINVAL; }
+    } else { g_err = "fw_ppo_update: FWSIM_PPO_SPLIT must be CHxN with CH in {16, 32, 64}, N in {1, 2, 4, 8} (8: not with FWSIM_PPO_RS=0), N chunks of CH samples in a minibatch"; return FW_EINVAL; }
   }
-  // four blocks per network: gradient tiles by reduce-scatter, updated weights by all-gather (FWSIM_PPO_RS=0: all-to-all, as for two blocks)
-  bool rs = cut.nsplit == kPMaxSplit;
-  if (const char* e = getenv("FWSIM_PPO_RS")) if (atoi(e) == 0) rs = false;
+  const int ns = cut.nsplit >= 4 && rs_env ? cut.nsplit : 0;      // the kernel's NS: 0 = all-to-all swap of whole partials
   const dim3 grid(16 * cut.nsplit);                 // (every 8th block works -- see the kernel)
-  if (cut.ch == 64 && rs) hipLaunchKernelGGL((fw_ppo_update_kernel<64, true>), grid, dim3(kPThreads), lds, st, A);
-  else if (cut.ch == 64) hipLaunchKernelGGL((fw_ppo_update_kernel<64, false>), grid, dim3(kPThreads), lds, st, A);
-  else if (cut.ch == 32 && rs) hipLaunchKernelGGL((fw_ppo_update_kernel<32, true>), grid, dim3(kPThreads), lds, st, A);
-  else if (cut.ch == 32) hipLaunchKernelGGL((fw_ppo_update_kernel<32, false>), grid, dim3(kPThreads), lds, st, A);
-  else if (rs) hipLaunchKernelGGL((fw_ppo_update_kernel<16, true>), grid, dim3(kPThreads), lds, st, A);
-  else hipLaunchKernelGGL((fw_ppo_update_kernel<16, false>), grid, dim3(kPThreads), lds, st, A);
+#define FW_PPO_LAUNCH(CH_, NS_) hipLaunchKernelGGL((fw_ppo_update_kernel<CH_, NS_>), grid, dim3(kPThreads), lds, st, A)
+  if (cut.ch == 64) { if (ns == 8) FW_PPO_LAUNCH(64, 8); else if (ns == 4) FW_PPO_LAUNCH(64, 4); else FW_PPO_LAUNCH(64, 0); }
+  else if (cut.ch == 32) { if (ns == 8) FW_PPO_LAUNCH(32, 8); else if (ns == 4) FW_PPO_LAUNCH(32, 4); else FW_PPO_LAUNCH(32, 0); }
+  else { if (ns == 8) FW_PPO_LAUNCH(16, 8); else if (ns == 4) FW_PPO_LAUNCH(16, 4); else FW_PPO_LAUNCH(16, 0); }
+#undef FW_PPO_LAUNCH
   HIP_TRY((fw_env*)nullptr, hipGetLastError());
   return FW_OK;
 }
@@ -2001,7 +2001,7 @@ int32_t fw_ppo_update_status(const void* workspace, int64_t workspace_bytes, uin
   HIP_TRY((fw_env*)nullptr, hipMemcpyAsync(w, (const unsigned long long*)workspace + kPpoWordPaths, sizeof w, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
   HIP_TRY((fw_env*)nullptr, hipStreamSynchronize((hipStream_t)hip_stream));
   static_assert(kPpoWordStatus == kPpoWordPaths + 1 && kPpoWordStatus < kPpoWords, "exchange-word layout");
-  static_assert(FW_PPO_ST_IDS == PPO_ST_IDS && FW_PPO_ST_SWAP == PPO_ST_SWAP && FW_PPO_ST_NORM == PPO_ST_NORM, "status bits of include/fwsim.h");
+  static_assert(FW_PPO_ST_IDS == PPO_ST_IDS && FW_PPO_ST_SWAP == PPO_ST_SWAP && FW_PPO_ST_NORM == PPO_ST_NORM && FW_PPO_ST_COMMIT == PPO_ST_COMMIT, "status bits of include/fwsim.h");
   if (paths_out) *paths_out = (uint32_t)w[0];
   *status_out = (uint32_t)w[1];
   return FW_OK;

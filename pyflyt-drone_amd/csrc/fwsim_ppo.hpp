@@ -35,7 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPH = 64;            // hidden width
 constexpr int kPChunk = 64;        // samples per pass through the networks (the 32-sample form of the kernel: template parameter CH)
-constexpr int kPMaxSplit = 4;      // blocks per network a minibatch is split over, at most
+constexpr int kPMaxSplit = 8;      // blocks per network a minibatch is split over, at most
 constexpr int kPLdh = kPH + 1;     // row stride of the hidden activations / of W2 in LDS (odd: conflict-free column reads)
 constexpr int kPLdx = 65;          // row stride of the gathered observations in LDS: a CONSTANT (the widest input + 1), so that every operand
                                    // address of the X-sided products is base + immediate.  (Round 3 had Dp + 1: with a run-time stride hipcc
@@ -189,8 +189,9 @@ __host__ __device__ inline int ppo_tile_slot(int net, int kind, int wave, int la
 // A block's gradient partial in the exchange buffer: [kind W2 | W1][wave][quarter q of the lane's 16 elements][lane][4] for the tiles -- one wave-level
 // 16-byte access is 1 KB in a row (the partners read it past their L1: every access is a request to the L2, and in moment-slot order, 64 bytes
 // per lane, each request would touch 64 lines for 16 bytes apiece) -- then the five per-thread elements [5][256].
+// Per-thread elements behind the tiles: [t < 64][gb1, gb2, gbo, gls] as one float4 per thread of the first wave, then gwo[256].
 constexpr int kPGxTile = 2 * 4 * 4 * 64 * 4;
-constexpr int kPGxSlots = kPGxTile + 5 * kPThreads;
+constexpr int kPGxSlots = kPGxTile + 2 * kPThreads;
 __host__ __device__ inline int ppo_gx_tile(int kind, int wave, int lane) { return (kind * 4 + wave) * 4 * 256 + lane * 4; }      // + q * 256
 
 // flat parameter index of every moment slot (-1 = padding); host side of the layout above
@@ -327,14 +328,16 @@ enum { PPO_FLAG_NO_L2_SWAP = 1,      // FWSIM_PPO_NO_L2_SWAP=1: every exchange t
 // xch[kPpoWordPaths]: which exchanges of this call went through a shared L2 -- bit 2 b: block b's gradient swap, bit 2 b + 1: its
 // norm exchange (b = 2 part + net).  xch[kPpoWordStatus]: 0, or PPO_ST_* of the waits that ran out: the blocks then leave
 // without writing the parameters back (the moments in memory are part-way through the call: the caller must not go on with them).
-constexpr int kPpoWordFlags = 4 * kPMaxSplit, kPpoWordIds = 8 * kPMaxSplit, kPpoWordPaths = 46, kPpoWordStatus = 47;
-constexpr int kPpoWordLoss = 48;     // [net][part]: the blocks' loss sums (float bits), added up in a fixed order by the block that finishes last
+constexpr int kPpoWordFlags = 4 * kPMaxSplit, kPpoWordIds = 8 * kPMaxSplit, kPpoWordPaths = 10 * kPMaxSplit, kPpoWordStatus = kPpoWordPaths + 1;
+constexpr int kPpoWordLoss = kPpoWordStatus + 1;     // [net][part]: the blocks' loss sums (float bits), added up in a fixed order by the block that finishes last
 constexpr int kPpoWordDone = kPpoWordLoss + 2 * kPMaxSplit;      // how many blocks have finished
-constexpr int kPpoWordFlags2 = 64, kPpoWords = kPpoWordFlags2 + 4 * kPMaxSplit;      // flags of the weight all-gather [parity][net][part] (reduce-scatter form)
-static_assert(kPpoWordIds + 2 * kPMaxSplit <= kPpoWordPaths && kPpoWordDone < kPpoWordFlags2, "exchange-word layout");
-// The updated weights a block owns in the reduce-scatter form, for the others to fetch: [net][part][kind W2 | W1][wave][lane][4]
-constexpr int kPWxFloats = 2 * kPMaxSplit * 2 * 1024;
-enum { PPO_ST_IDS = 1, PPO_ST_SWAP = 2, PPO_ST_NORM = 4 };
+constexpr int kPpoWordArrive = kPpoWordDone + 1;     // how many blocks got through their last minibatch with every wait answered
+constexpr int kPpoWordVerdict = kPpoWordArrive + 1;  // written once, by the last arriver: 1 = every block writes its results back, 2 = nobody does
+constexpr int kPpoWordFlags2 = 13 * kPMaxSplit, kPpoWords = kPpoWordFlags2 + 4 * kPMaxSplit;      // flags of the weight all-gather [parity][net][part] (reduce-scatter form)
+static_assert(kPpoWordIds + 2 * kPMaxSplit <= kPpoWordPaths && kPpoWordVerdict < kPpoWordFlags2, "exchange-word layout");
+// The updated weights a block owns in the reduce-scatter form, for the others to fetch: [net][part][kind W2 | W1][wave][lane][16 / NS]
+constexpr int kPWxFloats = 2 * 2 * 4 * 64 * 16;
+enum { PPO_ST_IDS = 1, PPO_ST_SWAP = 2, PPO_ST_NORM = 4, PPO_ST_COMMIT = 8 };
 
 // Bounded wait of one thread for a word another block publishes.  `done(word)` ends it; every 256 polls it also looks at the
 // status word, so that one block giving up releases the others at once instead of after their own budgets.  Returns false --
@@ -353,13 +356,42 @@ __device__ __forceinline__ bool ppo_wait(const PpoArgs& A, LOAD&& load, DONE&& d
 
 // CH = samples per pass through the network (64: 2 x 2 tiles of 32 x 32 per product; 32 / 16: 2 / 1 x 4 tiles of 16 x 16, see ppo_mfma16_rows);
 // part / nsplit: this block's place among the blocks of its network (chunk c of a minibatch is run by block c % nsplit).
-// RS (four blocks per network only): the gradient swap is a reduce-scatter -- block q fetches, of every block's partial, only the
-// tiles of wave q (a quarter), sums them, takes its share of the clipping norm from them and applies Adam to that quarter alone --
-// followed by an all-gather of the updated WEIGHTS.  A block then pulls 47 + 24 KB past its L1 per minibatch instead of 111 KB
-// (that path runs at ~20 B / clk: the swap was 9.4 k of the minibatch's 28.1 k cycles) and does a quarter of the tile Adam, for one
-// more latency round.  Thread (wave w, lane l) of block q owns elements 4 w .. 4 w + 3 of lane l of wave q's W2 and W1 tiles.
-template <int NET, int CH, bool RS>
+// NS = 0: the (1, 2 or 4) blocks of a network swap whole partials all to all.  NS = 4 / 8 (then nsplit == NS): the gradient swap is a
+// REDUCE-SCATTER -- block q fetches, of every block's partial, only 1 / NS of the tile elements (those of wave q * 4 / NS's tiles: a
+// quarter, or half of one), sums them, takes its share of the clipping norm from them and applies Adam to that share alone --
+// followed by an ALL-GATHER of the updated WEIGHTS.  A block then pulls ~one partial + the weights past its L1 per minibatch, whatever
+// NS is, instead of NS - 1 partials (that path runs at ~20 B / clk: the swap was 9.4 k of the minibatch's 28.1 k cycles with four
+// blocks) and does 1 / NS of the tile Adam, for one more latency round.  Thread (wave w, lane l) of block q owns elements 4 w + sub ..
+// 4 w + sub + 16 / NS - 1 of lane l of wave (q * 4 / NS)'s W2 and W1 tiles (sub = 0, or 0 / 2 by the parity of q with eight blocks).
+// Eight blocks (round 5): a 128-sample minibatch is 8 x 16 samples -- the chunk pass, which scales with the samples of a block, falls
+// from 11.4 k to 7.3 k cycles while the exchange volume per block stays what it was.
+// EPT floats from a raw buffer, past the L1 (sc1)
+template <int E> __device__ __forceinline__ void ppo_ld_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off, float (&out)[E]) {
+  static_assert(E == 4 || E == 2, "16 or 8 bytes");
+  typedef unsigned int ppo_u4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int ppo_u2 __attribute__((ext_vector_type(2)));
+  if constexpr (E == 4) {
+    const ppo_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = __uint_as_float(a[e]);
+  } else {
+    const ppo_u2 a = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 16);
+    out[0] = __uint_as_float(a[0]); out[1] = __uint_as_float(a[1]);
+  }
+}
+// sum of v[0 .. N) as a balanced tree over the index order: the same bits in every block, whoever's own partial sits where
+template <int N> __device__ __forceinline__ float ppo_tree_sum(const float (&v)[N]) {
+  static_assert(N == 2 || N == 4 || N == 8, "power of two");
+  if constexpr (N == 2) return v[0] + v[1];
+  else if constexpr (N == 4) return (v[0] + v[1]) + (v[2] + v[3]);
+  else return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+template <int NET, int CH, int NS>
 __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const int part, const int nsplit) {
+  static_assert(NS == 0 || NS == 4 || NS == 8, "blocks per network in the reduce-scatter form");
+  constexpr bool RS = NS != 0;
+  constexpr int NSd = RS ? NS : 4;                     // (array extents; the divisor where NS may be 0)
+  constexpr int EPT = 16 / NSd;                        // tile elements per thread and kind a block owns (RS)
   static_assert(CH == 64 || CH == 32 || CH == 16, "chunk size");
   constexpr int RT = CH == 64 ? 1 : CH / 16;     // row tiles of 16 in the 16 x 16 forms
   constexpr int n = NET, KO = NET == 0 ? 4 : 1;
@@ -391,7 +423,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   float* red = p; p += 8;
   float* sred = p; p += 32;                       // per wave: the four components of dbo and of dlog_std over its samples
   float* sink = p; p += kPThreads;                // one word per thread: where the Adam of a W1 tile "updates" the rows the network does not have
-  float* red8 = p; p += 8;                        // (RS) the eight blocks' shares of the squared gradient norm
+  float* red8 = p; p += 2 * kPMaxSplit;           // (RS) the blocks' shares of the squared gradient norm, [net][part]
 
   // flat offsets of this net
   const int nP0 = ppo_net_params(Dp, 4);
@@ -510,14 +542,18 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   // took 2.2 k cycles) -- because 472 registers left no room; the leaner gather and dW1 of round 4 did.  Both chunk halves apply
   // the same update to the same initial values; part 0 writes the result back at the end.
   float4 pm[2][4], pv[2][4];
-  float4 rm[2], rv[2];                              // RS: the moments of the 4 + 4 elements this thread owns (wave `part`'s tiles)
-  const bool ownW1 = RS && part < tilesW1;
-  const int rs_row = (part >> 1) * 32 + wave * 8 + hh * 4, rs_col = (part & 1) * 32 + r;      // RS: element e of mine is W[rs_row + e][rs_col]
+  float rm[2][EPT], rv[2][EPT];                     // RS: the moments of the EPT + EPT elements this thread owns (W2, W1)
+  const int tq = RS ? part * 4 / NSd : 0;           // RS: the wave whose tiles this block reduces ...
+  const int sub = RS ? (part % (NSd / 4)) * EPT : 0;      // ... and where its elements start inside the quarter (4 w ..) a thread handles
+  const bool ownW1 = RS && tq < tilesW1;
+  const int rs_row = (tq >> 1) * 32 + wave * 8 + hh * 4 + sub, rs_col = (tq & 1) * 32 + r;      // RS: element e of mine is W[rs_row + e][rs_col]
+  const int rs_s0 = ppo_tile_slot(n, 0, tq, lane) + 4 * wave + sub, rs_s1 = ppo_tile_slot(n, 1, tq, lane) + 4 * wave + sub;      // ... and moment slot rs_s + e
   if constexpr (RS) {
-    const int s0 = ppo_tile_slot(n, 0, part, lane) + 4 * wave, s1 = ppo_tile_slot(n, 1, part, lane) + 4 * wave;
-    rm[0] = *reinterpret_cast<const float4*>(mom_m + s0); rv[0] = *reinterpret_cast<const float4*>(mom_v + s0);
-    if (ownW1) { rm[1] = *reinterpret_cast<const float4*>(mom_m + s1); rv[1] = *reinterpret_cast<const float4*>(mom_v + s1); }
-    else { rm[1] = make_float4(0.f, 0.f, 0.f, 0.f); rv[1] = rm[1]; }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      rm[0][e] = mom_m[rs_s0 + e]; rv[0][e] = mom_v[rs_s0 + e];
+      rm[1][e] = ownW1 ? mom_m[rs_s1 + e] : 0.f; rv[1][e] = ownW1 ? mom_v[rs_s1 + e] : 0.f;
+    }
   } else {
     const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane);
 #pragma unroll
@@ -881,8 +917,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     const long long pfa = PPO_T(); pf_red += pfa - pf3;
 #endif
     // ---- swap gradient partials with the other blocks of this network (all to all, or tiles by reduce-scatter), keep the sum ----
-    typedef float ppo_f4 __attribute__((ext_vector_type(4)));
-    ppo_f4 g2q = {0.f, 0.f, 0.f, 0.f}, g1q = g2q;       // RS: the summed gradient of the 4 + 4 tile elements this thread owns
+    float g2q[EPT], g1q[EPT];                           // RS: the summed gradient of the EPT + EPT tile elements this thread owns
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) { g2q[e] = 0.f; g1q[e] = 0.f; }
     if (nsplit > 1) {
       float* gxb = A.gx + (size_t)((mb & 1) * 2 + NET) * kPMaxSplit * kPGxSlots;
       float* mine = gxb + (size_t)part * kPGxSlots;
@@ -894,15 +931,15 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       // flag / fence -- 14.5 k cycles: the memory system serves small device-scope accesses slowly.  Also measured, no gain: the tile
       // partials stored before the bias reductions (the wait moves, 8.7 k -> 7.9 k for the pair of sections), a register copy of the
       // lane's own weights so that Adam needs no LDS read (tile Adam 5.5 k -> 5.1 k, the chunk pass +1 k: 32 more live registers).)
-      const int sq = kPGxTile + t;
+      const int sq4 = kPGxTile + 4 * t, sqo = kPGxTile + kPThreads + t;      // per-thread elements: {gb1, gb2, gbo, gls} of thread t < 64; gwo of thread t
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         *reinterpret_cast<float4*>(mine + g0 + q * 256) = make_float4(gW2[4 * q], gW2[4 * q + 1], gW2[4 * q + 2], gW2[4 * q + 3]);
         if (hasW1) *reinterpret_cast<float4*>(mine + g1 + q * 256) = make_float4(gW1[4 * q], gW1[4 * q + 1], gW1[4 * q + 2], gW1[4 * q + 3]);
       }
-      // (per-thread elements: Wo's by every thread, the biases / log_std by threads of the first wave only)
-      mine[sq + 4 * kPThreads] = my_gwo;
-      if (wave == 0) { mine[sq] = gb1; mine[sq + kPThreads] = gb2; mine[sq + 2 * kPThreads] = my_gbo; mine[sq + 3 * kPThreads] = my_gls; }
+      // (per-thread elements: Wo's by every thread, the biases / log_std -- one float4 -- by threads of the first wave only)
+      mine[sqo] = my_gwo;
+      if (wave == 0) *reinterpret_cast<float4*>(mine + sq4) = make_float4(gb1, gb2, my_gbo, my_gls);
       // (the builtin, not inline assembly: the compiler's own wait-count bookkeeping must see that the stores are done, or it waits for
       // them one by one between the loads further down -- and with them, in order, for those loads)
       if (same_xcd) __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): my stores are in the L2 the partners read from
@@ -945,76 +982,89 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       // the builtin takes the cache policy, so the compiler schedules and waits for them itself.  (Round 3 / 4 had them as inline
       // assembly with a hand-placed wait; the compiler, not knowing that they were loads, put waits for older operations between
       // them, which -- the counter retires in order -- serialised the partners: 4.3 k cycles for 39 loads.)
-      // Partner j of 1 (2 blocks) or 3 (4 blocks) = the other blocks in ascending order.
       typedef unsigned int ppo_u4 __attribute__((ext_vector_type(4)));
-      ppo_f4 ta[3][4], tb[3][4];
-      ppo_f4 qa[4], qb[4];                         // RS: wave `part`'s W2 / W1 tile elements 4 w .. 4 w + 3 of every block's partial, in block order
-      float tsc[3][5];
+      typedef float ppo_f4 __attribute__((ext_vector_type(4)));
+      ppo_f4 ta[3][4], tb[3][4];                   // all-to-all form: partner j of 1 (2 blocks) or 3 (4 blocks) = the other blocks in ascending order
+      float qa[NSd][EPT], qb[NSd][EPT];            // RS: my elements of wave `tq`'s W2 / W1 tiles in every block's partial, in block order
+      float vs[5][NSd];                            // per-thread elements {gb1, gb2, gbo, gls, gwo} of every block, in block order (own ones in slot `part`)
       const int np = nsplit - 1;
       if (!same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gxb, 0, kPMaxSplit * kPGxSlots * (int)sizeof(float), 0x00020000);
       constexpr int kSc1 = 16;                     // cache-policy bit of the raw buffer loads
       if constexpr (RS) {
-        const int o0 = (ppo_gx_tile(0, part, lane) + wave * 256) * 4, o1 = (ppo_gx_tile(1, part, lane) + wave * 256) * 4;
+        const int o0 = (ppo_gx_tile(0, tq, lane) + wave * 256 + sub) * 4, o1 = (ppo_gx_tile(1, tq, lane) + wave * 256 + sub) * 4;
 #pragma unroll
-        for (int b_ = 0; b_ < 4; ++b_) {           // (own partial included: it comes back from the L2 my stores went to)
-          const ppo_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, b_ * kPGxSlots * (int)sizeof(float) + o0, 0, kSc1);
-          qa[b_] = ppo_f4{__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[2]), __uint_as_float(a[3])};
-          if (ownW1) {
-            const ppo_u4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, b_ * kPGxSlots * (int)sizeof(float) + o1, 0, kSc1);
-            qb[b_] = ppo_f4{__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3])};
-          } else qb[b_] = ppo_f4{0.f, 0.f, 0.f, 0.f};
+        for (int b_ = 0; b_ < NS; ++b_) {          // (own partial included: it comes back from the L2 my stores went to)
+          ppo_ld_sc1<EPT>(rs, b_ * kPGxSlots * (int)sizeof(float) + o0, qa[b_]);
+          if (ownW1) ppo_ld_sc1<EPT>(rs, b_ * kPGxSlots * (int)sizeof(float) + o1, qb[b_]);
+          else {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) qb[b_][e] = 0.f;
+          }
         }
-      }
+      } else {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        if (j < np) {
+        for (int j = 0; j < 3; ++j) {
           const int base = (j < part ? j : j + 1) * kPGxSlots * (int)sizeof(float);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            if (RS) break;                         // (the tiles went the other way)
-            const ppo_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (g0 + q * 256) * 4, 0, kSc1);
-            ta[j][q] = ppo_f4{__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[2]), __uint_as_float(a[3])};
-            if (hasW1) {
-              const ppo_u4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (g1 + q * 256) * 4, 0, kSc1);
-              tb[j][q] = ppo_f4{__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3])};
-            } else tb[j][q] = ppo_f4{0.f, 0.f, 0.f, 0.f};
+            if (j < np) {
+              const ppo_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (g0 + q * 256) * 4, 0, kSc1);
+              ta[j][q] = ppo_f4{__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[2]), __uint_as_float(a[3])};
+              if (hasW1) {
+                const ppo_u4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (g1 + q * 256) * 4, 0, kSc1);
+                tb[j][q] = ppo_f4{__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3])};
+              } else tb[j][q] = ppo_f4{0.f, 0.f, 0.f, 0.f};
+            } else { ta[j][q] = ppo_f4{0.f, 0.f, 0.f, 0.f}; tb[j][q] = ta[j][q]; }
           }
-#pragma unroll
-          for (int q = 0; q < 5; ++q) {
-            if (q == 4 || wave == 0) tsc[j][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, base + (sq + q * kPThreads) * 4, 0, kSc1));
-            else tsc[j][q] = 0.f;
-          }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { ta[j][q] = ppo_f4{0.f, 0.f, 0.f, 0.f}; tb[j][q] = ta[j][q]; }
-#pragma unroll
-          for (int q = 0; q < 5; ++q) tsc[j][q] = 0.f;
         }
       }
+      // per-thread elements, all to all in both forms: the first wave one float4 per partner, every wave Wo's word
+#pragma unroll
+      for (int b_ = 0; b_ < NSd; ++b_) {
+        const int base = b_ * kPGxSlots * (int)sizeof(float);
+        const bool other = b_ < nsplit && b_ != part;
+        if (other && wave == 0) {
+          const ppo_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, base + sq4 * 4, 0, kSc1);
+          vs[0][b_] = __uint_as_float(a[0]); vs[1][b_] = __uint_as_float(a[1]); vs[2][b_] = __uint_as_float(a[2]); vs[3][b_] = __uint_as_float(a[3]);
+        } else { vs[0][b_] = 0.f; vs[1][b_] = 0.f; vs[2][b_] = 0.f; vs[3][b_] = 0.f; }
+        vs[4][b_] = other ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, base + sqo * 4, 0, kSc1)) : 0.f;
+        if (b_ == part) { vs[0][b_] = gb1; vs[1][b_] = gb2; vs[2][b_] = my_gbo; vs[3][b_] = my_gls; vs[4][b_] = my_gwo; }
+      }
       PPO_HO(4);
-      // Every block must end up with the same bits: the four partials p0 .. p3 are summed as (p0 + p1) + (p2 + p3) everywhere (own partial
-      // in registers, the others as loaded; fp addition commutes).  Two blocks: own + partner.
+      // Every block must end up with the same bits: the partials p0 .. are summed as a balanced tree over the block order everywhere --
+      // (p0 + p1) + (p2 + p3) with four, ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)) with eight (own partial in registers, the
+      // others as loaded; fp addition commutes).  Two blocks: own + partner.
       auto sum4 = [&](auto own, auto t0, auto t1, auto t2) {
         if (np == 1) return own + t0;
         return part < 2 ? (own + t0) + (t1 + t2) : (t0 + t1) + (own + t2);
       };
-      if constexpr (RS) { g2q = (qa[0] + qa[1]) + (qa[2] + qa[3]); g1q = (qb[0] + qb[1]) + (qb[2] + qb[3]); }
+      auto tree = [&](const float (&v)[NSd]) {
+        if constexpr (RS) return ppo_tree_sum<NSd>(v);
+        else return np == 1 ? v[0] + v[1] : (v[0] + v[1]) + (v[2] + v[3]);      // (slots past nsplit hold zero)
+      };
+      if constexpr (RS) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (RS) break;
-        const ppo_f4 o2 = {gW2[4 * q], gW2[4 * q + 1], gW2[4 * q + 2], gW2[4 * q + 3]};
-        const ppo_f4 r2 = sum4(o2, ta[0][q], ta[1][q], ta[2][q]);
-        gW2[4 * q] = r2[0]; gW2[4 * q + 1] = r2[1]; gW2[4 * q + 2] = r2[2]; gW2[4 * q + 3] = r2[3];
-        if (hasW1) {
-          const ppo_f4 o1 = {gW1[4 * q], gW1[4 * q + 1], gW1[4 * q + 2], gW1[4 * q + 3]};
-          const ppo_f4 r1 = sum4(o1, tb[0][q], tb[1][q], tb[2][q]);
-          gW1[4 * q] = r1[0]; gW1[4 * q + 1] = r1[1]; gW1[4 * q + 2] = r1[2]; gW1[4 * q + 3] = r1[3];
+        for (int e = 0; e < EPT; ++e) {
+          float c2[NSd], c1[NSd];
+#pragma unroll
+          for (int b_ = 0; b_ < NSd; ++b_) { c2[b_] = qa[b_][e]; c1[b_] = qb[b_][e]; }
+          g2q[e] = ppo_tree_sum<NSd>(c2); g1q[e] = ppo_tree_sum<NSd>(c1);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const ppo_f4 o2 = {gW2[4 * q], gW2[4 * q + 1], gW2[4 * q + 2], gW2[4 * q + 3]};
+          const ppo_f4 r2 = sum4(o2, ta[0][q], ta[1][q], ta[2][q]);
+          gW2[4 * q] = r2[0]; gW2[4 * q + 1] = r2[1]; gW2[4 * q + 2] = r2[2]; gW2[4 * q + 3] = r2[3];
+          if (hasW1) {
+            const ppo_f4 o1 = {gW1[4 * q], gW1[4 * q + 1], gW1[4 * q + 2], gW1[4 * q + 3]};
+            const ppo_f4 r1 = sum4(o1, tb[0][q], tb[1][q], tb[2][q]);
+            gW1[4 * q] = r1[0]; gW1[4 * q + 1] = r1[1]; gW1[4 * q + 2] = r1[2]; gW1[4 * q + 3] = r1[3];
+          }
         }
       }
-      gb1 = sum4(gb1, tsc[0][0], tsc[1][0], tsc[2][0]); gb2 = sum4(gb2, tsc[0][1], tsc[1][1], tsc[2][1]);
-      my_gbo = sum4(my_gbo, tsc[0][2], tsc[1][2], tsc[2][2]); my_gls = sum4(my_gls, tsc[0][3], tsc[1][3], tsc[2][3]);
-      my_gwo = sum4(my_gwo, tsc[0][4], tsc[1][4], tsc[2][4]);
+      gb1 = tree(vs[0]); gb2 = tree(vs[1]); my_gbo = tree(vs[2]); my_gls = tree(vs[3]); my_gwo = tree(vs[4]);
       PPO_HO(5);
     }
 
@@ -1028,9 +1078,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     unsigned long long spec_w = 0ull;
     if (t == 0) spec_w = __hip_atomic_load(A.xch + ((mb & 1) * 2 + (1 - NET)) * kPMaxSplit + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float ss = 0.f;
-    if constexpr (RS) {                                   // my quarter of the tiles; the per-thread elements (every block holds their sums) count once
+    if constexpr (RS) {                                   // my share of the tiles; the per-thread elements (every block holds their sums) count once
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < EPT; ++e) {
         ss += g2q[e] * g2q[e];
         if (ownW1 && rs_row + e < D) ss += g1q[e] * g1q[e];
       }
@@ -1053,11 +1103,11 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     const long long pfx = PPO_T(); pf_norm += pfx - pfb;
 #endif
     if constexpr (RS) {
-      // all eight shares, summed in word order by everybody: lane i of the first wave fetches word i
+      // all 2 NS shares, summed in word order ([net][part]) by everybody: lane i of the first wave fetches word i
       unsigned long long* words = A.xch + (mb & 1) * 2 * kPMaxSplit;
       const int me = NET * kPMaxSplit + part;
       if (t == 0) ppo_word_store(words + me, ((unsigned long long)(unsigned)(mb + 1) << 32) | (unsigned long long)__float_as_uint(ss_mine), same_xcd_net);
-      if (t < 2 * kPMaxSplit) {
+      if (t < 2 * kPMaxSplit && (t & (kPMaxSplit - 1)) < NS) {
         unsigned long long w = (unsigned long long)__float_as_uint(ss_mine);
         if (t != me && !ppo_wait(A, [&]() { return ppo_word_load(words + t, same_xcd_net); }, [&](unsigned long long x) { return (unsigned)(x >> 32) == (unsigned)(mb + 1); },
                                  (unsigned long long)PPO_ST_NORM, w)) red[7] = 1.f;     // a block is gone
@@ -1065,10 +1115,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       }
       __syncthreads();
       if (red[7] != 0.f) { dead = true; break; }
-      ss_other = 0.f;
       float tot = red8[0];
 #pragma unroll
-      for (int i = 1; i < 2 * kPMaxSplit; ++i) tot += red8[i];
+      for (int i = 1; i < 2 * kPMaxSplit; ++i) if ((i & (kPMaxSplit - 1)) < NS) tot += red8[i];
       ss_other = tot;                                      // (the total; ss_mine is not added again below)
       (void)spec_w;
     } else {
@@ -1124,16 +1173,14 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #pragma unroll
       for (int v = 0; v < 16; ++v) *lds_of(v) = wv[v] - upd[v];
     };
-    float* const wxn = A.wx + (size_t)NET * kPMaxSplit * 2 * 1024;                       // (RS) this network's weight quarters
+    float* const wxn = A.wx + (size_t)NET * (kPWxFloats / 2);                           // (RS) this network's weight shares: [part][kind][wave * 64 + lane][EPT]
     unsigned long long* const fl2 = A.xch + kPpoWordFlags2 + ((mb & 1) * 2 + NET) * kPMaxSplit;
     if constexpr (RS) {
-      // Adam on the quarter this block owns: 4 + 4 elements per thread; the new weights go to this block's LDS image and to the exchange
-      // buffer, from where the other three blocks fetch them below (they hold the same old weights, so the copies stay the same bits)
-      auto adam4 = [&](const ppo_f4& g, float4& m4, float4& v4, float (&wv)[4]) {
-        float* mm = reinterpret_cast<float*>(&m4);
-        float* vv = reinterpret_cast<float*>(&v4);
+      // Adam on the share this block owns: EPT + EPT elements per thread; the new weights go to this block's LDS image and to the exchange
+      // buffer, from where the other blocks fetch them below (they hold the same old weights, so the copies stay the same bits)
+      auto adamE = [&](const float (&g)[EPT], float (&mm)[EPT], float (&vv)[EPT], float (&wv)[EPT]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < EPT; ++e) {
           const float gg = g[e] * clipc;
           const float mn = H.beta1 * mm[e] + (1.0f - H.beta1) * gg, vn = H.beta2 * vv[e] + (1.0f - H.beta2) * (gg * gg);
           mm[e] = mn; vv[e] = vn;
@@ -1141,20 +1188,25 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         }
       };
       float* w2p = W.W2 + rs_row * kPLdh + rs_col;
-      float* w1p[4];
-      float wv2[4], wv1[4];
+      float* w1p[EPT];
+      float wv2[EPT], wv1[EPT];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < EPT; ++e) {
         w1p[e] = (ownW1 && rs_row + e < D) ? W.W1 + (rs_row + e) * ldw1 + rs_col : sink + t;
         wv2[e] = w2p[e * kPLdh]; wv1[e] = *w1p[e];
       }
-      adam4(g2q, rm[0], rv[0], wv2);
-      if (ownW1) adam4(g1q, rm[1], rv[1], wv1);
+      adamE(g2q, rm[0], rv[0], wv2);
+      if (ownW1) adamE(g1q, rm[1], rv[1], wv1);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { w2p[e * kPLdh] = wv2[e]; *w1p[e] = wv1[e]; }
-      float* mine_w = wxn + (size_t)(part * 2) * 1024 + (wave * 64 + lane) * 4;
-      *reinterpret_cast<float4*>(mine_w) = make_float4(wv2[0], wv2[1], wv2[2], wv2[3]);
-      if (ownW1) *reinterpret_cast<float4*>(mine_w + 1024) = make_float4(wv1[0], wv1[1], wv1[2], wv1[3]);
+      for (int e = 0; e < EPT; ++e) { w2p[e * kPLdh] = wv2[e]; *w1p[e] = wv1[e]; }
+      float* mine_w = wxn + (size_t)(part * 2) * (kPThreads * EPT) + (wave * 64 + lane) * EPT;
+      if constexpr (EPT == 4) {
+        *reinterpret_cast<float4*>(mine_w) = make_float4(wv2[0], wv2[1], wv2[2], wv2[3]);
+        if (ownW1) *reinterpret_cast<float4*>(mine_w + kPThreads * EPT) = make_float4(wv1[0], wv1[1], wv1[2], wv1[3]);
+      } else {
+        *reinterpret_cast<float2*>(mine_w) = make_float2(wv2[0], wv2[1]);
+        if (ownW1) *reinterpret_cast<float2*>(mine_w + kPThreads * EPT) = make_float2(wv1[0], wv1[1]);
+      }
       if (same_xcd) __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), as for the partials
       else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __syncthreads();
@@ -1184,7 +1236,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       for (int q = 0; q < NQ; ++q) if (ws[q]) *ws[q] -= c1 * smm[q] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(svv[q]) * sc2 + H.eps);
     }
     if constexpr (RS) {
-      // ---- all-gather of the updated weights: the other three quarters, from the blocks that own them ----
+      // ---- all-gather of the updated weights: the other NS - 1 shares, from the blocks that own them ----
       if (t < nsplit && t != part) {
         unsigned long long w;
         if (!ppo_wait(A, [&]() { return ppo_word_load(fl2 + t, same_xcd); }, [&](unsigned long long x) { return (unsigned)x == (unsigned)(mb + 1); },
@@ -1193,25 +1245,28 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       __syncthreads();
       if (red[7] != 0.f) { dead = true; break; }
       if (!same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      typedef unsigned int ppo_u4 __attribute__((ext_vector_type(4)));
-      const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(wxn, 0, kPMaxSplit * 2 * 1024 * (int)sizeof(float), 0x00020000);
-      ppo_u4 wa[3], wb[3];
+      const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(wxn, 0, (kPWxFloats / 2) * (int)sizeof(float), 0x00020000);
+      float wa[NS - 1][EPT], wb[NS - 1][EPT];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      for (int j = 0; j < NS - 1; ++j) {
         const int pj = j < part ? j : j + 1;
-        const int o = ((pj * 2) * 1024 + (wave * 64 + lane) * 4) * (int)sizeof(float);
-        wa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, o, 0, 16);
-        if (pj < tilesW1) wb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, o + 1024 * (int)sizeof(float), 0, 16);
-        else wb[j] = ppo_u4{0u, 0u, 0u, 0u};
+        const int o = ((pj * 2) * (kPThreads * EPT) + (wave * 64 + lane) * EPT) * (int)sizeof(float);
+        ppo_ld_sc1<EPT>(rsw, o, wa[j]);
+        if (pj * 4 / NS < tilesW1) ppo_ld_sc1<EPT>(rsw, o + kPThreads * EPT * (int)sizeof(float), wb[j]);
+        else {
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) wb[j][e] = 0.f;
+        }
       }
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      for (int j = 0; j < NS - 1; ++j) {
         const int pj = j < part ? j : j + 1;
-        const int row = (pj >> 1) * 32 + wave * 8 + hh * 4, col = (pj & 1) * 32 + r;
+        const int tj = pj * 4 / NS, sj = (pj % (NS / 4)) * EPT;
+        const int row = (tj >> 1) * 32 + wave * 8 + hh * 4 + sj, col = (tj & 1) * 32 + r;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          W.W2[(row + e) * kPLdh + col] = __uint_as_float(wa[j][e]);
-          if (pj < tilesW1 && row + e < D) W.W1[(row + e) * ldw1 + col] = __uint_as_float(wb[j][e]);
+        for (int e = 0; e < EPT; ++e) {
+          W.W2[(row + e) * kPLdh + col] = wa[j][e];
+          if (tj < tilesW1 && row + e < D) W.W1[(row + e) * ldw1 + col] = wb[j][e];
         }
       }
     }
@@ -1221,12 +1276,36 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #endif
   }
 
-  // ---- write the weights back, report the losses (a block that gave up leaves the parameters as it found them) ----
-  if (dead) return;
-  if constexpr (RS) {                               // the tile moments: every block its quarter
-    const int s0 = ppo_tile_slot(n, 0, part, lane) + 4 * wave, s1 = ppo_tile_slot(n, 1, part, lane) + 4 * wave;
-    *reinterpret_cast<float4*>(mom_m + s0) = rm[0]; *reinterpret_cast<float4*>(mom_v + s0) = rv[0];
-    if (ownW1) { *reinterpret_cast<float4*>(mom_m + s1) = rm[1]; *reinterpret_cast<float4*>(mom_v + s1) = rv[1]; }
+  // ---- the verdict: results are written back only when EVERY block of the call got through its last minibatch with every wait
+  // answered.  A block that gave up (`dead`) does not arrive, so the count never fills and nobody writes; the block that arrives
+  // last reads the status word once more (a block may have raised it and still finished its own waits) and publishes the verdict
+  // the others wait for.  (Round 4 decided per block: one whose own waits had all succeeded wrote back beside partners that had
+  // given up -- mixed buffers under a non-zero status.  A verdict wait that itself runs out raises PPO_ST_COMMIT: status != 0 then
+  // means "some blocks may have written": the caller restores the buffers from its own copies, see include/fwsim.h.)
+  if (t == 0) {
+    bool commit = false;
+    if (!dead) {
+      const int total = 2 * nsplit;
+      const unsigned long long before = __hip_atomic_fetch_add(A.xch + kPpoWordArrive, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (before == (unsigned long long)(total - 1)) {
+        commit = __hip_atomic_load(A.xch + kPpoWordStatus, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0ull;
+        __hip_atomic_store(A.xch + kPpoWordVerdict, commit ? 1ull : 2ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        unsigned long long w = 0ull;
+        if (ppo_wait(A, [&]() { return __hip_atomic_load(A.xch + kPpoWordVerdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); },
+                     [](unsigned long long x) { return x != 0ull; }, (unsigned long long)PPO_ST_COMMIT, w)) commit = w == 1ull;
+      }
+    }
+    red[6] = commit ? 1.f : 0.f;
+  }
+  __syncthreads();
+  if (red[6] == 0.f) return;
+  if constexpr (RS) {                               // the tile moments: every block its share
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      mom_m[rs_s0 + e] = rm[0][e]; mom_v[rs_s0 + e] = rv[0][e];
+      if (ownW1) { mom_m[rs_s1 + e] = rm[1][e]; mom_v[rs_s1 + e] = rv[1][e]; }
+    }
   }
   if (part == ((A.flags & PPO_FLAG_WRITER_LAST) ? nsplit - 1 : 0)) {
     {
@@ -1282,24 +1361,25 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 // 256 threads per block, dynamic LDS = ppo_lds_bytes().  Every 8th block of the grid works (the others leave at once): where
 // workgroups are dealt round-robin to the 8 XCDs that puts all working blocks on ONE XCD, whose L2 then carries their
 // exchanges (checked at run time, see ppo_net_body).  Working block i = blockIdx / 8 runs network i & 1 (0: policy, 1: value)
-// as part i >> 1 of gridDim / 16 blocks per network (1, 2 or 4).
-template <int CH, bool RS>
+// as part i >> 1 of gridDim / 16 blocks per network (1, 2, 4 or 8).
+template <int CH, int NS>
 __global__ __launch_bounds__(kPThreads) void fw_ppo_update_kernel(PpoArgs A) {
   extern __shared__ __align__(16) float lds[];
   if (blockIdx.x & 7) return;
   const int i = (int)blockIdx.x >> 3;
-  const int part = i >> 1, nsplit = RS ? kPMaxSplit : (int)gridDim.x >> 4;
-  if ((i & 1) == 0) ppo_net_body<0, CH, RS>(A, lds, part, nsplit); else ppo_net_body<1, CH, RS>(A, lds, part, nsplit);
+  const int part = i >> 1, nsplit = NS ? NS : (int)gridDim.x >> 4;
+  if ((i & 1) == 0) ppo_net_body<0, CH, NS>(A, lds, part, nsplit); else ppo_net_body<1, CH, NS>(A, lds, part, nsplit);
 }
 
-// How a minibatch of B samples is cut: samples per pass (64 or 32) and blocks per network.  The path is sequential, so the
-// smaller the share of a block the better -- down to 32 samples (below that the 16 x 16 tiles no longer fill four waves) and
-// up to four blocks (each reads every other block's partials).
+// How a minibatch of B samples is cut: samples per pass (64, 32 or 16) and blocks per network.  The path is sequential, so the
+// smaller the share of a block the better -- down to 16 samples (one 16 x 16 row tile per wave) and up to eight blocks: from four
+// on they reduce-scatter, so the exchange volume per block does not grow with their number.  `max_blocks` = 4: the cuts of round 4
+// (FWSIM_PPO_RS=0 needs them: the all-to-all swap is written for up to four blocks).
 struct PpoSplit { int ch, nsplit; };
-inline PpoSplit ppo_split(int B) {
-  auto cut = [&](int ch) { PpoSplit s; s.ch = ch; const int c = B / ch; s.nsplit = c >= 4 ? 4 : c >= 2 ? 2 : 1; return s; };
+inline PpoSplit ppo_split(int B, int max_blocks = kPMaxSplit) {
+  auto cut = [&](int ch) { PpoSplit s; s.ch = ch; const int c = B / ch; s.nsplit = (c >= 8 && max_blocks >= 8) ? 8 : c >= 4 ? 4 : c >= 2 ? 2 : 1; return s; };
   // passes of the busiest block x what a pass costs (64 samples : 32 : 16 ~ 10 : 6 : 4), + 1 where the blocks of a network are two:
-  // they swap whole gradients, four swap quarters
+  // they swap whole gradients, four and eight swap shares
   auto cost = [&](PpoSplit s) { return ((B / s.ch + s.nsplit - 1) / s.nsplit) * (s.ch == 64 ? 10 : s.ch == 32 ? 6 : 4) + (s.nsplit == 2 ? 1 : 0); };
   PpoSplit best = cut(16);
   if (B % 32 == 0 && cost(cut(32)) <= cost(best)) best = cut(32);
@@ -1311,7 +1391,7 @@ inline size_t ppo_lds_bytes(int D) {
   (void)D;                                          // (sized for the larger of the two forms: W1 as 64 rows of 65)
   const int ldx = kPLdx;
   size_t f = (size_t)(kPH * kPLdh + kPH + kPH * kPLdh + kPH + kPH * 4 + 4) + 4 + (size_t)kPChunk * ldx + 64 + 2 * (size_t)kPChunk * kPLdh +
-             3 * (size_t)kPChunk * 4 + 8 * kPH + 8 + 32 + kPThreads + 8;
+             3 * (size_t)kPChunk * 4 + 8 * kPH + 8 + 32 + kPThreads + 2 * kPMaxSplit;
   return f * sizeof(float);
 }
 

@@ -212,6 +212,8 @@ class ReplayedEvaluation:
             return False
         if env.training or not env.norm_obs or not FusedPpoUpdate.fits(policy, env.obs_dim, torch.device(env.device)):
             return False
+        if env.obs_dim > 62:                   # fw_collect_step's act waves take up to 62 features (fits() allows the update's 64): torch replay path
+            return False
         return int(_lib.lib().fw_lanes_per_env(venv._h)) in (8, 16)
 
     def _fused_setup(self) -> None:

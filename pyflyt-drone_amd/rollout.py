@@ -25,8 +25,9 @@ from __future__ import annotations
 import ctypes as C
 import math
 import time
+import warnings
 from dataclasses import dataclass
-from typing import Dict, Optional
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 import torch
@@ -244,6 +245,28 @@ class VecNormalizeDevice:
     def _snapshot(self):
         return [t.clone() for t in (self.obs_rms.mean, self.obs_rms.var, self.obs_rms.count,
                                     self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count)]
+
+    # -- what a rollout moves, kept so that a void rollout (PPO.check_collect_status) can be taken back -------------------
+    def _stat_tensors(self):
+        return [self.obs_rms.mean, self.obs_rms.var, self.obs_rms.count, self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count, self.returns]
+
+    def save_statistics(self) -> None:
+        """First command of a rollout (inside its captured graph when there is one): one multi-tensor copy of the running
+        statistics and the discounted-return accumulators (2 D + 4 + N doubles) into persistent buffers."""
+        live = self._stat_tensors()
+        if getattr(self, "_stat_saved", None) is None:
+            self._stat_saved = [torch.zeros_like(t) for t in live]
+        torch._foreach_copy_(self._stat_saved, live)
+
+    def restore_statistics(self) -> bool:
+        """Back to what save_statistics() kept: the statistics (and, in a sharded job, the agreed base and the batch sums since) no
+        longer contain anything of the rollout in between.  False if nothing was saved."""
+        if getattr(self, "_stat_saved", None) is None:
+            return False
+        torch._foreach_copy_(self._stat_tensors(), self._stat_saved)
+        if self._obs_acc is not None:                        # (they were zero when the rollout began: every rollout ends with a sync)
+            self._obs_acc.zero_(); self._ret_acc.zero_(); self._snap = self._snapshot()
+        return True
 
     def sync_statistics(self) -> None:
         """Once per rollout in a sharded job (``stats_sync="rollout"``): all-reduce the accumulated batch sums (one small
@@ -513,6 +536,10 @@ class PPOConfig:
     one_launch_collect: bool = True        # the whole vec-step as ONE launch (fw_collect_step) where the env's lane mapping has it (8 lanes per env,
                                            # one wave per SIMD), fw_collect_act -> fw_step -> fw_collect_stats elsewhere or when False: 34.9 vs 47.9 us
                                            # per vec-step (waypoints, 4096 envs; profiles/r04_rollout_bench*.jsonl)
+    collect_fallback: bool = True          # a fw_collect_step status error (a bounded in-grid wait ran out: the launch assumed a workgroup dispatch order
+                                           # the platform does not promise) voids the rollout; True: take it back, re-arm on the three-launch
+                                           # collector (fw_collect_act -> fw_step -> fw_collect_stats: no in-grid wait), warn once and keep
+                                           # training; False: raise RuntimeError (SB3's "VecEnv.step returns or raises")
     detector: str = "none"                 # "cnn": CnnDetectorPolicy over the FPV render (fw_render) of a camera task -- torch path, gradient all-reduce
     image_res: int = 32                    #        side of the rendered image
     cnn_features: int = 32                 #        width of the extractor's output
@@ -551,6 +578,8 @@ class FusedPpoUpdate:
         self.synced = False                # flat / mom_m / mom_v are what the module and the optimiser hold (set by commit(); whoever changes
         self._step = 0                     # either behind this object's back clears it: PPO does wherever it clears _flat_current)
         self.last_paths = 0                # fw_ppo_update_status: which exchanges of the last call went through a shared L2
+        self._sig = None                   # state_signature() of module + optimiser when the images were last known equal to them (commit())
+        self._param_sig = None             # param_signature() when `flat` was last loaded from / stored to the module
 
     def _workspace(self, n_mb: int, batch_size: int) -> torch.Tensor:
         # exchange words + gradient hand-off buffer + the packed rows of every minibatch (a parallel pre-pass of the call writes them)
@@ -600,10 +629,34 @@ class FusedPpoUpdate:
         view = flat[off:off + int(np.prod(shape))].view(shape)
         dst.copy_(view[:dst.shape[1], :].t() if tr else view)
 
+    # The images are caches of the module / optimiser.  Whoever writes those tensors in place (``p.add_()``,
+    # ``policy.load_state_dict``, an edit of ``exp_avg``, ``optimizer.step()``) bumps their ``_version``; whoever replaces them
+    # (``optimizer.load_state_dict``) changes their address: the signatures below see both, and a mismatch reloads the image
+    # instead of trusting a flag.  (Writes through ``tensor.data`` bypass the version counter by design of torch: callers that
+    # do that say so with ``PPO.touch()``.)
+    def param_signature(self):
+        return tuple((t.data_ptr(), t._version) for t, _, _, _ in self._slots())
+
+    def state_signature(self):
+        sig = list(self.param_signature())
+        if self.opt is not None:
+            for t, _, _, _ in self._slots():
+                st = self.opt.state.get(t)
+                if not st:
+                    sig.append(None); continue
+                for k in ("exp_avg", "exp_avg_sq", "step"):
+                    v = st.get(k)
+                    sig.append((v.data_ptr(), v._version) if torch.is_tensor(v) else (k, v))
+        return tuple(sig)                  # (the hyper-parameters of the optimiser are read at every call: nothing of them is cached)
+
+    def params_current(self) -> bool:
+        return self._param_sig is not None and self._param_sig == self.param_signature()
+
     @torch.no_grad()
     def load_params_from_torch(self) -> None:
         for t, off, shape, tr in self._slots():
             self._put(self.flat, t.data, off, shape, tr)
+        self._param_sig = self.param_signature()
 
     @torch.no_grad()
     def load_from_torch(self) -> int:
@@ -638,8 +691,9 @@ class FusedPpoUpdate:
     def run(self, cfg, obs, act, old_logp, adv, ret, perm_i32, n_mb: int, g_mean: float, g_std: float):
         # (the images of the previous call are still current when nothing else touched the module / optimiser: ~70 small copies and a
         # host sync less per update)
-        step0 = self._step if self.synced else self.load_from_torch()
+        step0 = self._step if (self.synced and self._sig == self.state_signature()) else self.load_from_torch()
         self.synced = False                # until commit(): the kernel is about to move the images
+        self._param_sig = None
         pg = self.opt.param_groups[0]
         H = _PpoHyper(lr=pg["lr"], clip_range=cfg.clip_range, ent_coef=cfg.ent_coef, vf_coef=cfg.vf_coef,
                       max_grad_norm=cfg.max_grad_norm, beta1=pg["betas"][0], beta2=pg["betas"][1], eps=pg["eps"],
@@ -654,14 +708,16 @@ class FusedPpoUpdate:
                                       _p(perm_i32), n_mb, cfg.batch_size, self.D, C.byref(H), _p(self.loss), _p(ws), ws.numel(),
                                       _stream(obs.device))
         _lib.check(rc)
-        # the workgroups of the launch wait for each other, every wait bounded: a wait that ran out left the parameter image
-        # untouched and a status word behind -- surface it BEFORE anything is written back to the module / optimiser (they still
-        # hold the state of before the call)
+        # the workgroups of the launch wait for each other, every wait bounded: a wait that ran out leaves a status word behind and
+        # (unless the closing verdict itself was lost) untouched images -- surface it BEFORE anything is written back to the module /
+        # optimiser (they still hold the state of before the call)
         st, paths = C.c_uint32(0), C.c_uint32(0)
         _lib.check(_lib.lib().fw_ppo_update_status(_p(ws), ws.numel(), C.byref(st), C.byref(paths), _stream(obs.device)))
         self.last_paths = int(paths.value)
         if st.value:
-            names = [n for b, n in ((1, "block ids"), (2, "gradient swap"), (4, "norm exchange")) if st.value & b]
+            names = [n for b, n in ((1, "block ids"), (2, "gradient swap"), (4, "norm exchange"), (8, "closing verdict")) if st.value & b]
+            # (the flat images are undefined after a non-zero status -- include/fwsim.h -- and are reloaded at the next call; the
+            # module and the optimiser, which only commit() writes, still hold the state of before the call)
             raise RuntimeError(f"fw_ppo_update gave up inside the launch (status {st.value}: {', '.join(names)} wait ran out); "
                                "the policy and optimiser were left as they were before the call")
         self._pending_step = step0 + n_mb      # commit() moves the result into the module / optimiser
@@ -672,6 +728,8 @@ class FusedPpoUpdate:
         from run() so that a sharded job can first agree that the launch ran to its end on EVERY rank."""
         self.store_to_torch(self._pending_step)
         self._step, self.synced = self._pending_step, True
+        self._sig = self.state_signature()          # (taken AFTER the store: its copies moved the counters)
+        self._param_sig = self.param_signature()
 
 
 class PPO:
@@ -720,8 +778,12 @@ class PPO:
             self._act_env = torch.full((env.num_envs, 4), float("nan"), dtype=env.venv.torch_dtype, device=self.device)
             self._tval = torch.zeros(env.num_envs, dtype=torch.float32, device=self.device)
         # one launch per vec-step (fw_collect_step) where the handle's lane mapping has it: 8 lanes per env (either build)
-        self._one_launch = (self._collect_fused and bool(cfg.one_launch_collect) and hasattr(env.venv, "_h")
+        # (fw_collect_step's act waves take observations of up to 62 features -- wider ones go through fw_collect_act, which takes 64)
+        self._one_launch = (self._collect_fused and bool(cfg.one_launch_collect) and hasattr(env.venv, "_h") and env.obs_dim <= 62
                             and getattr(env.venv, "lanes_per_env", 0) == 8 and float(env.gamma) == float(cfg.gamma))
+        self._void_recoverable = False
+        self.collect_fallbacks = 0         # how many times a void rollout moved this object to the three-launch collector (0 or 1)
+        self._void_steps = 0               # timesteps the last rollout added to num_timesteps (taken back if it turns out void)
         self._ws_collect = None
         self._status_host = None           # CS_STATUS of the workspace, copied to pinned memory as the last command of every rollout
         self._status_pending = False
@@ -902,6 +964,8 @@ class PPO:
                             (8, "the workspace was never initialised"), (16, "the merge wave never saw the launch index"),
                             (32, "the policy produced a NaN action (diverged weights or statistics)"))
 
+    _COLLECT_STATUS_WAITS = 1 | 2 | 4 | 16
+
     def _queue_collect_status(self) -> None:
         """Last command of a rollout through fw_collect_step (inside the captured graph when there is one): the workspace's status
         word goes to pinned host memory -- 4 bytes behind the closing launch, nothing between two replays (an event + side-stream
@@ -912,57 +976,103 @@ class PPO:
             self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._status_host.copy_(self._ws_collect.view(torch.int32)[-16 + 3:-16 + 4], non_blocking=True)
 
-    def check_collect_status(self, wait: bool = True, collective: bool = False) -> None:
-        """Raise RuntimeError if a wait inside a fw_collect_step launch of the last rollout(s) ran out (the launch then went on
-        with zero actions / partial statistics: everything collected since is void).  SB3's contract for ``VecEnv.step`` is
-        "returns or raises"; a pipe to a dead SubprocVecEnv worker raises there
-        (train/train_Fixedwing_Waypoints_v3.py:251).  ``wait=False`` only looks if the stream has drained (no synchronisation).
-        ``collective=True`` (a point every rank of a sharded job reaches: train()): the ranks agree on the union of their words, so
-        that all of them raise together instead of one leaving the others in the next collective."""
+    def _collect_status_word(self, wait: bool, collective: bool) -> Tuple[int, int]:
+        """(this rank's word, union over the ranks' words) of the rollout(s) since the last look; (0, 0) when there is nothing to
+        look at (yet).  Consumes the pending flag when it looks."""
         td = _dist() if (collective and self._one_launch) else None      # (the same configuration on every rank: all or none take this branch)
         if td is None and (not self._status_pending or self._status_host is None):
-            return
+            return 0, 0
         st = 0
         if self._status_pending and self._status_host is not None:
             stream = torch.cuda.current_stream(self.device)
             if wait:
                 stream.synchronize()
             elif not stream.query():
-                return
+                return 0, 0
             self._status_pending = False
             st = int(self._status_host.item())
+        st_all = st
         if td is not None:
             bits = torch.tensor([float(bool(st & b)) for b, _ in self._COLLECT_STATUS_BITS], dtype=torch.float64, device=self.device)
             counts = all_reduce_sum_(bits).tolist()
             st_all = sum(b for (b, _), c in zip(self._COLLECT_STATUS_BITS, counts) if c > 0)
-            if st_all and not st:
-                self._ws_collect = None; self._g_rollout = None; self._warm_rollouts = 0
-                self._act_env.fill_(float("nan"))
-                raise RuntimeError(f"fw_collect_step: another rank of the job reported status word {st_all}; the rollout is void on every rank")
-        if st == 0:
-            return
-        why = "; ".join(t for b, t in self._COLLECT_STATUS_BITS if st & b)
-        # leave a usable object behind: fresh workspace and action words, no captured graph over the old ones
+        return st, st_all
+
+    def _take_back_void_rollout(self, st: int, st_all: int) -> str:
+        """A launch of the last rollout went on without something it waited for: nothing collected since may be used.  Leaves a
+        usable object behind -- fresh workspace and action words, no captured graph over the old ones, the normalisers' statistics
+        and return accumulators as they were when the rollout began, no advantages for train() to pick up, the timestep counter
+        without the void steps -- and, unless PPOConfig.collect_fallback is off, re-arms on the three-launch collector, which has no
+        in-grid wait to run out.  Returns the message for the caller to raise or to log."""
+        why = "; ".join(t for b, t in self._COLLECT_STATUS_BITS if st_all & b)
+        where = "" if st == st_all else f" (this rank's word: {st})"
         self._ws_collect = None
         self._g_rollout = None
         self._warm_rollouts = 0
         self._act_env.fill_(float("nan"))
-        raise RuntimeError(f"fw_collect_step: status word {st} ({why}); the rollout is void -- buffers and normaliser statistics "
-                           "since the last clean rollout must not be used")
+        restored = self.env.restore_statistics() if hasattr(self.env, "restore_statistics") else False
+        self.adv = self.ret = None
+        self.num_timesteps -= self._void_steps
+        self._void_steps = 0
+        msg = (f"fw_collect_step: status word {st_all}{where} ({why}); the rollout is void -- its buffers are dropped"
+               + (", the normaliser statistics are those of before it" if restored else ""))
+        # bits 1 / 2 / 4 / 16 are waits of one wave for another that ran out -- what the other collector cannot have; a workspace that
+        # was never initialised (8) or a policy that emits NaN (32) would fail there just the same: those always raise
+        self._void_recoverable = bool(self.cfg.collect_fallback) and not (st_all & ~self._COLLECT_STATUS_WAITS)
+        if self._void_recoverable:
+            self._one_launch = self._close_gae = False
+            self.collect_fallbacks += 1
+            msg += "; re-armed on the three-launch collector (fw_collect_act -> fw_step -> fw_collect_stats)"
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
+        return msg
+
+    def check_collect_status(self, wait: bool = True, collective: bool = False) -> None:
+        """Raise RuntimeError if a wait inside a fw_collect_step launch of the last rollout(s) ran out (the launch then went on
+        with zero actions / partial statistics: everything collected since is void).  SB3's contract for ``VecEnv.step`` is
+        "returns or raises"; a pipe to a dead SubprocVecEnv worker raises there
+        (train/train_Fixedwing_Waypoints_v3.py:251, :332-337).  ``wait=False`` only looks if the stream has drained (no
+        synchronisation).  ``collective=True`` (a point every rank of a sharded job reaches: train()): the ranks agree on the union
+        of their words, so that all of them raise together instead of one leaving the others in the next collective -- which is
+        why, in a sharded job, ONLY the collective look consumes the word: a rank-local look (collect_rollouts, state_dict,
+        checkpoint.snapshot -- rank 0 alone, typically) that raised would strand the other ranks.
+        Either way the object is usable afterwards (_take_back_void_rollout), on the three-launch collector unless
+        ``PPOConfig.collect_fallback`` is off; learn() / train() do not raise at all then but collect the rollout again."""
+        if not collective and self._one_launch and _dist() is not None:
+            return
+        st, st_all = self._collect_status_word(wait, collective)
+        if st_all:
+            raise RuntimeError(self._take_back_void_rollout(st, st_all))
+
+    def touch(self) -> None:
+        """Tell the object that module parameters or optimiser state were changed in a way torch's version counters do not see
+        (writes through ``tensor.data``): collector and update reload their images.  In-place writes (``p.add_()``,
+        ``load_state_dict``, edits of ``exp_avg``) and replaced tensors are noticed without this."""
+        self._flat_current = False
 
     @torch.no_grad()
     def collect_rollouts(self):
         cfg, env = self.cfg, self.env
-        self.check_collect_status(wait=False)      # the previous rollout's word, if its copy has arrived
+        if not (self._one_launch and _dist() is not None):      # (sharded: train()'s collective look only, see check_collect_status)
+            st, st_all = self._collect_status_word(wait=False, collective=False)      # the previous rollout's word, if its copy has arrived
+            if st_all:
+                msg = self._take_back_void_rollout(st, st_all)
+                if not self._void_recoverable:
+                    raise RuntimeError(msg)
         if self.last_obs is None:
             self.last_obs = env.reset().clone()
             if self._img:
                 env.venv.render_tensor(self.policy.image_res, out=self.last_img)
             self.last_starts.fill_(1.0)
             self.last_values = torch.zeros(env.num_envs, dtype=torch.float32, device=self.device)
+        if self._one_launch and not self._status_pending:
+            # every earlier rollout has been looked at: this is what a void rollout is taken back to (one multi-tensor copy in front of
+            # the rollout; rollouts queued behind an unread word keep the older base, so that ALL of them can be taken back)
+            if hasattr(env, "save_statistics"):
+                env.save_statistics()
+            self._void_steps = 0
         body = self._rollout_body
         if self._collect_fused:
-            if not self._flat_current:
+            if not self._flat_current or not self._fused.params_current():      # (flag: PPO's own moves; signature: everybody else's)
                 self._fused.load_params_from_torch(); self._flat_current = True
             body = self._rollout_body_fused
         key = (getattr(env, "version", 0), bool(env.training), bool(env.norm_reward), bool(env.norm_obs))
@@ -993,7 +1103,9 @@ class PPO:
             self.adv, self.ret = self._gae(self.buf_rew, self.buf_val, self.buf_start, self.last_values, self.last_starts,
                                            cfg.gamma, cfg.gae_lambda)
         td = _dist()
-        self.num_timesteps += cfg.n_steps * env.num_envs * (td.get_world_size() if td is not None else 1)
+        steps = cfg.n_steps * env.num_envs * (td.get_world_size() if td is not None else 1)
+        self._void_steps += steps                  # (since the last clean look at the status word)
+        self.num_timesteps += steps
 
     # ---- SB3 PPO.train ------------------------------------------------------------------------
     def _minibatch_step(self, obs, act, old_logp, adv, ret, idx, g_mean, g_std, params):
@@ -1056,7 +1168,14 @@ class PPO:
 
     def train(self):
         cfg = self.cfg
-        self.check_collect_status(collective=True)     # a void rollout must not reach the update -- on any rank
+        st, st_all = self._collect_status_word(wait=True, collective=True)     # a void rollout must not reach the update -- on any rank
+        if st_all:
+            msg = self._take_back_void_rollout(st, st_all)
+            if not self._void_recoverable:
+                raise RuntimeError(msg)
+            self.collect_rollouts()                    # the same rollout again, on the collector without in-grid waits (every rank: st_all is agreed)
+        if getattr(self, "adv", None) is None:
+            raise RuntimeError("train() without a rollout: the last one was void (check_collect_status raised) -- call collect_rollouts() first")
         obs, act, old_logp, adv, ret = self._update_buffers()
         B = obs.shape[0]
         if self._replicated:                                     # the gathered advantages ARE the global ones

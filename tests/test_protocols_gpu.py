@@ -32,9 +32,9 @@ def _bits(t):
 
 
 @pytest.mark.parametrize("d,bs,split", [(28, 128, None), (56, 64, None), (28, 192, None), (27, 256, None), (28, 128, "64x2"), (28, 256, "32x4"),
-                                         (28, 128, "all-to-all"), (40, 512, "all-to-all")])
+                                         (28, 128, "32x4"), (40, 512, None), (56, 128, None), (28, 128, "all-to-all"), (40, 512, "all-to-all")])
 def test_every_block_of_a_network_ends_the_update_with_the_same_bits(d, bs, split, monkeypatch):
-    """The blocks of a network (up to four) each apply Adam to their own LDS copy of the weights and their own register copy of the
+    """The blocks of a network (up to eight) each apply Adam to their own LDS copy of the weights and their own register copy of the
     moments, from gradient sums they each form themselves out of the same four partials: the sums must be formed in the same order
     everywhere, or the copies drift apart.  FWSIM_PPO_WRITER=last makes the last block write the result back instead of the first."""
     T, n = (3, 256) if bs == 192 else (4, 256)
@@ -58,10 +58,13 @@ def test_every_block_of_a_network_ends_the_update_with_the_same_bits(d, bs, spli
         assert torch.equal(_bits(x), _bits(y)), "the first and the last block of a network hold different bits"
 
 
-@pytest.mark.parametrize("d,bs,form", [(28, 128, "rs"), (56, 64, "rs"), (27, 256, "rs"), (28, 128, "all-to-all")])
+@pytest.mark.parametrize("d,bs,form", [(28, 128, "rs"), (56, 64, "rs"), (27, 256, "rs"), (28, 128, "all-to-all"), (28, 128, "32x4")])
 def test_ppo_update_is_bit_identical_on_the_shared_l2_and_the_device_scope_path(d, bs, form, monkeypatch):
+    """("rs" = the default cut: eight blocks per network for 128 / 256 samples, four for 64; "32x4": round 4's cut of 128 samples)"""
     if form == "all-to-all":
         monkeypatch.setenv("FWSIM_PPO_RS", "0")
+    elif form != "rs":
+        monkeypatch.setenv("FWSIM_PPO_SPLIT", form)
     T, n = 4, 256
     n_epochs = math.ceil(10240 / (T * n // bs))                      # >= 10 240 sequential minibatches
     runs = {}
@@ -118,8 +121,9 @@ def test_ppo_update_wait_that_runs_out_raises_and_leaves_the_policy_alone(monkey
 
 
 def test_collect_step_wait_that_runs_out_raises_in_python(monkeypatch):
+    """PPOConfig.collect_fallback=False: SB3's "step returns or raises", and the object stays on the one-launch collector."""
     env = P.FixedwingVecEnv(K.train_waypoints_v3_config(), 1024, seed=5)
-    ppo = R.PPO(R.VecNormalizeDevice(env), R.PPOConfig(n_steps=4, batch_size=128, n_epochs=1, seed=5))
+    ppo = R.PPO(R.VecNormalizeDevice(env), R.PPOConfig(n_steps=4, batch_size=128, n_epochs=1, seed=5, collect_fallback=False))
     assert ppo._one_launch
     ppo.collect_rollouts()
     ppo.check_collect_status()                                            # a healthy rollout: nothing raised
@@ -137,6 +141,79 @@ def test_collect_step_wait_that_runs_out_raises_in_python(monkeypatch):
     torch.cuda.synchronize()
     assert int(ppo._ws_collect.view(torch.int32)[-16 + 3]) == 0
     assert torch.isfinite(ppo.buf_obs).all() and torch.isfinite(ppo.adv).all()
+    assert ppo._one_launch and ppo.collect_fallbacks == 0
+
+
+@pytest.mark.parametrize("via", ["train", "learn", "next_rollout"])
+def test_a_void_rollout_is_taken_back_and_training_goes_on_on_the_three_launch_collector(via, monkeypatch):
+    """Default (PPOConfig.collect_fallback): the one-launch collector's forward progress rests on in-order workgroup dispatch,
+    which the platform does not promise.  Where the order differs every rollout would end in a status error -- so the first one
+    moves the SAME object (same process, other code path: fw_collect_act -> fw_step -> fw_collect_stats, no in-grid wait) and
+    training continues: the void rollout is collected again, the normalisers never see it, the timestep counter counts it once."""
+    T, N = 4, 1024
+    env = P.FixedwingVecEnv(K.train_waypoints_v3_config(), N, seed=5)
+    ppo = R.PPO(R.VecNormalizeDevice(env), R.PPOConfig(n_steps=T, batch_size=128, n_epochs=1, seed=5))
+    assert ppo._one_launch and ppo._close_gae
+    ppo.collect_rollouts(); ppo.train()                                   # rollout 0: healthy
+    torch.cuda.synchronize()
+    c_obs, c_ret, steps = float(ppo.env.obs_rms.count), float(ppo.env.ret_rms.count), ppo.num_timesteps
+    assert c_obs == pytest.approx(1e-4 + (T + 1) * N) and steps == T * N
+    before = [p.detach().clone() for p in ppo.policy.parameters()]
+    monkeypatch.setenv("FWSIM_SPIN_LOG2", "0")                            # rollout 1: every bounded wait gives up after one poll
+    ppo.invalidate_graphs()
+    collect = ppo.collect_rollouts
+
+    def collect_then_restore_the_budget():                                # (the budget is read per launch; fw_ppo_update reads it too and must get its own)
+        collect()
+        monkeypatch.delenv("FWSIM_SPIN_LOG2", raising=False)
+    ppo.collect_rollouts = collect_then_restore_the_budget
+    with pytest.warns(RuntimeWarning, match="re-armed on the three-launch collector"):
+        if via == "train":
+            ppo.collect_rollouts()
+            ppo.train()                                                   # sees the word, takes the rollout back, collects it again, updates
+        elif via == "learn":
+            ppo.learn(T * N, reset_num_timesteps=False)                   # one rollout + one update: never raises
+        else:
+            ppo.collect_rollouts()
+            ppo.collect_rollouts()                                        # (a caller that only collects: the next rollout notices and replaces it)
+            ppo.train()
+    torch.cuda.synchronize()
+    assert ppo.collect_fallbacks == 1 and not ppo._one_launch and not ppo._close_gae and ppo._collect_fused
+    # exactly ONE more rollout in the statistics and in the counter: the void one left nothing behind
+    assert float(ppo.env.obs_rms.count) == pytest.approx(c_obs + T * N) and float(ppo.env.ret_rms.count) == pytest.approx(c_ret + T * N)
+    assert ppo.num_timesteps == steps + T * N
+    assert torch.isfinite(ppo.buf_obs).all() and torch.isfinite(ppo.adv).all() and (ppo.buf_act.abs().sum(-1) > 0).all()      # (a void rollout flies zero actions)
+    assert any(not torch.equal(p, q) for p, q in zip(ppo.policy.parameters(), before))
+    # rollout k + 1 and on: the three-launch collector, whatever the spin budget (it has no in-grid wait), graph replays included
+    for _ in range(3):
+        ppo.collect_rollouts()
+    ppo.check_collect_status()
+    ppo.train()
+    torch.cuda.synchronize()
+    assert float(ppo.env.obs_rms.count) == pytest.approx(c_obs + 4 * T * N) and ppo.num_timesteps == steps + 4 * T * N
+    assert ppo.collect_fallbacks == 1 and all(torch.isfinite(p).all() for p in ppo.policy.parameters())
+
+
+def test_a_void_rollout_leaves_no_advantages_for_train_to_pick_up(monkeypatch):
+    """a caller that catches the error of check_collect_status() and calls train() again must not train on void data."""
+    env = P.FixedwingVecEnv(K.train_waypoints_v3_config(), 512, seed=6)
+    ppo = R.PPO(R.VecNormalizeDevice(env), R.PPOConfig(n_steps=4, batch_size=128, n_epochs=1, seed=6, collect_fallback=False))
+    ppo.collect_rollouts(); ppo.check_collect_status()
+    c_obs = float(ppo.env.obs_rms.count)
+    rets = ppo.env.returns.clone()
+    monkeypatch.setenv("FWSIM_SPIN_LOG2", "0")
+    ppo.invalidate_graphs()
+    ppo.collect_rollouts()
+    with pytest.raises(RuntimeError, match="fw_collect_step: status word"):
+        ppo.check_collect_status()
+    assert ppo.adv is None and ppo.ret is None
+    assert float(ppo.env.obs_rms.count) == c_obs and torch.equal(ppo.env.returns, rets)      # statistics and return trackers of before the void rollout
+    with pytest.raises(RuntimeError, match="train\\(\\) without a rollout"):
+        ppo.train()
+    from pyflyt_drone_amd import checkpoint
+    monkeypatch.delenv("FWSIM_SPIN_LOG2")
+    ppo.collect_rollouts()
+    checkpoint.snapshot(ppo, include_env_state=False)                     # (looks at the word too: a healthy rollout passes)
 
 
 def test_collect_step_status_through_the_c_abi():

@@ -154,7 +154,7 @@ def _filled_ppo(fused, d, bs, n_epochs, T=4, n=256, seed=5, scope="minibatch", s
                                         (28, 48, "minibatch"),       # three 16-sample passes on two blocks
                                         (28, 16, "minibatch"),       # one pass, one block per network: no swap
                                         (40, 512, "minibatch")])     # 64-sample chunks over four blocks, 2 each; K = 64 rows of W1 in the 32-sample form
-@pytest.mark.parametrize("split", [None, "64x2", "32x2", "64x1", "16x4", "16x1", "all-to-all"])
+@pytest.mark.parametrize("split", [None, "64x2", "32x2", "64x1", "16x4", "16x1", "32x4", "16x8", "32x8", "64x8", "all-to-all"])
 def test_fused_ppo_update_matches_the_torch_path(d, bs, scope, split, monkeypatch):
     """fw_ppo_update (one kernel for the whole minibatch sequence) against the plain torch PPO.train() on the same
     buffers, permutations, initial weights and Adam state: parameters, Adam moments and step count agree to fp32
@@ -185,6 +185,75 @@ def test_fused_ppo_update_matches_the_torch_path(d, bs, scope, split, monkeypatc
             assert a.logs[k] == pytest.approx(b.logs[k], rel=2e-3, abs=1e-5)
     # the update moved the policy and did not blow up
     assert all(torch.isfinite(p).all() for p in a.policy.parameters())
+
+
+def _edit_behind_ppos_back(ppo, edit):
+    """The same deterministic edit for a fused and a torch-path twin -- each the way a user would do it, none of them through PPO."""
+    pol, opt = ppo.policy, ppo.optimizer
+    with torch.no_grad():
+        if edit == "param_add":
+            pol.action_net.bias.add_(0.05)
+            pol.pi_net[0].weight.mul_(0.9)
+        elif edit == "policy_load_state_dict":
+            sd = {k: (v * 0.8 + 0.01) for k, v in pol.state_dict().items()}
+            pol.load_state_dict(sd)
+        elif edit == "exp_avg":
+            opt.state[pol.vf_net[2].weight]["exp_avg"].mul_(-3.0)
+            opt.state[pol.log_std]["exp_avg_sq"].add_(1e-3)
+        elif edit == "optimizer_load_state_dict":
+            sd = opt.state_dict()
+            for st in sd["state"].values():
+                st["exp_avg"] = st["exp_avg"] * 0.5
+            opt.load_state_dict(sd)                                   # (replaces the state tensors: new addresses, version 0)
+        elif edit == "data_write_plus_touch":
+            pol.value_net.bias.data.add_(0.2)                         # invisible to the version counter by design of torch ...
+            ppo.touch()                                               # ... so the caller says so
+        else:
+            raise AssertionError(edit)
+
+
+@pytest.mark.parametrize("edit", ["param_add", "policy_load_state_dict", "exp_avg", "optimizer_load_state_dict", "data_write_plus_touch"])
+def test_edits_of_module_or_optimiser_between_two_updates_are_seen_by_the_fused_update(edit):
+    """Round 4 let fw_ppo_update reuse the flat parameter / moment images of its previous call unless PPO itself had cleared a
+    flag: anything touching ``ppo.policy`` / ``ppo.optimizer`` behind PPO's back was silently ignored.  The images are now guarded
+    by the tensors' own version counters and addresses: after any such edit the fused update equals the torch path started from
+    the EDITED state (it would differ by the size of the edit otherwise)."""
+    a, b = _filled_ppo(True, 28, 128, 2), _filled_ppo(False, 28, 128, 2)
+    a.train(); b.train()
+    assert a._fused is not None and a._fused.synced and b._fused is None
+    sig = a._fused.state_signature()
+    assert sig == a._fused._sig
+    _edit_behind_ppos_back(a, edit); _edit_behind_ppos_back(b, edit)
+    if edit != "data_write_plus_touch":
+        assert a._fused.state_signature() != sig and a._fused.synced      # nobody told the object: only the signature knows
+    a.train(); b.train()
+    for (na, p), (_, q) in zip(a.policy.named_parameters(), b.policy.named_parameters()):
+        torch.testing.assert_close(p, q, rtol=2e-3, atol=2e-5, msg=lambda m: f"{na} after {edit}: {m}")
+        sa, sb = a.optimizer.state[p], b.optimizer.state[q]
+        assert float(sa["step"]) == float(sb["step"])
+        torch.testing.assert_close(sa["exp_avg"], sb["exp_avg"], rtol=5e-3, atol=1e-6)
+        torch.testing.assert_close(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=5e-3, atol=1e-9)
+    # ... and an untouched object still reuses its images (no reload: the staging copies are not rewritten)
+    a._fused.m.fill_(float("nan"))
+    a.train()
+    assert torch.isnan(a._fused.m).all() and all(torch.isfinite(p).all() for p in a.policy.parameters())
+
+
+@pytest.mark.parametrize("edit", ["param_add", "policy_load_state_dict"])
+def test_edits_of_the_policy_between_two_rollouts_are_seen_by_the_collector(edit):
+    """The collector's parameter image (what fw_collect_step's act waves read) follows in-place edits of the module too: the
+    next rollout's log-probs are those of the EDITED policy on the observations it stored."""
+    env = P.FixedwingVecEnv(K.train_waypoints_v3_config(), 512, seed=4)
+    ppo = R.PPO(R.VecNormalizeDevice(env), R.PPOConfig(n_steps=4, batch_size=128, n_epochs=1, seed=4))
+    ppo.collect_rollouts(); ppo.train(); ppo.collect_rollouts()
+    assert ppo._flat_current
+    _edit_behind_ppos_back(ppo, edit)
+    ppo.collect_rollouts()                                                # (a replay of the captured graph: the image is a fixed buffer)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        _, logp, _ = ppo.policy.evaluate_actions(ppo.buf_obs.reshape(-1, env.obs_dim), ppo.buf_act.reshape(-1, 4))
+    torch.testing.assert_close(logp.reshape(ppo.buf_logp.shape), ppo.buf_logp, rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(_flat_params(ppo.policy, env.obs_dim), ppo._fused.flat, rtol=0, atol=0)
 
 
 def test_fused_ppo_update_rejects_what_it_cannot_run():

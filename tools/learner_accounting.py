@@ -3,7 +3,12 @@ and of profiles/rNN_learner_pmc.json (tools/summarize_learner_pmc.py).  Peaks: M
 157.3 TFLOP/s per chip = 0.6145 TFLOP/s per CU, 256 CUs).
 
 "Algorithmic" = what the arithmetic needs to be moved once, whoever holds it in cache: every figure below is a count of
-array elements x element size, itemised so that a reader can recompute it.
+array elements x element size, itemised so that a reader can recompute it.  Two totals per kernel since round 5:
+  * `unique_bytes`    -- every buffer counted ONCE per launch: the figure an HBM roofline may be priced on (`bytes` is this);
+  * `l2_served_bytes` -- re-reads of a buffer that is already counted (the parameter image and the statistics, fetched again by
+                         every act wave): they never leave the L2, so they are reported under their own name and are NOT part of
+                         the HBM fraction (round 4 added them in: 7.4 % "of HBM" for a launch whose counter traffic was 0.54 x
+                         that sum).
 """
 HBM_PEAK_GBPS = 8000.0
 MFMA_F32_TFLOPS_CHIP = 157.3
@@ -30,18 +35,26 @@ def collect_step(N: int, D: int, step_words: int, env_word: int = 8, rows_per_ac
     finalisation of the previous step), the env step, the VecNormalize partial sums and their fold."""
     n_chunks = -(-N // rows_per_act_wave)
     nblk = -(-N // 8)
+    image = net_param_bytes(D, 4) + 16 + net_param_bytes(D, 1)      # both networks + log_std
+    stats = (4 * D + 8) * 8                                         # mean, var, totals: 4 D + 8 doubles
     it = {
         "env_step (fw_step's words per env-step x N)": step_words * env_word * N,
-        "raw observations read by the policy and the value wave": 2 * N * D * env_word,
+        "raw observations read (the policy and the value wave of a chunk read the same rows: counted once)": N * D * env_word,
         "previous step read by the value waves (reward, two flags)": N * (env_word + 2),
         "rollout-buffer rows written (obs D, action 4, log-prob, value, reward, start: float32)": N * (D + 8) * 4,
         "clipped actions written for the step waves": N * 4 * env_word,
-        "parameter image, once per act wave (policy net / value net; served by the L2)": n_chunks * (net_param_bytes(D, 4) + 16 + net_param_bytes(D, 1)),
-        "statistics read by every act wave (mean, var, totals: 4 D + 8 doubles)": 2 * n_chunks * (4 * D + 8) * 8,
+        "parameter image (policy net, value net, log_std), once": image,
+        "statistics (mean, var, totals), once": stats,
         "partial sums written by the step waves and read by the fold waves": 2 * nblk * (2 * D + 2) * 8,
     }
+    l2 = {
+        "parameter image again by every further act wave (a policy and a value wave per 16-row chunk)": n_chunks * image - image,
+        "statistics again by every further act wave": 2 * n_chunks * stats - stats,
+        "raw observations again by the chunk's second act wave": N * D * env_word,
+    }
     flops = 2 * N * (net_macs_forward(D, 4) + net_macs_forward(D, 1))
-    return {"bytes": sum(it.values()), "items": it, "mfma_flops": flops}
+    return {"bytes": sum(it.values()), "unique_bytes": sum(it.values()), "l2_served_bytes": sum(l2.values()), "items": it,
+            "l2_served_items": l2, "mfma_flops": flops}
 
 
 def collect_close(N: int, D: int, T: int, env_word: int = 8, rows_per_act_wave: int = 16) -> dict:
@@ -50,16 +63,18 @@ def collect_close(N: int, D: int, T: int, env_word: int = 8, rows_per_act_wave: 
         "GAE: values, rewards, episode starts read; advantages, returns written ([T, N] float32)": 5 * T * N * 4,
         "last observation read (raw) and written normalised": N * D * (env_word + 4),
         "last step read (reward, flags), last values / starts / rewards written": N * (env_word + 2 + 12),
-        "parameter image of the value net, once per wave": n_chunks * net_param_bytes(D, 1),
+        "parameter image of the value net, once": net_param_bytes(D, 1),
     }
-    return {"bytes": sum(it.values()), "items": it, "mfma_flops": 2 * N * net_macs_forward(D, 1)}
+    l2 = {"parameter image of the value net again by every further wave": (n_chunks - 1) * net_param_bytes(D, 1)}
+    return {"bytes": sum(it.values()), "unique_bytes": sum(it.values()), "l2_served_bytes": sum(l2.values()), "items": it,
+            "l2_served_items": l2, "mfma_flops": 2 * N * net_macs_forward(D, 1)}
 
 
-def ppo_split(B: int):
+def ppo_split(B: int, max_blocks: int = 8):
     """csrc/fwsim_ppo.hpp ppo_split: (samples per pass, blocks per network) of a B-sample minibatch."""
     def cut(ch):
         c = B // ch
-        return ch, (4 if c >= 4 else 2 if c >= 2 else 1)
+        return ch, (8 if (c >= 8 and max_blocks >= 8) else 4 if c >= 4 else 2 if c >= 2 else 1)
     def cost(s):
         return ((B // s[0] + s[1] - 1) // s[1]) * {64: 10, 32: 6, 16: 4}[s[0]] + (1 if s[1] == 2 else 0)
     best = cut(16)
@@ -91,10 +106,18 @@ def render(N: int, res: int) -> dict:
     return {"bytes": N * 2 * res * res * 4, "items": {"mask + depth, float32 [N, 2, res, res] written": N * 2 * res * res * 4}, "mfma_flops": 0}
 
 
-def roofline_hbm(bytes_per_launch: float, launch_us: float, traffic=None) -> dict:
+def roofline_hbm(bytes_per_launch: float, launch_us: float, traffic=None, l2_served_bytes: float = 0.0) -> dict:
+    """`frac` is priced on the unique bytes only; `l2_inclusive_gbps` (unique + re-reads out of the L2, over the same time) is what
+    the launch moves through its L2 and is not an HBM fraction."""
     ach = bytes_per_launch / (launch_us * 1e-6) / 1e9
-    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": bytes_per_launch, "launch_us": launch_us}
+    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+           "algorithmic_bytes_per_launch": bytes_per_launch, "unique_bytes": bytes_per_launch, "launch_us": launch_us}
+    if l2_served_bytes:
+        out["l2_served_bytes"] = l2_served_bytes
+        out["l2_inclusive_gbps"] = (bytes_per_launch + l2_served_bytes) / (launch_us * 1e-6) / 1e9
+    if traffic:
+        out["traffic_over_algorithmic"] = traffic / bytes_per_launch
+    return out
 
 
 def roofline_mfma(flops_per_launch: float, launch_us: float, peak_tflops: float, traffic=None) -> dict:

@@ -6,7 +6,14 @@ from pyflyt_drone_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, "tools", "_build", "libfwsim_ppoprof.so")
 from pyflyt_drone_amd import rollout as R
 L = _lib.lib()
-for D, B in ((28, 128), (28, 64), (56, 64), (28, 256)):
+CASES = [(28, 128, None), (28, 128, "32x4"), (28, 64, None), (56, 64, None), (28, 256, None), (28, 256, "64x4")]
+if len(sys.argv) > 1:          # "D,B[,CHxN]" ...
+    CASES = [(int(a.split(",")[0]), int(a.split(",")[1]), (a.split(",")[2] if a.count(",") > 1 else None)) for a in sys.argv[1:]]
+for D, B, split in CASES:
+    if split:
+        os.environ["FWSIM_PPO_SPLIT"] = split
+    else:
+        os.environ.pop("FWSIM_PPO_SPLIT", None)
     S, n_mb = 65536, 2000
     P = L.fw_ppo_param_count(D)
     g = torch.Generator(device="cuda"); g.manual_seed(0)
@@ -25,4 +32,4 @@ for D, B in ((28, 128), (28, 64), (56, 64), (28, 256)):
     run(); torch.cuda.synchronize()
     t0 = time.perf_counter(); run(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     l = loss.tolist()
-    print(f"D={D} B={B}: {dt / n_mb * 1e6:.1f} us/minibatch; cycles/minibatch pi: exchange {l[3]:.0f} gather {l[4]:.0f} net {l[5]:.0f} norm+adam {l[6]:.0f} | V: exchange {l[7]:.0f} gather {l[8]:.0f} net {l[9]:.0f} norm+adam {l[10]:.0f} || pi finish: reductions {l[11]:.0f} hand-off {l[12]:.0f} norm {l[13]:.0f} tile Adam {l[14]:.0f} thread Adam (+ weight all-gather) + barrier {l[15]:.0f} || pi hand-off: stores + wait + barrier {l[16]:.0f} flag + next gather {l[17]:.0f} poll (thread 0) {l[18]:.0f} barrier {l[19]:.0f} loads {l[28]:.0f} sums {l[29]:.0f} || pi chunk phases (per minibatch): L1 {l[20]:.0f} L2 {l[21]:.0f} head {l[22]:.0f} dWo {l[23]:.0f} G2 {l[24]:.0f} dW2 {l[25]:.0f} G1 {l[26]:.0f} dW1 {l[27]:.0f}", flush=True)
+    print(f"D={D} B={B} cut={split or 'default'}: {dt / n_mb * 1e6:.2f} us/minibatch; cycles/minibatch pi: exchange {l[3]:.0f} gather {l[4]:.0f} net {l[5]:.0f} norm+adam {l[6]:.0f} | V: exchange {l[7]:.0f} gather {l[8]:.0f} net {l[9]:.0f} norm+adam {l[10]:.0f} || pi finish: reductions {l[11]:.0f} hand-off {l[12]:.0f} norm {l[13]:.0f} tile Adam {l[14]:.0f} thread Adam (+ weight all-gather) + barrier {l[15]:.0f} || pi hand-off: stores + wait + barrier {l[16]:.0f} flag + next gather {l[17]:.0f} poll (thread 0) {l[18]:.0f} barrier {l[19]:.0f} loads {l[28]:.0f} sums {l[29]:.0f} || pi chunk phases (per minibatch): L1 {l[20]:.0f} L2 {l[21]:.0f} head {l[22]:.0f} dWo {l[23]:.0f} G2 {l[24]:.0f} dW2 {l[25]:.0f} G1 {l[26]:.0f} dW1 {l[27]:.0f}", flush=True)

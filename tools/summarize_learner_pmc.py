@@ -111,9 +111,9 @@ for key in sorted(os.listdir(src)):
                     e["roofline"] = A.roofline_mfma(acct["mfma_flops"], e["avg_us"], acct["mfma_peak_tflops"], traffic)
                     e["roofline"]["note"] = "fp32 MFMA peak of the workgroups the sequential dependency lets the update use (one CU each)"
                 else:
-                    e["roofline"] = A.roofline_hbm(acct["bytes"], e["avg_us"], traffic)
+                    e["roofline"] = A.roofline_hbm(acct["bytes"], e["avg_us"], traffic, acct.get("l2_served_bytes", 0.0))
             if traffic is not None and acct["bytes"]:
-                e["traffic_over_algorithmic"] = traffic / acct["bytes"]
+                e["traffic_over_algorithmic"] = traffic / acct["bytes"]      # (>= 1 by construction: `bytes` counts every buffer once)
         if "SQ_WAVE_CYCLES" in mean and mean["SQ_WAVE_CYCLES"] > 0:
             wc = mean["SQ_WAVE_CYCLES"]
             e["fractions_of_wave_cycles"] = {c: mean[c] / wc for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
