@@ -1926,7 +1926,7 @@ static long long spin_budget(long long dflt) {
 // workspace layout of fw_ppo_update: [0, kPpoWords x 8) exchange words (kPpoWordPaths: which exchanges shared an L2, kPpoWordStatus: include/fwsim.h) |
 // gradient hand-off buffer | the packed rows of every minibatch, in walking order (fw_ppo_pack_kernel)
 static constexpr size_t kPpoWsXch = kPpoWords * sizeof(unsigned long long);
-static constexpr size_t kPpoWsGx = sizeof(float) * (4 * kPMaxSplit * (size_t)kPGxSlots + kPWxFloats);      // gradient partials, then the weight quarters
+static constexpr size_t kPpoWsGx = sizeof(float) * (4 * kPMaxSplit * (size_t)kPGxSlots);      // [parity][net][part]: gradient partial + weight share
 int64_t fw_ppo_update_workspace_bytes(int32_t n_minibatches, int32_t batch_size, int32_t obs_dim) {
   if (n_minibatches <= 0 || batch_size <= 0 || obs_dim <= 0 || obs_dim > 64) return FW_EINVAL;
   return (int64_t)(kPpoWsXch + kPpoWsGx + sizeof(float) * (size_t)n_minibatches * (size_t)batch_size * (size_t)ppo_pack_width(obs_dim));
@@ -1960,7 +1960,6 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   PpoArgs A;
   A.params = params; A.mom_m = mom_m; A.mom_v = mom_v; A.packed = packed;
   A.n_mb = n_minibatches; A.B = batch_size; A.D = obs_dim; A.loss_acc = loss_acc; A.xch = xch; A.gx = gx;
-  A.wx = gx + 4 * kPMaxSplit * (size_t)kPGxSlots;
   A.spin = spin_budget(kPpoSpin);
   A.flags = 0;
   if (const char* e = getenv("FWSIM_PPO_NO_L2_SWAP")) if (atoi(e) != 0) A.flags |= PPO_FLAG_NO_L2_SWAP;

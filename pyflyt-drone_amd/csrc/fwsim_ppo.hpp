@@ -191,7 +191,14 @@ __host__ __device__ inline int ppo_tile_slot(int net, int kind, int wave, int la
 // per lane, each request would touch 64 lines for 16 bytes apiece) -- then the five per-thread elements [5][256].
 // Per-thread elements behind the tiles: [t < 64][gb1, gb2, gbo, gls] as one float4 per thread of the first wave, then gwo[256].
 constexpr int kPGxTile = 2 * 4 * 4 * 64 * 4;
-constexpr int kPGxSlots = kPGxTile + 2 * kPThreads;
+// ... and then the block's share of the UPDATED WEIGHTS in the reduce-scatter form, for the others to fetch ([set][wave][lane][4]; of the
+// four regions [parity][net] a block has, the one of parity 0 carries it).  In the block's own region, ~43 KB from the next block's:
+// kept as one dense [net][part] array of 8-KB shares (round 5, first version) every block of the call fetched its 7 shares from the
+// same 64 KB and the fetch of sixteen blocks took 3.5 k cycles where that of eight takes 1.4 k -- whatever serves those addresses
+// (L2 channel, fabric) is selected at a granularity that coarse; the gradient partials, a region apart, showed the same once all
+// blocks walked them in the same order.
+constexpr int kPWxShare = 2 * kPThreads * 4;
+constexpr int kPGxSlots = kPGxTile + 2 * kPThreads + kPWxShare;
 __host__ __device__ inline int ppo_gx_tile(int kind, int wave, int lane) { return (kind * 4 + wave) * 4 * 256 + lane * 4; }      // + q * 256
 
 // flat parameter index of every moment slot (-1 = padding); host side of the layout above
@@ -317,7 +324,6 @@ struct PpoArgs {
   unsigned long long* xch;           // [kPpoWords] exchange words (norm partials [parity][net][part], gradient flags + kPpoWordFlags, XCD ids of
                                      //      the blocks [net][part] + kPpoWordIds, kPpoWordPaths, kPpoWordStatus), zeroed by the host
   float* gx;                         // [2 parities][2 nets][kPMaxSplit parts][kPGxSlots] gradient partials of the blocks of a network
-  float* wx;                         // [kPWxFloats] updated weight quarters (reduce-scatter form)
   long long spin;                    // polls a wait for another block may take (kPpoSpin; FWSIM_SPIN_LOG2 shrinks it: tests provoke the timeout)
   int32_t flags;                     // PPO_FLAG_*
 };
@@ -333,10 +339,9 @@ constexpr int kPpoWordLoss = kPpoWordStatus + 1;     // [net][part]: the blocks'
 constexpr int kPpoWordDone = kPpoWordLoss + 2 * kPMaxSplit;      // how many blocks have finished
 constexpr int kPpoWordArrive = kPpoWordDone + 1;     // how many blocks got through their last minibatch with every wait answered
 constexpr int kPpoWordVerdict = kPpoWordArrive + 1;  // written once, by the last arriver: 1 = every block writes its results back, 2 = nobody does
-constexpr int kPpoWordFlags2 = 13 * kPMaxSplit, kPpoWords = kPpoWordFlags2 + 4 * kPMaxSplit;      // flags of the weight all-gather [parity][net][part] (reduce-scatter form)
+constexpr int kPpoWordFlags2 = 13 * kPMaxSplit;      // flags of the weight all-gather [parity][net][part] (reduce-scatter form)
+constexpr int kPpoWords = kPpoWordFlags2 + 4 * kPMaxSplit;
 static_assert(kPpoWordIds + 2 * kPMaxSplit <= kPpoWordPaths && kPpoWordVerdict < kPpoWordFlags2, "exchange-word layout");
-// The updated weights a block owns in the reduce-scatter form, for the others to fetch: [net][part][kind W2 | W1][wave][lane][16 / NS]
-constexpr int kPWxFloats = 2 * 2 * 4 * 64 * 16;
 enum { PPO_ST_IDS = 1, PPO_ST_SWAP = 2, PPO_ST_NORM = 4, PPO_ST_COMMIT = 8 };
 
 // Bounded wait of one thread for a word another block publishes.  `done(word)` ends it; every 256 polls it also looks at the
@@ -357,27 +362,29 @@ __device__ __forceinline__ bool ppo_wait(const PpoArgs& A, LOAD&& load, DONE&& d
 // CH = samples per pass through the network (64: 2 x 2 tiles of 32 x 32 per product; 32 / 16: 2 / 1 x 4 tiles of 16 x 16, see ppo_mfma16_rows);
 // part / nsplit: this block's place among the blocks of its network (chunk c of a minibatch is run by block c % nsplit).
 // NS = 0: the (1, 2 or 4) blocks of a network swap whole partials all to all.  NS = 4 / 8 (then nsplit == NS): the gradient swap is a
-// REDUCE-SCATTER -- block q fetches, of every block's partial, only 1 / NS of the tile elements (those of wave q * 4 / NS's tiles: a
-// quarter, or half of one), sums them, takes its share of the clipping norm from them and applies Adam to that share alone --
-// followed by an ALL-GATHER of the updated WEIGHTS.  A block then pulls ~one partial + the weights past its L1 per minibatch, whatever
-// NS is, instead of NS - 1 partials (that path runs at ~20 B / clk: the swap was 9.4 k of the minibatch's 28.1 k cycles with four
-// blocks) and does 1 / NS of the tile Adam, for one more latency round.  Thread (wave w, lane l) of block q owns elements 4 w + sub ..
-// 4 w + sub + 16 / NS - 1 of lane l of wave (q * 4 / NS)'s W2 and W1 tiles (sub = 0, or 0 / 2 by the parity of q with eight blocks).
+// REDUCE-SCATTER -- block q fetches, of every block's partial, only 1 / NS of the tile elements, sums them, takes its share of the
+// clipping norm from them and applies Adam to that share alone -- followed by an ALL-GATHER of the updated WEIGHTS.  A block then pulls
+// ~one partial + the weights past its L1 per minibatch, whatever NS is, instead of NS - 1 partials, and does 1 / NS of the tile Adam,
+// for one more latency round.  What a block owns are the tiles of wave tq = q * 4 / NS (W2's and W1's), and of them
+//   four blocks:  everything -- thread (wave w, lane l) owns elements 4 w .. 4 w + 3 of lane l of BOTH tiles (two "sets");
+//   eight blocks: half -- quarters 2 (q & 1), 2 (q & 1) + 1 of the lanes' 16 elements; waves 0, 1 take those quarters of the W2 tile, waves
+//                 2, 3 the same quarters of the W1 tile (one set per thread).
+// Either way a thread's set is 4 consecutive floats of a lane: every exchange access is 16 bytes per lane.  That is what counts:
+// tools/microbench_sc1.hip -- the CU's address unit takes 16 cycles per wave-level 8- or 16-byte load (4 for a 4-byte one), all four
+// waves in turn, 220 + 64 N cycles for N such loads per wave -- so the cost of an exchange is its INSTRUCTION count, not its lines.
 // Eight blocks (round 5): a 128-sample minibatch is 8 x 16 samples -- the chunk pass, which scales with the samples of a block, falls
-// from 11.4 k to 7.3 k cycles while the exchange volume per block stays what it was.
-// EPT floats from a raw buffer, past the L1 (sc1)
-template <int E> __device__ __forceinline__ void ppo_ld_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off, float (&out)[E]) {
-  static_assert(E == 4 || E == 2, "16 or 8 bytes");
+// from 11.4 k to 7.3 k cycles.
+// four floats from a raw buffer, past the L1 (sc1)
+__device__ __forceinline__ void ppo_ld_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off, float (&out)[4]) {
   typedef unsigned int ppo_u4 __attribute__((ext_vector_type(4)));
-  typedef unsigned int ppo_u2 __attribute__((ext_vector_type(2)));
-  if constexpr (E == 4) {
-    const ppo_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);
+  const ppo_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) out[e] = __uint_as_float(a[e]);
-  } else {
-    const ppo_u2 a = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 16);
-    out[0] = __uint_as_float(a[0]); out[1] = __uint_as_float(a[1]);
-  }
+  for (int e = 0; e < 4; ++e) out[e] = __uint_as_float(a[e]);
+}
+// A wave's 32 x 32 gradient tile to the exchange buffer (dst = the tile's base): quarter q of a lane's 16 elements at [q][lane][4]
+__device__ __forceinline__ void ppo_store_tile(float* dst, int lane, const f32x16& g) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst + q * 256 + lane * 4) = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
 }
 // sum of v[0 .. N) as a balanced tree over the index order: the same bits in every block, whoever's own partial sits where
 template <int N> __device__ __forceinline__ float ppo_tree_sum(const float (&v)[N]) {
@@ -391,7 +398,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   static_assert(NS == 0 || NS == 4 || NS == 8, "blocks per network in the reduce-scatter form");
   constexpr bool RS = NS != 0;
   constexpr int NSd = RS ? NS : 4;                     // (array extents; the divisor where NS may be 0)
-  constexpr int EPT = 16 / NSd;                        // tile elements per thread and kind a block owns (RS)
+  constexpr int NSETS = NS == 8 ? 1 : 2;               // RS: sets of 4 tile elements a thread owns (see above)
   static_assert(CH == 64 || CH == 32 || CH == 16, "chunk size");
   constexpr int RT = CH == 64 ? 1 : CH / 16;     // row tiles of 16 in the 16 x 16 forms
   constexpr int n = NET, KO = NET == 0 ? 4 : 1;
@@ -492,6 +499,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   const float invB = 1.0f / (float)B;
 #ifdef FW_PPO_PROF
   long long pf_stats = 0, pf_gather = 0, pf_net = 0, pf_adam = 0, pf_xch = 0, pf_red = 0, pf_ho = 0, pf_norm = 0, pf_tile = 0, pf_scal = 0;
+  long long pf_a[4] = {0, 0, 0, 0};            // the closing section: thread Adam, wait for the partners' weights, their fetch + LDS writes, closing barrier
   long long pf_g[4] = {0, 0, 0, 0}, pf_n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_h[6] = {0, 0, 0, 0, 0, 0};      // pf_h: the hand-off, piece by piece      // gather: barrier, commit, prefetch issue, barrier; the phases of the chunk pass
 #define PPO_T() ((long long)__builtin_readcyclecounter())
 #endif
@@ -542,18 +550,27 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   // took 2.2 k cycles) -- because 472 registers left no room; the leaner gather and dW1 of round 4 did.  Both chunk halves apply
   // the same update to the same initial values; part 0 writes the result back at the end.
   float4 pm[2][4], pv[2][4];
-  float rm[2][EPT], rv[2][EPT];                     // RS: the moments of the EPT + EPT elements this thread owns (W2, W1)
-  const int tq = RS ? part * 4 / NSd : 0;           // RS: the wave whose tiles this block reduces ...
-  const int sub = RS ? (part % (NSd / 4)) * EPT : 0;      // ... and where its elements start inside the quarter (4 w ..) a thread handles
-  const bool ownW1 = RS && tq < tilesW1;
-  const int rs_row = (tq >> 1) * 32 + wave * 8 + hh * 4 + sub, rs_col = (tq & 1) * 32 + r;      // RS: element e of mine is W[rs_row + e][rs_col]
-  const int rs_s0 = ppo_tile_slot(n, 0, tq, lane) + 4 * wave + sub, rs_s1 = ppo_tile_slot(n, 1, tq, lane) + 4 * wave + sub;      // ... and moment slot rs_s + e
+  // RS: what this thread owns -- set s_ = elements set_row .. + 3 of column set_col of W2 (kind 0) or W1 (kind 1), moments at set_slot ..
+  float rm[NSETS][4], rv[NSETS][4];
+  const int tq = RS ? part * 4 / NSd : 0;           // the wave whose tiles this block reduces
+  int set_kind[NSETS], set_q[NSETS], set_slot[NSETS], set_row[NSETS];
+  bool set_own[NSETS];
+  const int set_col = (tq & 1) * 32 + r;
+#pragma unroll
+  for (int s_ = 0; s_ < NSETS; ++s_) {
+    set_kind[s_] = NS == 8 ? wave >> 1 : s_;
+    set_q[s_] = NS == 8 ? 2 * (part & 1) + (wave & 1) : wave;
+    set_own[s_] = RS && (set_kind[s_] == 0 || tq < tilesW1);
+    set_slot[s_] = ppo_tile_slot(n, set_kind[s_], tq, lane) + 4 * set_q[s_];
+    set_row[s_] = (tq >> 1) * 32 + set_q[s_] * 8 + hh * 4;
+  }
   if constexpr (RS) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      rm[0][e] = mom_m[rs_s0 + e]; rv[0][e] = mom_v[rs_s0 + e];
-      rm[1][e] = ownW1 ? mom_m[rs_s1 + e] : 0.f; rv[1][e] = ownW1 ? mom_v[rs_s1 + e] : 0.f;
-    }
+    for (int s_ = 0; s_ < NSETS; ++s_)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        rm[s_][e] = set_own[s_] ? mom_m[set_slot[s_] + e] : 0.f; rv[s_][e] = set_own[s_] ? mom_v[set_slot[s_] + e] : 0.f;
+      }
   } else {
     const int s0 = ppo_tile_slot(n, 0, wave, lane), s1 = ppo_tile_slot(n, 1, wave, lane);
 #pragma unroll
@@ -917,9 +934,11 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     const long long pfa = PPO_T(); pf_red += pfa - pf3;
 #endif
     // ---- swap gradient partials with the other blocks of this network (all to all, or tiles by reduce-scatter), keep the sum ----
-    float g2q[EPT], g1q[EPT];                           // RS: the summed gradient of the EPT + EPT tile elements this thread owns
+    float gq[NSETS][4];                                 // RS: the summed gradient of the tile elements this thread owns
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) { g2q[e] = 0.f; g1q[e] = 0.f; }
+    for (int s_ = 0; s_ < NSETS; ++s_)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gq[s_][e] = 0.f;
     if (nsplit > 1) {
       float* gxb = A.gx + (size_t)((mb & 1) * 2 + NET) * kPMaxSplit * kPGxSlots;
       float* mine = gxb + (size_t)part * kPGxSlots;
@@ -932,11 +951,12 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       // partials stored before the bias reductions (the wait moves, 8.7 k -> 7.9 k for the pair of sections), a register copy of the
       // lane's own weights so that Adam needs no LDS read (tile Adam 5.5 k -> 5.1 k, the chunk pass +1 k: 32 more live registers).)
       const int sq4 = kPGxTile + 4 * t, sqo = kPGxTile + kPThreads + t;      // per-thread elements: {gb1, gb2, gbo, gls} of thread t < 64; gwo of thread t
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<float4*>(mine + g0 + q * 256) = make_float4(gW2[4 * q], gW2[4 * q + 1], gW2[4 * q + 2], gW2[4 * q + 3]);
-        if (hasW1) *reinterpret_cast<float4*>(mine + g1 + q * 256) = make_float4(gW1[4 * q], gW1[4 * q + 1], gW1[4 * q + 2], gW1[4 * q + 3]);
-      }
+      typedef unsigned int ppo_u4 __attribute__((ext_vector_type(4)));
+      typedef float ppo_f4 __attribute__((ext_vector_type(4)));
+      float qs[NSETS][NSd][4];                     // RS: my sets in every block's partial, in block order
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gxb, 0, kPMaxSplit * kPGxSlots * (int)sizeof(float), 0x00020000);
+      ppo_store_tile(mine + ppo_gx_tile(0, wave, 0), lane, gW2);
+      if (hasW1) ppo_store_tile(mine + ppo_gx_tile(1, wave, 0), lane, gW1);
       // (per-thread elements: Wo's by every thread, the biases / log_std -- one float4 -- by threads of the first wave only)
       mine[sqo] = my_gwo;
       if (wave == 0) *reinterpret_cast<float4*>(mine + sq4) = make_float4(gb1, gb2, my_gbo, my_gls);
@@ -982,24 +1002,23 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       // the builtin takes the cache policy, so the compiler schedules and waits for them itself.  (Round 3 / 4 had them as inline
       // assembly with a hand-placed wait; the compiler, not knowing that they were loads, put waits for older operations between
       // them, which -- the counter retires in order -- serialised the partners: 4.3 k cycles for 39 loads.)
-      typedef unsigned int ppo_u4 __attribute__((ext_vector_type(4)));
-      typedef float ppo_f4 __attribute__((ext_vector_type(4)));
       ppo_f4 ta[3][4], tb[3][4];                   // all-to-all form: partner j of 1 (2 blocks) or 3 (4 blocks) = the other blocks in ascending order
-      float qa[NSd][EPT], qb[NSd][EPT];            // RS: my elements of wave `tq`'s W2 / W1 tiles in every block's partial, in block order
       float vs[5][NSd];                            // per-thread elements {gb1, gb2, gbo, gls, gwo} of every block, in block order (own ones in slot `part`)
       const int np = nsplit - 1;
       if (!same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gxb, 0, kPMaxSplit * kPGxSlots * (int)sizeof(float), 0x00020000);
       constexpr int kSc1 = 16;                     // cache-policy bit of the raw buffer loads
       if constexpr (RS) {
-        const int o0 = (ppo_gx_tile(0, tq, lane) + wave * 256 + sub) * 4, o1 = (ppo_gx_tile(1, tq, lane) + wave * 256 + sub) * 4;
 #pragma unroll
-        for (int b_ = 0; b_ < NS; ++b_) {          // (own partial included: it comes back from the L2 my stores went to)
-          ppo_ld_sc1<EPT>(rs, b_ * kPGxSlots * (int)sizeof(float) + o0, qa[b_]);
-          if (ownW1) ppo_ld_sc1<EPT>(rs, b_ * kPGxSlots * (int)sizeof(float) + o1, qb[b_]);
-          else {
+        for (int s_ = 0; s_ < NSETS; ++s_) {
+          const int o = (ppo_gx_tile(set_kind[s_], tq, lane) + set_q[s_] * 256) * (int)sizeof(float);
+          if (set_own[s_]) {                       // (ONE branch around all the loads of a set, never one per load: see the note below)
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) qb[b_][e] = 0.f;
+            for (int b_ = 0; b_ < NS; ++b_) ppo_ld_sc1(rs, (b_ ^ part) * kPGxSlots * (int)sizeof(float) + o, qs[s_][b_]);      // (own partial included: it comes back from the L2 my stores went to)
+          } else {
+#pragma unroll
+            for (int b_ = 0; b_ < NS; ++b_)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) qs[s_][b_][e] = 0.f;
           }
         }
       } else {
@@ -1019,19 +1038,38 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
           }
         }
       }
-      // per-thread elements, all to all in both forms: the first wave one float4 per partner, every wave Wo's word
+      // per-thread elements, all to all in both forms: Wo's word of every thread and, for the first wave, one float4 {gb1, gb2, gbo, gls}
+      // per block.  No load sits in a branch of its own (own slot and slots past nsplit included: they are inside the buffer and merely
+      // not used) and the choice is a select afterwards: a load inside a branch on `part` makes the compiler wait for it at the join,
+      // one L2 round trip after the other (measured: loads 3.0 k -> 4.3 k cycles with four blocks, 6.7 k with eight).
+      ppo_u4 va[NSd];
+      unsigned vo[NSd];
 #pragma unroll
-      for (int b_ = 0; b_ < NSd; ++b_) {
-        const int base = b_ * kPGxSlots * (int)sizeof(float);
-        const bool other = b_ < nsplit && b_ != part;
-        if (other && wave == 0) {
-          const ppo_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, base + sq4 * 4, 0, kSc1);
-          vs[0][b_] = __uint_as_float(a[0]); vs[1][b_] = __uint_as_float(a[1]); vs[2][b_] = __uint_as_float(a[2]); vs[3][b_] = __uint_as_float(a[3]);
-        } else { vs[0][b_] = 0.f; vs[1][b_] = 0.f; vs[2][b_] = 0.f; vs[3][b_] = 0.f; }
-        vs[4][b_] = other ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, base + sqo * 4, 0, kSc1)) : 0.f;
-        if (b_ == part) { vs[0][b_] = gb1; vs[1][b_] = gb2; vs[2][b_] = my_gbo; vs[3][b_] = my_gls; vs[4][b_] = my_gwo; }
+      for (int b_ = 0; b_ < NSd; ++b_) vo[b_] = __builtin_amdgcn_raw_buffer_load_b32(rs, (b_ ^ part) * kPGxSlots * (int)sizeof(float) + sqo * 4, 0, kSc1);      // ALL the loads first ...
+      if (wave == 0) {                             // (one branch, the last loads of the section: the wait at its join is the wait for everything anyway)
+#pragma unroll
+        for (int b_ = 0; b_ < NSd; ++b_) va[b_] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b_ ^ part) * kPGxSlots * (int)sizeof(float) + sq4 * 4, 0, kSc1);
+      } else {
+#pragma unroll
+        for (int b_ = 0; b_ < NSd; ++b_) va[b_] = ppo_u4{0u, 0u, 0u, 0u};
+      }
+      // (... the selects behind them: with a select next to its load the compiler emitted load, wait, select per block -- eight round
+      // trips in a row, most of the 4.5 k cycles this section took)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b_ = 0; b_ < NSd; ++b_) {           // slot b_ = block b_ ^ part (slot 0: my own, from registers; blocks past nsplit: nothing)
+        const bool other = b_ != 0 && (b_ ^ part) < nsplit;
+        vs[0][b_] = b_ == 0 ? gb1 : other ? __uint_as_float(va[b_][0]) : 0.f;
+        vs[1][b_] = b_ == 0 ? gb2 : other ? __uint_as_float(va[b_][1]) : 0.f;
+        vs[2][b_] = b_ == 0 ? my_gbo : other ? __uint_as_float(va[b_][2]) : 0.f;
+        vs[3][b_] = b_ == 0 ? my_gls : other ? __uint_as_float(va[b_][3]) : 0.f;
+        vs[4][b_] = b_ == 0 ? my_gwo : other ? __uint_as_float(vo[b_]) : 0.f;
       }
       PPO_HO(4);
+      // WHICH block's partial a slot holds: slot i = block i ^ part.  At every step of the fetch the blocks of a network are then at
+      // DIFFERENT partials (round 5: all of them walking 0, 1, 2 .. together queued at whatever part of the L2 holds that partial -- the
+      // fetch of eight blocks took twice that of four for 1.3 x the instructions).  The sum does not notice: an XOR of the leaf index
+      // swaps the two children of some nodes of a balanced tree, and fp addition commutes.
       // Every block must end up with the same bits: the partials p0 .. are summed as a balanced tree over the block order everywhere --
       // (p0 + p1) + (p2 + p3) with four, ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)) with eight (own partial in registers, the
       // others as loaded; fp addition commutes).  Two blocks: own + partner.
@@ -1045,12 +1083,14 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       };
       if constexpr (RS) {
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-          float c2[NSd], c1[NSd];
+        for (int s_ = 0; s_ < NSETS; ++s_)
 #pragma unroll
-          for (int b_ = 0; b_ < NSd; ++b_) { c2[b_] = qa[b_][e]; c1[b_] = qb[b_][e]; }
-          g2q[e] = ppo_tree_sum<NSd>(c2); g1q[e] = ppo_tree_sum<NSd>(c1);
-        }
+          for (int e = 0; e < 4; ++e) {
+            float c[NSd];
+#pragma unroll
+            for (int b_ = 0; b_ < NSd; ++b_) c[b_] = qs[s_][b_][e];
+            gq[s_][e] = ppo_tree_sum<NSd>(c);
+          }
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1080,10 +1120,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
     float ss = 0.f;
     if constexpr (RS) {                                   // my share of the tiles; the per-thread elements (every block holds their sums) count once
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        ss += g2q[e] * g2q[e];
-        if (ownW1 && rs_row + e < D) ss += g1q[e] * g1q[e];
-      }
+      for (int s_ = 0; s_ < NSETS; ++s_)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (set_own[s_] && (set_kind[s_] == 0 || set_row[s_] + e < D)) ss += gq[s_][e] * gq[s_][e];
     } else {
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
@@ -1173,39 +1213,38 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #pragma unroll
       for (int v = 0; v < 16; ++v) *lds_of(v) = wv[v] - upd[v];
     };
-    float* const wxn = A.wx + (size_t)NET * (kPWxFloats / 2);                           // (RS) this network's weight shares: [part][kind][wave * 64 + lane][EPT]
+    float* const wxn = A.gx + (size_t)NET * kPMaxSplit * kPGxSlots + (kPGxTile + 2 * kPThreads);      // (RS) this network's weight shares: part p's at + p * kPGxSlots, [set][wave * 64 + lane][4]
     unsigned long long* const fl2 = A.xch + kPpoWordFlags2 + ((mb & 1) * 2 + NET) * kPMaxSplit;
     if constexpr (RS) {
-      // Adam on the share this block owns: EPT + EPT elements per thread; the new weights go to this block's LDS image and to the exchange
+      // Adam on the share this block owns: 4 elements per set; the new weights go to this block's LDS image and to the exchange
       // buffer, from where the other blocks fetch them below (they hold the same old weights, so the copies stay the same bits)
-      auto adamE = [&](const float (&g)[EPT], float (&mm)[EPT], float (&vv)[EPT], float (&wv)[EPT]) {
+      float* wp[NSETS][4];
+      float wv[NSETS][4];
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-          const float gg = g[e] * clipc;
-          const float mn = H.beta1 * mm[e] + (1.0f - H.beta1) * gg, vn = H.beta2 * vv[e] + (1.0f - H.beta2) * (gg * gg);
-          mm[e] = mn; vv[e] = vn;
-          wv[e] -= (mn * c1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vn) * sc2 + H.eps);
+      for (int s_ = 0; s_ < NSETS; ++s_)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = set_row[s_] + e;
+          wp[s_][e] = !set_own[s_] ? sink + t : set_kind[s_] == 0 ? W.W2 + row * kPLdh + set_col : row < D ? W.W1 + row * ldw1 + set_col : sink + t;
+          wv[s_][e] = *wp[s_][e];
         }
-      };
-      float* w2p = W.W2 + rs_row * kPLdh + rs_col;
-      float* w1p[EPT];
-      float wv2[EPT], wv1[EPT];
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        w1p[e] = (ownW1 && rs_row + e < D) ? W.W1 + (rs_row + e) * ldw1 + rs_col : sink + t;
-        wv2[e] = w2p[e * kPLdh]; wv1[e] = *w1p[e];
+      for (int s_ = 0; s_ < NSETS; ++s_) {
+        if (set_own[s_]) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float gg = gq[s_][e] * clipc;
+            const float mn = H.beta1 * rm[s_][e] + (1.0f - H.beta1) * gg, vn = H.beta2 * rv[s_][e] + (1.0f - H.beta2) * (gg * gg);
+            rm[s_][e] = mn; rv[s_][e] = vn;
+            wv[s_][e] -= (mn * c1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vn) * sc2 + H.eps);
+          }
+        }
       }
-      adamE(g2q, rm[0], rv[0], wv2);
-      if (ownW1) adamE(g1q, rm[1], rv[1], wv1);
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) { w2p[e * kPLdh] = wv2[e]; *w1p[e] = wv1[e]; }
-      float* mine_w = wxn + (size_t)(part * 2) * (kPThreads * EPT) + (wave * 64 + lane) * EPT;
-      if constexpr (EPT == 4) {
-        *reinterpret_cast<float4*>(mine_w) = make_float4(wv2[0], wv2[1], wv2[2], wv2[3]);
-        if (ownW1) *reinterpret_cast<float4*>(mine_w + kPThreads * EPT) = make_float4(wv1[0], wv1[1], wv1[2], wv1[3]);
-      } else {
-        *reinterpret_cast<float2*>(mine_w) = make_float2(wv2[0], wv2[1]);
-        if (ownW1) *reinterpret_cast<float2*>(mine_w + kPThreads * EPT) = make_float2(wv1[0], wv1[1]);
+      for (int s_ = 0; s_ < NSETS; ++s_) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *wp[s_][e] = wv[s_][e];
+        if (set_own[s_]) *reinterpret_cast<float4*>(wxn + (size_t)part * kPGxSlots + (s_ * kPThreads + t) * 4) = make_float4(wv[s_][0], wv[s_][1], wv[s_][2], wv[s_][3]);
       }
       if (same_xcd) __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), as for the partials
       else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1235,6 +1274,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #pragma unroll
       for (int q = 0; q < NQ; ++q) if (ws[q]) *ws[q] -= c1 * smm[q] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(svv[q]) * sc2 + H.eps);
     }
+#ifdef FW_PPO_PROF
+    const long long pa1 = PPO_T(); pf_a[0] += pa1 - pfd;
+    long long pa3 = pa1;
+#endif
     if constexpr (RS) {
       // ---- all-gather of the updated weights: the other NS - 1 shares, from the blocks that own them ----
       if (t < nsplit && t != part) {
@@ -1244,35 +1287,48 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       }
       __syncthreads();
       if (red[7] != 0.f) { dead = true; break; }
+#ifdef FW_PPO_PROF
+      const long long pa2 = PPO_T(); pf_a[1] += pa2 - pa1;
+#endif
       if (!same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(wxn, 0, (kPWxFloats / 2) * (int)sizeof(float), 0x00020000);
-      float wa[NS - 1][EPT], wb[NS - 1][EPT];
+      const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(wxn, 0, kPMaxSplit * kPGxSlots * (int)sizeof(float), 0x00020000);
+      float wg[NS - 1][NSETS][4];
+      // (every load unconditional -- a share of W1 nobody owns is read and not used: loads inside branches wait one by one at the joins)
 #pragma unroll
       for (int j = 0; j < NS - 1; ++j) {
-        const int pj = j < part ? j : j + 1;
-        const int o = ((pj * 2) * (kPThreads * EPT) + (wave * 64 + lane) * EPT) * (int)sizeof(float);
-        ppo_ld_sc1<EPT>(rsw, o, wa[j]);
-        if (pj * 4 / NS < tilesW1) ppo_ld_sc1<EPT>(rsw, o + kPThreads * EPT * (int)sizeof(float), wb[j]);
-        else {
+        const int pj = (j + 1) ^ part;             // (every block at a different partner at every step, as in the reduce-scatter)
 #pragma unroll
-          for (int e = 0; e < EPT; ++e) wb[j][e] = 0.f;
-        }
+        for (int s_ = 0; s_ < NSETS; ++s_) ppo_ld_sc1(rsw, (int)((pj * kPGxSlots + (s_ * kPThreads + t) * 4) * sizeof(float)), wg[j][s_]);
       }
+      // partner thread (w, l) of block pj wrote what its sets are: the same wave and lane as mine, block pj's tiles and quarters.
+      // Branch-free: every element is stored, to its place or -- rows W1 does not have, W1 tiles nobody owns -- to this thread's sink
+      // word.  (Written as `if (kind == 0) W2[..] = x; else if (row < D) W1[..] = x;` the eight-block form, whose `kind` is a run-time
+      // scalar, compiled into a branch, an exec mask and two spilled-SGPR reloads PER ELEMENT: 1.5 k cycles for 28 LDS writes.)
 #pragma unroll
       for (int j = 0; j < NS - 1; ++j) {
-        const int pj = j < part ? j : j + 1;
-        const int tj = pj * 4 / NS, sj = (pj % (NS / 4)) * EPT;
-        const int row = (tj >> 1) * 32 + wave * 8 + hh * 4 + sj, col = (tj & 1) * 32 + r;
+        const int pj = (j + 1) ^ part;
+        const int tj = pj * 4 / NS, col = (tj & 1) * 32 + r;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-          W.W2[(row + e) * kPLdh + col] = wa[j][e];
-          if (tj < tilesW1 && row + e < D) W.W1[(row + e) * ldw1 + col] = wb[j][e];
+        for (int s_ = 0; s_ < NSETS; ++s_) {
+          const int kind = NS == 8 ? wave >> 1 : s_, qj = NS == 8 ? 2 * (pj & 1) + (wave & 1) : wave;
+          const int row = (tj >> 1) * 32 + qj * 8 + hh * 4;
+          const int ld = kind == 0 ? kPLdh : ldw1;
+          float* const base = (kind == 0 ? W.W2 : W.W1) + row * ld + col;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = kind == 0 || (tj < tilesW1 && row + e < D);
+            float* const d = ok ? base + e * ld : sink + t;
+            *d = wg[j][s_][e];
+          }
         }
       }
     }
+#ifdef FW_PPO_PROF
+    if constexpr (RS) { pa3 = PPO_T(); pf_a[2] += pa3 - pa1 - 0; }      // (from the end of the thread Adam: wait + fetch + LDS writes)
+#endif
     __syncthreads();
 #ifdef FW_PPO_PROF
-    { const long long pfe = PPO_T(); pf_adam += pfe - pf3; pf_scal += pfe - pfd; }
+    { const long long pfe = PPO_T(); pf_adam += pfe - pf3; pf_scal += pfe - pfd; pf_a[3] += pfe - pa3; }
 #endif
   }
 
@@ -1302,10 +1358,11 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   if (red[6] == 0.f) return;
   if constexpr (RS) {                               // the tile moments: every block its share
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      mom_m[rs_s0 + e] = rm[0][e]; mom_v[rs_s0 + e] = rv[0][e];
-      if (ownW1) { mom_m[rs_s1 + e] = rm[1][e]; mom_v[rs_s1 + e] = rv[1][e]; }
-    }
+    for (int s_ = 0; s_ < NSETS; ++s_)
+      if (set_own[s_]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { mom_m[set_slot[s_] + e] = rm[s_][e]; mom_v[set_slot[s_] + e] = rv[s_][e]; }
+      }
   }
   if (part == ((A.flags & PPO_FLAG_WRITER_LAST) ? nsplit - 1 : 0)) {
     {
@@ -1353,6 +1410,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       for (int i = 0; i < 4; ++i) A.loss_acc[16 + i] = (float)pf_h[i] / n_mb;      // (the profiling tool hands a 32-float buffer)
       A.loss_acc[28] = (float)pf_h[4] / n_mb; A.loss_acc[29] = (float)pf_h[5] / n_mb; (void)pf_g;
       for (int i = 0; i < 8; ++i) A.loss_acc[20 + i] = (float)pf_n[i] / n_mb;
+      for (int i = 0; i < 4; ++i) A.loss_acc[30 + i] = (float)pf_a[i] / n_mb;      // (the profiling tool hands a 40-float buffer)
     }
 #endif
   }

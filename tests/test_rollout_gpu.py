@@ -233,10 +233,11 @@ def test_edits_of_module_or_optimiser_between_two_updates_are_seen_by_the_fused_
         assert float(sa["step"]) == float(sb["step"])
         torch.testing.assert_close(sa["exp_avg"], sb["exp_avg"], rtol=5e-3, atol=1e-6)
         torch.testing.assert_close(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=5e-3, atol=1e-9)
-    # ... and an untouched object still reuses its images (no reload: the staging copies are not rewritten)
-    a._fused.m.fill_(float("nan"))
+    # ... and an untouched object still reuses its images: no reload from the module / optimiser
+    reloads, load = [], a._fused.load_from_torch
+    a._fused.load_from_torch = lambda: reloads.append(1) or load()
     a.train()
-    assert torch.isnan(a._fused.m).all() and all(torch.isfinite(p).all() for p in a.policy.parameters())
+    assert not reloads and all(torch.isfinite(p).all() for p in a.policy.parameters())
 
 
 @pytest.mark.parametrize("edit", ["param_add", "policy_load_state_dict"])
