@@ -600,6 +600,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #ifdef FW_PPO_PROF
     pf_stats += PPO_T() - pf0;
 #endif
+    // (policy head: log_std and 1 / sigma^2 of the action component this lane takes -- they only change with the Adam step)
+    const float ls_c = NET == 0 ? log_std[(t % HSL) & 3] : 0.f;
+    const float iv_c = NET == 0 ? expf(-2.0f * ls_c) : 0.f;
     // gradient accumulators of this minibatch (registers)
     f32x16 gW2, gW1;
     float gb1p = 0.f, gb2p = 0.f;                                     // column-sum partials of this thread's 16 rows
@@ -705,58 +708,67 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       PPO_PHASE(1);
       // ---- head and loss gradient, on the vector ALU by all four waves (the 64 x KO head is 6 % of a 32 x 32 MFMA tile):
       // thread (sample hs, slice hq) sums hidden units HPER hq .. HPER hq + HPER - 1 for all KO outputs, the slices are
-      // combined by a butterfly inside the group, and every lane of the group then holds the sample's head output ----
+      // combined by a butterfly inside the group, and every lane of the group then holds the sample's head output.
+      // Straight-line code, every LDS operand of the phase fetched up front: written with the bias added inside the choice of the
+      // component, log_std / the action / the sample's scalars read where they are used and the three cases of the surrogate's gradient
+      // as branches, the phase was five exposed LDS round trips and six branches long -- 1.7 k cycles at 16 samples, the longest phase of
+      // the chunk pass (the ISA is in CHANGELOG, round 5) ----
       {
-        float o[KO];
-#pragma unroll
-        for (int k = 0; k < KO; ++k) o[k] = 0.f;
+        const int s = hs, hc = hq & 3;
+        float hv[HPER];
+        float4 w4[HPER];
         const float* h2 = H2 + hs * kPLdh + HPER * hq;
         const float* wo = W.Wo + HPER * hq * KO;
 #pragma unroll
         for (int j = 0; j < HPER; ++j) {
-          const float h = h2[j];
-          if (KO == 4) {
-            const float4 w4 = reinterpret_cast<const float4*>(wo)[j];
-            o[0] += h * w4.x; o[KO > 1 ? 1 : 0] += h * w4.y; o[KO > 2 ? 2 : 0] += h * w4.z; o[KO > 3 ? 3 : 0] += h * w4.w;
-          } else {
-            o[0] += h * wo[j];
-          }
+          hv[j] = h2[j];
+          if (KO == 4) w4[j] = reinterpret_cast<const float4*>(wo)[j];
+          else w4[j] = make_float4(wo[j], 0.f, 0.f, 0.f);
+        }
+        const float bo_c = W.bo[KO == 4 ? hc : 0];
+        float act_c = 0.f, old_lp = 0.f, adv_s = 0.f, ret_s = 0.f;
+        if (NET == 0) { act_c = sA[s * 4 + hc]; const float2 sv = *reinterpret_cast<const float2*>(sS + s * 4); old_lp = sv.x; adv_s = sv.y; }
+        else ret_s = sS[s * 4 + 2];
+        float o[KO];
+#pragma unroll
+        for (int k = 0; k < KO; ++k) o[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < HPER; ++j) {
+          o[0] += hv[j] * w4[j].x;
+          if (KO == 4) { o[KO > 1 ? 1 : 0] += hv[j] * w4[j].y; o[KO > 2 ? 2 : 0] += hv[j] * w4[j].z; o[KO > 3 ? 3 : 0] += hv[j] * w4[j].w; }
         }
 #pragma unroll
         for (int k = 0; k < KO; ++k) {
           o[k] += ppo_dpp<kDppXor1>(o[k]); o[k] += ppo_dpp<kDppXor2>(o[k]);
           if (HSL >= 8) o[k] += ppo_dpp<kDppHalfMirror>(o[k]);
           if (HSL == 16) o[k] += ppo_dpp<kDppRowMirror>(o[k]);
-          o[k] += W.bo[k];
         }
-        const int s = hs;
         if (NET == 0) {
           // log pi(a|s), ratio, clipped surrogate (SB3 PPO.train): lane hc of the group's first quad takes action component hc
-          // (32-sample form: the second quad of a group of 8 computes along and contributes nothing)
-          const int hc = hq & 3;
+          // (32- / 16-sample forms: the other quads of a group compute along and contribute nothing)
           const bool hl = hq < 4;
-          const float mu = hc == 0 ? o[0] : hc == 1 ? o[KO > 1 ? 1 : 0] : hc == 2 ? o[KO > 2 ? 2 : 0] : o[KO > 3 ? 3 : 0];
-          const float ls = log_std[hc];
-          const float iv = expf(-2.0f * ls);                  // 1 / sigma^2
-          const float z = sA[s * 4 + hc] - mu;
+          const float mu = (hc == 0 ? o[0] : hc == 1 ? o[KO > 1 ? 1 : 0] : hc == 2 ? o[KO > 2 ? 2 : 0] : o[KO > 3 ? 3 : 0]) + bo_c;
+          const float ls = ls_c, iv = iv_c;                   // log_std and 1 / sigma^2 of component hc: per minibatch (see the top of the loop)
+          const float z = act_c - mu;
           float logp = -0.5f * z * z * iv - ls - 0.9189385332046727f;
           logp += ppo_dpp<kDppXor1>(logp); logp += ppo_dpp<kDppXor2>(logp);
-          const float a = sS[s * 4 + 1];
-          const float ratio = expf(logp - sS[s * 4 + 0]);
+          const float a = adv_s;
+          const float ratio = expf(logp - old_lp);
           const float rc = fminf(fmaxf(ratio, 1.0f - H.clip_range), 1.0f + H.clip_range);
           const float l1 = a * ratio, l2 = a * rc;
           if (hq == 0) acc_l += -fminf(l1, l2);
           // d(-min(l1, l2))/dlogp: through l1 when it is the smaller; on a tie (ratio inside the range: rc == ratio)
           // torch.min halves the gradient between the two branches and the clamp passes its half
           const bool inside = ratio >= 1.0f - H.clip_range && ratio <= 1.0f + H.clip_range;
-          const float coef = (l1 < l2 || (l1 == l2 && inside)) ? -a * ratio * invB : (l1 == l2 ? -0.5f * a * ratio * invB : 0.f);
+          const float cf = -a * ratio * invB;
+          const bool tie = l1 == l2;
+          const float coef = (l1 < l2 || (tie && inside)) ? cf : (tie ? 0.5f * cf : 0.f);
           const float g = coef * z * iv;                                  // dL/dmu_k = dL/dlogp * (a_k - mu_k) / sigma_k^2
-          if (hl) {
-            gls_p += coef * (z * z * iv - 1.0f);                          // dL/dlog_std_k of this thread's samples
-            gout[s * 4 + hc] = g; gbo_p += g;
-          }
+          gls_p += hl ? coef * (z * z * iv - 1.0f) : 0.f;                 // dL/dlog_std_k of this thread's samples
+          gbo_p += hl ? g : 0.f;
+          if (hl) gout[s * 4 + hc] = g;
         } else {
-          const float dv = o[0] - sS[s * 4 + 2];
+          const float dv = (o[0] + bo_c) - ret_s;
           if (hq == 0) acc_l += dv * dv;
           const float g = H.vf_coef * 2.0f * dv * invB;
           if (hq == 0) { gout[s * 4] = g; gbo_p += g; }
@@ -975,17 +987,12 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
         // (relaxed: the ordering is the waves' release / acquire -- or, on a shared L2, their store wait / L1 drop -- around the barriers)
         ppo_word_store(fl + part, (unsigned long long)(unsigned)(mb + 1), same_xcd);
       }
-      // While the partners' partials are on their way (two L2 round trips: ~4 k cycles), the inputs of the NEXT minibatch's first
-      // chunk go to LDS and the loads of the chunk after are issued -- X / sA / sS were last read in this minibatch's chunk
-      // pass, and the barrier behind the poll below stands in for the one a chunk's gather ends with.
-      if (mb + 1 < n_mb) {
-        commit();
-        if (pmb < n_mb) {
-          prefetch(pmb * cpm + pci);
-          pci += nsplit; if (pci >= cpm) { pmb += 1; pci = part; }
-        }
-        gathered = true;
-      }
+      // While the partners' flags are on their way, the inputs of the NEXT minibatch's first chunk go to LDS -- X / sA / sS were last
+      // read in this minibatch's chunk pass, and the barrier behind the poll below stands in for the one a chunk's gather ends with.
+      // (The loads of the chunk AFTER that one are issued further down, behind the fetches of the exchange: they come from HBM -- every
+      // packed row is read once -- and the counter retires in order, so issued here they made the wait for the partners' partials,
+      // which the L2 serves in a fraction of that time, a wait for HBM.)
+      if (mb + 1 < n_mb) { commit(); gathered = true; }
       PPO_HO(1);
       if (t < nsplit && t != part) {               // thread q waits for block q
         unsigned long long w;
@@ -1052,6 +1059,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       } else {
 #pragma unroll
         for (int b_ = 0; b_ < NSd; ++b_) va[b_] = ppo_u4{0u, 0u, 0u, 0u};
+      }
+      if (mb + 1 < n_mb && pmb < n_mb) {           // the prefetch of the chunk after next: behind everything the sums below wait for
+        prefetch(pmb * cpm + pci);
+        pci += nsplit; if (pci >= cpm) { pmb += 1; pci = part; }
       }
       // (... the selects behind them: with a select next to its load the compiler emitted load, wait, select per block -- eight round
       // trips in a row, most of the 4.5 k cycles this section took)

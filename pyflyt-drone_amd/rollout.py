@@ -248,24 +248,28 @@ class VecNormalizeDevice:
 
     # -- what a rollout moves, kept so that a void rollout (PPO.check_collect_status) can be taken back -------------------
     def _stat_tensors(self):
-        return [self.obs_rms.mean, self.obs_rms.var, self.obs_rms.count, self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count, self.returns]
+        live = [self.obs_rms.mean, self.obs_rms.var, self.obs_rms.count, self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count, self.returns]
+        if self._obs_acc is not None:                        # sharded job: the batch sums since the last exchange belong to the state too
+            live += [self._obs_acc, self._ret_acc]           # (not zero before the first rollout: the reset's observations are in them)
+        return live
 
     def save_statistics(self) -> None:
-        """First command of a rollout (inside its captured graph when there is one): one multi-tensor copy of the running
-        statistics and the discounted-return accumulators (2 D + 4 + N doubles) into persistent buffers."""
+        """In front of a rollout: one multi-tensor copy of the running statistics, the discounted-return accumulators and (sharded job)
+        the batch sums not yet exchanged -- 2 D + 4 + N (+ 2 D + 4) doubles -- into persistent buffers."""
         live = self._stat_tensors()
         if getattr(self, "_stat_saved", None) is None:
             self._stat_saved = [torch.zeros_like(t) for t in live]
         torch._foreach_copy_(self._stat_saved, live)
+        self._snap_saved = getattr(self, "_snap", None)      # (the agreed base of a sharded job: replaced at every exchange, never written in place)
 
     def restore_statistics(self) -> bool:
         """Back to what save_statistics() kept: the statistics (and, in a sharded job, the agreed base and the batch sums since) no
-        longer contain anything of the rollout in between.  False if nothing was saved."""
+        longer contain anything of the rollout(s) in between.  False if nothing was saved."""
         if getattr(self, "_stat_saved", None) is None:
             return False
         torch._foreach_copy_(self._stat_tensors(), self._stat_saved)
-        if self._obs_acc is not None:                        # (they were zero when the rollout began: every rollout ends with a sync)
-            self._obs_acc.zero_(); self._ret_acc.zero_(); self._snap = self._snapshot()
+        if self._obs_acc is not None:
+            self._snap = self._snap_saved
         return True
 
     def sync_statistics(self) -> None:
@@ -1005,7 +1009,7 @@ class PPO:
         without the void steps -- and, unless PPOConfig.collect_fallback is off, re-arms on the three-launch collector, which has no
         in-grid wait to run out.  Returns the message for the caller to raise or to log."""
         why = "; ".join(t for b, t in self._COLLECT_STATUS_BITS if st_all & b)
-        where = "" if st == st_all else f" (this rank's word: {st})"
+        where = "" if st == st_all else f" (another rank of the job reported status word {st_all & ~st}; this rank's own word: {st})"
         self._ws_collect = None
         self._g_rollout = None
         self._warm_rollouts = 0

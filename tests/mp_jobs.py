@@ -76,7 +76,7 @@ def sharded_training(rank, world, task, n_envs, n_steps, batch_size, n_epochs, i
                 logs=dict(ppo.logs), finite=bool(np.isfinite(flat).all()))
 
 
-def status_agreement(rank, world, n_envs):
+def status_agreement(rank, world, n_envs, fallback=False):
     """Both ranks collect a clean rollout; rank 1's copy of the collector status word is then poisoned (as if a wait inside one of
     ITS launches had run out).  train() is the collective point: both ranks must raise, rank 0 on rank 1's word."""
     import torch
@@ -85,19 +85,25 @@ def status_agreement(rank, world, n_envs):
     from pyflyt_drone_amd import rollout as R
     torch.cuda.set_device(0)
     venv = P.FixedwingVecEnv(K.train_waypoints_v3_config(), n_envs, device=0, seed=42, global_env_offset=rank * n_envs)
-    ppo = R.PPO(R.VecNormalizeDevice(venv), R.PPOConfig(n_steps=4, batch_size=128, n_epochs=1, seed=42))
+    ppo = R.PPO(R.VecNormalizeDevice(venv), R.PPOConfig(n_steps=4, batch_size=128, n_epochs=1, seed=42, collect_fallback=bool(fallback)))
     assert ppo._one_launch
     ppo.collect_rollouts()
     torch.cuda.synchronize()
     assert int(ppo._status_host.item()) == 0
     if rank == 1:
         ppo._status_host.fill_(2)                     # "a fold wave summed without every partial sum"
-    try:
-        ppo.train()
-    except RuntimeError as e:
-        msg = str(e)
-    else:
-        msg = "no error"
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        try:
+            ppo.train()
+        except RuntimeError as e:
+            msg = str(e)
+        else:
+            msg = "no error"
+    warned = [str(w.message) for w in caught if "three-launch collector" in str(w.message)]
+    after = dict(one_launch=bool(ppo._one_launch), fallbacks=int(ppo.collect_fallbacks), warned=warned, num_timesteps=int(ppo.num_timesteps),
+                 obs_count=float(ppo.env.obs_rms.count), checksum=ppo.replica_checksum())
     # the object is usable afterwards on both ranks
     ppo.collect_rollouts(); ppo.train()
     # ... and the same for the update: rank 1's fw_ppo_update is made to give up (one poll per wait); rank 0's runs to its end
@@ -114,4 +120,4 @@ def status_agreement(rank, world, n_envs):
         msg2 = "no error"
     finally:
         os.environ.pop("FWSIM_SPIN_LOG2", None)
-    return dict(msg=msg, msg2=msg2, checksum=ppo.replica_checksum())
+    return dict(msg=msg, msg2=msg2, checksum=ppo.replica_checksum(), after=after)

@@ -42,9 +42,24 @@ def test_allreduce_mode_keeps_the_replicas_identical_on_the_gpu(two_ranks):
 def test_every_rank_raises_when_one_rank_reports_a_collector_timeout(two_ranks):
     """The status word of fw_collect_step is rank-local; the update is a collective point.  If only the rank with the non-zero word
     raised, the others would sit in the rollout all-gather: the ranks agree on the union of their words first."""
-    a, b = two_ranks("status_agreement", n_envs=512)
+    a, b = two_ranks("status_agreement", n_envs=512, fallback=False)
     assert "another rank of the job reported status word 2" in a["msg"], a["msg"]
     assert "status word 2" in b["msg"] and "fold wave" in b["msg"], b["msg"]
     assert "gave up on another rank" in a["msg2"], a["msg2"]
     assert "fw_ppo_update gave up inside the launch" in b["msg2"], b["msg2"]
     assert a["checksum"] == 0.0 and b["checksum"] == 0.0      # rank 0 discarded its (completed) update with rank 1's: still replicas
+
+
+def test_every_rank_falls_back_together_when_one_rank_reports_a_collector_timeout(two_ranks):
+    """Default (PPOConfig.collect_fallback): the ranks agree on the union of their words, ALL of them take the void rollout back --
+    statistics, timestep counter -- re-arm on the three-launch collector and collect the rollout again; nobody raises, nobody is left
+    in a collective, the replicas stay bit-identical and count every sample once."""
+    a, b = two_ranks("status_agreement", n_envs=512, fallback=True)
+    for r in (a, b):
+        assert r["msg"] == "no error", r["msg"]
+        f = r["after"]
+        assert f["fallbacks"] == 1 and not f["one_launch"] and len(f["warned"]) == 1, f
+        assert f["num_timesteps"] == 4 * 512 * 2                   # ONE rollout of both ranks: the void one was taken back
+        assert f["obs_count"] == pytest.approx(1e-4 + (4 + 1) * 512 * 2)
+        assert f["checksum"] == 0.0 and r["checksum"] == 0.0
+    assert "another rank of the job reported status word 2" in a["after"]["warned"][0]
