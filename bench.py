@@ -562,7 +562,7 @@ def main():
     # HBM bytes per launch from the PMC counters are collected offline (rocprofv3 --pmc cannot run inside this process:
     # tools/collect_profiles.sh); the newest committed summary is quoted when it was taken on this very workload, else null.
     traffic, traffic_src = None, None
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if traffic is None and n == 4096 and args.dtype == "float64" and os.path.exists(pmc_path):
             with open(pmc_path) as f:
@@ -575,7 +575,7 @@ def main():
     # SQ_INSTS_VALU counter of the shipped kernel (profiles/rNN_valu_count.json, made by tools/summarize_profiles.py:
     # wave-level VALU instructions per launch x 64 lanes / envs); achieved = that x env-steps per second.
     valu = None
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         vpath = os.path.join(ROOT, "profiles", f"{rnd}_valu_count.json")
         if valu is None and os.path.exists(vpath):
             with open(vpath) as f:
