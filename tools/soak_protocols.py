@@ -34,6 +34,7 @@ for name, cfg, n, hp in CASES:
     got = float(env.obs_rms.count)
     assert abs(got - want) < 0.5, (name, got, want)
     assert all(torch.isfinite(p).all() for p in ppo.policy.parameters()) and torch.isfinite(ppo.buf_obs).all()
+    assert ppo._one_launch and ppo.collect_fallbacks == 0, (name, "the object fell back to the three-launch collector: a status word was raised")
     print(f"{name}: {n} envs, {rollouts} rollouts = {rollouts * T} fw_collect_step launches + {rollouts} closing launches, {updates} updates "
           f"({updates * hp['n_epochs'] * (T * n // hp['batch_size'])} minibatches, L2 paths {ppo._fused.last_paths:#x}); status 0 throughout, "
           f"{got:.0f} samples in the observation statistics (= expected); {time.time() - t0:.0f} s", flush=True)
