@@ -197,7 +197,7 @@ constexpr int kPGxTile = 2 * 4 * 4 * 64 * 4;
 // same 64 KB and the fetch of sixteen blocks took 3.5 k cycles where that of eight takes 1.4 k -- whatever serves those addresses
 // (L2 channel, fabric) is selected at a granularity that coarse; the gradient partials, a region apart, showed the same once all
 // blocks walked them in the same order.
-constexpr int kPWxShare = 2 * kPThreads * 4;
+constexpr int kPWxShare = 3 * kPThreads * 4;      // (three tagged granules per thread in the self-announcing form, two plain float4s otherwise)
 constexpr int kPGxSlots = kPGxTile + 2 * kPThreads + kPWxShare;
 __host__ __device__ inline int ppo_gx_tile(int kind, int wave, int lane) { return (kind * 4 + wave) * 4 * 256 + lane * 4; }      // + q * 256
 
@@ -399,6 +399,9 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
   constexpr bool RS = NS != 0;
   constexpr int NSd = RS ? NS : 4;                     // (array extents; the divisor where NS may be 0)
   constexpr int NSETS = NS == 8 ? 1 : 2;               // RS: sets of 4 tile elements a thread owns (see above)
+  constexpr bool TAGGED = NS == 4;                     // the weight all-gather as self-announcing granules (see there): pays with four blocks
+                                                       // (7.90 -> 7.72 us per (56, 64) minibatch), not with eight, whose rounds are 14 fetches
+                                                       // per wave from seven partners that sixteen blocks poll at once (7.88 -> 8.25 us)
   static_assert(CH == 64 || CH == 32 || CH == 16, "chunk size");
   constexpr int RT = CH == 64 ? 1 : CH / 16;     // row tiles of 16 in the 16 x 16 forms
   constexpr int n = NET, KO = NET == 0 ? 4 : 1;
@@ -1255,12 +1258,30 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       for (int s_ = 0; s_ < NSETS; ++s_) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) *wp[s_][e] = wv[s_][e];
-        if (set_own[s_]) *reinterpret_cast<float4*>(wxn + (size_t)part * kPGxSlots + (s_ * kPThreads + t) * 4) = make_float4(wv[s_][0], wv[s_][1], wv[s_][2], wv[s_][3]);
+        if (!(TAGGED && same_xcd) && set_own[s_]) *reinterpret_cast<float4*>(wxn + (size_t)part * kPGxSlots + (s_ * kPThreads + t) * 4) = make_float4(wv[s_][0], wv[s_][1], wv[s_][2], wv[s_][3]);
       }
-      if (same_xcd) __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), as for the partials
-      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __syncthreads();
-      if (t == 0) ppo_word_store(fl2 + part, (unsigned long long)(unsigned)(mb + 1), same_xcd);
+      if (TAGGED && same_xcd) {
+        // SELF-ANNOUNCING shares (blocks on one XCD): a thread's new weights leave as 16-byte granules of three floats and a TAG (the
+        // minibatch number) -- [granule][thread][4], 1 KB in a row per wave -- and the readers poll the granules themselves.  No wait
+        // for the stores, no barrier, no flag, no poll of a flag: one hop between CUs instead of two (the flag's took 0.65 k cycles of
+        // waiting behind 0.5 k of draining).  A 16-byte aligned store is one request to the L2: a reader sees all of a granule or
+        // none of it; granules nobody needs (W1 shares nobody owns) are written all the same, so that every tag can be waited for.
+        float* gp = wxn + (size_t)part * kPGxSlots + t * 4;
+        const float tagf = __uint_as_float((unsigned)(mb + 1));
+        if constexpr (NSETS == 2) {
+          *reinterpret_cast<float4*>(gp) = make_float4(wv[0][0], wv[0][1], wv[0][2], tagf);
+          *reinterpret_cast<float4*>(gp + kPThreads * 4) = make_float4(wv[0][3], wv[NSETS - 1][0], wv[NSETS - 1][1], tagf);
+          *reinterpret_cast<float4*>(gp + 2 * kPThreads * 4) = make_float4(wv[NSETS - 1][2], wv[NSETS - 1][3], 0.f, tagf);
+        } else {
+          *reinterpret_cast<float4*>(gp) = make_float4(wv[0][0], wv[0][1], wv[0][2], tagf);
+          *reinterpret_cast<float4*>(gp + kPThreads * 4) = make_float4(wv[0][3], 0.f, 0.f, tagf);
+        }
+      } else {
+        if (same_xcd) __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), as for the partials
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (t == 0) ppo_word_store(fl2 + part, (unsigned long long)(unsigned)(mb + 1), same_xcd);
+      }
     } else {
     adam_tile(gW2, pm[0], pv[0], [&](int v) { return W.W2 + (mt * 32 + ppo_acc_row(v)) * kPLdh + nt * 32 + r; });
     if (hasW1) adam_tile(gW1, pm[1], pv[1],
@@ -1291,25 +1312,58 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #endif
     if constexpr (RS) {
       // ---- all-gather of the updated weights: the other NS - 1 shares, from the blocks that own them ----
-      if (t < nsplit && t != part) {
-        unsigned long long w;
-        if (!ppo_wait(A, [&]() { return ppo_word_load(fl2 + t, same_xcd); }, [&](unsigned long long x) { return (unsigned)x == (unsigned)(mb + 1); },
-                      (unsigned long long)PPO_ST_SWAP, w)) red[7] = 1.f;
-      }
-      __syncthreads();
-      if (red[7] != 0.f) { dead = true; break; }
-#ifdef FW_PPO_PROF
-      const long long pa2 = PPO_T(); pf_a[1] += pa2 - pa1;
-#endif
-      if (!same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(wxn, 0, kPMaxSplit * kPGxSlots * (int)sizeof(float), 0x00020000);
       float wg[NS - 1][NSETS][4];
-      // (every load unconditional -- a share of W1 nobody owns is read and not used: loads inside branches wait one by one at the joins)
+      const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(wxn, 0, kPMaxSplit * kPGxSlots * (int)sizeof(float), 0x00020000);
+      if (TAGGED && same_xcd) {
+        // every wave polls the granules it needs itself (no block-wide wait): fetch all of them, look at the tags, again if one is old
+        constexpr int NG = NSETS == 2 ? 3 : 2;
+        const unsigned want = (unsigned)(mb + 1);
+        float gr[NS - 1][NG][4];
+        bool ok = false;
+        for (long long rounds = 0; rounds < A.spin && !ok; ++rounds) {
+          asm volatile("" ::: "memory");           // (the fetches of a round are not those of the last one: nothing may be hoisted out of the loop)
 #pragma unroll
-      for (int j = 0; j < NS - 1; ++j) {
-        const int pj = (j + 1) ^ part;             // (every block at a different partner at every step, as in the reduce-scatter)
+          for (int j = 0; j < NS - 1; ++j) {
+            const int pj = (j + 1) ^ part;         // (every block at a different partner at every step, as in the reduce-scatter)
 #pragma unroll
-        for (int s_ = 0; s_ < NSETS; ++s_) ppo_ld_sc1(rsw, (int)((pj * kPGxSlots + (s_ * kPThreads + t) * 4) * sizeof(float)), wg[j][s_]);
+            for (int g = 0; g < NG; ++g) ppo_ld_sc1(rsw, (int)((pj * kPGxSlots + (g * kPThreads + t) * 4) * sizeof(float)), gr[j][g]);
+          }
+          bool mine = true;
+#pragma unroll
+          for (int j = 0; j < NS - 1; ++j)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) mine = mine && __float_as_uint(gr[j][g][3]) == want;
+          ok = __builtin_amdgcn_ballot_w64(!mine) == 0ull;
+          if (!ok && (rounds & 255) == 255 && __hip_atomic_load(A.xch + kPpoWordStatus, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+        }
+        if (!ok) {                                 // a partner is gone (or the budget was one round: tests)
+          if (lane == 0) { (void)__hip_atomic_fetch_or(A.xch + kPpoWordStatus, (unsigned long long)PPO_ST_SWAP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); red[7] = 1.f; }
+        }
+#pragma unroll
+        for (int j = 0; j < NS - 1; ++j) {
+          if constexpr (NSETS == 2) {
+            wg[j][0][0] = gr[j][0][0]; wg[j][0][1] = gr[j][0][1]; wg[j][0][2] = gr[j][0][2]; wg[j][0][3] = gr[j][1][0];
+            wg[j][NSETS - 1][0] = gr[j][1][1]; wg[j][NSETS - 1][1] = gr[j][1][2]; wg[j][NSETS - 1][2] = gr[j][NG - 1][0]; wg[j][NSETS - 1][3] = gr[j][NG - 1][1];
+          } else {
+            wg[j][0][0] = gr[j][0][0]; wg[j][0][1] = gr[j][0][1]; wg[j][0][2] = gr[j][0][2]; wg[j][0][3] = gr[j][1][0];
+          }
+        }
+      } else {
+        if (t < nsplit && t != part) {
+          unsigned long long w;
+          if (!ppo_wait(A, [&]() { return ppo_word_load(fl2 + t, same_xcd); }, [&](unsigned long long x) { return (unsigned)x == (unsigned)(mb + 1); },
+                        (unsigned long long)PPO_ST_SWAP, w)) red[7] = 1.f;
+        }
+        __syncthreads();
+        if (red[7] != 0.f) { dead = true; break; }
+        if (!same_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // (every load unconditional -- a share of W1 nobody owns is read and not used: loads inside branches wait one by one at the joins)
+#pragma unroll
+        for (int j = 0; j < NS - 1; ++j) {
+          const int pj = (j + 1) ^ part;
+#pragma unroll
+          for (int s_ = 0; s_ < NSETS; ++s_) ppo_ld_sc1(rsw, (int)((pj * kPGxSlots + (s_ * kPThreads + t) * 4) * sizeof(float)), wg[j][s_]);
+        }
       }
       // partner thread (w, l) of block pj wrote what its sets are: the same wave and lane as mine, block pj's tiles and quarters.
       // Branch-free: every element is stored, to its place or -- rows W1 does not have, W1 tiles nobody owns -- to this thread's sink
@@ -1341,6 +1395,7 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #ifdef FW_PPO_PROF
     { const long long pfe = PPO_T(); pf_adam += pfe - pf3; pf_scal += pfe - pfd; pf_a[3] += pfe - pa3; }
 #endif
+    if (red[7] != 0.f) { dead = true; break; }     // (a wave's poll of the partners' weight granules ran out)
   }
 
   // ---- the verdict: results are written back only when EVERY block of the call got through its last minibatch with every wait
