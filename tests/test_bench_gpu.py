@@ -38,6 +38,13 @@ def test_bare_gpus_2_launches_its_own_ranks_on_the_gpu(launcher):
     assert b["n_gpus"] == 2 and "cpu_baseline" not in b and b["config"]["parallelism"] == "env-shard x2"
     assert b["value"] == pytest.approx(2 * 4096 * 1e3 / b["ms_per_step"], rel=1e-9)
     assert "update_allgather" in b and b["update_allgather"].get("samples_per_rank") == 16 * 4096
+    # the world > 1 form of the line: every rank's own clock, and the sharded collector object with the
+    # reference's samples per update held (n_steps = 65 536 / (4096 x world))
+    assert len(b["per_rank_kernel_ms_per_step"]) == 2 and b["per_rank_kernel_ms_per_step_min"] <= b["per_rank_kernel_ms_per_step_max"]
+    c = b["collector"]
+    assert "error" not in c, c
+    assert c["world"] == 2 and c["n_steps"] == 8 and c["samples_per_update"] == 65536 and c["replica_checksum"] == 0.0
+    assert c["collect_fallbacks"] == 0 and c["end_to_end_env_steps_per_s"] > 1e5 and c["update_allgather_bytes_per_rank"] == 8 * 4096 * 35 * 4
 
 
 def test_gpus_mismatch_is_an_error_not_a_one_gpu_line(launcher):
