@@ -1925,7 +1925,10 @@ static long long spin_budget(long long dflt) {
 
 // workspace layout of fw_ppo_update: [0, kPpoWords x 8) exchange words (kPpoWordPaths: which exchanges shared an L2, kPpoWordStatus: include/fwsim.h) |
 // gradient hand-off buffer | the packed rows of every minibatch, in walking order (fw_ppo_pack_kernel)
-static constexpr size_t kPpoWsXch = kPpoWords * sizeof(unsigned long long);
+// (the words first -- everything that is polled -- and the data a whole 64 KB behind them: the blocks that wait spin on these lines with
+// loads past their L1, and whatever part of the L2 serves the words should not also serve the first partial's tiles)
+static constexpr size_t kPpoWsXch = 65536;
+static_assert(kPpoWords * sizeof(unsigned long long) <= kPpoWsXch, "exchange words");
 static constexpr size_t kPpoWsGx = sizeof(float) * (4 * kPMaxSplit * (size_t)kPGxSlots);      // [parity][net][part]: gradient partial + weight share
 int64_t fw_ppo_update_workspace_bytes(int32_t n_minibatches, int32_t batch_size, int32_t obs_dim) {
   if (n_minibatches <= 0 || batch_size <= 0 || obs_dim <= 0 || obs_dim > 64) return FW_EINVAL;
@@ -1956,7 +1959,7 @@ int32_t fw_ppo_update(float* params, float* mom_m, float* mom_v, const float* ob
   unsigned long long* xch = (unsigned long long*)workspace;
   float* gx = (float*)((char*)workspace + kPpoWsXch);
   float* packed = (float*)((char*)workspace + kPpoWsXch + kPpoWsGx);
-  HIP_TRY((fw_env*)nullptr, hipMemsetAsync(xch, 0, kPpoWsXch, st));
+  HIP_TRY((fw_env*)nullptr, hipMemsetAsync(xch, 0, kPpoWords * sizeof(unsigned long long), st));
   PpoArgs A;
   A.params = params; A.mom_m = mom_m; A.mom_v = mom_v; A.packed = packed;
   A.n_mb = n_minibatches; A.B = batch_size; A.D = obs_dim; A.loss_acc = loss_acc; A.xch = xch; A.gx = gx;

@@ -344,6 +344,8 @@ constexpr int kPpoWords = kPpoWordFlags2 + 4 * kPMaxSplit;
 static_assert(kPpoWordIds + 2 * kPMaxSplit <= kPpoWordPaths && kPpoWordVerdict < kPpoWordFlags2, "exchange-word layout");
 enum { PPO_ST_IDS = 1, PPO_ST_SWAP = 2, PPO_ST_NORM = 4, PPO_ST_COMMIT = 8 };
 
+// (Measured, round 5: an `s_sleep 1` between two looks -- to take pressure off the lines sixteen blocks spin on -- costs 0.1-0.2 us per
+// minibatch: the reaction time of the waiter is what counts.)
 // Bounded wait of one thread for a word another block publishes.  `done(word)` ends it; every 256 polls it also looks at the
 // status word, so that one block giving up releases the others at once instead of after their own budgets.  Returns false --
 // and raises `bit` in the status word -- when the budget ran out or somebody else had given up.
@@ -642,6 +644,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #ifdef FW_PPO_PROF
         pf_g[3] += PPO_T() - pg3;
 #endif
+      }
+      else if (pmb < n_mb) {                                             // (gathered inside the last hand-off: only the prefetch is left to do)
+        prefetch(pmb * cpm + pci);
+        pci += nsplit; if (pci >= cpm) { pmb += 1; pci = part; }
       }
       gathered = false;
 #ifdef FW_PPO_PROF
@@ -992,9 +998,10 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       }
       // While the partners' flags are on their way, the inputs of the NEXT minibatch's first chunk go to LDS -- X / sA / sS were last
       // read in this minibatch's chunk pass, and the barrier behind the poll below stands in for the one a chunk's gather ends with.
-      // (The loads of the chunk AFTER that one are issued further down, behind the fetches of the exchange: they come from HBM -- every
-      // packed row is read once -- and the counter retires in order, so issued here they made the wait for the partners' partials,
-      // which the L2 serves in a fraction of that time, a wait for HBM.)
+      // (The loads of the chunk AFTER that one are issued at the start of the next chunk pass, which waits for no memory operation
+      // for thousands of cycles: they come from HBM -- every packed row is read once -- and the counter retires in order, so
+      // issued here they made every wait of the exchange, whose data the L2 serves in a fraction of that time, a wait for HBM;
+      // behind the exchange's fetches but inside a branch, they still did: the compiler's wait counts must hold on both paths.)
       if (mb + 1 < n_mb) { commit(); gathered = true; }
       PPO_HO(1);
       if (t < nsplit && t != part) {               // thread q waits for block q
@@ -1062,10 +1069,6 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
       } else {
 #pragma unroll
         for (int b_ = 0; b_ < NSd; ++b_) va[b_] = ppo_u4{0u, 0u, 0u, 0u};
-      }
-      if (mb + 1 < n_mb && pmb < n_mb) {           // the prefetch of the chunk after next: behind everything the sums below wait for
-        prefetch(pmb * cpm + pci);
-        pci += nsplit; if (pci >= cpm) { pmb += 1; pci = part; }
       }
       // (... the selects behind them: with a select next to its load the compiler emitted load, wait, select per block -- eight round
       // trips in a row, most of the 4.5 k cycles this section took)
