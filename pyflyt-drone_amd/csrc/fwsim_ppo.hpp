@@ -376,6 +376,20 @@ __device__ __forceinline__ bool ppo_wait(const PpoArgs& A, LOAD&& load, DONE&& d
 // waves in turn, 220 + 64 N cycles for N such loads per wave -- so the cost of an exchange is its INSTRUCTION count, not its lines.
 // Eight blocks (round 5): a 128-sample minibatch is 8 x 16 samples -- the chunk pass, which scales with the samples of a block, falls
 // from 11.4 k to 7.3 k cycles.
+// A pointer every lane holds the same value of, as the compiler can SEE it (two v_readfirstlane).  What it is for: hipcc's divergence
+// analysis takes the minibatch counter of fw_ppo_update's loop -- whose exits hang on values read from LDS -- for divergent, and with it
+// every address derived from it; a buffer resource built from such a pointer lives in VECTOR registers, and every buffer load through
+// it is wrapped in a waterfall loop (readfirstlane x 4, two compares, exec mask, load, branch): ~80 cycles of issue per load, 24 loads
+// in a row in the gradient fetch -- half of the 2.9 k cycles that fetch took with eight blocks, where the same fetch in isolation
+// takes 0.7 k (tools/microbench_rs.hip).  Round 4's "a CU pulls lines past its L1 at ~20 B / clk" was this.
+template <typename P> __device__ __forceinline__ P* ppo_uniform_ptr(P* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (P*)(((unsigned long long)hi << 32) | lo);
+}
+// (Measured and dropped, round 5: the block-uniform flags read back from LDS -- same_xcd, the give-up flag the loop exits hang on --
+// passed through v_readfirstlane so that the control flow on them is scalar: 7.72 -> 7.80 us per (28, 128) minibatch, 7.70 -> 7.83 per
+// (56, 64): more values in scalar registers, of which the kernel already spills 290.)
 // four floats from a raw buffer, past the L1 (sc1)
 __device__ __forceinline__ void ppo_ld_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off, float (&out)[4]) {
   typedef unsigned int ppo_u4 __attribute__((ext_vector_type(4)));
@@ -961,7 +975,11 @@ __device__ __forceinline__ void ppo_net_body(const PpoArgs& A, float* lds, const
 #pragma unroll
       for (int e = 0; e < 4; ++e) gq[s_][e] = 0.f;
     if (nsplit > 1) {
+      // (uniform for the compiler with eight blocks only -- measured on one box, product builds, us per minibatch: (28, 128) 7.79 -> 7.62;
+      // with four blocks the burst of fetches it allows costs more elsewhere than it saves: (56, 64) 7.59 -> 7.72, (28, 64) 7.23 -> 7.20;
+      // and never for the all-gather, whose readers poll: 7.62 -> 7.71 and 7.72 -> 7.86)
       float* gxb = A.gx + (size_t)((mb & 1) * 2 + NET) * kPMaxSplit * kPGxSlots;
+      if constexpr (NS == 8) gxb = ppo_uniform_ptr(gxb);
       float* mine = gxb + (size_t)part * kPGxSlots;
       unsigned long long* fl = A.xch + kPpoWordFlags + ((mb & 1) * 2 + NET) * kPMaxSplit;
       const int g0 = ppo_gx_tile(0, wave, lane), g1 = ppo_gx_tile(1, wave, lane);
