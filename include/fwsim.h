@@ -146,7 +146,10 @@ typedef struct fw_config {
   int32_t duck_lock_decay_steps;
   int32_t duck_switch_min_consecutive_seen;
   int32_t camera_resolution;    /* square, pixels (analytic camera model) */
-  int32_t reserved_i[8];
+  int32_t duck_vision_no_deltas; /* ObjLock: 1 = duck_vision_use_deltas=False of the reference (envs/fixedwing_objlock_env.py:69-70, 440-441):
+                                  * the observation ends with the 27 history values, without the 4 frame-to-frame deltas (52 wide, not 56).
+                                  * (Round 5; one of the former reserved words, which callers zero: same layout, same ABI version.) */
+  int32_t reserved_i[7];
 
   /* ---- env / task scalars ---- */
   double flight_dome_size;

@@ -241,7 +241,8 @@ static int validate(const fw_config* c, char* msg, int n) {
 
 static int obs_dim_of(const fw_config* c) {
   int att = (c->angle_representation == 0 ? 12 : 13) + 4 + 6;
-  if (c->task == FW_TASK_OBJLOCK) return att + 3 + FW_VISION_FEATS * FW_VISION_HIST + 4;
+  /* duck_vision_use_deltas=False (envs/fixedwing_objlock_env.py:163-165, 440-441): the history alone */
+  if (c->task == FW_TASK_OBJLOCK) return att + 3 + FW_VISION_FEATS * FW_VISION_HIST + (c->duck_vision_no_deltas ? 0 : 4);
   return att + 3 * c->context_length;
 }
 
@@ -1038,7 +1039,8 @@ static void flatten_obs(const struct fw_env* h, const oenv* e, double* out) {
   if (h->cfg.task == FW_TASK_OBJLOCK) {          /* envs/flatten_objlock_env.py:41-46: concat(...).astype(np.float32) */
     for (int k = 0; k < att; ++k) out[o++] = (double)(float)e->attitude[k];
     for (int k = 0; k < 3; ++k) out[o++] = (double)(float)e->obj_target_vector[k];
-    for (int k = 0; k < FW_VISION_HIST * FW_VISION_FEATS + 4; ++k) out[o++] = e->obj_duck_vision[k];
+    const int nv = FW_VISION_HIST * FW_VISION_FEATS + (h->cfg.duck_vision_no_deltas ? 0 : 4);      /* :440-441 */
+    for (int k = 0; k < nv; ++k) out[o++] = e->obj_duck_vision[k];
     return;
   }
   for (int k = 0; k < att; ++k) out[o++] = e->attitude[k];

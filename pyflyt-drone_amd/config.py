@@ -80,7 +80,7 @@ class FwConfig(C.Structure):
         ("n_collision_pts", C.c_int32), ("num_obstacles", C.c_int32),
         ("duck_camera_capture_interval_steps", C.c_int32), ("duck_lock_hold_steps", C.c_int32),
         ("duck_lock_decay_steps", C.c_int32), ("duck_switch_min_consecutive_seen", C.c_int32),
-        ("camera_resolution", C.c_int32), ("reserved_i", C.c_int32 * 8),
+        ("camera_resolution", C.c_int32), ("duck_vision_no_deltas", C.c_int32), ("reserved_i", C.c_int32 * 7),
         # env / task scalars
         ("flight_dome_size", C.c_double), ("max_duration_seconds", C.c_double),
         ("goal_reach_distance", C.c_double), ("waypoint_min_height", C.c_double),
@@ -561,13 +561,12 @@ def objlock_config_from_reference_kwargs(*, dtype: str = "float64", motor_noise:
     del duck_urdf_path, use_egl                                   # renderer plumbing: no device counterpart needed
     if int(max(1, duck_vision_history_len)) != FW_VISION_HIST:
         raise ValueError(f"duck_vision_history_len must be {FW_VISION_HIST} on the device env (the observation layout is compiled in)")
-    if not bool(duck_vision_use_deltas):
-        raise ValueError("duck_vision_use_deltas=False is not available on the device env (the 4 deltas are part of the 56-wide observation)")
     if camera_profile != "cockpit_fpv":
         raise ValueError(f"camera_profile {camera_profile!r} is not available on the device env (body-fixed 'cockpit_fpv' only; "
                          "'chase' is a tracking camera)")
     res = _camera_resolution_of(render_mode, render_resolution, camera_resolution)
     c = objlock_config(dtype=dtype, motor_noise=motor_noise, auto_reset=auto_reset, camera_resolution=res, **env_kwargs)
+    c.duck_vision_no_deltas = 0 if bool(duck_vision_use_deltas) else 1      # :69-70, 440-441: history only, 52 values instead of 56
     if camera_position_offset is not None:                        # :194-201
         _set_vec(c.camera_offset, [float(v) for v in camera_position_offset])
     if camera_angle_degrees is not None:                          # :203-209 (the reference truncates to int)
@@ -593,7 +592,7 @@ def waypoint_objlock_config_from_reference_kwargs(*, dtype: str = "float64", mot
 def obs_dim(c: FwConfig) -> int:
     att = (12 if c.angle_representation == 0 else 13) + 4 + 6
     if c.task == FW_TASK_OBJLOCK:
-        return att + 3 + FW_VISION_FEATS * FW_VISION_HIST + 4
+        return att + 3 + FW_VISION_FEATS * FW_VISION_HIST + (0 if c.duck_vision_no_deltas else 4)      # (:163-165)
     return att + 3 * c.context_length
 
 

@@ -1192,7 +1192,7 @@ int validate(const fw_config* c, std::string& msg) {
 
 int obs_dim_of(const fw_config* c) {
   int att = (c->angle_representation == 0 ? 12 : 13) + 4 + 6;
-  if (c->task == FW_TASK_OBJLOCK) return att + 3 + FW_VISION_FEATS * FW_VISION_HIST + 4;
+  if (c->task == FW_TASK_OBJLOCK) return att + 3 + FW_VISION_FEATS * FW_VISION_HIST + (c->duck_vision_no_deltas ? 0 : 4);
   return att + 3 * c->context_length;
 }
 

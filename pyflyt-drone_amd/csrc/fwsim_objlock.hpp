@@ -1243,6 +1243,7 @@ __device__ __forceinline__ void obj_write_obs(const Params<T>& P, const ObjState
   put(o++, f32r(tv[0])); put(o++, f32r(tv[1])); put(o++, f32r(tv[2]));
 #pragma unroll
   for (int k = 0; k < kHist; ++k) put(o++, (T)O.hist[k]);
+  if (o + 4 > P.obs_dim) return;                       // duck_vision_use_deltas=False (:440-441): the row ends with the history
   const bool both = O.filled >= (T)2 && O.hist[0] > 0.5f && O.hist[FW_VISION_FEATS] > 0.5f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) put(o++, both ? (T)(O.hist[1 + k] - O.hist[FW_VISION_FEATS + 1 + k]) : (T)0);

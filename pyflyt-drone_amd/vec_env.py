@@ -360,7 +360,7 @@ class FixedwingObjLockVecEnv(FixedwingVecEnv):
     """``FlattenObjLockEnv(FixedwingObjLockEnv(...))`` vectorised (envs/fixedwing_objlock_env.py:37-81,
     envs/flatten_objlock_env.py; constructed at train/train_objlock.py:113-153).  Accepts the reference
     constructor's full keyword set (``config.objlock_config_from_reference_kwargs``: render-only arguments are ignored,
-    options the device env cannot honour raise ``ValueError``).  Observations are the reference's 56 float32 values
+    options the device env cannot honour raise ``ValueError``).  Observations are the reference's 56 float32 values (52 with ``duck_vision_use_deltas=False``)
     (22 attitude + 3 target vector + 31 duck vision); with ``dtype="float64"`` they are stored in float64 tensors
     but already rounded to float32."""
 

@@ -122,7 +122,13 @@ def test_reference_make_env_keyword_sets_are_accepted():
                                                 duck_urdf_path="duck_vhacd.urdf", flight_mode=0)
     assert list(c2.camera_offset) == [0.5, 0.0, 0.2] and c2.camera_angle_deg == -10.0 and c2.camera_fov_deg == 60.0
     assert c2.camera_resolution == 64
-    for bad, match in ((dict(duck_vision_history_len=5), "duck_vision_history_len"), (dict(duck_vision_use_deltas=False), "use_deltas"),
+    # duck_vision_use_deltas=False (:69-70, 163-165, 440-441): 9 x 3 history values without the 4 deltas -> 22 + 3 + 27 = 52
+    c3 = K.objlock_config_from_reference_kwargs(**{**objlock_kw, "duck_vision_use_deltas": False})
+    assert c3.duck_vision_no_deltas == 1 and c.duck_vision_no_deltas == 0
+    from pyflyt_drone_amd import _lib
+    import ctypes as C
+    assert _lib.lib().fw_obs_dim(C.byref(c3)) == 52 and _lib.lib().fw_obs_dim(C.byref(c)) == 56
+    for bad, match in ((dict(duck_vision_history_len=5), "duck_vision_history_len"),
                        (dict(camera_profile="chase"), "camera_profile"), (dict(flight_mode=-1), "flight_mode"),
                        (dict(render_mode="human"), "render mode"), (dict(camera_resolution=(64, 48)), "square")):
         with pytest.raises(ValueError, match=match):

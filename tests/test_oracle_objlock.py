@@ -184,6 +184,23 @@ def test_vision_history_shift_fill_and_deltas(oracle):
     assert np.all(o3[0, 52:56] == 0) and o3[0, 25] == 0 and o3[0, 34] == 1                # deltas only if both visible
 
 
+def test_history_without_deltas_is_the_first_52_values(oracle):
+    """duck_vision_use_deltas=False (envs/fixedwing_objlock_env.py:69-70, 163-165, 440-441): `history_flat` alone -- the same
+    27 values, the 4 deltas gone, everything else of the step unchanged."""
+    cfg0, cfg1 = quiet(), quiet()
+    cfg1.duck_vision_no_deltas = 1
+    assert K.obs_dim(cfg0) == 56 and K.obs_dim(cfg1) == 52
+    a, b = make(oracle, cfg0), make(oracle, cfg1)
+    for env in (a, b):
+        set_frame(env, 1.0, cx=0.4, cy=0.6, area=0.01, depth=90.0)
+        step0(env)
+        set_frame(env, 1.0, cx=0.45, cy=0.55, area=0.02, depth=85.0)
+    (oa, ra, *_), (ob, rb, *_) = step0(a), step0(b)
+    assert oa.shape == (1, 56) and ob.shape == (1, 52) and np.any(oa[0, 52:56] != 0)
+    np.testing.assert_array_equal(ob[0], oa[0, :52])
+    assert ra[0] == rb[0]
+
+
 # ---- the reference's image functionals (:662-743) on the analytic render: an independent numpy restatement as the checker
 def np_render_frame(oracle, cfg, st, res):
     """Literal numpy version of what _compute_vision_features / _estimate_obstacle_zone_distances_m / _estimate_distance

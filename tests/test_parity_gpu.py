@@ -69,6 +69,8 @@ def lockstep_cases():
     yield "objlock_sparse_nowind", K.objlock_config(sparse_reward=True, flight_dome_size=120.0, num_obstacles=3,
                                                     duck_camera_capture_interval_steps=1, angle_representation="euler",
                                                     motor_noise=False), "uniform"
+    # duck_vision_use_deltas=False (envs/fixedwing_objlock_env.py:69-70, 440-441): the observation ends with the history, 52 wide
+    yield "objlock_no_deltas", _mutate(K.train_objlock_config(duck_camera_capture_interval_steps=2), duck_vision_no_deltas=1), "gentle"
 
 
 def _mutate(cfg, **kw):
