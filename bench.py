@@ -393,7 +393,9 @@ def main():
                                        f"(torch.distributed.run --nproc-per-node {args.gpus}) or run `python bench.py --gpus {args.gpus}` bare",
                               "n_gpus_requested": args.gpus, "world_size": world}), flush=True)
         sys.exit(3)
-    dist = world > 1
+    # FW_DIST_FORCE=1 (tests, one-GPU box): a ONE-rank job still goes through the process group and every collective below --
+    # the only way to run the RCCL branches (device tensors, all_gather_into_tensor) without a second GPU
+    dist = world > 1 or (bool(os.environ.get("FW_DIST_FORCE")) and env_world is not None)
     dry = bool(os.environ.get("FW_BENCH_DRY"))         # launcher rehearsal on a box without a GPU (tests only): no env, no timing
     if not args.no_cpu_baseline and world == 1 and not dry:
         # the CPU-baseline library is compiled for THIS machine's cores (-march=native); do it before anything touches the

@@ -455,7 +455,8 @@ class EvalCallback:
         self.evaluations_timesteps.append(timesteps)
         self.evaluations_results.append(r.episode_rewards); self.evaluations_length.append(r.episode_lengths)
         writer = ppo.rank == 0               # multi-process job: every rank evaluates (identical weights), ONE rank writes files
-        if ppo.world_size > 1:               # ... and every rank keeps rank 0's figure, so best_mean_reward agrees everywhere
+        from .rollout import _dist
+        if _dist() is not None:              # ... and every rank keeps rank 0's figure, so best_mean_reward agrees everywhere
             import torch.distributed as td
             t = torch.tensor([r.mean_reward], dtype=torch.float64, device=ppo.device if td.get_backend() == "nccl" else "cpu")
             td.broadcast(t, src=0)

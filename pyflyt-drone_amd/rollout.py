@@ -44,9 +44,17 @@ def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _rehearse_one_rank() -> bool:
+    """``FW_DIST_FORCE=1``: treat a ONE-rank process group as a sharded job, so that every collective of the multi-GPU path runs
+    -- on device tensors, over RCCL -- on a box with a single GPU (RCCL refuses two ranks on one device; gloo rehearsals with two
+    ranks take the host-copy branches instead).  Results are those of the single-process job; only the code path differs."""
+    import os
+    return bool(os.environ.get("FW_DIST_FORCE"))
+
+
 def _dist():
     import torch.distributed as td
-    return td if (td.is_available() and td.is_initialized() and td.get_world_size() > 1) else None
+    return td if (td.is_available() and td.is_initialized() and (td.get_world_size() > 1 or _rehearse_one_rank())) else None
 
 
 def init_distributed_from_env():
@@ -57,7 +65,7 @@ def init_distributed_from_env():
     import os
     import torch.distributed as td
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not (_rehearse_one_rank() and "MASTER_PORT" in os.environ):
         return 1, 0, 0
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("FW_DIST_SINGLE_DEVICE"):

@@ -47,6 +47,28 @@ def test_bare_gpus_2_launches_its_own_ranks_on_the_gpu(launcher):
     assert c["collect_fallbacks"] == 0 and c["end_to_end_env_steps_per_s"] > 1e5 and c["update_allgather_bytes_per_rank"] == 8 * 4096 * 35 * 4
 
 
+def test_one_rank_job_over_rccl_prints_the_multi_gpu_form_of_the_line(launcher):
+    """FW_DIST_FORCE=1: one rank, but through the process group -- the RCCL branches of bench.py (rank count by all-reduce on the GPU,
+    per-rank gather, all_gather_into_tensor of the update shard, the sharded collector object) on the real library, which the
+    two-rank gloo rehearsal above cannot reach."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    rc, out, err = launcher([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--repeats", "5", "--no-cpu-baseline"],
+                            env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "FW_DIST_FORCE": "1"})
+    assert rc == 0, err[-3000:]
+    b = _line(out)
+    assert b["n_gpus"] == 1 and b["ranks_seen"] == 1 and b["backend"].startswith("RCCL") and b["value"] > 1e6
+    g = b["update_allgather"]
+    assert "error" not in g, g
+    assert g["collective"].startswith("all_gather_into_tensor (RCCL)") and g["bytes_per_rank"] == 16 * 4096 * 35 * 4
+    assert len(b["per_rank_kernel_ms_per_step"]) == 1
+    c = b["collector"]
+    assert "error" not in c, c
+    assert c["world"] == 1 and c["n_steps"] == 16 and c["samples_per_update"] == 65536 and c["replica_checksum"] == 0.0 and c["collect_fallbacks"] == 0
+    assert c["one_launch_collect"] and c["end_to_end_env_steps_per_s"] > 5e5
+
+
 def test_gpus_mismatch_is_an_error_not_a_one_gpu_line(launcher):
     rc, out, _ = launcher([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env={"WORLD_SIZE": "1", "RANK": "0"})
     b = _line(out)

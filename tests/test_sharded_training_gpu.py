@@ -4,6 +4,9 @@ rank) as a world_size-2 job -- fused hipGraph collector on every rank, one all-g
 the same fused fw_ppo_update on every rank.  (Two ranks share the one GPU of the box, so the collectives run over gloo;
 with RCCL the same code path issues all_gather_into_tensor / all_reduce on device tensors.)
 Reference callers: train/train_Fixedwing_Waypoints_v3.py:293-337, train/train_Fixedwing_Waypoints_ObjLock.py:287-403."""
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -63,3 +66,34 @@ def test_every_rank_falls_back_together_when_one_rank_reports_a_collector_timeou
         assert f["obs_count"] == pytest.approx(1e-4 + (4 + 1) * 512 * 2)
         assert f["checksum"] == 0.0 and r["checksum"] == 0.0
     assert "another rank of the job reported status word 2" in a["after"]["warned"][0]
+
+
+def test_one_rank_job_over_rccl_runs_every_collective_on_device_tensors(launcher):
+    """The other half of the rehearsal (the two-rank jobs above run over gloo and stage through the host): ONE rank over RCCL with
+    FW_DIST_FORCE=1, so that the `backend == "nccl"` branches -- weight broadcast, statistics all-reduce, all_gather_into_tensor of the
+    rollout shard, the gradient all-reduce of dist_update="allreduce", train()'s collective status look, the evaluation broadcast --
+    run on the real library, beside the single-process job on the same seed."""
+    import socket
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    job = [sys.executable, os.path.join(root, "tests", "rccl_one_rank_job.py")]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    rdv = {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "FW_DIST_FORCE": "1"}
+    rc, out, err = launcher(job, env=rdv, timeout=600)
+    assert rc == 0, err[-3000:]
+    forced = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    rc, out, err = launcher(job, timeout=600)
+    assert rc == 0, err[-3000:]
+    plain = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert forced["initialised"] and forced["backend"] == "nccl" and not plain["initialised"]
+    for mode in ("replicated", "allreduce"):
+        f, p = forced[mode], plain[mode]
+        assert f["sharded"] and not p["sharded"] and f["finite"] and f["fallbacks"] == 0 and f["checksum"] == 0.0
+        assert f["replicated"] == (mode == "replicated") and f["timesteps"] == p["timesteps"] == 2 * 8 * 256
+        if mode == "replicated":
+            assert f["allgather_bytes"] == 8 * 256 * 35 * 4 and f["one_launch"] and f["graphs"] and f["eval_mean_reward"] == 2.0
+        # same samples counted, same scale of weights; not the same bits: a sharded job exchanges the normaliser's statistics BETWEEN
+        # rollouts (stats_sync="rollout") where the single-process job updates them at every step, and dist_update="allreduce"
+        # steps through torch + all-reduce where the single-process job takes the fused update
+        assert f["count"] == p["count"] and f["weights_abs"] == pytest.approx(p["weights_abs"], rel=2e-2)
