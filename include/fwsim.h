@@ -274,6 +274,7 @@ enum {
   FW_CTR_SHADOW_HITS = 2,    /* ... served by a pre-simulated ("shadow") episode start: wind / camera tasks */
   FW_CTR_SCENARIO_HITS = 3,  /* ... served by pre-sampled waypoints: wind-free waypoints task */
   FW_CTR_FALLBACKS = 4,      /* ... served by the in-kernel sampler / warm-up */
+  FW_CTR_HELPER_TIMEOUTS = 5,/* camera tasks, 8-lane mapping: waits of a step wave for its capture wave that gave up (a protocol error; 0 always) */
   FW_CTR_DIM = 8
 };
 
@@ -570,6 +571,10 @@ int32_t fw_num_envs(fw_handle h);
  * 16 = the same mapping built for two waves per SIMD (256 registers), 1 = one lane per env (throughput mapping); chosen by
  * fw_create from the env count.  Diagnostic; results do not depend on it. */
 int32_t fw_lanes_per_env(fw_handle h);
+/* 1 when this handle's fw_step workgroups carry a capture wave (camera tasks on the 8-lane mapping, opt-in: environment variable
+ * FWSIM_CAPTURE_WAVE=1 at fw_create; csrc/fwsim_objlock.hpp "The capture wave"), else 0.  Diagnostic; results agree with the
+ * one-wave kernel to rounding. */
+int32_t fw_capture_wave(fw_handle h);
 const char* fw_last_error(fw_handle h); /* h may be NULL: last create/validate error */
 int32_t fw_destroy(fw_handle h);
 

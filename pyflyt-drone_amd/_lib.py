@@ -19,7 +19,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 EXPORTS = (
     "fw_sizeof_config", "fw_abi_version", "fw_state_dim", "fw_obs_dim", "fw_validate_config", "fw_create", "fw_reset",
-    "fw_step", "fw_seed", "fw_get_state", "fw_set_state", "fw_get_counters", "fw_observe", "fw_render", "fw_num_envs", "fw_lanes_per_env", "fw_last_error",
+    "fw_step", "fw_seed", "fw_get_state", "fw_set_state", "fw_get_counters", "fw_observe", "fw_render", "fw_num_envs", "fw_lanes_per_env", "fw_capture_wave", "fw_last_error",
     "fw_destroy", "fw_gae", "fw_eval_track", "fw_normalize_obs", "fw_normalize_obs_workspace_bytes", "fw_ppo_update_workspace_bytes", "fw_ppo_param_count", "fw_ppo_moment_count", "fw_ppo_moment_map", "fw_ppo_update", "fw_policy_act", "fw_policy_terminal_value", "fw_rollout_post", "fw_collect_act", "fw_collect_stats", "fw_collect_stats_workspace_bytes", "fw_collect_step", "fw_collect_finish", "fw_collect_step_workspace_bytes", "fw_collect_workspace_init", "fw_collect_close", "fw_collect_status", "fw_ppo_update_status",
 )
 
@@ -94,6 +94,7 @@ def lib() -> C.CDLL:
         L.fw_get_counters.restype = i32; L.fw_get_counters.argtypes = [vp, vp]
         L.fw_num_envs.restype = i32; L.fw_num_envs.argtypes = [vp]
         L.fw_lanes_per_env.restype = i32; L.fw_lanes_per_env.argtypes = [vp]
+        L.fw_capture_wave.restype = i32; L.fw_capture_wave.argtypes = [vp]
         L.fw_render.restype = i32; L.fw_render.argtypes = [vp, i32, vp, vp]
         L.fw_last_error.restype = C.c_char_p; L.fw_last_error.argtypes = [vp]
         L.fw_destroy.restype = i32; L.fw_destroy.argtypes = [vp]

@@ -47,7 +47,7 @@ ST_DUCK_PHASE, ST_SEEN_CONSEC, ST_NUM_OBST, ST_OBST, ST_DIM = 47, 48, 49, 50, 11
 INFO_NUM_TARGETS_REACHED, INFO_COLLISION, INFO_OUT_OF_BOUNDS, INFO_ENV_COMPLETE = 0, 1, 2, 3
 INFO_DUCK_STRIKE, INFO_IS_SUCCESS, INFO_EP_LEN = 4, 5, 6
 # fw_get_counters columns (fwsim.h FW_CTR_*)
-CTR_LAUNCHES, CTR_RESETS, CTR_SHADOW_HITS, CTR_SCENARIO_HITS, CTR_FALLBACKS, FW_CTR_DIM = 0, 1, 2, 3, 4, 8
+CTR_LAUNCHES, CTR_RESETS, CTR_SHADOW_HITS, CTR_SCENARIO_HITS, CTR_FALLBACKS, CTR_HELPER_TIMEOUTS, FW_CTR_DIM = 0, 1, 2, 3, 4, 5, 8
 
 
 class SurfaceParams(C.Structure):

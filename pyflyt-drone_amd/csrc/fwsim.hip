@@ -120,14 +120,14 @@ __device__ __forceinline__ unsigned long long pack_done(uint32_t ep, uint32_t ep
   return ((unsigned long long)ep << 32) | ((unsigned long long)(epoch & 0xFFFFFFu) << 8) | (unsigned long long)(done & 0xFF);
 }
 
-// worker: one chunk of work on the shadows of the envs of block `blk`
+// worker: one chunk of work on the shadows of the envs of block `blk` (at most `max_chunk` warm-up Aviary steps; 0 = step_ratio)
 template <typename T, int G, int TKIND>
-__device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> D, int blk) {
+__device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> D, int blk, int max_chunk = 0) {
   constexpr bool OBJ = TKIND == FW_TASK_OBJLOCK, COMB = TKIND == FW_TASK_WAYPOINT_OBJLOCK, HASOBJ = OBJ || COMB;
   constexpr int EPW = kWave / G;
   const Params<T>& P = *Pp;
   const ObjC<T>& OC = *OCp;
-  const int lane = threadIdx.x, sub = (G == 1) ? 0 : (lane & (G - 1)), row = lane / G;
+  const int lane = threadIdx.x & (kWave - 1), sub = (G == 1) ? 0 : (lane & (G - 1)), row = lane / G;     // (the capture wave of a two-wave workgroup works here too)
   const bool leader = sub == 0;
   const int env = blk * EPW + row;
   const bool active = env < D.n;
@@ -139,7 +139,7 @@ __device__ __forceinline__ void shadow_worker(const Params<T>* __restrict__ Pp, 
   const bool fresh = active && (uint32_t)req != D.epoch && req != ~0ull;     // a request of an earlier launch
   int done = (int)(dn & 0xFF);
   const bool begin = fresh && (uint32_t)(dn >> 32) != target;   // new episode wanted: (re)start
-  int left = (fresh && !begin) ? min(total - done, P.step_ratio) : 0;
+  int left = (fresh && !begin) ? min(total - done, max_chunk > 0 ? max_chunk : P.step_ratio) : 0;
   if (__ballot(begin || left > 0) == 0ull) return;              // nothing to do in this wave: the common case
   const DevState<T> V = shadow_view<T>(D);
   if (begin) {
@@ -296,7 +296,8 @@ enum Phase : int { PH_STEP = 0, PH_WARM = 1, PH_DONE = 2 };
 // wave-uniform (scalar loads); used between 8 192 and 65 536 envs, where the 1-wave build would run its waves in two rounds.
 // COLLECT = the step waves of fw_collect_step (fwsim_fused.hpp): block indices are offset by the act waves in front, the
 // actions are waited for and read coherently, and the epilogue carries the statistics of VecNormalize.step_wait.
-template <typename T, bool GENERAL, int G, int TKIND, int WPE = 1, bool COLLECT = false>
+// HELP = the workgroup has a capture wave (fwsim_objlock.hpp, "The capture wave"): camera tasks on the 8-lane mapping.
+template <typename T, bool GENERAL, int G, int TKIND, int WPE = 1, bool COLLECT = false, bool HELP = false>
 __device__ __forceinline__
 void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp, DevState<T> Dg,
                const T* __restrict__ actions, T* __restrict__ obs, T* __restrict__ reward,
@@ -464,6 +465,13 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
   constexpr bool STASH = (!DEFER && !HASOBJ) || COLLECT;
   double* latch = STASH ? reinterpret_cast<double*>(smem_raw + Dg.stash_off) : nullptr;        // [EPW][4]: reward, done, (num_reached, flags), (strike, step_count)
   int it = 0, warm_left = 0;
+  // HELP: the request of the previous sub-step that is still with the capture wave (0 = none), and what this lane owes it:
+  // bit 0 the frame-dependent half of that sub-step's task logic, bit 1 a frame, bit 2 "no collision / not out of bounds then",
+  // bit 3 (combined) "all waypoints were reached then"; the distance to the duck of that sub-step (ObjLock's reward reads it)
+  const Mbox<T> MB = mbox_at<T>(HELP ? Dg.mbox_off : 0);
+  uint32_t n_posted = 0, pend_seq = 0;
+  int pend = 0;
+  T dist_keep = (T)0;
   bool resetting = false;                            // DEFER: auto-reset pending for the epilogue
   bool step_over = active && done_at_entry;          // nothing to simulate: finalise immediately
 
@@ -568,6 +576,111 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
         contact = aviary_step<T, false, G, HASOBJ>(P, C, OC, D, env, O, S, R, cmd, tick, z0, z1, wb, wa, gust, mine, wmask, LA);    // :339
       }
     }
+    if constexpr (HELP) {
+      // ---- the camera on the capture wave, one sub-step behind the physics ----
+      const bool due = stepped && OC.camera_ratio_ticks > 0 && (tick % OC.camera_ratio_ticks) == 0;
+      FWP(const long long p_c0 = FWP_NOW(); p_avi += p_c0 - p_b;)
+      const uint32_t seq_cur = cap_post<T>(MB, n_posted, due, row, leader, O, S, R);
+      // the frame-independent half of THIS sub-step's task logic first: it reads the state as the physics left it; rew / flags
+      // of the previous sub-step's other half are complete only below, and the order of their updates is the reference's:
+      // (previous: frame half) comes before (this: -100 assignments), see the two halves
+      FWP(const long long p_w0 = FWP_NOW();)
+      cap_collect<T>(MB, pend_seq, (pend & 2) != 0, row, O, D.stats);
+      FWP(p_task += FWP_NOW() - p_w0;)
+      pend_seq = 0;
+      auto frame_half = [&](int keep) {             // compute_state + the rewards that read the frame (fixedwing_objlock_env.py:253-287, 296-372)
+        if (OBJ) {
+          obj_compute_state<T>(O);
+          if ((keep & 4) && obj_reward<T>(OC, P.sparse, O, dist_keep, rew)) { flags |= FL_TERM | FL_COMPLETE; out_strike = 1; }
+        } else {
+          comb_compute_state<T>(OC, O, (keep & 8) != 0);
+          if (keep & 4) {
+            if (!(keep & 8)) comb_obstacle_penalty<T>(OC, O, (T)1, rew);
+            else {
+              comb_obstacle_penalty<T>(OC, O, (T)0.5, rew);
+              if (comb_duck_reward<T>(OC, P.sparse, O, rew)) { flags |= FL_TERM | FL_COMPLETE; out_strike = 1; }
+            }
+          }
+        }
+      };
+      if (pend & 1) frame_half(pend);
+      pend = 0;
+      int keep = 0;
+      bool now = false;                             // this lane needs its frame before the next sub-step's physics
+      if (stepped) {
+        if (stepping) {
+          keep = 1 | (due ? 2 : 0);
+          int nleft = 0;
+          T old_dist = new_dist;
+          if (COMB) {
+            nleft = P.num_targets - num_reached;
+            if (nleft > 0) {
+              T dx = tcur[0] - S.p[0], dy = tcur[1] - S.p[1], dz = tcur[2] - S.p[2];
+              new_dist = M<T>::sqrt_(dx * dx + dy * dy + dz * dz);
+            }
+            tgt_obs = num_reached;
+            if (nleft == 0) keep |= 8;
+          }
+          if (step_count > P.max_steps) flags |= FL_TRUNC;
+          if (contact) { rew = (T)-100; flags |= FL_COLLISION | FL_TERM; }
+          if (S.p[0] * S.p[0] + S.p[1] * S.p[1] + S.p[2] * S.p[2] > P.dome * P.dome) { rew = (T)-100; flags |= FL_OOB | FL_TERM; }
+          bool can_strike = false;
+          if (!(flags & (FL_COLLISION | FL_OOB))) {
+            keep |= 4;
+            if (OBJ) {
+              T dx = O.duck[0] - S.p[0], dy = O.duck[1] - S.p[1], dz = O.duck[2] - S.p[2];
+              dist_keep = M<T>::sqrt_(dx * dx + dy * dy + dz * dz);
+              // obj_reward: a strike needs lock_steps >= hold_steps AFTER this sub-step's (at most +1) update, and the distance
+              can_strike = O.lock_steps + (T)1 >= (T)OC.hold_steps && dist_keep <= OC.strike_dist;
+            } else if (nleft > 0) {
+              if (!P.sparse) {
+                T progress = (old_dist != (T)0) ? (old_dist - new_dist) : (T)0;
+                rew += M<T>::fmax_((T)3 * progress, (T)0);
+                rew += M<T>::rcp_(new_dist);
+              }
+              if (new_dist < P.reach) {
+                rew = (T)100;
+                num_reached += 1;
+                if (num_reached == P.num_targets) flags &= ~(FL_TERM | FL_TRUNC);          // :297-300
+                const int i1 = min(num_reached + 1, FW_MAX_TARGETS - 1);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { tcur[k] = tnext[k]; tnext[k] = D.r[(size_t)(RF_TARGETS + 3 * i1 + k) * n + env]; }
+              }
+            } else {
+              flags &= ~FL_TERM;                                                            // :306
+              // comb_duck_reward: a strike needs the duck phase (which this sub-step's frame may switch on) and the lock counter
+              can_strike = O.lock_steps + (T)1 >= (T)OC.hold_steps;
+            }
+          }
+          step_over = (it + 1 >= P.step_ratio) || (flags & (FL_TERM | FL_TRUNC));
+          now = can_strike || step_over;
+        } else {
+          now = true;                               // warm-up of an in-kernel reset: its last sub-step reads the frame
+        }
+      }
+      if (__ballot(now) != 0ull) {
+        // somebody's agent step ends here (or could, by a strike): finish the sub-step as the one-wave kernel does
+        FWP(const long long p_w1 = FWP_NOW();)
+        cap_collect<T>(MB, seq_cur, due, row, O, D.stats);
+        FWP(p_task += FWP_NOW() - p_w1; p_nhit += 1;)
+        if (stepped) {
+          if (stepping) {
+            frame_half(keep);
+            step_over = (it + 1 >= P.step_ratio) || (flags & (FL_TERM | FL_TRUNC));
+          } else {
+            warm_left -= 1;
+            if (warm_left == 0) {
+              if (OBJ) obj_compute_state<T>(O);
+              else { new_dist = end_reset<T, G>(P, D, env, episode, S); comb_compute_state<T>(OC, O, P.num_targets == 0); }
+              phase = PH_DONE;
+            }
+          }
+        }
+      } else {
+        pend_seq = seq_cur;                         // ... else the frames come back behind the next sub-step's physics
+        pend = keep;
+      }
+    } else {
     if (HASOBJ) obj_capture_step<T, G, COLLECT>(OC, D, stepped, envc, O, S, R, tick);     // the camera, by the whole wave
     FWP(const long long p_c = FWP_NOW(); p_avi += p_c - p_b;)
     if (stepped) {
@@ -665,6 +778,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
         }
       }
       FWP(p_task += FWP_NOW() - p_c;)
+    }
     }
     it += 1;
   }
@@ -900,7 +1014,8 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       ip[1] = make_int4(o_st, OBJ ? o_st : 0, o_sc, 0);
     }
   }
-  __syncthreads();
+  if (HELP) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }   // (the capture wave takes no part: no s_barrier)
+  else __syncthreads();
   // (COLLECT: the partial sums first -- the fold waves at the end of the launch are waiting for them, nobody for the observation rows)
   if (COLLECT) collect_stats_tail<T>(*CAp, D.epoch, tile, ld, min(EPW, D.n - env0), wg, nblk, active && leader, latch[4 * row], latch[4 * row + 1] != 0.0, env, c_ret);
   flush_obs_tile<T>(tile, ld, obs, env0, EPW, D.n, Dobs);
@@ -919,7 +1034,8 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       const long long t3 = FWP_NOW();
       w[0] = t3 - p_t0; w[1] = p_t1 - p_t0; w[2] = p_reset; w[3] = p_avi; w[4] = p_task; w[5] = t3 - p_t2; w[6] = it | (nr << 8) | (nh << 16); w[7] = p_t0; w[8] = p_r1; w[9] = p_r2; w[10] = p_r3;
       w[11] = p_capmax | ((long long)p_ncapw << 48);
-      if (HASOBJ) { w[8] = O.p_capm[0]; w[9] = O.p_capm[1]; w[10] = O.p_capm[2]; w[7] = O.p_capm[3];
+      if (HELP) { w[8] = p_nhit; w[9] = n_posted; }
+      else if (HASOBJ) { w[8] = O.p_capm[0]; w[9] = O.p_capm[1]; w[10] = O.p_capm[2]; w[7] = O.p_capm[3];
         if (getenv_ph) { w[1] = O.p_ph[0]; w[3] = O.p_ph[1]; w[4] = O.p_ph[2]; w[5] = O.p_ph[3]; w[9] = O.p_ph[4]; w[6] = O.p_ph[5]; } }     // (the reset split is unused by these kernels)
     } })
 }
@@ -949,6 +1065,40 @@ template <typename T, int TKIND>
 __global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g8(FW_STEP_ARGS) { FW_STEP_RUN(T, true, 8, TKIND); }
 template <typename T, int TKIND>
 __global__ __launch_bounds__(kWave) void fw_step_kernel_obj_g1(FW_STEP_ARGS) { FW_STEP_RUN(T, true, 1, TKIND); }
+#ifndef FW_HELP_CHUNK
+#define FW_HELP_CHUNK 2      // warm-up Aviary steps of shadow work a capture wave does per launch
+#endif
+// ... with a capture wave beside every step wave (fwsim_objlock.hpp, "The capture wave"): 128 threads, wave 0 steps, wave 1 serves
+template <typename T, int TKIND>
+__global__ __launch_bounds__(2 * kWave) void fw_step_kernel_obj_g8h(FW_STEP_ARGS) {
+  const Mbox<T> MB = mbox_at<T>(D.mbox_off);
+  if (threadIdx.x < 4) MB.ctl[threadIdx.x] = 0u;
+  __syncthreads();                                   // the ONE s_barrier both waves meet at: the mailbox words are zero
+  if (threadIdx.x >= kWave) {
+    // The grid of this kernel is the step workgroups alone -- with one wave per SIMD (the whole register file each) 512 step waves
+    // + 512 capture waves fill the chip, and separate worker workgroups would run BEHIND them (measured: + 15 us).  The capture
+    // wave is the shadow worker of its tile as well: one warm-up Aviary step per launch (instead of step_ratio), at the start,
+    // while the step wave is in its prologue and first sub-step and cannot have posted anything yet.
+    const int nblk = (D.npad + 7) / 8, bx = (int)blockIdx.x % nblk;
+    const int blk = ((nblk & 7) == 0) ? (bx & 7) * (nblk >> 3) + (bx >> 3) : bx;       // (step_body's XCD-aware map)
+    D.epoch = launch_index(D.lctr);
+    const DevState<T> V = tile_view<T, 8>(D, blk);
+    // (Tried: the mailbox looked at in front of every warm-up Aviary step of the shadow work, requests first -- combined 60.2 ->
+    // 61.5 us: the wave is short of time, not badly ordered.)
+    FWP(const long long h0 = FWP_NOW(); long long hcap = 0; int hreq = 0;)
+    if (D.shadow_on) shadow_worker<T, 8, TKIND>(Pp, OCp, V, blk, FW_HELP_CHUNK);
+    FWP(const long long h1 = FWP_NOW();)
+    capture_server<T>(MB, 0u, *OCp, V, blk * 8 FWP(, &hcap, &hreq));
+    FWP(if (D.prof && threadIdx.x == kWave) {
+      long long* w = D.prof + ((size_t)(D.epoch % kProfSlots) * 2 * nblk + nblk + blockIdx.x) * kProfWords;
+      w[0] = (h1 - h0) + hcap; w[1] = h1 - h0; w[2] = hcap; w[3] = hreq; w[4] = FWP_NOW() - h0; })
+    return;
+  }
+  D.epoch = launch_index(D.lctr);
+  step_body<T, true, 8, TKIND, 1, false, true>(FW_STEP_PASS);
+  launch_done(D.lctr, D.epoch);
+  if (threadIdx.x == 0) __hip_atomic_store(MB.ctl + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);     // every path of wave 0 ends here
+}
 
 // fw_collect_step (fwsim_fused.hpp): act waves in front, then the step waves of the same step kernels with COLLECT on.  The
 // 8-lane mapping at one wave per SIMD only (the collector's regime: thousands of envs per GPU).
@@ -1302,6 +1452,7 @@ struct fw_env {
   int32_t n = 0, npad = 0, device = 0;
   int32_t lanes_per_env = 1;    // 1: throughput mapping, 8: latency mapping (see fwsim_device.hpp)
   int32_t g8_waves = 1;         // 8-lane mapping, waypoints task: waves per SIMD the step kernel is built for (1 | 2)
+  int32_t capture_wave = 0;     // 8-lane mapping, camera tasks: fw_step workgroups carry a capture wave (fw_step_kernel_obj_g8h)
   uint64_t seed = 0;
   int64_t env_offset = 0;
   void* params_dev = nullptr;   // Params<T>
@@ -1356,11 +1507,13 @@ int device_of(const void* p) {
 int ensure_learner_lds(int dev, int which /*0: fw_ppo_update, 1: fw_policy_act*/, size_t bytes);
 
 template <typename T> size_t tile_bytes(const fw_env* h);
+template <typename T> size_t step_lds_bytes(const fw_env* h);
 template <typename T> DevState<T> dev_state(fw_env* h) {
   DevState<T> D; D.r = (T*)h->r_dev; D.i = h->i_dev; D.n = h->n; D.npad = h->npad;
   D.rs = (T*)h->rs_dev; D.is = h->is_dev; D.sobs = (T*)h->sobs_dev; D.sreq = h->sreq_dev; D.sdone = h->sdone_dev; D.epoch = 0; D.shadow_on = h->shadow_on;
   D.lctr = h->lctr_dev; D.stats = h->stats_dev;
   D.stash_off = (int32_t)((tile_bytes<T>(h) + 15) & ~(size_t)15);
+  D.mbox_off = (int32_t)((step_lds_bytes<T>(h) + 15) & ~(size_t)15);
   FWP(D.prof = h->prof_dev;)
   return D;
 }
@@ -1396,6 +1549,8 @@ template <typename T> size_t tile_bytes(const fw_env* h) {
 }
 // dynamic LDS of a step launch: the tile (or the camera's map) + the output stash of the envs of a wave
 template <typename T> size_t step_lds_bytes(const fw_env* h) { return ((tile_bytes<T>(h) + 15) & ~(size_t)15) + sizeof(double) * 4 * (size_t)(kWave / h->lanes_per_env); }
+// ... of a step launch whose workgroups carry a capture wave: + the mailbox
+template <typename T> size_t step_lds_bytes_h(const fw_env* h) { return ((step_lds_bytes<T>(h) + 15) & ~(size_t)15) + mbox_bytes(sizeof(T)); }
 inline dim3 grid_of(const fw_env* h) { return dim3((unsigned)(h->npad / (kWave / h->lanes_per_env))); }
 
 // ObjLock task constants (analytic camera axes, shaping coefficients of envs/fixedwing_objlock_env.py:54-80)
@@ -1482,16 +1637,18 @@ int create_T(fw_env* h) {
   // the camera's LDS map outgrows what a workgroup gets without asking from ~700 columns on.  The attribute belongs to the
   // (device, kernel) pair, not to the handle: keep the maximum ever asked for and only ever raise it, so a later, smaller
   // handle cannot lower the cap under an earlier one
-  if (const size_t lds = step_lds_bytes<T>(h); lds > 48 * 1024) {
+  if (const size_t lds = step_lds_bytes_h<T>(h); lds > 48 * 1024) {
     if (lds > 160 * 1024) { h->err = "camera_resolution x num_obstacles needs more LDS than a CU has"; return FW_EINVAL; }
     const int which = (h->cfg.task == FW_TASK_OBJLOCK ? 0 : 1) + (sizeof(T) == 8 ? 0 : 2);
     static size_t have[64][4] = {};
     if (h->device < 64 && lds > have[h->device][which]) {
       if (h->cfg.task == FW_TASK_OBJLOCK) {
         HIP_TRY(h, hipFuncSetAttribute((const void*)fw_step_kernel_obj_g8<T, FW_TASK_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)fw_step_kernel_obj_g8h<T, FW_TASK_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(h, hipFuncSetAttribute((const void*)fw_reset_kernel<T, 8, FW_TASK_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       } else {
         HIP_TRY(h, hipFuncSetAttribute((const void*)fw_step_kernel_obj_g8<T, FW_TASK_WAYPOINT_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)fw_step_kernel_obj_g8h<T, FW_TASK_WAYPOINT_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(h, hipFuncSetAttribute((const void*)fw_reset_kernel<T, 8, FW_TASK_WAYPOINT_OBJLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       }
       have[h->device][which] = lds;
@@ -1507,6 +1664,10 @@ int create_T(fw_env* h) {
   hipLaunchKernelGGL((KERNEL), step_grid, dim3(kWave), step_lds_bytes<T>(h), st, (const Params<T>*)h->params_dev,    \
                      (const ObjC<T>*)h->objc_dev, dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term,  \
                      trunc, (T*)tobs, info)
+#define FW_LAUNCH_STEP_H(KERNEL)   /* step wave + capture wave per workgroup */                                      \
+  hipLaunchKernelGGL((KERNEL), step_grid, dim3(2 * kWave), step_lds_bytes_h<T>(h), st, (const Params<T>*)h->params_dev, \
+                     (const ObjC<T>*)h->objc_dev, dev_state<T>(h), (const T*)actions, (T*)obs, (T*)reward, term,  \
+                     trunc, (T*)tobs, info)
 
 template <typename T>
 int step_T(fw_env* h, const void* actions, void* obs, void* reward, uint8_t* term, uint8_t* trunc, void* tobs,
@@ -1514,11 +1675,14 @@ int step_T(fw_env* h, const void* actions, void* obs, void* reward, uint8_t* ter
   const bool general = h->cfg.wind_mode != FW_WIND_OFF;
   const bool g8 = h->lanes_per_env == 8;
   dim3 step_grid = grid_of(h);
-  if (h->shadow_on) step_grid.x *= 2;          // second half of the grid = shadow workers
+  const bool two_wave = g8 && h->capture_wave && h->cfg.task != FW_TASK_WAYPOINTS;
+  if (h->shadow_on && !two_wave) step_grid.x *= 2;          // second half of the grid = shadow workers (two-wave workgroups: the capture wave is the worker)
   if (h->cfg.task == FW_TASK_OBJLOCK) {
-    if (g8) FW_LAUNCH_STEP((fw_step_kernel_obj_g8<T, FW_TASK_OBJLOCK>)); else FW_LAUNCH_STEP((fw_step_kernel_obj_g1<T, FW_TASK_OBJLOCK>));
+    if (g8 && h->capture_wave) FW_LAUNCH_STEP_H((fw_step_kernel_obj_g8h<T, FW_TASK_OBJLOCK>));
+    else if (g8) FW_LAUNCH_STEP((fw_step_kernel_obj_g8<T, FW_TASK_OBJLOCK>)); else FW_LAUNCH_STEP((fw_step_kernel_obj_g1<T, FW_TASK_OBJLOCK>));
   } else if (h->cfg.task == FW_TASK_WAYPOINT_OBJLOCK) {
-    if (g8) FW_LAUNCH_STEP((fw_step_kernel_obj_g8<T, FW_TASK_WAYPOINT_OBJLOCK>)); else FW_LAUNCH_STEP((fw_step_kernel_obj_g1<T, FW_TASK_WAYPOINT_OBJLOCK>));
+    if (g8 && h->capture_wave) FW_LAUNCH_STEP_H((fw_step_kernel_obj_g8h<T, FW_TASK_WAYPOINT_OBJLOCK>));
+    else if (g8) FW_LAUNCH_STEP((fw_step_kernel_obj_g8<T, FW_TASK_WAYPOINT_OBJLOCK>)); else FW_LAUNCH_STEP((fw_step_kernel_obj_g1<T, FW_TASK_WAYPOINT_OBJLOCK>));
   } else if (general) {
     if (g8 && h->g8_waves == 2) FW_LAUNCH_STEP((fw_step_kernel_g8w2<T, true>));
     else if (g8) FW_LAUNCH_STEP((fw_step_kernel_g8<T, true>)); else FW_LAUNCH_STEP((fw_step_kernel_g1<T, true>));
@@ -1723,6 +1887,11 @@ int32_t fw_create(const fw_config* cfg, int32_t num_envs, int32_t device, uint64
     int v = atoi(ev);
     if ((v == 1 || v == 2) && h->lanes_per_env == 8 && wp) h->g8_waves = v;
   }
+  // Camera tasks on the 8-lane mapping, opt-in (FWSIM_CAPTURE_WAVE=1): a second wave per step workgroup takes the captures
+  // (fwsim_objlock.hpp, "The capture wave").  Off by default: measured in round 5 it shortens the MEAN wave (ObjLock - 6 %,
+  // combined - 8 %) but not the launch, which lasts as long as its slowest wave (CHANGELOG round 5).
+  h->capture_wave = 0;
+  if (const char* ev = getenv("FWSIM_CAPTURE_WAVE")) { if (atoi(ev) != 0 && h->lanes_per_env == 8 && !wp) h->capture_wave = 1; }
   DeviceGuard g(device);
   rc = (cfg->dtype == FW_F64) ? create_T<double>(h) : create_T<float>(h);
   if (rc != FW_OK) {
@@ -2248,6 +2417,7 @@ int32_t fw_rollout_post(const void* reward, int32_t rew_is_f64, const uint8_t* t
 }
 
 int32_t fw_num_envs(fw_handle h) { return h ? h->n : FW_EINVAL; }
+int32_t fw_capture_wave(fw_handle h) { return h ? h->capture_wave : FW_EINVAL; }
 int32_t fw_lanes_per_env(fw_handle h) { return h ? (h->lanes_per_env == 8 && h->g8_waves == 2 ? 16 : h->lanes_per_env) : FW_EINVAL; }
 
 const char* fw_last_error(fw_handle h) { return h ? h->err.c_str() : g_err.c_str(); }

@@ -101,6 +101,7 @@ struct DevState {
   unsigned long long* sdone; // [npad]  worker -> live:  (episode built << 32) | (launch index & 0xFFFFFF) << 8 | progress
   uint32_t epoch;            // launch index of this fw_step: set IN the kernel from `lctr` (launch_index below)
   int32_t shadow_on;
+  int32_t mbox_off;          // camera tasks, two-wave step workgroups: byte offset in dynamic LDS of the capture mailbox (fwsim_objlock.hpp)
   int32_t stash_off;         // byte offset in dynamic LDS of the step waves' output stash ([envs per wave][4] doubles, behind the tile / camera map)
   uint32_t* lctr;            // [fw_step grid]  per-workgroup launch counters (launch_index below)
   unsigned long long* stats;  // [FW_CTR_DIM]  hand-off counters (fw_get_counters), bumped on resets only

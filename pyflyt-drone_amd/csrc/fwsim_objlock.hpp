@@ -1293,4 +1293,139 @@ __device__ __forceinline__ void obj_capture_step(const ObjC<T>& OC, const DevSta
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// The capture wave (8-lane mapping, fw_step_kernel_obj_g8h).  At 4096 envs half the SIMDs of the chip are idle and a step wave runs
+// physics, camera and task logic one after the other.  Here the workgroup has a SECOND wave on another SIMD of the same CU that does
+// nothing but the captures: the step wave posts the poses of the envs that are due (LDS mailbox, two slots), goes on with the NEXT
+// sub-step's physics, and only then collects the frame and runs the half of the task logic that reads it (fwsim.hip, step_body
+// HELP).  Nothing is speculated: the only frame-dependent way a sub-step can end the agent step is a strike, and whether a strike
+// is possible at all is known without the frame (lock counter one short of the hold, close enough); where it is -- or where a
+// lane's agent step ends anyway -- the wave collects at once, as the one-wave kernel always does.  Same arithmetic in the same
+// order as obj_capture_wave / the one-wave loop: same bits.
+// Both waves of a workgroup are resident together (a workgroup is placed on its CU as a whole), so the waits below cannot
+// starve; they are bounded all the same (a protocol error ends in FW_CTR_HELPER_TIMEOUTS, not in a hung queue).
+// ------------------------------------------------------------------------------------------
+constexpr int kMboxReqWords = 16;            // per env row: position [3], rotation [9], duck [3], (obstacle count | due << 16)
+#ifndef FW_MBOX_SPIN_LOG2
+#define FW_MBOX_SPIN_LOG2 22
+#endif
+constexpr uint32_t kMboxSpin = 1u << FW_MBOX_SPIN_LOG2;     // polls (each >= 64 cycles of s_sleep) before a wait gives up
+template <typename T> struct Mbox {
+  uint32_t* ctl;     // [0] requests posted  [1] requests served  [2] step wave is done  [3] (spare)
+  T* req;            // [2 slots][8 rows][kMboxReqWords]
+  T* resp;           // [2 slots][8 rows][8]
+};
+__host__ __device__ inline size_t mbox_bytes(size_t word) { return 16 + word * 2 * 8 * (size_t)(kMboxReqWords + 8); }
+template <typename T> __device__ __forceinline__ Mbox<T> mbox_at(int off) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  Mbox<T> M;
+  M.ctl = reinterpret_cast<uint32_t*>(smem_raw + off);
+  M.req = reinterpret_cast<T*>(smem_raw + off + 16);
+  M.resp = M.req + 2 * 8 * kMboxReqWords;
+  return M;
+}
+
+// step wave: hand this sub-step's due envs to the capture wave.  Returns the request's sequence number, 0 if nobody was due.
+// Wave-uniform call (all 64 lanes).
+template <typename T>
+__device__ __forceinline__ uint32_t cap_post(const Mbox<T>& M, uint32_t& n_posted, bool due, int row, bool leader,
+                                             const ObjState<T>& O, const Rigid<T>& S, const T R[9]) {
+  if (__ballot(due) == 0ull) return 0u;
+  const uint32_t seq = ++n_posted;
+  if (leader) {
+    T* q = M.req + ((seq & 1u) * 8 + row) * kMboxReqWords;
+    if (due) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { q[i] = S.p[i]; q[12 + i] = O.duck[i]; }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) q[3 + i] = R[i];
+    }
+    *reinterpret_cast<int32_t*>(q + 15) = (O.nob & 0xFFFF) | (due ? 0x10000 : 0);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((threadIdx.x & (kWave - 1)) == 0) __hip_atomic_store(M.ctl + 0, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return seq;
+}
+
+// step wave: wait for request `seq` (0 = there was none) and take the frames of the lanes that were due in it.  Wave-uniform call.
+template <typename T>
+__device__ __forceinline__ void cap_collect(const Mbox<T>& M, uint32_t seq, bool due, int row, ObjState<T>& O, unsigned long long* stats) {
+  if (seq == 0u) return;
+  uint32_t spins = 0;
+  while (__hip_atomic_load(M.ctl + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) {
+    if (++spins > kMboxSpin) { if ((threadIdx.x & (kWave - 1)) == 0) stat_add(stats, FW_CTR_HELPER_TIMEOUTS); break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (due) {
+    const T* r = M.resp + ((seq & 1u) * 8 + row) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) O.frame[i] = r[i];
+    O.frame_has = (T)1;
+  }
+}
+
+// the capture wave: one request (number `want`, which has been posted)
+template <typename T>
+__device__ __forceinline__ void capture_serve_one(const Mbox<T>& M, uint32_t want, const ObjC<T>& OC, const DevState<T>& D, int env0
+#ifdef FW_PROFILE
+                                                  , long long* p_busy, int* p_nreq     // dev-only: cycles in captures, requests served
+#endif
+                                                  ) {
+#ifdef FW_PROFILE
+  const long long c0 = (long long)__builtin_readcyclecounter();
+#endif
+  const int lane = (int)threadIdx.x & (kWave - 1), sub = lane & 7, row = lane >> 3;
+  const T* q = M.req + ((want & 1u) * 8 + row) * kMboxReqWords;
+  const int32_t word = *reinterpret_cast<const int32_t*>(q + 15);
+  const bool due = (word & 0x10000) != 0;
+  ObjState<T> O;
+  Rigid<T> S;
+  T R[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { S.p[i] = due ? q[i] : (T)0; O.duck[i] = due ? q[12 + i] : (T)0; }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = due ? q[3 + i] : (T)0;
+  O.nob = word & 0xFFFF;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) O.frame[i] = (T)0;
+  O.frame_has = (T)0;
+  obj_capture_wave<T, 8>(OC, D, due, env0 + row, O, S, R);
+  if (due && sub == 0) {
+    T* r = M.resp + ((want & 1u) * 8 + row) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = O.frame[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(M.ctl + 1, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef FW_PROFILE
+  *p_busy += (long long)__builtin_readcyclecounter() - c0; *p_nreq += 1;
+#endif
+}
+#ifdef FW_PROFILE
+#define FW_CAP_PROF_ARGS , p_busy, p_nreq
+#define FW_CAP_PROF_PARAMS , long long* p_busy, int* p_nreq
+#else
+#define FW_CAP_PROF_ARGS
+#define FW_CAP_PROF_PARAMS
+#endif
+
+// ... and in order until the step wave says it is done
+template <typename T>
+__device__ __forceinline__ void capture_server(const Mbox<T>& M, uint32_t served, const ObjC<T>& OC, const DevState<T>& D, int env0 FW_CAP_PROF_PARAMS) {
+  for (;;) {
+    const uint32_t want = served + 1u;
+    uint32_t spins = 0;
+    bool go = false;
+    for (;;) {
+      if (__hip_atomic_load(M.ctl + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) { go = true; break; }
+      if (__hip_atomic_load(M.ctl + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) break;   // (set after the last collect: nothing is outstanding)
+      if (++spins > (kMboxSpin << 2)) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (!go) return;
+    capture_serve_one<T>(M, want, OC, D, env0 FW_CAP_PROF_ARGS);
+    served = want;
+  }
+}
+
 }  // namespace fwsim

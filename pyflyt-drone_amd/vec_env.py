@@ -126,6 +126,7 @@ class FixedwingVecEnv(_VecEnvBase):
         self._h = h
         self.lanes_per_env = int(_lib.lib().fw_lanes_per_env(h))    # which lane mapping fw_create picked (diagnostic)
         self.g8_waves = 2 if self.lanes_per_env == 16 else 1
+        self.capture_wave = bool(_lib.lib().fw_capture_wave(h))      # camera tasks: step workgroups with a capture wave (FWSIM_CAPTURE_WAVE=1)
         if self.lanes_per_env == 16:                                # (16 = the 8-lane mapping built for two waves per SIMD)
             self.lanes_per_env = 8
         n, d = self.num_envs, self.obs_dim
@@ -324,7 +325,8 @@ class FixedwingVecEnv(_VecEnvBase):
         c = np.zeros(K.FW_CTR_DIM, dtype=np.uint64)
         _lib.check(_lib.lib().fw_get_counters(self._h, c.ctypes.data_as(C.c_void_p)), self._h)
         return {"launches": int(c[K.CTR_LAUNCHES]), "resets": int(c[K.CTR_RESETS]), "shadow_hits": int(c[K.CTR_SHADOW_HITS]),
-                "scenario_hits": int(c[K.CTR_SCENARIO_HITS]), "fallbacks": int(c[K.CTR_FALLBACKS])}
+                "scenario_hits": int(c[K.CTR_SCENARIO_HITS]), "fallbacks": int(c[K.CTR_FALLBACKS]),
+                "capture_wave_timeouts": int(c[K.CTR_HELPER_TIMEOUTS])}
 
     def set_state(self, state: np.ndarray) -> None:
         s = np.ascontiguousarray(state, dtype=np.float64).reshape(self.num_envs, K.FW_STATE_DIM)

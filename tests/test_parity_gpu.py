@@ -120,10 +120,22 @@ def test_lockstep_f64(oracle, name, lanes3):
 def test_objlock_aimed_flights_lock_and_strike(oracle, lanes):
     """Aircraft aimed at their duck from 60-200 m: frames become visible, the lock counter runs,
     strikes (+400, is_success) happen -- identically in the kernel and the oracle."""
+    _aimed_flights(oracle)
+
+
+def test_objlock_aimed_flights_lock_and_strike_with_a_capture_wave(oracle, monkeypatch):
+    """... and with the captures on a second wave (FWSIM_CAPTURE_WAVE=1): a strike is the one frame-dependent way a sub-step ends
+    the agent step, i.e. the case in which the step wave must NOT run ahead of its frame."""
+    monkeypatch.setenv("FWSIM_LANES_PER_ENV", "8"); monkeypatch.setenv("FWSIM_CAPTURE_WAVE", "1")
+    _aimed_flights(oracle, capture_wave=True)
+
+
+def _aimed_flights(oracle, capture_wave=False):
     import torch
     cfg = K.train_objlock_config(duck_camera_capture_interval_steps=2, wind_config=None)
     n = 256
     hip = P.FixedwingVecEnv(cfg, n, seed=77); ora = oracle.OracleEnv(cfg, n, seed=77)
+    assert hip.capture_wave == capture_wave
     hip.reset_tensor(); ora.reset()
     s = ora.get_state()
     rng = np.random.default_rng(8)
@@ -152,6 +164,7 @@ def test_objlock_aimed_flights_lock_and_strike(oracle, lanes):
         strikes += int(o_info[:, K.INFO_DUCK_STRIKE].sum()); visible += int((o_obs[:, 25] > 0.5).sum())
     assert visible > 500 and strikes >= 3, (visible, strikes)
     np.testing.assert_allclose(hip.get_state(), ora.get_state(), rtol=0, atol=1e-6)
+    assert hip.get_counters()["capture_wave_timeouts"] == 0
 
 
 def test_baseline_size_4096_envs_against_oracle(oracle, lanes3):
@@ -160,6 +173,29 @@ def test_baseline_size_4096_envs_against_oracle(oracle, lanes3):
     hip = P.FixedwingVecEnv(cfg, 4096, seed=42)
     ora = oracle.OracleEnv(cfg, 4096, seed=42)
     run_lockstep(hip, ora, 24, np.random.default_rng(0), kind="uniform", atol=1e-7, rtol=0)
+
+
+@pytest.mark.parametrize("name", sorted(n for n in CASES if n.split("_")[0] in ("objlock", "combined")))
+def test_lockstep_f64_with_a_capture_wave(oracle, name, monkeypatch):
+    """The opt-in two-wave form of the camera step kernels (FWSIM_CAPTURE_WAVE=1; csrc/fwsim_objlock.hpp "The capture wave"): the
+    captures run on a second wave of the workgroup one sub-step behind the physics, the frame-dependent half of the task logic
+    follows them, the capture wave is the tile's shadow worker as well.  Same traces as the one-wave kernel against the oracle,
+    resets and strikes included, and no wait between the two waves ever gave up."""
+    cfg, kind = CASES[name]
+    monkeypatch.setenv("FWSIM_LANES_PER_ENV", "8"); monkeypatch.setenv("FWSIM_CAPTURE_WAVE", "1")
+    n = 192 + 7
+    hip = P.FixedwingVecEnv(cfg, n, seed=1234)
+    assert hip.lanes_per_env == 8 and hip.capture_wave
+    ora = oracle.OracleEnv(cfg, n, seed=1234)
+    obj = cfg.task == K.FW_TASK_OBJLOCK
+    worst = run_lockstep(hip, ora, 240, np.random.default_rng(5), kind=kind, atol=2e-5 if obj else 1e-7, rtol=0, state_atol=1e-7)
+    assert worst["obs"] < (2e-5 if obj else 1e-7) and worst["state"] < 1e-7
+    assert hip.get_counters()["capture_wave_timeouts"] == 0
+    hip = P.FixedwingVecEnv(cfg, 4096, seed=42)
+    ora = oracle.OracleEnv(cfg, 4096, seed=42)
+    run_lockstep(hip, ora, 24, np.random.default_rng(0), kind="uniform", atol=1e-7, rtol=0)
+    c = hip.get_counters()
+    assert c["capture_wave_timeouts"] == 0 and hip.capture_wave
 
 
 @pytest.mark.parametrize("task,n,steps", [("objlock", 4096, 10), ("combined", 2048, 10), ("combined", 16384, 8)])
