@@ -581,6 +581,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       const bool due = stepped && OC.camera_ratio_ticks > 0 && (tick % OC.camera_ratio_ticks) == 0;
       FWP(const long long p_c0 = FWP_NOW(); p_avi += p_c0 - p_b;)
       const uint32_t seq_cur = cap_post<T>(MB, n_posted, due, row, leader, O, S, R);
+      FWP(p_r1 += FWP_NOW() - p_c0;)
       // the frame-independent half of THIS sub-step's task logic first: it reads the state as the physics left it; rew / flags
       // of the previous sub-step's other half are complete only below, and the order of their updates is the reference's:
       // (previous: frame half) comes before (this: -100 assignments), see the two halves
@@ -603,7 +604,9 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
           }
         }
       };
+      FWP(const long long p_f0 = FWP_NOW();)
       if (pend & 1) frame_half(pend);
+      FWP(const long long p_f1 = FWP_NOW(); p_r2 += p_f1 - p_f0;)
       pend = 0;
       int keep = 0;
       bool now = false;                             // this lane needs its frame before the next sub-step's physics
@@ -658,27 +661,39 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
           now = true;                               // warm-up of an in-kernel reset: its last sub-step reads the frame
         }
       }
-      if (__ballot(now) != 0ull) {
-        // somebody's agent step ends here (or could, by a strike): finish the sub-step as the one-wave kernel does
+      auto finish_now = [&]() {                     // the rest of this sub-step for a lane whose frame (if it is due one) is in O
+        if (stepping) {
+          frame_half(keep);
+          step_over = (it + 1 >= P.step_ratio) || (flags & (FL_TERM | FL_TRUNC));
+        } else {
+          warm_left -= 1;
+          if (warm_left == 0) {
+            if (OBJ) obj_compute_state<T>(O);
+            else { new_dist = end_reset<T, G>(P, D, env, episode, S); comb_compute_state<T>(OC, O, P.num_targets == 0); }
+            phase = PH_DONE;
+          }
+        }
+      };
+      // Wait here if somebody's agent step ends at this sub-step (or could, by a strike) -- ObjLock: ... AND that lane reads a
+      // frame of this very sub-step; a lane that ends on the frame it already has finishes at once and the others' frames come
+      // back behind the next sub-step's physics.  (The combined kernel keeps the simpler rule: with the finer one its build
+      // trips the spill-before-exec-restore check of tools/check_isa.py.)
+      FWP(const long long p_f2 = FWP_NOW(); p_r3 += p_f2 - p_f1;)
+      bool wait_here;
+      if constexpr (OBJ) wait_here = __ballot(now && due) != 0ull; else wait_here = __ballot(now) != 0ull;
+      if (wait_here) {
         FWP(const long long p_w1 = FWP_NOW();)
         cap_collect<T>(MB, seq_cur, due, row, O, D.stats);
         FWP(p_task += FWP_NOW() - p_w1; p_nhit += 1;)
-        if (stepped) {
-          if (stepping) {
-            frame_half(keep);
-            step_over = (it + 1 >= P.step_ratio) || (flags & (FL_TERM | FL_TRUNC));
-          } else {
-            warm_left -= 1;
-            if (warm_left == 0) {
-              if (OBJ) obj_compute_state<T>(O);
-              else { new_dist = end_reset<T, G>(P, D, env, episode, S); comb_compute_state<T>(OC, O, P.num_targets == 0); }
-              phase = PH_DONE;
-            }
-          }
-        }
+        FWP(const long long p_f3 = FWP_NOW();)
+        if (stepped) finish_now();               // ... and the sub-step is finished for everybody, as in the one-wave kernel
+        FWP(p_r2 += FWP_NOW() - p_f3;)
       } else {
-        pend_seq = seq_cur;                         // ... else the frames come back behind the next sub-step's physics
-        pend = keep;
+        FWP(const long long p_f3 = FWP_NOW();)
+        if constexpr (OBJ) { if (now) finish_now(); else pend = keep; }
+        else pend = keep;
+        FWP(p_r2 += FWP_NOW() - p_f3;)
+        pend_seq = seq_cur;
       }
     } else {
     if (HASOBJ) obj_capture_step<T, G, COLLECT>(OC, D, stepped, envc, O, S, R, tick);     // the camera, by the whole wave
@@ -1034,7 +1049,7 @@ void step_body(const Params<T>* __restrict__ Pp, const ObjC<T>* __restrict__ OCp
       const long long t3 = FWP_NOW();
       w[0] = t3 - p_t0; w[1] = p_t1 - p_t0; w[2] = p_reset; w[3] = p_avi; w[4] = p_task; w[5] = t3 - p_t2; w[6] = it | (nr << 8) | (nh << 16); w[7] = p_t0; w[8] = p_r1; w[9] = p_r2; w[10] = p_r3;
       w[11] = p_capmax | ((long long)p_ncapw << 48);
-      if (HELP) { w[8] = p_nhit; w[9] = n_posted; }
+      if (HELP) { w[8] = p_nhit; w[9] = n_posted; w[7] = p_r1; w[10] = p_r2; w[11] = p_r3; }
       else if (HASOBJ) { w[8] = O.p_capm[0]; w[9] = O.p_capm[1]; w[10] = O.p_capm[2]; w[7] = O.p_capm[3];
         if (getenv_ph) { w[1] = O.p_ph[0]; w[3] = O.p_ph[1]; w[4] = O.p_ph[2]; w[5] = O.p_ph[3]; w[9] = O.p_ph[4]; w[6] = O.p_ph[5]; } }     // (the reset split is unused by these kernels)
     } })

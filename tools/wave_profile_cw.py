@@ -27,6 +27,7 @@ f = lambda a: f"{a.mean():9.0f}"
 print(f"{which} N={N}: {nblk} workgroups/launch, last 256 of {steps} launches; cycles")
 print(f"  step wave, mean        : total {f(st[:,:,0])} prologue {f(st[:,:,1])} reset {f(st[:,:,2])} physics {f(st[:,:,3])} waiting for frames {f(st[:,:,4])} epilogue {f(st[:,:,5])}  immediate sub-steps {st[:,:,8].mean():.2f}  requests {st[:,:,9].mean():.2f}")
 print(f"  step wave, slowest     : total {f(S[:,0])} prologue {f(S[:,1])} reset {f(S[:,2])} physics {f(S[:,3])} waiting for frames {f(S[:,4])} epilogue {f(S[:,5])}  immediate sub-steps {S[:,8].mean():.2f}  requests {S[:,9].mean():.2f}")
+print(f"  step wave, mean        : posting {f(st[:,:,7])} frame halves of the task logic {f(st[:,:,10])} frame-independent halves {f(st[:,:,11])}   slowest: {f(S[:,7])} {f(S[:,10])} {f(S[:,11])}")
 print(f"  capture wave, mean     : busy {f(hp[:,:,0])} shadow work {f(hp[:,:,1])} captures {f(hp[:,:,2])} requests {hp[:,:,3].mean():.2f} alive {f(hp[:,:,4])}   with shadow work: {100.0 * (hp[:,:,1] > 2000).mean():.1f}% of waves")
 print(f"  capture wave of slowest: busy {f(H[:,0])} shadow work {f(H[:,1])} captures {f(H[:,2])} requests {H[:,3].mean():.2f} alive {f(H[:,4])}")
 print(f"  counters: {e.get_counters()}")
