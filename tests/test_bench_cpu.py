@@ -50,6 +50,22 @@ def test_a_rank_that_dies_takes_the_eight_rank_job_down_non_zero_within_the_time
     assert time.perf_counter() - t0 < 120
 
 
+def test_one_rank_job_goes_through_the_process_group_when_forced():
+    """FW_DIST_FORCE=1 + a one-rank rendezvous (the form in which the -m gpu tests run the RCCL branches on a one-GPU box): the rank
+    joins a process group, is counted over it and gathers its own figure -- here over gloo and dry."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    rc, lines, err = _run(["--gpus", "1", "--steps", "20", "--warmup", "5"], FW_BENCH_DRY="1", FW_BENCH_BACKEND="gloo", FW_DIST_FORCE="1",
+                          WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1 and lines[0]["ranks_seen"] == 1 and lines[0]["backend"] == "gloo" and lines[0]["per_rank"] == [1.0]
+    # ... and without the switch the same environment is a plain single-process run
+    rc, lines, err = _run(["--gpus", "1", "--steps", "20", "--warmup", "5"], FW_BENCH_DRY="1", FW_BENCH_BACKEND="gloo",
+                          WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    assert rc == 0 and lines[0]["backend"].startswith("none"), (lines, err)
+
+
 def test_gpus_that_disagrees_with_the_world_size_exits_non_zero():
     """`--gpus 8` under a launcher that started one rank must never print `"n_gpus": 1`."""
     rc, lines, _ = _run(["--gpus", "8"], WORLD_SIZE="1", RANK="0", FW_BENCH_DRY="1")

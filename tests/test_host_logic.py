@@ -286,3 +286,28 @@ _Z23fw_collect_stats_kernelIdEvN5fwsim9StatsArgsE:
     assert m.scan_ticket(good) == []
     assert [h[1] for h in m.scan_ticket(bad)] == ["ticket"]
     assert m.scan_ticket(other) == []
+
+
+def test_a_one_rank_process_group_counts_as_a_sharded_job_only_when_forced(monkeypatch):
+    """rollout._dist(): FW_DIST_FORCE=1 is what lets a one-GPU box run the collectives of the sharded path (one rank over RCCL in the
+    -m gpu tests; here over gloo).  Sums and gathers over one rank are the identity."""
+    import socket
+    import torch
+    import torch.distributed as td
+    from pyflyt_drone_amd import rollout as R
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    for k, v in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(port)), ("FW_DIST_BACKEND", "gloo")):
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("FW_DIST_FORCE", raising=False)
+    assert R.init_distributed_from_env() == (1, 0, 0) and not td.is_initialized()
+    monkeypatch.setenv("FW_DIST_FORCE", "1")
+    try:
+        assert R.init_distributed_from_env() == (1, 0, 0) and td.is_initialized() and R._dist() is td
+        x = torch.arange(6, dtype=torch.float64).reshape(2, 3)
+        assert torch.equal(R.all_reduce_sum_(x.clone()), x) and torch.equal(R.all_gather_cat(x), x)
+        monkeypatch.delenv("FW_DIST_FORCE")
+        assert R._dist() is None
+    finally:
+        if td.is_initialized():
+            td.destroy_process_group()
