@@ -198,6 +198,25 @@ def test_lockstep_f64_with_a_capture_wave(oracle, name, monkeypatch):
     assert c["capture_wave_timeouts"] == 0 and hip.capture_wave
 
 
+@pytest.mark.parametrize("n", [1, 9, 130])
+@pytest.mark.parametrize("name", ["objlock_train", "combined_big_reach"])
+def test_capture_wave_with_in_kernel_resets_and_ragged_env_counts(oracle, name, n, monkeypatch):
+    """The two-wave kernels where the hand-off of pre-simulated episode starts is off (FWSIM_NO_SHADOW=1): every auto-reset then
+    runs its warm-up inside the step wave, whose captures go through the mailbox and are waited for at once (the warm-up's last
+    sub-step reads its frame) -- and at env counts that leave the last workgroup partly or almost wholly empty."""
+    cfg, kind = CASES[name]
+    monkeypatch.setenv("FWSIM_LANES_PER_ENV", "8"); monkeypatch.setenv("FWSIM_CAPTURE_WAVE", "1"); monkeypatch.setenv("FWSIM_NO_SHADOW", "1")
+    hip = P.FixedwingVecEnv(cfg, n, seed=99)
+    assert hip.capture_wave
+    ora = oracle.OracleEnv(cfg, n, seed=99)
+    obj = cfg.task == K.FW_TASK_OBJLOCK
+    worst = run_lockstep(hip, ora, 400, np.random.default_rng(3), kind="uniform", atol=2e-5 if obj else 1e-7, rtol=0, state_atol=1e-7)
+    c = hip.get_counters()
+    assert c["capture_wave_timeouts"] == 0 and c["shadow_hits"] == 0
+    if n >= 9:
+        assert c["resets"] > 0 and c["fallbacks"] == c["resets"], c      # the case was meant to reset, and in the kernel
+
+
 @pytest.mark.parametrize("task,n,steps", [("objlock", 4096, 10), ("combined", 2048, 10), ("combined", 16384, 8)])
 def test_baseline_size_camera_tasks_against_oracle(oracle, task, n, steps):
     """configs[2] of BASELINE.json (ObjLock, 4096 envs: train/train_objlock.py:27-86), configs[4]'s per-GPU share (combined env,
