@@ -1294,14 +1294,15 @@ __device__ __forceinline__ void obj_capture_step(const ObjC<T>& OC, const DevSta
 }
 
 // ------------------------------------------------------------------------------------------
-// The capture wave (8-lane mapping, fw_step_kernel_obj_g8h).  At 4096 envs half the SIMDs of the chip are idle and a step wave runs
-// physics, camera and task logic one after the other.  Here the workgroup has a SECOND wave on another SIMD of the same CU that does
-// nothing but the captures: the step wave posts the poses of the envs that are due (LDS mailbox, two slots), goes on with the NEXT
+// The capture wave (8-lane mapping, fw_step_kernel_obj_g8h; opt-in, FWSIM_CAPTURE_WAVE=1).  A step wave runs physics, camera and
+// task logic one after the other.  Here the workgroup has a SECOND wave on another SIMD of the same CU that does the captures (and
+// the tile's shadow work: with one wave per SIMD, step waves + capture waves are all 1024 SIMDs of the chip at 4096 envs): the step wave posts the poses of the envs that are due (LDS mailbox, two slots), goes on with the NEXT
 // sub-step's physics, and only then collects the frame and runs the half of the task logic that reads it (fwsim.hip, step_body
 // HELP).  Nothing is speculated: the only frame-dependent way a sub-step can end the agent step is a strike, and whether a strike
 // is possible at all is known without the frame (lock counter one short of the hold, close enough); where it is -- or where a
 // lane's agent step ends anyway -- the wave collects at once, as the one-wave kernel always does.  Same arithmetic in the same
-// order as obj_capture_wave / the one-wave loop: same bits.
+// order as obj_capture_wave / the one-wave loop; the two kernels agree to rounding (1e-11 over thousands of steps: the compiler
+// contracts FMAs differently at the two inlining sites), not bit for bit.
 // Both waves of a workgroup are resident together (a workgroup is placed on its CU as a whole), so the waits below cannot
 // starve; they are bounded all the same (a protocol error ends in FW_CTR_HELPER_TIMEOUTS, not in a hung queue).
 // ------------------------------------------------------------------------------------------
