@@ -4,7 +4,7 @@ They pin  HIP kernel == oracle  and guard the oracle against regressions; they d
 NOT pin oracle == PyBullet (the reference cannot run here: PyFlyt / pybullet /
 gymnasium are absent and the reference ships no fixtures -- SURVEY.md section 8c).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [name ...]
 """
 import os
 import sys
@@ -38,11 +38,18 @@ def cases():
                                                          obstacle_safe_distance_m=60.0), "gentle", 4, 100, 21
     yield "combined_train_config", K.train_waypoint_objlock_config(goal_reach_distance=30.0, duck_camera_capture_interval_steps=2,
                                                                    obstacle_safe_distance_m=40.0), "gentle", 4, 100, 31
+    # duck_vision_use_deltas=False (envs/fixedwing_objlock_env.py:69-70, 440-441): the observation ends with the history, 52 wide
+    nd = K.train_objlock_config(duck_camera_capture_interval_steps=2)
+    nd.duck_vision_no_deltas = 1
+    yield "objlock_no_deltas", nd, "gentle", 4, 100, 41
 
 
-def main():
+def main(only=None):
+    """`python tests/golden/make_golden.py [name ...]`: all cases, or only the named ones (the others' files stay as committed)."""
     O.build()
     for name, cfg, kind, n, steps, seed in cases():
+        if only and name not in only:
+            continue
         env = O.OracleEnv(cfg, n, seed=seed)
         rng = np.random.default_rng(seed)
         obs0 = env.reset()
@@ -60,4 +67,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])
