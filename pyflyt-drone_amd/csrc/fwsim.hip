@@ -1989,7 +1989,8 @@ int32_t fw_render(fw_handle h, int32_t res, float* out, void* hip_stream) {
   const int tile = kWave / h->lanes_per_env;
   hipStream_t st = (hipStream_t)hip_stream;
   const size_t lds = sizeof(double) * (size_t)res;       // the image-plane coordinate of every pixel column / row
-  const int threads = 256;                               // (measured at 4096 x 32 x 32 on the 1 / t kernel with 16 x 16 tiles: 64 threads per env 52.7 us, 128: 50.8, 256: 48.2)
+  int threads = 256;                                     // (measured at 4096 x 32 x 32 on the 1 / t kernel with 16 x 16 tiles: 64 threads per env 52.7 us, 128: 50.8, 256: 48.2)
+  if (const char* e = std::getenv("FWSIM_RENDER_THREADS")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) threads = v; }   // (measurement knob)
   if (c.dtype == FW_F64) hipLaunchKernelGGL(fw_render_kernel<double>, dim3((unsigned)h->n), dim3(threads), lds, st, (const double*)h->r_dev, tile, h->n, K, res, out);
   else hipLaunchKernelGGL(fw_render_kernel<float>, dim3((unsigned)h->n), dim3(threads), lds, st, (const float*)h->r_dev, tile, h->n, K, res, out);
   HIP_TRY(h, hipGetLastError());

@@ -28,6 +28,9 @@
 //     of the cull is seven orders of magnitude above rounding; what survives is decided by the exact expressions.
 //   * every thread derives the pose / duck constants for itself (same loads, same arithmetic: no broadcast barrier for them).
 #pragma once
+#ifndef FW_RENDER_KO
+#define FW_RENDER_KO 0
+#endif
 #include "fwsim_device.hpp"
 #include "fwsim_objlock.hpp"
 
@@ -44,38 +47,79 @@ struct RenderC {            // camera constants in double (built on the host fro
 // (16 x 16 tiles kept ~4 of 20 cylinders alive per tile, every one of them ~40 vector instructions for every pixel of the tile).
 constexpr int kRTileW = 4, kRTileH = 64;
 
+// A wave-uniform double moved into scalar registers (two v_readfirstlane): what every lane read from the same LDS word needs no
+// vector register per lane, and a vector instruction takes one scalar operand for free.
+__device__ __forceinline__ double render_uniform(double v) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+  u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.d;
+}
+__device__ __forceinline__ double render_from_lane(double v, int src_lane) {      // lane `src_lane`'s value, in scalar registers
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src_lane);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src_lane);
+  return u.d;
+}
+// Four gathers from one scalar base with 32-bit byte offsets, issued back to back and waited for once.  Written out because hipcc,
+// given the four loads as C++, waits for the first before it has even formed the addresses of the others (two round trips, not one).
+__device__ __forceinline__ void render_gather4(const double* base, unsigned oa, unsigned ox, unsigned oy, unsigned oh, double& a, double& x, double& y, double& h) {
+  asm volatile("global_load_dwordx2 %0, %4, %8\n\tglobal_load_dwordx2 %1, %5, %8\n\tglobal_load_dwordx2 %2, %6, %8\n\tglobal_load_dwordx2 %3, %7, %8\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(a), "=&v"(x), "=&v"(y), "=&v"(h) : "v"(oa), "v"(ox), "v"(oy), "v"(oh), "s"(base) : "memory");
+}
+__device__ __forceinline__ void render_gather4(const float* base, unsigned oa, unsigned ox, unsigned oy, unsigned oh, float& a, float& x, float& y, float& h) {
+  asm volatile("global_load_dword %0, %4, %8\n\tglobal_load_dword %1, %5, %8\n\tglobal_load_dword %2, %6, %8\n\tglobal_load_dword %3, %7, %8\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(a), "=&v"(x), "=&v"(y), "=&v"(h) : "v"(oa), "v"(ox), "v"(oy), "v"(oh), "s"(base) : "memory");
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r, int tile, int n_envs, RenderC K, int res,
                                                         float* __restrict__ out) {
 #pragma clang fp contract(off)                    // this kernel only: multiply-adds stay two roundings, as in the CPU checker's C
   __shared__ double s_pose[28];                   // R[9] cam[3] zc xc yc k2 | Hf Hr Hd (the camera axes in the world frame)
+  __shared__ float s_dbox[4];                     // image-plane box that holds the duck's silhouette: a min / max, b min / max (culling only)
   __shared__ double s_cyl[FW_MAX_OBSTACLES][4];   // ox, oy, cc, height: cam - axis (horizontal), |.|^2 - radius^2
   __shared__ float s_wedge[FW_MAX_OBSTACLES][2][3];   // the two tangent half-planes as affine forms g(a, b) = g0 + a g1 + b g2 (>= 0 inside); [.][0][0] = +inf: never cull
   __shared__ float s_margin[FW_MAX_OBSTACLES];
-  __shared__ int s_blocked;
+  __shared__ int s_blocked, s_nob;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* s_ab = reinterpret_cast<double*>(smem_raw);      // [res]: (i - u0) / F, the image-plane coordinate of pixel column / row i (the image is square)
-  const int env = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int env = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   if (env >= n_envs) return;
-  auto fld = [&](int f) { return (double)r[tile_index(tile, RF_COUNT, f, env)]; };
-  int nob = (int)fld(RF_TASK + FW_ST_NUM_OBST);
-  nob = nob < 0 ? 0 : (nob > FW_MAX_OBSTACLES ? FW_MAX_OBSTACLES : nob);
+  const int nwaves = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6)), setup_wave = env & (nwaves - 1);
   const double W = (double)res, F = 0.5 * W / K.tan_half_fov, u0 = 0.5 * (W - 1.0), near = K.near_, far = K.far_;
-  for (int i = t; i < res; i += (int)blockDim.x) s_ab[i] = ((double)i - u0) / F;      // (one IEEE division per column, not four per pixel)
-  if (wave == (env & ((int)(blockDim.x >> 6) - 1))) {
+  // (one IEEE division per column, not four per pixel; the wave BEHIND the set-up wave starts the table, so the two run side by side)
+  for (int i = ((wave - setup_wave - 1) & (nwaves - 1)) * 64 + lane; i < res; i += (int)blockDim.x) s_ab[i] = ((double)i - u0) / F;
+  if (wave == setup_wave) {
     // the pose, the duck in the camera frame, the ray basis: every lane of ONE wave for itself (no broadcast inside the wave), lane 0
     // leaves them for the other waves.  Which wave rotates with the env: a workgroup's wave i runs on SIMD i, and with the pixel loop
-    // as short as it now is the set-up would otherwise queue sixteen deep on SIMD 0 of every CU
+    // as short as it now is the set-up would otherwise queue sixteen deep on SIMD 0 of every CU.
+    // Everything the set-up reads comes in ONE round trip: four lane-indexed gathers issued back to back (lane l of the first fetches
+    // the l-th of quaternion 4, position 3, duck 3, cylinder count; lane o of the others cylinder o's x / y / height -- the slots exist
+    // whatever the count), handed out by v_readlane.  As scalar loads behind their uses the same words were four round trips in a
+    // row (count, quaternion, position + duck, cylinders), and a workgroup is idle until they are in: without its pixel arithmetic this
+    // kernel took 18.6 of its 27.4 us (4096 x 32 x 32)
+    const T* rb = r + tile_index(tile, RF_COUNT, 0, env);
+    const int fA = lane < 4 ? RF_QUAT + lane : lane < 7 ? RF_POS + (lane - 4) : lane < 10 ? RF_TASK + FW_ST_DUCK_POS + (lane - 7) : RF_TASK + FW_ST_NUM_OBST;
+    const int lo = lane < FW_MAX_OBSTACLES ? lane : 0;
+    const unsigned fstride = (unsigned)tile * (unsigned)sizeof(T), oX = (unsigned)(RF_TASK + FW_ST_OBST + 3 * lo) * fstride;       // (a tile of <= 64 envs x 171 fields: 32-bit offsets)
+    T gA, gX, gY, gH;
+    render_gather4(rb, (unsigned)fA * fstride, oX, oX + fstride, oX + 2u * fstride, gA, gX, gY, gH);
+    auto fld = [&](int l) { return render_from_lane((double)gA, l); };
+    int nob = (int)fld(10);
+    nob = nob < 0 ? 0 : (nob > FW_MAX_OBSTACLES ? FW_MAX_OBSTACLES : nob);
     double R[9], cam[3], relw[3], zc, xc, yc, k2, Hf[3], Hr[3], Hd[3];
-    const double x = fld(RF_QUAT), y = fld(RF_QUAT + 1), z = fld(RF_QUAT + 2), w = fld(RF_QUAT + 3);
+    const double x = fld(0), y = fld(1), z = fld(2), w = fld(3);
     const double d = x * x + y * y + z * z + w * w, s = 2.0 / d;                 // btMatrix3x3::setRotation
     const double xs = x * s, ys = y * s, zs = z * s, wx = w * xs, wy = w * ys, wz = w * zs;
     const double xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
     R[0] = 1.0 - (yy + zz); R[1] = xy - wz; R[2] = xz + wy; R[3] = xy + wz; R[4] = 1.0 - (xx + zz); R[5] = yz - wx;
     R[6] = xz - wy; R[7] = yz + wx; R[8] = 1.0 - (xx + yy);
-    for (int k = 0; k < 3; ++k) cam[k] = fld(RF_POS + k) + (R[3 * k] * K.cam_off[0] + R[3 * k + 1] * K.cam_off[1] + R[3 * k + 2] * K.cam_off[2]);
+    for (int k = 0; k < 3; ++k) cam[k] = fld(4 + k) + (R[3 * k] * K.cam_off[0] + R[3 * k + 1] * K.cam_off[1] + R[3 * k + 2] * K.cam_off[2]);
     const double Rd = K.duck_radius;
-    const double C[3] = { fld(RF_TASK + FW_ST_DUCK_POS), fld(RF_TASK + FW_ST_DUCK_POS + 1), fld(RF_TASK + FW_ST_DUCK_POS + 2) + Rd };
+    const double C[3] = { fld(7), fld(8), fld(9) + Rd };
     for (int k = 0; k < 3; ++k) relw[k] = C[k] - cam[k];
     double relb[3];
     for (int k = 0; k < 3; ++k) relb[k] = R[k] * relw[0] + R[3 + k] * relw[1] + R[6 + k] * relw[2];       // R^T relw
@@ -94,14 +138,21 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
       s_pose[12] = zc; s_pose[13] = xc; s_pose[14] = yc; s_pose[15] = k2;
       for (int k = 0; k < 3; ++k) { s_pose[16 + k] = Hf[k]; s_pose[19 + k] = Hr[k]; s_pose[22 + k] = Hd[k]; }
       s_pose[25] = cam[2] > 0.0 ? -1.0 / cam[2] : 0.0;
+      // the silhouette's box (culling only): a point C + Rd u of the sphere projects to a = (xc + Rd ux) / (zc + Rd uz), which is off
+      // xc / zc by |Rd (ux zc - uz xc)| / (zc (zc + Rd uz)) <= Rd (zc + |xc|) / (zc (zc - Rd)) -- asked only where zc - Rd > near > 0
+      // (duck_possible below); the margin is orders of magnitude above the float conversions of the box and of the pixel coordinates
+      const double zs_ = zc - Rd > 1e-9 ? zc - Rd : 1e-9, izz = 1.0 / (zc * zs_);
+      const double ca = xc * zs_ * izz, cb = yc * zs_ * izz, wa = Rd * (zc + ::fabs(xc)) * izz, wb = Rd * (zc + ::fabs(yc)) * izz;
+      const double ma = 1e-5 * (1.0 + ::fabs(ca) + wa), mb = 1e-5 * (1.0 + ::fabs(cb) + wb);
+      s_dbox[0] = (float)(ca - wa - ma); s_dbox[1] = (float)(ca + wa + ma); s_dbox[2] = (float)(cb - wb - mb); s_dbox[3] = (float)(cb + wb + mb);
     }
     bool blocked_any = false;
     if (lane < FW_MAX_OBSTACLES) {                   // lane o: cylinder o
       bool blocked = false;
       double ox = 0.0, oy = 0.0, cc = 1.0, hh = 0.0;
       if (lane < nob) {
-        const double ax = fld(RF_TASK + FW_ST_OBST + 3 * lane), ay = fld(RF_TASK + FW_ST_OBST + 3 * lane + 1);
-        hh = fld(RF_TASK + FW_ST_OBST + 3 * lane + 2);
+        const double ax = (double)gX, ay = (double)gY;
+        hh = (double)gH;
         ox = cam[0] - ax; oy = cam[1] - ay;
         cc = ox * ox + oy * oy - K.obst_radius * K.obst_radius;
         // occluded(): the segment cam -> duck centre against this cylinder
@@ -133,33 +184,42 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
       blocked_any = blocked;
     }
     blocked_any = __any(blocked_any);
-    if (lane == 0) s_blocked = blocked_any ? 1 : 0;
+    if (lane == 0) { s_blocked = blocked_any ? 1 : 0; s_nob = nob; }
   }
   __syncthreads();
+  const int nob = __builtin_amdgcn_readfirstlane(s_nob);
+  // the pose constants are the same in every lane: all but one operand of each expression below live in scalar registers (20 vector
+  // registers fewer: eight waves per SIMD instead of six or seven)
   double cam[3], Hf[3], Hr[3], Hd[3];
-  for (int k = 0; k < 3; ++k) { cam[k] = s_pose[9 + k]; Hf[k] = s_pose[16 + k]; Hr[k] = s_pose[19 + k]; Hd[k] = s_pose[22 + k]; }
-  const double zc = s_pose[12], xc = s_pose[13], yc = s_pose[14], k2 = s_pose[15];
+  for (int k = 0; k < 3; ++k) { Hf[k] = s_pose[16 + k]; Hr[k] = render_uniform(s_pose[19 + k]); Hd[k] = render_uniform(s_pose[22 + k]); }
+  cam[2] = render_uniform(s_pose[11]);
+  const double zc = s_pose[12], xc = render_uniform(s_pose[13]), yc = render_uniform(s_pose[14]), k2 = render_uniform(s_pose[15]);
   const double inv_near = K.inv_near, inv_far = K.inv_far, db_c1 = K.db_c1;
-  const double kground = s_pose[25];                                                 // -1 / (camera height); 0 for a camera at or below the ground (it sees none: 1 / t stays at 1 / far)
+  const double kground = render_uniform(s_pose[25]);                                                 // -1 / (camera height); 0 for a camera at or below the ground (it sees none: 1 / t stays at 1 / far)
   const bool duck_possible = zc - K.duck_radius > near && zc - K.duck_radius < far && s_blocked == 0;
   float* img = out + (size_t)env * 2 * res * res;
-  const int tpr = (res + kRTileW - 1) / kRTileW, ntiles = tpr * ((res + kRTileH - 1) / kRTileH);
-  for (int tl = wave; tl < ntiles; tl += (int)(blockDim.x >> 6)) {
-    const int ty = tl / tpr, tx = tl - ty * tpr;
-    const int x0 = tx * kRTileW, y0 = ty * kRTileH, x1 = min(x0 + kRTileW, res) - 1, y1 = min(y0 + kRTileH, res) - 1;
-    // ---- cull: lane c looks at cylinder c -- a half-plane that holds none of the four corners of the tile holds no pixel of it ----
+  float* img1 = img + (size_t)res * res;
+  const int tpr = (res + kRTileW - 1) / kRTileW;
+  // (`wave` went through v_readfirstlane above: the strip counters, the row loop and their exits are scalar control flow -- with a
+  // wave number the compiler takes for divergent, every loop here carried an exec-mask protocol and the strip index a vector division)
+  for (int y0 = 0; y0 < res; y0 += kRTileH)
+  for (int tx = wave; tx < tpr; tx += nwaves) {
+    const int x0 = tx * kRTileW, x1 = min(x0 + kRTileW, res) - 1, y1 = min(y0 + kRTileH, res) - 1;
+    // ---- cull: lane c looks at cylinder c -- a half-plane that holds none of the four corners of the tile holds no pixel of it
+    // (the largest corner value of an affine form is its constant plus the larger end of either coordinate's term) ----
     unsigned int alive = 0u;
+    const float a0 = (float)s_ab[x0], a1 = (float)s_ab[x1], b0 = (float)s_ab[y0], b1 = (float)s_ab[y1];
+    // (wave-uniform: a strip the silhouette's box does not reach skips the silhouette test of its pixels)
+    const bool duck_tile = duck_possible && a0 <= s_dbox[1] && a1 >= s_dbox[0] && b0 <= s_dbox[3] && b1 >= s_dbox[2];
     {
       bool keep = false;
       if (lane < nob) {
-        const float a0 = (float)s_ab[x0], a1 = (float)s_ab[x1], b0 = (float)s_ab[y0], b1 = (float)s_ab[y1];
         const float m = -s_margin[lane];
         bool in[2];
 #pragma unroll
         for (int hp = 0; hp < 2; ++hp) {
           const float g0 = s_wedge[lane][hp][0], g1 = s_wedge[lane][hp][1], g2 = s_wedge[lane][hp][2];
-          const float u0_ = g0 + a0 * g1, u1_ = g0 + a1 * g1, v0_ = b0 * g2, v1_ = b1 * g2;
-          in[hp] = u0_ + v0_ >= m || u1_ + v0_ >= m || u0_ + v1_ >= m || u1_ + v1_ >= m;
+          in[hp] = g0 + fmaxf(a0 * g1, a1 * g1) + fmaxf(b0 * g2, b1 * g2) >= m;
         }
         keep = in[0] && in[1];
       }
@@ -167,15 +227,21 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
     }
     // ---- pixels of the tile ----
     const int xi = x0 + (lane & (kRTileW - 1));
+    const int krows = min(kRTileW * kRTileH / 64, (res - y0 + 64 / kRTileW - 1) / (64 / kRTileW));       // (the strip may be taller than the image)
 #pragma unroll 1
-    for (int k = 0; k < kRTileW * kRTileH / 64; ++k) {
+    for (int k = 0; k < krows; ++k) {
       const int yi = y0 + (lane >> 2) + (64 / kRTileW) * k;
-      if (y0 + (64 / kRTileW) * k >= res) break;                                       // (wave-uniform: the strip is taller than the image)
-      if (xi >= res || yi >= res) continue;
+      if (xi < res && yi < res) {
+#if FW_RENDER_KO == 2          // (timing knock-out: set-up and stores, no pixel arithmetic)
+        const unsigned int off2 = (unsigned int)(yi * res + xi) * 4u;
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(img) + off2) = (float)kground;
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(img1) + off2) = (float)(alive + (duck_tile ? 1u : 0u));
+        continue;
+#endif
       const double a = s_ab[xi], b = s_ab[yi];
       bool is_duck = false;
       double inv_t = 0.0;                                                            // 1 / (view-axis depth) of the nearest fragment
-      if (duck_possible) {
+      if (duck_tile) {
         const double q = 1.0 + a * a + b * b, p = zc + a * xc + b * yc, disc = p * p - q * k2;       // (the checker's expressions: the silhouette)
         if (disc >= 0.0 && p > 0.0) {
           const double num = p - M<double>::sqrt_(disc);
@@ -191,9 +257,9 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
       }
       if (!is_duck) {
         const double dwx = fma(b, Hd[0], fma(a, Hr[0], Hf[0])), dwy = fma(b, Hd[1], fma(a, Hr[1], Hf[1])), dwz = fma(b, Hd[2], fma(a, Hr[2], Hf[2]));
-        inv_t = inv_far;                                                             // ray_depth(): best = far ...
-        const double ig = dwz * kground;                                             // ... the ground at t = -cam z / dw z (dw z < 0, t > 0) ...
-        if (dwz < 0.0 && ig > inv_t) inv_t = ig;
+        // ray_depth(): best = far, or the ground at t = -cam z / dw z (dw z < 0, t > 0): kground <= 0, so 1 / t = dw z kground is positive
+        // exactly where dw z < 0, and one maximum says both
+        inv_t = ::fmax(inv_far, dwz * kground);
         const double qa = fma(dwx, dwx, dwy * dwy);
         if (qa > 0.0) {
           unsigned int m = alive;
@@ -208,17 +274,23 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
             if (!(num > 0.0)) continue;
             const double ic = M<double>::div_(qa, num);
             const double zi = fma(cam[2], ic, dwz);                                  // z / t of the hit: 0 <= z <= height
-            if (zi < 0.0 || zi > hh * ic) continue;
-            if (ic > inv_t) inv_t = ic;
+            const double it2 = ::fmax(inv_t, ic);
+            inv_t = (zi >= 0.0 && zi <= hh * ic) ? it2 : inv_t;
           }
         }
       }
-      inv_t = inv_t > inv_near ? inv_near : inv_t;                                   // t clipped to [near, far]
-      inv_t = inv_t < inv_far ? inv_far : inv_t;
+      inv_t = ::fmax(::fmin(inv_t, inv_near), inv_far);                              // t clipped to [near, far]
       const double dv = db_c1 * fma(-near, inv_t, 1.0);                              // far (t - near) / (t (far - near))
-      const int px = yi * res + xi;
-      img[px] = is_duck ? 1.0f : 0.0f;
-      img[(size_t)res * res + px] = (float)dv;
+      const unsigned int off = (unsigned int)(yi * res + xi) * 4u;                  // (res <= 1024: an unsigned 32-bit byte offset on a scalar base)
+#if FW_RENDER_KO == 1          // (timing knock-out: everything but the stores)
+      if (dv == 123456.0) {
+#endif
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(img) + off) = is_duck ? 1.0f : 0.0f;
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(img1) + off) = (float)dv;
+#if FW_RENDER_KO == 1
+      }
+#endif
+      }
     }
   }
 }
