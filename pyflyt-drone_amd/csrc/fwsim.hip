@@ -1988,11 +1988,23 @@ int32_t fw_render(fw_handle h, int32_t res, float* out, void* hip_stream) {
   K.inv_near = 1.0 / K.near_; K.inv_far = 1.0 / K.far_; K.db_c1 = K.far_ / (K.far_ - K.near_);
   const int tile = kWave / h->lanes_per_env;
   hipStream_t st = (hipStream_t)hip_stream;
-  const size_t lds = sizeof(double) * (size_t)res;       // the image-plane coordinate of every pixel column / row
+  // LDS behind the kernel's static tables: the image-plane coordinate of every pixel column / row, and from 64 x 64 pixels on a stage
+  // of 2048 pixels per channel through which the image leaves as whole rows (16 KB: eight workgroups per CU keep their place).
+  // Measured at 4096 envs, stage against direct stores: 32 x 32 28.1 / 26.8 us (a 1024-pixel image is two store instructions per lane
+  // either way: the stage only adds its barrier), 64 x 64 62.6 / 63.5, 128 x 128 223 / 273
+  int stage_px = (res >= 64 && res <= 128) ? 2048 : 0;
+  if (const char* e = std::getenv("FWSIM_RENDER_STAGE")) { const int v = std::atoi(e); if (v >= 0 && v <= 8192) stage_px = v & ~3; }       // (measurement knob)
+  if (((stage_px / res) & ~15) == 0) stage_px = 0;
+  const size_t lds = sizeof(double) * (size_t)((res + 1) & ~1) + 2 * sizeof(float) * (size_t)stage_px;
   int threads = 256;                                     // (measured at 4096 x 32 x 32 on the 1 / t kernel with 16 x 16 tiles: 64 threads per env 52.7 us, 128: 50.8, 256: 48.2)
   if (const char* e = std::getenv("FWSIM_RENDER_THREADS")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) threads = v; }   // (measurement knob)
-  if (c.dtype == FW_F64) hipLaunchKernelGGL(fw_render_kernel<double>, dim3((unsigned)h->n), dim3(threads), lds, st, (const double*)h->r_dev, tile, h->n, K, res, out);
-  else hipLaunchKernelGGL(fw_render_kernel<float>, dim3((unsigned)h->n), dim3(threads), lds, st, (const float*)h->r_dev, tile, h->n, K, res, out);
+  if (c.dtype == FW_F64) {
+    if (stage_px) hipLaunchKernelGGL((fw_render_kernel<double, true>), dim3((unsigned)h->n), dim3(threads), lds, st, (const double*)h->r_dev, tile, h->n, K, res, out, stage_px);
+    else hipLaunchKernelGGL((fw_render_kernel<double, false>), dim3((unsigned)h->n), dim3(threads), lds, st, (const double*)h->r_dev, tile, h->n, K, res, out, 0);
+  } else {
+    if (stage_px) hipLaunchKernelGGL((fw_render_kernel<float, true>), dim3((unsigned)h->n), dim3(threads), lds, st, (const float*)h->r_dev, tile, h->n, K, res, out, stage_px);
+    else hipLaunchKernelGGL((fw_render_kernel<float, false>), dim3((unsigned)h->n), dim3(threads), lds, st, (const float*)h->r_dev, tile, h->n, K, res, out, 0);
+  }
   HIP_TRY(h, hipGetLastError());
   return FW_OK;
 }

@@ -28,9 +28,6 @@
 //     of the cull is seven orders of magnitude above rounding; what survives is decided by the exact expressions.
 //   * every thread derives the pose / duck constants for itself (same loads, same arithmetic: no broadcast barrier for them).
 #pragma once
-#ifndef FW_RENDER_KO
-#define FW_RENDER_KO 0
-#endif
 #include "fwsim_device.hpp"
 #include "fwsim_objlock.hpp"
 
@@ -74,9 +71,9 @@ __device__ __forceinline__ void render_gather4(const float* base, unsigned oa, u
                : "=&v"(a), "=&v"(x), "=&v"(y), "=&v"(h) : "v"(oa), "v"(ox), "v"(oy), "v"(oh), "s"(base) : "memory");
 }
 
-template <typename T>
+template <typename T, bool STAGE>
 __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r, int tile, int n_envs, RenderC K, int res,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int stage_px) {
 #pragma clang fp contract(off)                    // this kernel only: multiply-adds stay two roundings, as in the CPU checker's C
   __shared__ double s_pose[28];                   // R[9] cam[3] zc xc yc k2 | Hf Hr Hd (the camera axes in the world frame)
   __shared__ float s_dbox[4];                     // image-plane box that holds the duck's silhouette: a min / max, b min / max (culling only)
@@ -137,14 +134,14 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
       for (int k = 0; k < 3; ++k) s_pose[9 + k] = cam[k];
       s_pose[12] = zc; s_pose[13] = xc; s_pose[14] = yc; s_pose[15] = k2;
       for (int k = 0; k < 3; ++k) { s_pose[16 + k] = Hf[k]; s_pose[19 + k] = Hr[k]; s_pose[22 + k] = Hd[k]; }
-      s_pose[25] = cam[2] > 0.0 ? -1.0 / cam[2] : 0.0;
+      s_pose[25] = cam[2] > 0.0 ? -M<double>::div_(1.0, cam[2]) : 0.0;      // (depth only: ~1 ulp, not the IEEE sequence)
       // the silhouette's box (culling only): a point C + Rd u of the sphere projects to a = (xc + Rd ux) / (zc + Rd uz), which is off
       // xc / zc by |Rd (ux zc - uz xc)| / (zc (zc + Rd uz)) <= Rd (zc + |xc|) / (zc (zc - Rd)) -- asked only where zc - Rd > near > 0
       // (duck_possible below); the margin is orders of magnitude above the float conversions of the box and of the pixel coordinates
-      const double zs_ = zc - Rd > 1e-9 ? zc - Rd : 1e-9, izz = 1.0 / (zc * zs_);
-      const double ca = xc * zs_ * izz, cb = yc * zs_ * izz, wa = Rd * (zc + ::fabs(xc)) * izz, wb = Rd * (zc + ::fabs(yc)) * izz;
-      const double ma = 1e-5 * (1.0 + ::fabs(ca) + wa), mb = 1e-5 * (1.0 + ::fabs(cb) + wb);
-      s_dbox[0] = (float)(ca - wa - ma); s_dbox[1] = (float)(ca + wa + ma); s_dbox[2] = (float)(cb - wb - mb); s_dbox[3] = (float)(cb + wb + mb);
+      const float zf = (float)zc, xf = (float)xc, yf = (float)yc, rf = (float)Rd, zs_ = fmaxf(zf - rf, 1e-9f), izz = __builtin_amdgcn_rcpf(zf * zs_);
+      const float ca = xf * zs_ * izz, cb = yf * zs_ * izz, wa = rf * (zf + fabsf(xf)) * izz, wb = rf * (zf + fabsf(yf)) * izz;
+      const float ma = 1e-5f * (1.0f + fabsf(ca) + wa), mb = 1e-5f * (1.0f + fabsf(cb) + wb);
+      s_dbox[0] = ca - wa - ma; s_dbox[1] = ca + wa + ma; s_dbox[2] = cb - wb - mb; s_dbox[3] = cb + wb + mb;
     }
     bool blocked_any = false;
     if (lane < FW_MAX_OBSTACLES) {                   // lane o: cylinder o
@@ -170,7 +167,7 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
       // tan(beta) (h . e) -+ (h x e) >= 0, sin(beta) = radius / |e|, tan(beta) = radius / sqrt(cc)
       float g[2][3] = {{__builtin_inff(), 0.f, 0.f}, {0.f, 0.f, 0.f}}, margin = 0.f;
       if (lane < nob && cc > 1e-9) {
-        const float ex = (float)-ox, ey = (float)-oy, tb = (float)(K.obst_radius / ::sqrt(cc));
+        const float ex = (float)-ox, ey = (float)-oy, tb = (float)K.obst_radius * __builtin_amdgcn_rsqf((float)cc);
         const float H[3][2] = {{(float)Hf[0], (float)Hf[1]}, {(float)Hr[0], (float)Hr[1]}, {(float)Hd[0], (float)Hd[1]}};
         for (int k = 0; k < 3; ++k) {
           const float dot = H[k][0] * ex + H[k][1] * ey, crs = H[k][0] * ey - H[k][1] * ex;
@@ -202,9 +199,17 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
   const int tpr = (res + kRTileW - 1) / kRTileW;
   // (`wave` went through v_readfirstlane above: the strip counters, the row loop and their exits are scalar control flow -- with a
   // wave number the compiler takes for divergent, every loop here carried an exec-mask protocol and the strip index a vector division)
-  for (int y0 = 0; y0 < res; y0 += kRTileH)
+  // STAGE: the image leaves through LDS (stage_px pixels per channel behind the coordinate table; a build of its own so that the
+  // direct form keeps its 64 registers): a strip is four
+  // pixels wide, so a wave's store instruction wrote 16 rows x 16 bytes -- sixteen partial lines per instruction, and the stores alone
+  // (no pixel arithmetic) took 12 of this kernel's 25.6 us at 4096 x 32 x 32.  A band of rows that fits the stage is rendered into LDS,
+  // and the workgroup writes it out as whole rows, 16 bytes per lane and 1 KB per wave instruction.
+  float* s_img = reinterpret_cast<float*>(smem_raw + (size_t)((res + 1) & ~1) * sizeof(double));
+  const int band = STAGE ? min(kRTileH, (stage_px / res) & ~15) : kRTileH;       // rows per pass (a multiple of the 16 rows one instruction covers)
+  for (int y0 = 0; y0 < res; y0 += band) {
+  const int yend = min(y0 + band, res);
   for (int tx = wave; tx < tpr; tx += nwaves) {
-    const int x0 = tx * kRTileW, x1 = min(x0 + kRTileW, res) - 1, y1 = min(y0 + kRTileH, res) - 1;
+    const int x0 = tx * kRTileW, x1 = min(x0 + kRTileW, res) - 1, y1 = yend - 1;
     // ---- cull: lane c looks at cylinder c -- a half-plane that holds none of the four corners of the tile holds no pixel of it
     // (the largest corner value of an affine form is its constant plus the larger end of either coordinate's term) ----
     unsigned int alive = 0u;
@@ -227,17 +232,11 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
     }
     // ---- pixels of the tile ----
     const int xi = x0 + (lane & (kRTileW - 1));
-    const int krows = min(kRTileW * kRTileH / 64, (res - y0 + 64 / kRTileW - 1) / (64 / kRTileW));       // (the strip may be taller than the image)
+    const int krows = (yend - y0 + 64 / kRTileW - 1) / (64 / kRTileW);
 #pragma unroll 1
     for (int k = 0; k < krows; ++k) {
       const int yi = y0 + (lane >> 2) + (64 / kRTileW) * k;
-      if (xi < res && yi < res) {
-#if FW_RENDER_KO == 2          // (timing knock-out: set-up and stores, no pixel arithmetic)
-        const unsigned int off2 = (unsigned int)(yi * res + xi) * 4u;
-        *reinterpret_cast<float*>(reinterpret_cast<char*>(img) + off2) = (float)kground;
-        *reinterpret_cast<float*>(reinterpret_cast<char*>(img1) + off2) = (float)(alive + (duck_tile ? 1u : 0u));
-        continue;
-#endif
+      if (xi < res && yi < yend) {
       const double a = s_ab[xi], b = s_ab[yi];
       bool is_duck = false;
       double inv_t = 0.0;                                                            // 1 / (view-axis depth) of the nearest fragment
@@ -281,17 +280,33 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
       }
       inv_t = ::fmax(::fmin(inv_t, inv_near), inv_far);                              // t clipped to [near, far]
       const double dv = db_c1 * fma(-near, inv_t, 1.0);                              // far (t - near) / (t (far - near))
-      const unsigned int off = (unsigned int)(yi * res + xi) * 4u;                  // (res <= 1024: an unsigned 32-bit byte offset on a scalar base)
-#if FW_RENDER_KO == 1          // (timing knock-out: everything but the stores)
-      if (dv == 123456.0) {
-#endif
-      *reinterpret_cast<float*>(reinterpret_cast<char*>(img) + off) = is_duck ? 1.0f : 0.0f;
-      *reinterpret_cast<float*>(reinterpret_cast<char*>(img1) + off) = (float)dv;
-#if FW_RENDER_KO == 1
+      if (STAGE) {
+        const int sp = (yi - y0) * res + xi;
+        s_img[sp] = is_duck ? 1.0f : 0.0f;
+        s_img[stage_px + sp] = (float)dv;
+      } else {
+        const unsigned int off = (unsigned int)(yi * res + xi) * 4u;                // (res <= 1024: an unsigned 32-bit byte offset on a scalar base)
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(img) + off) = is_duck ? 1.0f : 0.0f;
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(img1) + off) = (float)dv;
       }
-#endif
       }
     }
+  }
+  if (STAGE) {
+    __syncthreads();
+    const int nfl = (yend - y0) * res;                                              // the band's rows are one run of memory per channel
+    float* g0 = img + (size_t)y0 * res;
+    float* g1 = img1 + (size_t)y0 * res;
+    if ((res & 3) == 0) {                                                           // (16-byte pieces: every run starts on a multiple of 4 pixels)
+      for (int i = t * 4; i < nfl; i += (int)blockDim.x * 4) {
+        *reinterpret_cast<float4*>(g0 + i) = *reinterpret_cast<const float4*>(s_img + i);
+        *reinterpret_cast<float4*>(g1 + i) = *reinterpret_cast<const float4*>(s_img + stage_px + i);
+      }
+    } else {
+      for (int i = t; i < nfl; i += (int)blockDim.x) { g0[i] = s_img[i]; g1[i] = s_img[stage_px + i]; }
+    }
+    if (yend < res) __syncthreads();                                                // (the next band overwrites the stage)
+  }
   }
 }
 
