@@ -1993,7 +1993,7 @@ int32_t fw_render(fw_handle h, int32_t res, float* out, void* hip_stream) {
   // Measured at 4096 envs, stage against direct stores: 32 x 32 28.1 / 26.8 us (a 1024-pixel image is two store instructions per lane
   // either way: the stage only adds its barrier), 64 x 64 62.6 / 63.5, 128 x 128 223 / 273
   int stage_px = (res >= 64 && res <= 128) ? 2048 : 0;
-  if (const char* e = std::getenv("FWSIM_RENDER_STAGE")) { const int v = std::atoi(e); if (v >= 0 && v <= 8192) stage_px = v & ~3; }       // (measurement knob)
+  if (const char* e = std::getenv("FWSIM_RENDER_STAGE")) { const int v = std::atoi(e); if (v >= 0 && v <= 4096) stage_px = v & ~3; }       // (measurement knob)
   if (((stage_px / res) & ~15) == 0) stage_px = 0;
   const size_t lds = sizeof(double) * (size_t)((res + 1) & ~1) + 2 * sizeof(float) * (size_t)stage_px;
   int threads = 256;                                     // (measured at 4096 x 32 x 32 on the 1 / t kernel with 16 x 16 tiles: 64 threads per env 52.7 us, 128: 50.8, 256: 48.2)

@@ -69,6 +69,36 @@ def test_render_matches_the_oracle_pixel_by_pixel_on_directed_poses(oracle, lane
         hip.close()
 
 
+def test_render_through_the_lds_stage_equals_the_direct_stores(oracle, monkeypatch):
+    """From 64 x 64 pixels on the image leaves through an LDS stage as whole rows (bands of rows that fit the stage); below, and
+    above 128 x 128, every lane stores its own pixels.  Same pixels either way, bit for bit: forced stages and forced direct
+    stores at sizes with one band, several bands, a ragged last band and a width that is not a multiple of four pixels (the
+    scalar copy-out), and with one, two and four waves per env (FWSIM_RENDER_THREADS, a measurement knob)."""
+    rng = np.random.default_rng(77)
+    cfg = K.train_waypoint_objlock_config(motor_noise=False)
+    cfg.auto_reset = 0; cfg.num_obstacles = 20; cfg.flight_dome_size = 1e5
+    n = 70
+    hip, ora = P.FixedwingVecEnv(cfg, n, seed=9), oracle.OracleEnv(cfg, n, seed=9)
+    hip.reset_tensor(); ora.reset()
+    s = _directed_state(oracle, ora.get_state(), rng, 20)
+    hip.set_state(s); ora.set_state(s)
+    for res, stages in ((32, ("1024", "2048")), (48, ("1024", "2048")), (64, ("1024", "2048", "4096")), (66, ("2048",)), (100, ("2048", "4096")), (128, ("2048",))):
+        monkeypatch.setenv("FWSIM_RENDER_STAGE", "0"); monkeypatch.delenv("FWSIM_RENDER_THREADS", raising=False)
+        direct = hip.render_tensor(res).cpu().numpy()
+        if res in (32, 64):                                              # the direct form against the checker once more, the rest against the direct form
+            want = ora.render(res)
+            assert np.array_equal(direct[:, 0], want[:, 0])
+            np.testing.assert_allclose(direct[:, 1], want[:, 1], rtol=0, atol=1e-7)
+        for st in stages:
+            for th in ("256", "128", "64"):
+                monkeypatch.setenv("FWSIM_RENDER_STAGE", st); monkeypatch.setenv("FWSIM_RENDER_THREADS", th)
+                got = hip.render_tensor(res).cpu().numpy()
+                assert np.array_equal(got, direct), (res, st, th, int((got != direct).sum()))
+        monkeypatch.delenv("FWSIM_RENDER_STAGE"); monkeypatch.delenv("FWSIM_RENDER_THREADS")
+        assert np.array_equal(hip.render_tensor(res).cpu().numpy(), direct), res          # (the default choice)
+    hip.close()
+
+
 def test_render_follows_the_env_through_steps_and_resets(oracle):
     """The image is the scene of the env's CURRENT state: after 40 random agent steps (episodes end, auto-resets place new ducks
     and cylinders) the render still equals the oracle's, which was stepped alongside (its state, not a copy of the kernel's)."""

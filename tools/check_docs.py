@@ -9,6 +9,7 @@ Sources (ROUND = the newest rNN with a headline bench):
   rNN_headline_bench.json            `python bench.py` on one MI355X, as the driver runs it (not under a profiler)
   rNN_<task>_kernel_stats.csv        rocprofv3 --kernel-trace --stats of bench.py --task <task>  (tools/collect_profiles.sh)
   rNN_rollout_bench.jsonl            tools/bench_rollout.py per task (tools/collect_rollout_benches.sh)
+  rNN_render_<res>px_kernel_stats.csv rocprofv3 --kernel-trace --stats of tools/bench_render.py 4096 <res> render_only (tools/collect_render_pmc.sh)
   the test suite itself              `pytest --collect-only -m gpu` / `-m "not gpu"`
 """
 import csv
@@ -53,6 +54,12 @@ def rollout(task, envs=4096):
     raise KeyError(task)
 
 
+def render_avg_us(res):
+    with open(P(f"render_{res}px_kernel_stats.csv")) as f:
+        rows = [r for r in csv.DictReader(f) if "fw_render_kernel" in r["Name"]]
+    return float(rows[0]["AverageNs"]) / 1e3
+
+
 def collected(marker):
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "--collect-only", "-q", "-m", marker],
                          capture_output=True, text=True, cwd=ROOT).stdout
@@ -78,6 +85,10 @@ FIGURES = [
     ("DESIGN.md", r"the kernel alone \*\*([\d.]+) µs\*\* per 4096-env step", lambda: kernel_avg_us("waypoints"), 0.01, "rocprofv3 kernel average"),
     ("DESIGN.md", r"CPU restatement:\s+([\d.]+) M env-steps/s", lambda: headline()["cpu_baseline"]["value"] / 1e6, 0.05, "CPU restatement"),
     ("DESIGN.md", r"update ([\d.]+)\s+s per 65 536 samples", lambda: rollout("waypoints")["update_s"], 0.02, "update seconds"),
+    ("DESIGN.md", r"\| `fw_render_kernel` \| 33.5 MB written \| ([\d.]+) µs", lambda: render_avg_us(32), 0.01, "fw_render at 32 x 32"),
+    ("DESIGN.md", r"\| `fw_render_kernel` \|[^|]*\|[^|]*64²: ([\d.]+) µs", lambda: render_avg_us(64), 0.01, "fw_render at 64 x 64"),
+    ("DESIGN.md", r"\| `fw_render_kernel` \|[^|]*\|[^|]*128²: ([\d.]+) µs", lambda: render_avg_us(128), 0.01, "fw_render at 128 x 128"),
+    ("README.md", r"`fw_render` ([\d.]+) µs per 4096 × 32² images", lambda: render_avg_us(32), 0.01, "fw_render at 32 x 32"),
     ("DESIGN.md", r"end to end ([\d.]+) k \(waypoints\)", lambda: rollout("waypoints")["end_to_end_env_steps_per_s_reference_hparams"] / 1e3, 0.02, "end to end, waypoints"),
     ("DESIGN.md", r"\(waypoints\) / ([\d.]+) k \(ObjLock\)", lambda: rollout("objlock")["end_to_end_env_steps_per_s_reference_hparams"] / 1e3, 0.02, "end to end, ObjLock"),
     ("DESIGN.md", r"\(ObjLock\) / ([\d.]+) k \(combined\)", lambda: rollout("combined")["end_to_end_env_steps_per_s_reference_hparams"] / 1e3, 0.02, "end to end, combined"),
