@@ -99,6 +99,33 @@ def test_render_through_the_lds_stage_equals_the_direct_stores(oracle, monkeypat
     hip.close()
 
 
+def test_render_from_a_float32_handle_equals_the_float64_handle_on_the_same_values(oracle, lanes):
+    """fw_render_kernel<float, .> reads a float32 state (its own gather instructions) and computes in double like the float64
+    build: from a state whose every value is float32-representable both handles must write the same image, bit for bit, on the
+    direct path (33 pixels) and through the LDS stage (64 pixels); the float64 one is the one the checker is compared with."""
+    rng = np.random.default_rng(12)
+    n = 70
+    envs = []
+    for dtype in ("float64", "float32"):
+        cfg = K.objlock_config(dtype=dtype, motor_noise=False, auto_reset=False, flight_dome_size=1e5, num_obstacles=20, obstacle_radius=2.0,
+                               duck_global_scaling=60.0)
+        e = P.FixedwingVecEnv(cfg, n, seed=3); e.reset_tensor(); envs.append(e)
+    cfg64 = K.objlock_config(motor_noise=False, auto_reset=False, flight_dome_size=1e5, num_obstacles=20, obstacle_radius=2.0, duck_global_scaling=60.0)
+    ora = oracle.OracleEnv(cfg64, n, seed=3); ora.reset()
+    s = _directed_state(oracle, ora.get_state(), rng, 20).astype(np.float32).astype(np.float64)
+    ora.set_state(s)
+    for e in envs:
+        e.set_state(s)
+    for res in (33, 64):
+        a, b = (e.render_tensor(res).cpu().numpy() for e in envs)
+        assert np.array_equal(a, b), (res, int((a != b).sum()))
+        want = ora.render(res)
+        assert np.array_equal(a[:, 0], want[:, 0]) and a[:, 0].sum() > 0
+        np.testing.assert_allclose(a[:, 1], want[:, 1], rtol=0, atol=1e-7)
+    for e in envs:
+        e.close()
+
+
 def test_render_follows_the_env_through_steps_and_resets(oracle):
     """The image is the scene of the env's CURRENT state: after 40 random agent steps (episodes end, auto-resets place new ducks
     and cylinders) the render still equals the oracle's, which was stepped alongside (its state, not a copy of the kernel's)."""
