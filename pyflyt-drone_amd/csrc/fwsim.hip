@@ -1998,14 +1998,47 @@ int32_t fw_render(fw_handle h, int32_t res, float* out, void* hip_stream) {
   const size_t lds = sizeof(double) * (size_t)((res + 1) & ~1) + 2 * sizeof(float) * (size_t)stage_px;
   int threads = 256;                                     // (measured at 4096 x 32 x 32 on the 1 / t kernel with 16 x 16 tiles: 64 threads per env 52.7 us, 128: 50.8, 256: 48.2)
   if (const char* e = std::getenv("FWSIM_RENDER_THREADS")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) threads = v; }   // (measurement knob)
+#ifdef FW_RENDER_PROF
+  static long long* rprof = nullptr; static size_t rprof_n = 0;
+  const size_t rp_n = (size_t)h->n * 4 * 8;
+  if (rprof_n < rp_n) { if (rprof) (void)hipFree(rprof); HIP_TRY(h, hipMalloc((void**)&rprof, rp_n * sizeof(long long))); rprof_n = rp_n; }
+  HIP_TRY(h, hipMemsetAsync(rprof, 0, rp_n * sizeof(long long), st));
+  HIP_TRY(h, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_render_prof), &rprof, sizeof(rprof), 0, hipMemcpyHostToDevice, st));
+#endif
   if (c.dtype == FW_F64) {
-    if (stage_px) hipLaunchKernelGGL((fw_render_kernel<double, true>), dim3((unsigned)h->n), dim3(threads), lds, st, (const double*)h->r_dev, tile, h->n, K, res, out, stage_px);
-    else hipLaunchKernelGGL((fw_render_kernel<double, false>), dim3((unsigned)h->n), dim3(threads), lds, st, (const double*)h->r_dev, tile, h->n, K, res, out, 0);
+    if (stage_px) hipLaunchKernelGGL((fw_render_kernel<double, true>), dim3((unsigned)h->n), dim3(threads), lds, st, (const double*)h->r_dev, tile, h->n, threads / 64, K, res, out, stage_px);
+    else hipLaunchKernelGGL((fw_render_kernel<double, false>), dim3((unsigned)h->n), dim3(threads), lds, st, (const double*)h->r_dev, tile, h->n, threads / 64, K, res, out, 0);
   } else {
-    if (stage_px) hipLaunchKernelGGL((fw_render_kernel<float, true>), dim3((unsigned)h->n), dim3(threads), lds, st, (const float*)h->r_dev, tile, h->n, K, res, out, stage_px);
-    else hipLaunchKernelGGL((fw_render_kernel<float, false>), dim3((unsigned)h->n), dim3(threads), lds, st, (const float*)h->r_dev, tile, h->n, K, res, out, 0);
+    if (stage_px) hipLaunchKernelGGL((fw_render_kernel<float, true>), dim3((unsigned)h->n), dim3(threads), lds, st, (const float*)h->r_dev, tile, h->n, threads / 64, K, res, out, stage_px);
+    else hipLaunchKernelGGL((fw_render_kernel<float, false>), dim3((unsigned)h->n), dim3(threads), lds, st, (const float*)h->r_dev, tile, h->n, threads / 64, K, res, out, 0);
   }
   HIP_TRY(h, hipGetLastError());
+#ifdef FW_RENDER_PROF
+  if (std::getenv("FWSIM_RENDER_PROF_DUMP")) {       // per-wave cycle stamps -> mean phase lengths, set-up waves and the others apart
+    HIP_TRY(h, hipStreamSynchronize(st));
+    std::vector<long long> P(rp_n);
+    HIP_TRY(h, hipMemcpy(P.data(), rprof, rp_n * sizeof(long long), hipMemcpyDeviceToHost));
+    const int nw = threads / 64;
+    double su[6] = {0}, ot[6] = {0}; long long nsu = 0, not_ = 0; long long t0min = -1, t5max = 0; double life_su = 0, life_ot = 0;
+    for (int e = 0; e < h->n; ++e) for (int w = 0; w < nw; ++w) {
+      const long long* q = &P[((size_t)e * 4 + w) * 8];
+      if (!q[0] || !q[5]) continue;
+      if (t0min < 0 || q[0] < t0min) t0min = q[0];
+      if (q[5] > t5max) t5max = q[5];
+      const bool is_su = (w == (e & (nw - 1))) || (w == ((e + 1) & (nw - 1)));
+      double* d = is_su ? su : ot;
+      if (is_su) { d[0] += (double)(q[1] - q[0]); d[1] += (double)(q[2] - q[1]); ++nsu; life_su += (double)(q[5] - q[0]); }
+      else { d[0] += 0; d[1] += (double)(q[2] - q[0]); ++not_; life_ot += (double)(q[5] - q[0]); }
+      d[2] += (double)(q[3] - q[2]); d[3] += (double)(q[4] - q[3]); d[4] += (double)(q[5] - q[4]);
+    }
+    std::fprintf(stderr, "fw_render wave profile (cycles of the counter, mean per wave; res %d, %d envs, %d waves per env, stage %d)\n", res, h->n, nw, stage_px);
+    std::fprintf(stderr, "  set-up waves (%lld): start->gather in %.0f, set-up arithmetic %.0f, at the barrier %.0f, constants %.0f, strips %.0f, life %.0f\n",
+                 nsu, su[0] / nsu, su[1] / nsu, su[2] / nsu, su[3] / nsu, su[4] / nsu, life_su / nsu);
+    std::fprintf(stderr, "  other waves  (%lld): start->barrier arrival %.0f, at the barrier %.0f, constants %.0f, strips %.0f, life %.0f\n",
+                 not_, ot[1] / not_, ot[2] / not_, ot[3] / not_, ot[4] / not_, life_ot / not_);
+    std::fprintf(stderr, "  first stamp to last stamp of the launch: %lld\n", t5max - t0min);
+  }
+#endif
   return FW_OK;
 }
 

@@ -7,7 +7,8 @@
 //   out[env][1][y][x] = depth-buffer value in [0, 1] of the nearest fragment (duck pixels: the sphere; others: ground or
 //                       cylinder; sky = 1.0), far (t - near) / (t (far - near)) with t clipped to [near, far]
 // at `res` x `res` pixels of the same body-fixed camera (FOV, tilt, offset of fw_config; the focal length scales with the
-// width), for the env's CURRENT pose.  One workgroup (four waves) per env; a wave takes 16 x 16-pixel tiles.
+// width), for the env's CURRENT pose.  One workgroup (four waves) per env; two waves share the set-up, then every wave takes
+// strips of 4 columns.
 //   * The duck MASK is an exact comparison against 0 at the silhouette, so the test asks for the same bits, not for a tolerance:
 //     the pose, the duck in the camera frame and the silhouette discriminant are the CPU checker's expressions statement by
 //     statement in double, no FMA contraction (multiplications and additions only: cheap); the clip-plane test of a duck pixel
@@ -26,7 +27,8 @@
 //     pixels for every cylinder at once (lane = cylinder x corner) -- an affine form that is negative at all four corners of a
 //     rectangle is negative inside -- and a pixel loops over the surviving cylinders only (bit mask, wave-uniform).  The margin
 //     of the cull is seven orders of magnitude above rounding; what survives is decided by the exact expressions.
-//   * every thread derives the pose / duck constants for itself (same loads, same arithmetic: no broadcast barrier for them).
+//   * the set-up waves leave pose, duck and cylinder tables in LDS; behind the barrier every wave moves the wave-uniform ones into
+//     scalar registers (v_readfirstlane), and strip, row and cylinder loops are scalar control flow.
 #pragma once
 #include "fwsim_device.hpp"
 #include "fwsim_objlock.hpp"
@@ -64,15 +66,23 @@ __device__ __forceinline__ double render_from_lane(double v, int src_lane) {    
 // given the four loads as C++, waits for the first before it has even formed the addresses of the others (two round trips, not one).
 __device__ __forceinline__ void render_gather4(const double* base, unsigned oa, unsigned ox, unsigned oy, unsigned oh, double& a, double& x, double& y, double& h) {
   asm volatile("global_load_dwordx2 %0, %4, %8\n\tglobal_load_dwordx2 %1, %5, %8\n\tglobal_load_dwordx2 %2, %6, %8\n\tglobal_load_dwordx2 %3, %7, %8\n\ts_waitcnt vmcnt(0)"
-               : "=&v"(a), "=&v"(x), "=&v"(y), "=&v"(h) : "v"(oa), "v"(ox), "v"(oy), "v"(oh), "s"(base) : "memory");
+               : "=&v"(a), "=&v"(x), "=&v"(y), "=&v"(h) : "v"(oa), "v"(ox), "v"(oy), "v"(oh), "s"(base));
 }
 __device__ __forceinline__ void render_gather4(const float* base, unsigned oa, unsigned ox, unsigned oy, unsigned oh, float& a, float& x, float& y, float& h) {
   asm volatile("global_load_dword %0, %4, %8\n\tglobal_load_dword %1, %5, %8\n\tglobal_load_dword %2, %6, %8\n\tglobal_load_dword %3, %7, %8\n\ts_waitcnt vmcnt(0)"
-               : "=&v"(a), "=&v"(x), "=&v"(y), "=&v"(h) : "v"(oa), "v"(ox), "v"(oy), "v"(oh), "s"(base) : "memory");
+               : "=&v"(a), "=&v"(x), "=&v"(y), "=&v"(h) : "v"(oa), "v"(ox), "v"(oy), "v"(oh), "s"(base));
 }
 
+// Dev-only (-DFW_RENDER_PROF, tools/render_wave_profile.sh): lane 0 of every wave leaves the cycle counter at six points of its life
+#ifdef FW_RENDER_PROF
+__device__ long long* g_render_prof = nullptr;      // [n_envs][4 waves][8]
+#define FW_RP(i) do { if (lane == 0 && g_render_prof) g_render_prof[((size_t)env * 4 + wave) * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define FW_RP(i) do { } while (0)
+#endif
+
 template <typename T, bool STAGE>
-__global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r, int tile, int n_envs, RenderC K, int res,
+__global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r, int tile, int n_envs, int nwaves, RenderC K, int res,
                                                         float* __restrict__ out, int stage_px) {
 #pragma clang fp contract(off)                    // this kernel only: multiply-adds stay two roundings, as in the CPU checker's C
   __shared__ double s_pose[28];                   // R[9] cam[3] zc xc yc k2 | Hf Hr Hd (the camera axes in the world frame)
@@ -84,15 +94,13 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* s_ab = reinterpret_cast<double*>(smem_raw);      // [res]: (i - u0) / F, the image-plane coordinate of pixel column / row i (the image is square)
   const int env = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  // (nwaves = blockDim.x / 64, handed in: a scalar the compiler knows is uniform, no fetch from the dispatch packet)
   if (env >= n_envs) return;
-  const int nwaves = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6)), setup_wave = env & (nwaves - 1);
-  const double W = (double)res, F = 0.5 * W / K.tan_half_fov, u0 = 0.5 * (W - 1.0), near = K.near_, far = K.far_;
-  // (one IEEE division per column, not four per pixel; the wave BEHIND the set-up wave starts the table, so the two run side by side)
-  for (int i = ((wave - setup_wave - 1) & (nwaves - 1)) * 64 + lane; i < res; i += (int)blockDim.x) s_ab[i] = ((double)i - u0) / F;
-  if (wave == setup_wave) {
-    // the pose, the duck in the camera frame, the ray basis: every lane of ONE wave for itself (no broadcast inside the wave), lane 0
-    // leaves them for the other waves.  Which wave rotates with the env: a workgroup's wave i runs on SIMD i, and with the pixel loop
-    // as short as it now is the set-up would otherwise queue sixteen deep on SIMD 0 of every CU.
+  const int setup_wave = env & (nwaves - 1), cyl_wave = (setup_wave + 1) & (nwaves - 1);
+  const bool do_pose = wave == setup_wave, do_cyl = wave == cyl_wave;
+  FW_RP(0);
+  T gA = (T)0, gX = (T)0, gY = (T)0, gH = (T)0;
+  if (do_pose || do_cyl) {                          // (first thing in the kernel: the fetch is the longest single wait of a set-up wave, 3.3 k of its 17.4 k cycles)
     // Everything the set-up reads comes in ONE round trip: four lane-indexed gathers issued back to back (lane l of the first fetches
     // the l-th of quaternion 4, position 3, duck 3, cylinder count; lane o of the others cylinder o's x / y / height -- the slots exist
     // whatever the count), handed out by v_readlane.  As scalar loads behind their uses the same words were four round trips in a
@@ -102,8 +110,19 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
     const int fA = lane < 4 ? RF_QUAT + lane : lane < 7 ? RF_POS + (lane - 4) : lane < 10 ? RF_TASK + FW_ST_DUCK_POS + (lane - 7) : RF_TASK + FW_ST_NUM_OBST;
     const int lo = lane < FW_MAX_OBSTACLES ? lane : 0;
     const unsigned fstride = (unsigned)tile * (unsigned)sizeof(T), oX = (unsigned)(RF_TASK + FW_ST_OBST + 3 * lo) * fstride;       // (a tile of <= 64 envs x 171 fields: 32-bit offsets)
-    T gA, gX, gY, gH;
     render_gather4(rb, (unsigned)fA * fstride, oX, oX + fstride, oX + 2u * fstride, gA, gX, gY, gH);
+    FW_RP(1);
+  }
+  const double W = (double)res, F = 0.5 * W / K.tan_half_fov, u0 = 0.5 * (W - 1.0), near = K.near_, far = K.far_;
+  // (one IEEE division per column, not four per pixel; the wave BEHIND the two set-up waves starts the table, so the three run side by side)
+  for (int i = ((wave - setup_wave - 2) & (nwaves - 1)) * 64 + lane; i < res; i += nwaves * 64) s_ab[i] = ((double)i - u0) / F;
+  // Two waves share the set-up (one, with 64 threads per env): both fetch the state and rotate the camera, `setup_wave` goes on to the
+  // duck and the ray basis, `cyl_wave` to the cylinders (occlusion of the duck, tangent wedges) -- the wave profile put 4.3 k of a
+  // wave's 17.4 k cycles into this arithmetic, one dependent chain with three waves waiting for it
+  if (do_pose || do_cyl) {
+    // the pose, the duck in the camera frame, the ray basis: every lane of ONE wave for itself (no broadcast inside the wave), lane 0
+    // leaves them for the other waves.  Which wave rotates with the env: a workgroup's wave i runs on SIMD i, and with the pixel loop
+    // as short as it now is the set-up would otherwise queue sixteen deep on SIMD 0 of every CU.
     auto fld = [&](int l) { return render_from_lane((double)gA, l); };
     int nob = (int)fld(10);
     nob = nob < 0 ? 0 : (nob > FW_MAX_OBSTACLES ? FW_MAX_OBSTACLES : nob);
@@ -129,7 +148,7 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
       Hr[k] = R[3 * k] * K.cam_r[0] + R[3 * k + 1] * K.cam_r[1] + R[3 * k + 2] * K.cam_r[2];
       Hd[k] = R[3 * k] * K.cam_d[0] + R[3 * k + 1] * K.cam_d[1] + R[3 * k + 2] * K.cam_d[2];
     }
-    if (lane == 0) {
+    if (do_pose && lane == 0) {
       for (int k = 0; k < 9; ++k) s_pose[k] = R[k];
       for (int k = 0; k < 3; ++k) s_pose[9 + k] = cam[k];
       s_pose[12] = zc; s_pose[13] = xc; s_pose[14] = yc; s_pose[15] = k2;
@@ -144,7 +163,7 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
       s_dbox[0] = ca - wa - ma; s_dbox[1] = ca + wa + ma; s_dbox[2] = cb - wb - mb; s_dbox[3] = cb + wb + mb;
     }
     bool blocked_any = false;
-    if (lane < FW_MAX_OBSTACLES) {                   // lane o: cylinder o
+    if (do_cyl && lane < FW_MAX_OBSTACLES) {         // lane o: cylinder o
       bool blocked = false;
       double ox = 0.0, oy = 0.0, cc = 1.0, hh = 0.0;
       if (lane < nob) {
@@ -181,9 +200,11 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
       blocked_any = blocked;
     }
     blocked_any = __any(blocked_any);
-    if (lane == 0) { s_blocked = blocked_any ? 1 : 0; s_nob = nob; }
+    if (do_cyl && lane == 0) { s_blocked = blocked_any ? 1 : 0; s_nob = nob; }
   }
+  FW_RP(2);
   __syncthreads();
+  FW_RP(3);
   const int nob = __builtin_amdgcn_readfirstlane(s_nob);
   // the pose constants are the same in every lane: all but one operand of each expression below live in scalar registers (20 vector
   // registers fewer: eight waves per SIMD instead of six or seven)
@@ -197,6 +218,7 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
   float* img = out + (size_t)env * 2 * res * res;
   float* img1 = img + (size_t)res * res;
   const int tpr = (res + kRTileW - 1) / kRTileW;
+  FW_RP(4);
   // (`wave` went through v_readfirstlane above: the strip counters, the row loop and their exits are scalar control flow -- with a
   // wave number the compiler takes for divergent, every loop here carried an exec-mask protocol and the strip index a vector division)
   // STAGE: the image leaves through LDS (stage_px pixels per channel behind the coordinate table; a build of its own so that the
@@ -298,16 +320,17 @@ __global__ __launch_bounds__(256) void fw_render_kernel(const T* __restrict__ r,
     float* g0 = img + (size_t)y0 * res;
     float* g1 = img1 + (size_t)y0 * res;
     if ((res & 3) == 0) {                                                           // (16-byte pieces: every run starts on a multiple of 4 pixels)
-      for (int i = t * 4; i < nfl; i += (int)blockDim.x * 4) {
+      for (int i = t * 4; i < nfl; i += nwaves * 256) {
         *reinterpret_cast<float4*>(g0 + i) = *reinterpret_cast<const float4*>(s_img + i);
         *reinterpret_cast<float4*>(g1 + i) = *reinterpret_cast<const float4*>(s_img + stage_px + i);
       }
     } else {
-      for (int i = t; i < nfl; i += (int)blockDim.x) { g0[i] = s_img[i]; g1[i] = s_img[stage_px + i]; }
+      for (int i = t; i < nfl; i += nwaves * 64) { g0[i] = s_img[i]; g1[i] = s_img[stage_px + i]; }
     }
     if (yend < res) __syncthreads();                                                // (the next band overwrites the stage)
   }
   }
+  FW_RP(5);
 }
 
 }  // namespace fwsim
